@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py — multimodal forward samples/s (224x224 image + 50 tokens) @ ViT-L/14 + Perceiver + 24L/2048d.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RCCL over xGMI for N > 1).  A "step" is one pass of the hot path
+(`Kosmos.forward`, /root/reference/kosmosx/model.py:208-253) over one per-GPU shard of synthetic
+input already resident in HBM: `--batch` samples (default 32 = BASELINE.json configs[3] per-GPU share,
+256 / 8), each one 1x3x224x224 image + 50 text tokens -> logits [114, 32002]; for N > 1 the step ends
+with the all-gather of logits (bf16 on the wire, overlapped with the next step's compute).
+Weak scaling: per-GPU work is fixed as N grows.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "kosmos-x_amd"), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("KOSMOSX_NO_LOGGING_CONFIG", "1")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
+    ap.add_argument("--text-len", type=int, default=50)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-gather", action="store_true", help="skip the logits all-gather (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
+    ap.add_argument("--prof-steps", type=int, default=3, help="instrumented steps for the roofline leg")
+    return ap.parse_args()
+
+
+def kernel_report(records, steps):
+    """Aggregate kx_prof records (one per kernel launch) into per-kernel totals per step."""
+    agg = {}
+    for kind, a, b, c, ms in records:
+        e = agg.setdefault(kind, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        e["launches"] += 1
+        e["ms"] += ms
+        if kind.startswith("gemm"):
+            e["flops"] += 2.0 * a * b * c                     # algorithmic: 2*M*N*K per launch
+        elif kind.startswith("attn"):
+            e["flops"] += 4.0 * a * b * c * 64                # dense QK^T + PV, head_dim 64 (B*H, Tq, Tk)
+        elif kind == "layernorm":
+            e["bytes"] += a * b * 6.0                         # fp32 row in, bf16 row out
+    for e in agg.values():
+        e["launches"] /= steps
+        e["ms"] /= steps
+        e["flops"] /= steps
+        e["bytes"] /= steps
+    return agg
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the Kosmos-X HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from kosmosx import _hip
+    from kosmosx.config import DecoderConfig, KosmosConfig
+    from kosmosx.model import Kosmos
+    from kosmosx.parallel import LogitsGatherer
+
+    cfg = KosmosConfig(decoder=DecoderConfig())
+    t_build = time.time()
+    model = Kosmos._from_config(cfg, seed=0).eval()            # identical weights on every rank (replicated)
+    cpu_weights = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from helpers import oracle_weights
+        cpu_weights = oracle_weights(model)                     # shares the CPU storage, no copy
+    model = model.to(dev)
+    model.precision = args.precision
+    t_build = time.time() - t_build
+
+    g = torch.Generator().manual_seed(1000 + rank)              # per-rank synthetic shard
+    B, Tt = args.batch, args.text_len
+    tok = torch.randint(0, cfg.vocab, (B, Tt), generator=g).to(dev)
+    img = torch.randn(B, 3, cfg.vit.image, cfg.vit.image, generator=g).to(dev)
+    gatherer = LogitsGatherer(wire_dtype=torch.bfloat16) if (world > 1 and not args.no_gather) else None
+
+    def step():
+        with torch.no_grad():
+            logits = model(tok, img)
+            if gatherer is not None:
+                return gatherer.gather(logits)
+            return logits
+
+    def fence():
+        if gatherer is not None:
+            gatherer.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape[-1] == cfg.vocab and out.shape[-2] == Tt + cfg.perceiver.latents
+
+    # ---- roofline leg: the same step, instrumented launch by launch with HIP events on the launch stream ----
+    roofline, breakdown = None, None
+    if rank == 0:
+        _hip.prof_enable(True)
+        for _ in range(args.prof_steps):
+            with torch.no_grad():
+                model(tok, img)
+        torch.cuda.synchronize()
+        recs = _hip.prof_collect()
+        _hip.prof_enable(False)
+        agg = kernel_report(recs, args.prof_steps)
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        e = agg[dom]
+        if e["flops"] > 0:
+            peak = PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS
+            ach = e["flops"] / (e["ms"] * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None,
+                        "launches_per_step": e["launches"], "avg_launch_ms": round(e["ms"] / e["launches"], 5),
+                        "algorithmic_flops_per_step": e["flops"]}
+        else:
+            ach = e["bytes"] / (e["ms"] * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "launches_per_step": e["launches"], "avg_launch_ms": round(e["ms"] / e["launches"], 5)}
+        breakdown = {k: {"ms_per_step": round(v["ms"], 4), "launches_per_step": v["launches"],
+                         **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] else {}),
+                         **({"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] else {})}
+                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+
+    # ---- cpu_baseline: the oracle (a port — the reference's third-party stack is absent) on the host cores ----
+    cpu_baseline = None
+    if cpu_weights is not None:
+        from helpers import oracle_cfg
+        from oracle import kosmos_oracle as O
+        ocfg = oracle_cfg(cfg)
+        ctok, cimg = tok[:1].cpu(), img[:1].cpu()
+        O.kosmos_forward(cpu_weights, ctok, cimg, ocfg)          # warm-up (page-in, thread pool)
+        n, t_cpu = 0, 0.0
+        while (t_cpu < args.cpu_seconds and n < 64) or n < 2:
+            t1 = time.perf_counter()
+            O.kosmos_forward(cpu_weights, ctok, cimg, ocfg)
+            t_cpu += time.perf_counter() - t1
+            n += 1
+        cpu_baseline = {"value": round(n / t_cpu, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
+                        "kind": "port",
+                        "sample": f"{n} x (1 image + {Tt} tokens) forward, fp32 torch CPU oracle (oracle/kosmos_oracle.py), "
+                                  f"batch 1, {t_cpu:.1f} s"}
+
+    if rank == 0:
+        from oracle.kosmos_oracle import flops_per_sample
+        from helpers import oracle_cfg
+        fl = flops_per_sample(oracle_cfg(cfg), Tt)
+        total = world * B * args.steps
+        line = {
+            "metric": "multimodal forward samples/sec (224x224 img + 50 tok) @ 24L/2048d",
+            "value": round(total / elapsed, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"{B} samples/GPU/step, each 1x3x224x224 image + {Tt} text tokens -> logits "
+                                   f"[{Tt + cfg.perceiver.latents},{cfg.vocab}]; CLIP ViT-L/14 + Perceiver(257->64) + "
+                                   "24L/2048d sub-LN XPos decoder, random-init weights (BASELINE.json configs[3] per-GPU share)",
+                       "batch_per_gpu": B, "global_batch": world * B, "seq_len": Tt + cfg.perceiver.latents,
+                       "text_len": Tt, "parallelism": f"dp{world}",
+                       "logits_gather": (None if gatherer is None else "RCCL all-gather, bf16 wire, overlapped")},
+            "algorithmic_gflop_per_sample": round(fl["total"] / 1e9, 2),
+            "model_tflops": round(fl["total"] * total / elapsed / 1e12, 2),
+            "mfma_peak_frac_end_to_end": round(fl["total"] * total / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernel_breakdown": breakdown,
+            "build_seconds": round(t_build, 1),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

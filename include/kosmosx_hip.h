@@ -1,0 +1,247 @@
+/*
+ * kosmosx_hip.h — C ABI of libkosmosx_hip.so: the MI355X (gfx950) hot path behind
+ * kosmosx.model.Kosmos.forward / KosmosLanguage.forward.
+ *
+ * The reference (kyegomez/Kosmos-X) has no FFI of its own: its hot path is Python glue
+ * (/root/reference/kosmosx/model.py:208-253, :310-320) over four third-party torch modules.
+ * Each entry point below therefore cites the reference call site (or the third-party module
+ * behind it) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes
+ * binding a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, non-zero kx_status on failure; message via kx_last_error()
+ *     (thread-local).  No C++ exception crosses the boundary.
+ *   - every pointer is a caller-owned DEVICE pointer unless the parameter says "host";
+ *     the library never allocates or frees user-visible memory.  Scratch is passed in with an
+ *     explicit byte size (query with kx_*_workspace_bytes).
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     launches are asynchronous on it, the library never synchronises, so every call is
+ *     capturable into a hipGraph.
+ *   - activations are row-major; "rows" are tokens.  Linear weights are [out, in] row-major
+ *     (PyTorch convention) and are consumed as the K-contiguous B^T operand.
+ *   - precision KX_PREC_BF16: GEMM/attention operands bf16 (MFMA 16x16x32 bf16), residual
+ *     stream, LayerNorm statistics, softmax, GELU and all accumulators fp32.
+ *     precision KX_PREC_F32: operands fp32 on the exact-f32 MFMA (16x16x4 f32).
+ */
+#ifndef KOSMOSX_HIP_H
+#define KOSMOSX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KX_ABI_VERSION 1
+
+typedef enum {
+  KX_OK = 0,
+  KX_ERR_INVALID_ARG = 1,   /* shape / alignment / null pointer */
+  KX_ERR_WORKSPACE = 2,     /* workspace too small */
+  KX_ERR_LAUNCH = 3,        /* hipGetLastError() after a launch */
+  KX_ERR_UNSUPPORTED = 4
+} kx_status;
+
+typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1 } kx_precision;
+typedef enum { KX_F32 = 0, KX_BF16 = 1 } kx_dtype;
+typedef enum { KX_ACT_NONE = 0, KX_ACT_GELU = 1, KX_ACT_QUICK_GELU = 2 } kx_act;
+typedef enum { KX_ATTN_FULL = 0, KX_ATTN_CAUSAL = 1 } kx_attn_mask;
+
+int kx_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
+int kx_last_error(char* buf, size_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Primitive ops (exported so each kernel is parity-tested on its own)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Row LayerNorm, y = LN(x [+ pre_add]) * gamma + beta, statistics in fp32.
+ * Replaces torch.nn.LayerNorm / apex FusedLayerNorm as reached from torchscale
+ * (self_attn_layer_norm, inner_attn_ln, final_layer_norm, ffn_layernorm, decoder.layer_norm),
+ * HF CLIP (pre_layrnorm, layer_norm1/2) and flamingo (norm_media, norm_latents, FeedForward[0],
+ * norm) — SURVEY.md §2.2 row "layer_norm".
+ * x: [rows, cols] fp32.  y: dtype ydt.  cols % 4 == 0, cols <= 8192.
+ * Output row remap (used to assemble the Perceiver's cat(media, latents) key/value input,
+ * flamingo PerceiverAttention.forward `torch.cat((x, latents), dim=-2)`):
+ *   out_row = (row / rows_per_group) * out_group_stride + out_row_offset + row % rows_per_group
+ * pass rows_per_group = rows, out_group_stride = 0, out_row_offset = 0 for the identity map.
+ * pre_add: optional [cols] fp32 vector added to every row before the statistics
+ * (flamingo `x + media_pos_emb[:times]`). */
+int kx_layernorm(const float* x, const float* pre_add, const float* gamma, const float* beta,
+                 void* y, kx_dtype ydt, int64_t rows, int64_t cols, float eps,
+                 int64_t rows_per_group, int64_t out_group_stride, int64_t out_row_offset,
+                 void* stream);
+
+/* C = epilogue(A · Wᵀ).  Replaces every nn.Linear on the path (cuBLAS GEMM + bias,
+ * SURVEY.md §2.2) with the elementwise work that follows it fused into the epilogue.
+ *   A [M,K] (lda), W [N,K] (ldw): dtype of `prec`.  K % 64 == 0 (bf16) / K % 32 == 0 (f32),
+ *   lda/ldw multiples of 8 (bf16) / 4 (f32) elements, 16-byte aligned bases.
+ *   epilogue, in order:  v = acc + bias[n];  v *= qscale for n < qcols;
+ *     XPos rotation/scale for n < 2*xpos_dim when xpos tables are given
+ *     (torchscale XPOS.forward + apply_rotary_pos_emb; q columns [0,xpos_dim) use the q tables,
+ *      k columns [xpos_dim,2*xpos_dim) the k tables; position = row % xpos_T; head_dim 64);
+ *     v = act(v);  v += residual[m,n] (fp32, may alias C);  store as cdt. */
+typedef struct {
+  const void* A; int64_t lda;
+  const void* W; int64_t ldw;
+  void* C; int64_t ldc; int32_t cdt;          /* kx_dtype */
+  const float* bias;                          /* [N] or NULL */
+  const float* residual; int64_t ldr;         /* [M,N] fp32 or NULL */
+  int64_t M, N, K;
+  int32_t act;                                /* kx_act */
+  float qscale; int64_t qcols;                /* 1.0f / 0 to disable */
+  const float* xq_cs; const float* xq_ss;     /* [xpos_T, 32] fp32: cos*scale, sin*scale for q */
+  const float* xk_cs; const float* xk_ss;     /* same for k (downscale) */
+  int64_t xpos_T; int64_t xpos_dim;           /* 0 to disable */
+  int32_t prec;                               /* kx_precision */
+  int32_t tile;                               /* 0 = auto; kernel variant override for tests/bench */
+} kx_gemm_args;
+int kx_gemm(const kx_gemm_args* args, void* stream);
+
+/* Fused softmax(Q·Kᵀ [+causal mask])·V, head_dim 64, flash-style (no T×T tensor in HBM).
+ * Replaces torchscale MultiheadAttention's bmm/nan_to_num/+mask/softmax(fp32)/bmm chain,
+ * HF eager_attention_forward, and flamingo PerceiverAttention's einsum/amax/softmax/einsum.
+ * Q is expected pre-scaled (and XPos-rotated) by the producing GEMM epilogue.
+ *   q: [B, Tq, H, 64] with element strides (q_batch_stride, q_row_stride), head h at +h*64.
+ *   k, v: [B, Tk, H, 64] with (kv_batch_stride, kv_row_stride).   dtype of `prec`.
+ *   out: [B, Tq, H*64] contiguous rows of out_row_stride elements, dtype odt. */
+typedef struct {
+  const void* q; int64_t q_batch_stride; int64_t q_row_stride;
+  const void* k; const void* v; int64_t kv_batch_stride; int64_t kv_row_stride;
+  void* out; int64_t out_batch_stride; int64_t out_row_stride; int32_t odt;
+  int64_t B, H, Tq, Tk;
+  int32_t mask;                               /* kx_attn_mask */
+  int32_t prec;
+} kx_attn_args;
+int kx_attention(const kx_attn_args* args, void* stream);
+
+/* Decoder input assembly (a6-a8): token gather + learned positions (fairseq offset 2) +
+ * image-token splice + second position add.
+ * Replaces Decoder.forward_embedding(text_tokens)[1] → torch.cat([x[:, :2], images, x[:, 2:]])
+ * → Decoder.forward_embedding(model_input, token_embedding=model_input)[0]
+ * (/root/reference/kosmosx/model.py:238-244).
+ *   tokens [B,Tt] int64; embed [vocab,d] fp32; pos [max_pos,d] fp32; img [B,n_img,d] fp32 or
+ *   NULL with n_img = 0 (KosmosLanguage path, model.py:319: single position add);
+ *   out [B, Tt+n_img, d] fp32.  The n_img rows of img are spliced in after the first `splice_at`
+ *   text rows (2 on the Kosmos path: "<s> <image>" | image features | "</image> text").
+ *   Tt = 0, splice_at = 0 adds positions to an already-embedded sequence
+ *   (forward_embedding(x, token_embedding=x)).  u1_alias: 1 = first forward_embedding's [1] return
+ *   already contains positions (in-place `x += positions`), so text rows get positions
+ *   twice.  Returns KX_ERR_INVALID_ARG ("position ... out of range") when Tt+n_img+2 > max_pos —
+ *   the condition under which the reference's F.embedding raises IndexError.
+ *   Token ids are clamped to [0, vocab) for memory safety. */
+int kx_embed_splice(const int64_t* tokens, const float* embed, const float* pos, const float* img,
+                    float* out, int64_t B, int64_t Tt, int64_t n_img, int64_t d, int64_t vocab,
+                    int64_t max_pos, int64_t splice_at, int32_t u1_alias, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage-level entry points (what kosmosx.model calls).  Weight structs hold device pointers
+ * to tensors packed by the Python side from the reference's state_dict key namespace
+ * (SURVEY.md §8b); `w*` GEMM operands are in the dtype of `prec`, everything else fp32.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *ln1_g, *ln1_b;                 /* layer_norm1 */
+  const void* wqkv; const float* bqkv;        /* cat(q_proj,k_proj,v_proj) [3d,d] */
+  const void* wo;   const float* bo;          /* out_proj */
+  const float *ln2_g, *ln2_b;                 /* layer_norm2 */
+  const void* w1;   const float* b1;          /* mlp.fc1 */
+  const void* w2;   const float* b2;          /* mlp.fc2 */
+} kx_vit_layer;
+
+typedef struct {
+  int32_t image, patch, dim, heads, ffn, layers, act; float eps;
+  int32_t kpad;                               /* padded im2col K (multiple of 64) */
+  const void* wpatch;                         /* [dim, kpad]  (conv weight flattened c,ky,kx, zero padded) */
+  const float* cls;                           /* embeddings.class_embedding [dim] */
+  const float* pos;                           /* embeddings.position_embedding.weight [tokens, dim] */
+  const float *pre_g, *pre_b;                 /* pre_layrnorm */
+  const kx_vit_layer* layer;                  /* host array [layers] */
+} kx_vit_weights;
+
+/* CLIP ViT-L/14 vision tower: clip_model(pixel_values=images)["last_hidden_state"]
+ * (/root/reference/kosmosx/model.py:230; HF CLIPVisionTransformer.forward).
+ * pixels [B,3,image,image] fp32 -> out [B, tokens, dim] fp32. */
+size_t kx_vit_workspace_bytes(const kx_vit_weights* w, int64_t B, int32_t prec);
+int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int64_t B, float* out,
+                   void* workspace, size_t workspace_bytes, int32_t prec, void* stream);
+
+typedef struct {
+  const float *nm_g, *nm_b, *nl_g, *nl_b;     /* norm_media, norm_latents */
+  const void *wq, *wkv, *wout;                /* to_q [inner,dim], to_kv [2*inner,dim], to_out [dim,inner] */
+  const float *ff_g, *ff_b;                   /* layers.i.1.0 (LayerNorm) */
+  const void *w1, *w2;                        /* layers.i.1.1 [dim*mult,dim], layers.i.1.3 [dim,dim*mult] */
+} kx_perceiver_layer;
+
+typedef struct {
+  int32_t dim, depth, heads, latents, ff_mult, out_dim; float eps;
+  const float* latents_p;                     /* perceive.latents [latents, dim] */
+  const float* media_pos;                     /* perceive.media_pos_emb[0,0,:] [dim] */
+  const kx_perceiver_layer* layer;            /* host array [depth] */
+  const float *norm_g, *norm_b;               /* perceive.norm */
+  const void* wproj;                          /* image_proj.weight [out_dim, dim] */
+} kx_perceiver_weights;
+
+/* PerceiverResampler + image_proj: self.image_proj(self.perceive(images).squeeze(1))
+ * (/root/reference/kosmosx/model.py:231-232).  x [B, m, dim] fp32 -> out [B, latents, out_dim] fp32.
+ * lat_out (optional, may be NULL): the resampler output before image_proj [B, latents, dim] fp32.
+ * out may be NULL (and wproj NULL) when only lat_out is wanted (standalone PerceiverResampler call). */
+size_t kx_perceiver_workspace_bytes(const kx_perceiver_weights* w, int64_t B, int64_t m, int32_t prec);
+int kx_perceiver_forward(const kx_perceiver_weights* w, const float* x, int64_t B, int64_t m,
+                         float* out, float* lat_out, void* workspace, size_t workspace_bytes,
+                         int32_t prec, void* stream);
+
+typedef struct {
+  const float *sa_g, *sa_b;                   /* self_attn_layer_norm.A */
+  const void* wqkv; const float* bqkv;        /* cat(q,k,v)_proj.A [3d,d] */
+  const float *in_g, *in_b;                   /* self_attn.inner_attn_ln.A (sub-LN) */
+  const void* wo;   const float* bo;          /* self_attn.out_proj.A */
+  const float *fl_g, *fl_b;                   /* final_layer_norm.A */
+  const void* w1;   const float* b1;          /* ffn.A.fc1 */
+  const float *fn_g, *fn_b;                   /* ffn.A.ffn_layernorm (sub-LN) */
+  const void* w2;   const float* b2;          /* ffn.A.fc2 */
+} kx_decoder_layer;
+
+typedef struct {
+  int32_t layers, dim, heads, ffn, vocab, act, subln, xpos; float eps;
+  const kx_decoder_layer* layer;              /* host array [layers] */
+  const float *ln_g, *ln_b;                   /* decoder.layer_norm */
+  const void* wout;                           /* output_projection.weight [vocab, dim] */
+} kx_decoder_weights;
+
+/* Decoder.forward(x, passed_x=x)[0] (/root/reference/kosmosx/model.py:250, :320; torchscale
+ * Decoder.forward with the README.md:179-193 patch): `layers` × DecoderLayer, final LayerNorm,
+ * output_projection.   x [B,T,dim] fp32 (overwritten: it is the residual stream),
+ * XPos tables [T,32] fp32 for this T (xq_*: q, xk_*: k/downscale; may be NULL when xpos == 0),
+ * logits [B,T,vocab] dtype ldt. */
+size_t kx_decoder_workspace_bytes(const kx_decoder_weights* w, int64_t B, int64_t T, int32_t prec);
+int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t B, int64_t T,
+                       const float* xq_cs, const float* xq_ss, const float* xk_cs, const float* xk_ss,
+                       void* logits, int32_t ldt, void* workspace, size_t workspace_bytes,
+                       int32_t prec, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * In-process kernel timing (bench.py's roofline leg; the reference's own ad-hoc equivalents are the
+ * wall-clock fences of /root/reference/tests/test_benchmarking.py:68-95,192-196).
+ * When enabled, every kernel launch made through this library is bracketed by hipEventRecord on
+ * the launch stream.  kx_prof_collect synchronises the recorded events and returns one record
+ * per launch, in launch order.  Not for use under hipGraph capture.
+ * ---------------------------------------------------------------------------------------- */
+typedef enum {
+  KX_K_GEMM_BF16_128 = 0, KX_K_GEMM_BF16_64 = 1, KX_K_GEMM_F32_128 = 2, KX_K_GEMM_F32_64 = 3,
+  KX_K_LAYERNORM = 4, KX_K_ATTN_BF16 = 5, KX_K_ATTN_F32 = 6, KX_K_EMBED = 7, KX_K_MISC = 8
+} kx_kernel_kind;
+typedef struct {
+  int32_t kind;      /* kx_kernel_kind */
+  int32_t reserved;
+  int64_t a, b, c;   /* GEMM: M,N,K.  LayerNorm: rows, cols, 0.  Attention: B*H, Tq, Tk.  else rows, cols, 0 */
+  float ms;          /* device time of the launch */
+  float reserved2;
+} kx_prof_record;
+int kx_prof_enable(int on);                               /* on != 0: clear records and start recording */
+int kx_prof_collect(kx_prof_record* out, int max_records); /* returns the number of records written */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOSMOSX_HIP_H */

@@ -1,0 +1,63 @@
+"""Build libkosmosx_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    python kosmos-x_amd/build.py [--force]
+
+Output: kosmos-x_amd/kosmosx/lib/libkosmosx_hip.so (git-ignored, travels with gpurun snapshots).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OUT_DIR = HERE / "kosmosx" / "lib"
+BUILD_DIR = HERE / "build"
+LIB = OUT_DIR / "libkosmosx_hip.so"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-I", str(HERE.parent / "include")]
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in sorted(list(CSRC.glob("*")) + [HERE.parent / "include" / "kosmosx_hip.h"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    OUT_DIR.mkdir(parents=True, exist_ok=True)
+    BUILD_DIR.mkdir(parents=True, exist_ok=True)
+    stamp = OUT_DIR / "libkosmosx_hip.digest"
+    dg = _digest()
+    if not force and LIB.exists() and stamp.exists() and stamp.read_text() == dg:
+        return LIB
+    srcs = sorted(CSRC.glob("*.hip"))
+
+    def cc(src: Path) -> Path:
+        obj = BUILD_DIR / (src.stem + ".o")
+        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(cc, srcs))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    stamp.write_text(dg)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,244 @@
+// Fused attention for gfx950, head_dim 64: softmax(Q·Kᵀ [+causal]) · V without the T×T tensor in HBM.
+//
+// bf16 path (flash-style, MFMA 16x16x32 bf16), "transposed" formulation so the softmax never
+// leaves registers:
+//   Sᵀ = K·Qᵀ      — MFMA A = K rows (keys), B = Q rows (queries): lane (g,i) of the accumulator
+//                    holds 4 consecutive KEYS (4g..4g+3) of query i ⇒ a query's scores live in the
+//                    4 lanes {i, i+16, i+32, i+48}; row max / row sum are 2 shuffles.
+//   Oᵀ = Vᵀ·Pᵀ     — MFMA A = Vᵀ rows (head-dim d), B = P (per query): the P fragment is exactly
+//                    the exponentiated Sᵀ accumulator packed to bf16 (no LDS round trip), and the
+//                    O accumulator column is again query i ⇒ the online-softmax rescale is lane-local.
+//   K tile row-major in LDS (16-B fragment reads), V tile stored transposed in LDS (8-B reads).
+// One workgroup = 4 waves × 16 queries, KV tiles of 64 keys, causal tiles above the diagonal skipped.
+//
+// f32 path (fp32 parity mode): one wave per query row, scores staged in LDS, exact expf.
+#include "kx_common.h"
+
+namespace {
+
+struct AttnParams {
+  const char* q; long long qbs, qrs;          // element strides
+  const char* k; const char* v; long long kbs, krs;
+  void* out; long long obs, ors; int o_bf16;
+  int B, H, Tq, Tk;
+};
+
+constexpr int KSTR = 72;  // LDS row stride (elements) for the 64-wide K / Vᵀ tiles: 144 B, 16-B aligned rows
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * KSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qblk0 = blockIdx.x * 64;
+  const int qi = qblk0 + wave * 16 + li;               // this lane's query (column of Sᵀ / Oᵀ)
+  const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + (long long)b * p.qbs + (long long)h * 64;
+  const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + (long long)b * p.kbs + (long long)h * 64;
+  const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + (long long)b * p.kbs + (long long)h * 64;
+
+  u32x4_t qf[2];
+  {
+    const bf16_t* qr = qp + (long long)min(qi, p.Tq - 1) * p.qrs + 8 * g;
+    qf[0] = *reinterpret_cast<const u32x4_t*>(qr);
+    qf[1] = *reinterpret_cast<const u32x4_t*>(qr + 32);
+  }
+  f32x4_t ot[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) ot[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  int ntiles = (p.Tk + 63) >> 6;
+  if (CAUSAL) ntiles = min(ntiles, (min(qblk0 + 63, p.Tq - 1) >> 6) + 1);
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * 64;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + 256 * j, row = c >> 3, part = c & 7;
+      const int key = kv0 + row;
+      u32x4_t kk = (u32x4_t){0u, 0u, 0u, 0u}, vv = kk;
+      if (key < p.Tk) {
+        kk = *reinterpret_cast<const u32x4_t*>(kp + (long long)key * p.krs + part * 8);
+        vv = *reinterpret_cast<const u32x4_t*>(vp + (long long)key * p.krs + part * 8);
+      }
+      *reinterpret_cast<u32x4_t*>(&Ks[row * KSTR + part * 8]) = kk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Vt[(part * 8 + 2 * e) * KSTR + row] = (bf16_t)(vv[e] & 0xffffu);
+        Vt[(part * 8 + 2 * e + 1) * KSTR + row] = (bf16_t)(vv[e] >> 16);
+      }
+    }
+    __syncthreads();
+
+    // ---- Sᵀ = K·Qᵀ ----
+    f32x4_t st[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      st[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(&Ks[(kb * 16 + li) * KSTR + ks * 32 + 8 * g]);
+        st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                         __builtin_bit_cast(bf16x8_t, qf[ks]), st[kb], 0, 0, 0);
+      }
+    }
+    // ---- mask + online softmax (query = lane&15, keys spread over regs and the 4 lane groups) ----
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kv0 + kb * 16 + 4 * g + r;
+        const bool ok = key < p.Tk && (!CAUSAL || key <= qi);
+        st[kb][r] = ok ? st[kb][r] : -INFINITY;
+        mloc = fmaxf(mloc, st[kb][r]);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_safe);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[kb][r] = __expf(st[kb][r] - m_safe);
+        psum += st[kb][r];
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ot[d] *= alpha;
+    u32x4_t pf[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      pf[c][0] = pack_bf16x2(st[2 * c][0], st[2 * c][1]);
+      pf[c][1] = pack_bf16x2(st[2 * c][2], st[2 * c][3]);
+      pf[c][2] = pack_bf16x2(st[2 * c + 1][0], st[2 * c + 1][1]);
+      pf[c][3] = pack_bf16x2(st[2 * c + 1][2], st[2 * c + 1][3]);
+    }
+    // ---- Oᵀ += Vᵀ·Pᵀ : k index (g,v) ↔ key 32c + 16(v>>2) + 4g + (v&3) on BOTH operands ----
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bf16_t* vr = &Vt[(d * 16 + li) * KSTR + 32 * c + 4 * g];
+        const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(vr);
+        const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(vr + 16);
+        const u32x4_t vf = (u32x4_t){lo[0], lo[1], hi[0], hi[1]};
+        ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                        __builtin_bit_cast(bf16x8_t, pf[c]), ot[d], 0, 0, 0);
+      }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_run;
+  if (qi < p.Tq) {
+    const long long ooff = (long long)b * p.obs + (long long)qi * p.ors + (long long)h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float o0 = ot[d][0] * inv, o1 = ot[d][1] * inv, o2 = ot[d][2] * inv, o3 = ot[d][3] * inv;
+      if (p.o_bf16) {
+        uint2 pk; pk.x = pack_bf16x2(o0, o1); pk.y = pack_bf16x2(o2, o3);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + ooff + d * 16) = pk;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + ooff + d * 16) = make_float4(o0, o1, o2, o3);
+      }
+    }
+  }
+}
+
+// fp32 parity path: one wave per query, exact expf, scores in LDS.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 4;
+  const int qi = q0 + wave;
+  const int qc = min(qi, p.Tq - 1);
+  float* qs = lds + wave * (64 + p.Tk);
+  float* sc = qs + 64;
+  const float* qp = reinterpret_cast<const float*>(p.q) + (long long)b * p.qbs + (long long)qc * p.qrs + h * 64;
+  const float* kp = reinterpret_cast<const float*>(p.k) + (long long)b * p.kbs + h * 64;
+  const float* vp = reinterpret_cast<const float*>(p.v) + (long long)b * p.kbs + h * 64;
+  const int kmax = CAUSAL ? min(p.Tk, min(q0 + 3, p.Tq - 1) + 1) : p.Tk;  // block-uniform loop bound
+  qs[lane] = qp[lane];
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int key = lane; key < kmax; key += 64) {
+    const float4* kr = reinterpret_cast<const float4*>(kp + (long long)key * p.krs);
+    float dot = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < 16; ++d4) {
+      const float4 kk = kr[d4];
+      dot = fmaf(qs[4 * d4 + 0], kk.x, dot);
+      dot = fmaf(qs[4 * d4 + 1], kk.y, dot);
+      dot = fmaf(qs[4 * d4 + 2], kk.z, dot);
+      dot = fmaf(qs[4 * d4 + 3], kk.w, dot);
+    }
+    if (CAUSAL && key > qc) dot = -INFINITY;
+    sc[key] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  mx = wave_max(mx);
+  __syncthreads();
+  float sum = 0.f;
+  for (int key = lane; key < kmax; key += 64) {
+    const float e = expf(sc[key] - mx);
+    sc[key] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float o = 0.f;
+  for (int key = 0; key < kmax; ++key) o = fmaf(sc[key], vp[(long long)key * p.krs + lane], o);
+  o /= sum;
+  if (qi < p.Tq) {
+    const long long ooff = (long long)b * p.obs + (long long)qi * p.ors + (long long)h * 64 + lane;
+    if (p.o_bf16) reinterpret_cast<bf16_t*>(p.out)[ooff] = f32_to_bf16(o);
+    else reinterpret_cast<float*>(p.out)[ooff] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
+  KX_REQUIRE(a != nullptr, "kx_attention: null args");
+  KX_REQUIRE(a->q && a->k && a->v && a->out, "kx_attention: null pointer");
+  KX_REQUIRE(a->B > 0 && a->H > 0 && a->Tq > 0 && a->Tk > 0, "kx_attention: empty problem");
+  KX_REQUIRE(a->H < 65536 && a->B < 65536, "kx_attention: B/H exceed the grid limits");
+  KX_REQUIRE(a->mask != KX_ATTN_CAUSAL || a->Tq == a->Tk, "kx_attention: the causal mask needs Tq == Tk");
+  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32, "kx_attention: bad precision");
+  const int es = a->prec == KX_PREC_BF16 ? 2 : 4;
+  KX_REQUIRE((a->q_row_stride * es) % 16 == 0 && (a->kv_row_stride * es) % 16 == 0 &&
+                 (a->q_batch_stride * es) % 16 == 0 && (a->kv_batch_stride * es) % 16 == 0,
+             "kx_attention: strides must keep 16-byte alignment");
+  KX_REQUIRE((((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) & 15) == 0,
+             "kx_attention: pointers must be 16-byte aligned");
+  KX_REQUIRE(a->out_row_stride % 4 == 0 && a->out_batch_stride % 4 == 0, "kx_attention: output strides % 4");
+  AttnParams p;
+  p.q = (const char*)a->q; p.qbs = a->q_batch_stride; p.qrs = a->q_row_stride;
+  p.k = (const char*)a->k; p.v = (const char*)a->v; p.kbs = a->kv_batch_stride; p.krs = a->kv_row_stride;
+  p.out = a->out; p.obs = a->out_batch_stride; p.ors = a->out_row_stride; p.o_bf16 = a->odt == KX_BF16;
+  p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(a->prec == KX_PREC_BF16 ? KX_K_ATTN_BF16 : KX_K_ATTN_F32, a->B * a->H, a->Tq, a->Tk, s);
+  if (a->prec == KX_PREC_BF16) {
+    dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
+    if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid((unsigned)((a->Tq + 3) / 4), (unsigned)a->H, (unsigned)a->B);
+    const size_t lds = 4 * (64 + (size_t)a->Tk) * sizeof(float);
+    KX_REQUIRE(lds <= 64 * 1024, "kx_attention(f32): Tk=%lld exceeds the LDS score buffer", (long long)a->Tk);
+    if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(attn_f32_kernel<false>, grid, dim3(256), lds, s, p);
+  }
+  KX_CHECK_LAUNCH("kx_attention");
+  return KX_OK;
+}

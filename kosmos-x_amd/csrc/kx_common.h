@@ -1,0 +1,83 @@
+// Shared device/host helpers for libkosmosx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/kosmosx_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+// ---- host-side error plumbing (thread-local message, no exceptions across the ABI) ----
+void kx_set_error(const char* fmt, ...);
+#define KX_REQUIRE(cond, ...)                 \
+  do {                                        \
+    if (!(cond)) {                            \
+      kx_set_error(__VA_ARGS__);              \
+      return KX_ERR_INVALID_ARG;              \
+    }                                         \
+  } while (0)
+#define KX_CHECK_LAUNCH(name)                                           \
+  do {                                                                  \
+    hipError_t e__ = hipGetLastError();                                 \
+    if (e__ != hipSuccess) {                                            \
+      kx_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return KX_ERR_LAUNCH;                                             \
+    }                                                                   \
+  } while (0)
+#define KX_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != KX_OK) return rc__; \
+  } while (0)
+
+// ---- in-process launch timing (kx_prof_*) ----
+bool kx_prof_on();
+void kx_prof_begin(int kind, int64_t a, int64_t b, int64_t c, hipStream_t s);
+void kx_prof_end(hipStream_t s);
+struct KxProfScope {
+  hipStream_t s; bool on;
+  KxProfScope(int kind, int64_t a, int64_t b, int64_t c, hipStream_t st) : s(st), on(kx_prof_on()) {
+    if (on) kx_prof_begin(kind, a, b, c, s);
+  }
+  ~KxProfScope() { if (on) kx_prof_end(s); }
+};
+
+// ---- device helpers ----
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+// round-to-nearest-even, NaN preserved (matches torch .to(torch.bfloat16))
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+  return act == KX_ACT_GELU ? gelu_erf(x) : (act == KX_ACT_QUICK_GELU ? quick_gelu(x) : x);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- internal launchers shared between translation units ----
+int kx_launch_rows_bcast(const float* src, float* dst, int64_t B, int64_t rows, int64_t cols, hipStream_t s);
+int kx_launch_patchify(const float* pixels, void* patches, int64_t B, int image, int patch, int kpad, int prec,
+                       hipStream_t s);
+int kx_launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x, int64_t B,
+                           int tokens, int dim, hipStream_t s);

@@ -1,0 +1,313 @@
+// Stage-level entry points of libkosmosx_hip.so: the launch sequences for the CLIP ViT-L/14 tower,
+// the Perceiver resampler (+image_proj) and the Magneto sub-LN / XPos decoder.  Pure launch
+// orchestration: no allocation, no synchronisation, everything asynchronous on the caller's stream
+// (hipGraph-capturable).  Scratch comes from one caller-owned workspace carved deterministically.
+#include <stdarg.h>
+#include <vector>
+#include "kx_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = {0};
+void kx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" int kx_version(void) { return KX_ABI_VERSION; }
+extern "C" int kx_last_error(char* buf, size_t n) {
+  const size_t len = strlen(g_err);
+  if (buf && n) {
+    const size_t c = len < n - 1 ? len : n - 1;
+    memcpy(buf, g_err, c);
+    buf[c] = 0;
+  }
+  return (int)len;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch timing
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { int kind; int64_t a, b, c; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;
+bool g_prof_enabled = false;
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+bool kx_prof_on() { return g_prof_enabled; }
+void kx_prof_begin(int kind, int64_t a, int64_t b, int64_t c, hipStream_t s) {
+  ProfRec r{kind, a, b, c, prof_event(), prof_event()};
+  (void)hipEventRecord(r.e0, s);
+  g_prof.push_back(r);
+}
+void kx_prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().e1, s); }
+extern "C" int kx_prof_enable(int on) {
+  for (auto& r : g_prof) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+  g_prof.clear();
+  g_prof_enabled = on != 0;
+  return KX_OK;
+}
+extern "C" int kx_prof_collect(kx_prof_record* out, int max_records) {
+  int n = 0;
+  for (auto& r : g_prof) {
+    if (n >= max_records) break;
+    float ms = 0.f;
+    (void)hipEventSynchronize(r.e1);
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    out[n].kind = r.kind; out[n].reserved = 0; out[n].a = r.a; out[n].b = r.b; out[n].c = r.c;
+    out[n].ms = ms; out[n].reserved2 = 0.f;
+    ++n;
+  }
+  return n;
+}
+
+namespace {
+
+struct Carver {
+  char* base; size_t off;
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += (bytes + 255) & ~(size_t)255;
+    return p;
+  }
+};
+inline size_t esz(int prec) { return prec == KX_PREC_BF16 ? 2 : 4; }
+inline int cdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : KX_F32; }
+
+int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t ldc, int cdtype, int64_t M, int64_t N,
+         const float* bias, const float* residual, int act, float qscale, int64_t qcols, int prec, hipStream_t s,
+         const float* xq_cs = nullptr, const float* xq_ss = nullptr, const float* xk_cs = nullptr,
+         const float* xk_ss = nullptr, int64_t xT = 0, int64_t xdim = 0) {
+  kx_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = ldc; g.cdt = cdtype;
+  g.bias = bias; g.residual = residual; g.ldr = ldc; g.M = M; g.N = N; g.K = K;
+  g.act = act; g.qscale = qscale; g.qcols = qcols;
+  g.xq_cs = xq_cs; g.xq_ss = xq_ss; g.xk_cs = xk_cs; g.xk_ss = xk_ss; g.xpos_T = xT; g.xpos_dim = xdim;
+  g.prec = prec; g.tile = 0;
+  return kx_gemm(&g, (void*)s);
+}
+
+int ln(const float* x, const float* pre, const float* g, const float* b, void* y, int ydt, int64_t rows, int64_t cols,
+       float eps, hipStream_t s, int64_t rpg = 0, int64_t ogs = 0, int64_t oro = 0) {
+  return kx_layernorm(x, pre, g, b, y, (kx_dtype)ydt, rows, cols, eps, rpg ? rpg : rows, ogs, oro, (void*)s);
+}
+
+// ---------------- ViT ----------------
+struct VitBufs { void *patches, *h, *qkv, *att, *ff; float *patch_out, *xpre; size_t total; };
+VitBufs vit_plan(const kx_vit_weights* w, int64_t B, int prec, char* base) {
+  const int64_t G = w->image / w->patch, P = G * G, S = P + 1, M = B * S, MP = B * P;
+  const size_t es = esz(prec);
+  Carver c{base, 0};
+  VitBufs v;
+  v.patches = c.take((size_t)MP * w->kpad * es);
+  v.patch_out = (float*)c.take((size_t)MP * w->dim * 4);
+  v.xpre = (float*)c.take((size_t)M * w->dim * 4);
+  v.h = c.take((size_t)M * w->dim * es);
+  v.qkv = c.take((size_t)M * 3 * w->dim * es);
+  v.att = c.take((size_t)M * w->dim * es);
+  v.ff = c.take((size_t)M * w->ffn * es);
+  v.total = c.off;
+  return v;
+}
+
+// ---------------- Perceiver ----------------
+struct PerBufs { float* lat; void *kvin, *lnq, *qb, *kvb, *att, *ffh, *fin; size_t total; };
+PerBufs per_plan(const kx_perceiver_weights* w, int64_t B, int64_t m, int prec, char* base) {
+  const int64_t n = w->latents, inner = (int64_t)w->heads * 64, MQ = B * n, MK = B * (m + n);
+  const size_t es = esz(prec);
+  Carver c{base, 0};
+  PerBufs p;
+  p.lat = (float*)c.take((size_t)MQ * w->dim * 4);
+  p.kvin = c.take((size_t)MK * w->dim * es);
+  p.lnq = c.take((size_t)MQ * w->dim * es);
+  p.qb = c.take((size_t)MQ * inner * es);
+  p.kvb = c.take((size_t)MK * 2 * inner * es);
+  p.att = c.take((size_t)MQ * inner * es);
+  p.ffh = c.take((size_t)MQ * w->dim * w->ff_mult * es);
+  p.fin = c.take((size_t)MQ * w->dim * es);
+  p.total = c.off;
+  return p;
+}
+
+// ---------------- Decoder ----------------
+struct DecBufs { void *h, *qkv, *aln, *gln; float *att, *g; size_t total; };
+DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, char* base) {
+  const int64_t M = B * T;
+  const size_t es = esz(prec);
+  Carver c{base, 0};
+  DecBufs d;
+  d.h = c.take((size_t)M * w->dim * es);
+  d.qkv = c.take((size_t)M * 3 * w->dim * es);
+  d.att = (float*)c.take((size_t)M * w->dim * 4);
+  d.aln = c.take((size_t)M * w->dim * es);
+  d.g = (float*)c.take((size_t)M * w->ffn * 4);
+  d.gln = c.take((size_t)M * w->ffn * es);
+  d.total = c.off;
+  return d;
+}
+
+}  // namespace
+
+extern "C" size_t kx_vit_workspace_bytes(const kx_vit_weights* w, int64_t B, int32_t prec) {
+  return w ? vit_plan(w, B, prec, nullptr).total : 0;
+}
+
+extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int64_t B, float* out, void* workspace,
+                              size_t workspace_bytes, int32_t prec, void* stream) {
+  KX_REQUIRE(w && pixels && out && workspace, "kx_vit_forward: null pointer");
+  KX_REQUIRE(B > 0, "kx_vit_forward: empty batch");
+  KX_REQUIRE(w->dim == w->heads * 64, "kx_vit_forward: head_dim must be 64 (dim=%d heads=%d)", w->dim, w->heads);
+  KX_REQUIRE(w->image % w->patch == 0 && w->kpad >= 3 * w->patch * w->patch && w->kpad % 64 == 0,
+             "kx_vit_forward: bad patch geometry");
+  KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_vit_forward: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const VitBufs v = vit_plan(w, B, prec, (char*)workspace);
+  if (v.total > workspace_bytes) {
+    kx_set_error("kx_vit_forward: workspace %zu < required %zu", workspace_bytes, v.total);
+    return KX_ERR_WORKSPACE;
+  }
+  const int64_t G = w->image / w->patch, P = G * G, S = P + 1, M = B * S, MP = B * P, D = w->dim;
+  const int ct = cdt(prec);
+  const size_t es = esz(prec);
+  KX_TRY(kx_launch_patchify(pixels, v.patches, B, w->image, w->patch, w->kpad, prec, s));
+  KX_TRY(gemm(v.patches, w->kpad, w->wpatch, w->kpad, v.patch_out, D, KX_F32, MP, D, nullptr, nullptr, 0, 1.f, 0,
+              prec, s));
+  KX_TRY(kx_launch_vit_assemble(v.patch_out, w->cls, w->pos, v.xpre, B, (int)S, (int)D, s));
+  KX_TRY(ln(v.xpre, nullptr, w->pre_g, w->pre_b, out, KX_F32, M, D, w->eps, s));
+  for (int i = 0; i < w->layers; ++i) {
+    const kx_vit_layer& L = w->layer[i];
+    KX_TRY(ln(out, nullptr, L.ln1_g, L.ln1_b, v.h, ct, M, D, w->eps, s));
+    KX_TRY(gemm(v.h, D, L.wqkv, D, v.qkv, 3 * D, ct, M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s));
+    kx_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.q = v.qkv; a.q_batch_stride = S * 3 * D; a.q_row_stride = 3 * D;
+    a.k = (char*)v.qkv + D * es; a.v = (char*)v.qkv + 2 * D * es;
+    a.kv_batch_stride = S * 3 * D; a.kv_row_stride = 3 * D;
+    a.out = v.att; a.out_batch_stride = S * D; a.out_row_stride = D; a.odt = ct;
+    a.B = B; a.H = w->heads; a.Tq = S; a.Tk = S; a.mask = KX_ATTN_FULL; a.prec = prec;
+    KX_TRY(kx_attention(&a, stream));
+    KX_TRY(gemm(v.att, D, L.wo, D, out, D, KX_F32, M, D, L.bo, out, 0, 1.f, 0, prec, s));
+    KX_TRY(ln(out, nullptr, L.ln2_g, L.ln2_b, v.h, ct, M, D, w->eps, s));
+    KX_TRY(gemm(v.h, D, L.w1, D, v.ff, w->ffn, ct, M, w->ffn, L.b1, nullptr, w->act, 1.f, 0, prec, s));
+    KX_TRY(gemm(v.ff, w->ffn, L.w2, w->ffn, out, D, KX_F32, M, D, L.b2, out, 0, 1.f, 0, prec, s));
+  }
+  return KX_OK;
+}
+
+extern "C" size_t kx_perceiver_workspace_bytes(const kx_perceiver_weights* w, int64_t B, int64_t m, int32_t prec) {
+  return w ? per_plan(w, B, m, prec, nullptr).total : 0;
+}
+
+extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* x, int64_t B, int64_t m, float* out,
+                                    float* lat_out, void* workspace, size_t workspace_bytes, int32_t prec,
+                                    void* stream) {
+  KX_REQUIRE(w && x && workspace, "kx_perceiver_forward: null pointer");
+  KX_REQUIRE((out && w->wproj && w->out_dim > 0) || lat_out, "kx_perceiver_forward: nothing to produce");
+  KX_REQUIRE(B > 0 && m > 0, "kx_perceiver_forward: empty input");
+  KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_perceiver_forward: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const PerBufs p = per_plan(w, B, m, prec, (char*)workspace);
+  if (p.total > workspace_bytes) {
+    kx_set_error("kx_perceiver_forward: workspace %zu < required %zu", workspace_bytes, p.total);
+    return KX_ERR_WORKSPACE;
+  }
+  const int64_t n = w->latents, D = w->dim, inner = (int64_t)w->heads * 64, MQ = B * n, MK = B * (m + n);
+  const int64_t F = D * w->ff_mult;
+  const int ct = cdt(prec);
+  const size_t es = esz(prec);
+  KX_TRY(kx_launch_rows_bcast(w->latents_p, p.lat, B, n, D, s));
+  for (int i = 0; i < w->depth; ++i) {
+    const kx_perceiver_layer& L = w->layer[i];
+    // kv_input = cat(norm_media(x + media_pos_emb[:1]), norm_latents(latents)) along the token axis
+    KX_TRY(ln(x, w->media_pos, L.nm_g, L.nm_b, p.kvin, ct, B * m, D, w->eps, s, m, m + n, 0));
+    KX_TRY(ln(p.lat, nullptr, L.nl_g, L.nl_b, p.kvin, ct, MQ, D, w->eps, s, n, m + n, m));
+    KX_TRY(ln(p.lat, nullptr, L.nl_g, L.nl_b, p.lnq, ct, MQ, D, w->eps, s));
+    KX_TRY(gemm(p.lnq, D, L.wq, D, p.qb, inner, ct, MQ, inner, nullptr, nullptr, 0, 0.125f, inner, prec, s));
+    KX_TRY(gemm(p.kvin, D, L.wkv, D, p.kvb, 2 * inner, ct, MK, 2 * inner, nullptr, nullptr, 0, 1.f, 0, prec, s));
+    kx_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.q = p.qb; a.q_batch_stride = n * inner; a.q_row_stride = inner;
+    a.k = p.kvb; a.v = (char*)p.kvb + inner * es;
+    a.kv_batch_stride = (m + n) * 2 * inner; a.kv_row_stride = 2 * inner;
+    a.out = p.att; a.out_batch_stride = n * inner; a.out_row_stride = inner; a.odt = ct;
+    a.B = B; a.H = w->heads; a.Tq = n; a.Tk = m + n; a.mask = KX_ATTN_FULL; a.prec = prec;
+    KX_TRY(kx_attention(&a, stream));
+    KX_TRY(gemm(p.att, inner, L.wout, inner, p.lat, D, KX_F32, MQ, D, nullptr, p.lat, 0, 1.f, 0, prec, s));
+    KX_TRY(ln(p.lat, nullptr, L.ff_g, L.ff_b, p.lnq, ct, MQ, D, w->eps, s));
+    KX_TRY(gemm(p.lnq, D, L.w1, D, p.ffh, F, ct, MQ, F, nullptr, nullptr, KX_ACT_GELU, 1.f, 0, prec, s));
+    KX_TRY(gemm(p.ffh, F, L.w2, F, p.lat, D, KX_F32, MQ, D, nullptr, p.lat, 0, 1.f, 0, prec, s));
+  }
+  if (lat_out) KX_TRY(ln(p.lat, nullptr, w->norm_g, w->norm_b, lat_out, KX_F32, MQ, D, w->eps, s));
+  if (out && w->wproj) {
+    KX_TRY(ln(p.lat, nullptr, w->norm_g, w->norm_b, p.fin, ct, MQ, D, w->eps, s));
+    KX_TRY(gemm(p.fin, D, w->wproj, D, out, w->out_dim, KX_F32, MQ, w->out_dim, nullptr, nullptr, 0, 1.f, 0, prec,
+                s));
+  }
+  return KX_OK;
+}
+
+extern "C" size_t kx_decoder_workspace_bytes(const kx_decoder_weights* w, int64_t B, int64_t T, int32_t prec) {
+  return w ? dec_plan(w, B, T, prec, nullptr).total : 0;
+}
+
+extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t B, int64_t T, const float* xq_cs,
+                                  const float* xq_ss, const float* xk_cs, const float* xk_ss, void* logits,
+                                  int32_t ldt, void* workspace, size_t workspace_bytes, int32_t prec, void* stream) {
+  KX_REQUIRE(w && x && logits && workspace, "kx_decoder_forward: null pointer");
+  KX_REQUIRE(B > 0 && T > 0, "kx_decoder_forward: empty input");
+  KX_REQUIRE(w->dim == w->heads * 64, "kx_decoder_forward: head_dim must be 64 (dim=%d heads=%d)", w->dim, w->heads);
+  KX_REQUIRE(!w->xpos || (xq_cs && xq_ss && xk_cs && xk_ss), "kx_decoder_forward: XPos tables missing");
+  KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_decoder_forward: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const DecBufs d = dec_plan(w, B, T, prec, (char*)workspace);
+  if (d.total > workspace_bytes) {
+    kx_set_error("kx_decoder_forward: workspace %zu < required %zu", workspace_bytes, d.total);
+    return KX_ERR_WORKSPACE;
+  }
+  const int64_t M = B * T, D = w->dim, F = w->ffn;
+  const int ct = cdt(prec);
+  const size_t es = esz(prec);
+  for (int i = 0; i < w->layers; ++i) {
+    const kx_decoder_layer& L = w->layer[i];
+    // x = x + out_proj(inner_attn_ln(attn(xpos(q), xpos(k), v)))   on self_attn_layer_norm(x)
+    KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
+    KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
+                w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? T : 0, w->xpos ? D : 0));
+    kx_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.q = d.qkv; a.q_batch_stride = T * 3 * D; a.q_row_stride = 3 * D;
+    a.k = (char*)d.qkv + D * es; a.v = (char*)d.qkv + 2 * D * es;
+    a.kv_batch_stride = T * 3 * D; a.kv_row_stride = 3 * D;
+    a.B = B; a.H = w->heads; a.Tq = T; a.Tk = T; a.mask = KX_ATTN_CAUSAL; a.prec = prec;
+    if (w->subln) {
+      a.out = d.att; a.out_batch_stride = T * D; a.out_row_stride = D; a.odt = KX_F32;
+      KX_TRY(kx_attention(&a, stream));
+      KX_TRY(ln(d.att, nullptr, L.in_g, L.in_b, d.aln, ct, M, D, w->eps, s));
+    } else {
+      a.out = d.aln; a.out_batch_stride = T * D; a.out_row_stride = D; a.odt = ct;
+      KX_TRY(kx_attention(&a, stream));
+    }
+    KX_TRY(gemm(d.aln, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s));
+    // x = x + fc2(ffn_layernorm(gelu(fc1(final_layer_norm(x)))))
+    KX_TRY(ln(x, nullptr, L.fl_g, L.fl_b, d.h, ct, M, D, w->eps, s));
+    if (w->subln) {
+      KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, KX_F32, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s));
+      KX_TRY(ln(d.g, nullptr, L.fn_g, L.fn_b, d.gln, ct, M, F, w->eps, s));
+    } else {
+      KX_TRY(gemm(d.h, D, L.w1, D, d.gln, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s));
+    }
+    KX_TRY(gemm(d.gln, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s));
+  }
+  KX_TRY(ln(x, nullptr, w->ln_g, w->ln_b, d.h, ct, M, D, w->eps, s));
+  KX_TRY(gemm(d.h, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab, nullptr, nullptr, 0, 1.f, 0, prec, s));
+  return KX_OK;
+}

@@ -1,0 +1,253 @@
+// HBM-bound row kernels of the Kosmos-X forward path (gfx950): LayerNorm, decoder input assembly,
+// ViT patch gather (im2col) and embedding assembly, latent broadcast.
+// All are one-pass streaming kernels: 16-byte coalesced accesses, one workgroup per row, fp32
+// statistics with wave-64 shuffles + one LDS hop.  They are bound by HBM bandwidth, never by VALU.
+#include "kx_common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();  // protect `red` from the previous reduction's readers
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// One workgroup (256 threads) per row; a thread owns up to 8 float4 (cols <= 8192).
+// Two-pass statistics on the register-resident row: mean, then centred variance (what
+// torch.nn.functional.layer_norm computes), eps inside the rsqrt.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ pre_add,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ y,
+                                                        int cols, float eps, long long rows_per_group,
+                                                        long long out_group_stride, long long out_row_offset) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const float* xr = x + row * (long long)cols;
+  const int nv = cols >> 2;  // float4 per row
+  float4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nv) {
+      v[i] = reinterpret_cast<const float4*>(xr)[c];
+      if (pre_add) {
+        const float4 a = reinterpret_cast<const float4*>(pre_add)[c];
+        v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+      }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = block_sum(s, red) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float var = block_sum(q, red) / (float)cols;
+  const float rstd = rsqrtf(var + eps);
+  const long long orow = (row / rows_per_group) * out_group_stride + out_row_offset + row % rows_per_group;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nv) {
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
+      const float4 bt = reinterpret_cast<const float4*>(beta)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+      o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+      o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+      o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+      if (OUT_BF16) {
+        uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
+        reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + orow * (long long)cols)[c] = pk;
+      } else {
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + orow * (long long)cols)[c] = o;
+      }
+    }
+  }
+}
+
+// Decoder input assembly, one workgroup per output row (b, t), s = splice_at (2 on the Kosmos path):
+//   t < s           : tok[b,t]     (+pos[2+t] if u1) + pos[2+t]
+//   s <= t < s+n    : img[b,t-s]                     + pos[2+t]
+//   t >= s+n        : tok[b,t-n]   (+pos[2+t-n] if u1) + pos[2+t]
+// n_img == 0 (text-only, KosmosLanguage): tok[b,t] + pos[2+t] once.
+__global__ __launch_bounds__(256) void embed_splice_kernel(const long long* __restrict__ tokens,
+                                                           const float* __restrict__ embed,
+                                                           const float* __restrict__ pos,
+                                                           const float* __restrict__ img, float* __restrict__ out,
+                                                           int Tt, int n_img, int d, long long vocab, int splice_at,
+                                                           int u1_alias) {
+  const int T = Tt + n_img;
+  const long long row = blockIdx.x;
+  const int b = (int)(row / T), t = (int)(row % T);
+  const float4* src;
+  const float4* p1 = nullptr;  // first-call positions (text rows only)
+  const float4* p2 = reinterpret_cast<const float4*>(pos + (long long)(2 + t) * d);
+  bool text = true;
+  int tt = t;
+  if (n_img > 0) {
+    if (t >= splice_at && t < splice_at + n_img) text = false;
+    else if (t >= splice_at + n_img) tt = t - n_img;
+  }
+  if (text) {
+    long long id = tokens[(long long)b * Tt + tt];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // memory safety only; the boundary validates ids
+    src = reinterpret_cast<const float4*>(embed + id * d);
+    if (n_img > 0 && u1_alias) p1 = reinterpret_cast<const float4*>(pos + (long long)(2 + tt) * d);
+  } else {
+    src = reinterpret_cast<const float4*>(img + ((long long)b * n_img + (t - splice_at)) * d);
+  }
+  float4* o = reinterpret_cast<float4*>(out + row * d);
+  for (int c = threadIdx.x; c < (d >> 2); c += 256) {
+    float4 v = src[c];
+    if (p1) { const float4 a = p1[c]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    const float4 a2 = p2[c];
+    v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w;
+    o[c] = v;
+  }
+}
+
+// im2col for the stride==kernel patch conv: patches[b*P + py*G + px][c*ps*ps + ky*ps + kx] =
+// pixels[b][c][py*ps+ky][px*ps+kx]; columns >= 3*ps*ps are zero padding up to kpad.
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ pixels, T* __restrict__ patches,
+                                                       int image, int ps, int kpad) {
+  const int G = image / ps;
+  const long long prow = blockIdx.x;  // b*G*G + py*G + px
+  const int b = (int)(prow / (G * G)), pp = (int)(prow % (G * G));
+  const int py = pp / G, px = pp % G;
+  const int kreal = 3 * ps * ps;
+  for (int k = threadIdx.x; k < kpad; k += 256) {
+    float v = 0.f;
+    if (k < kreal) {
+      const int c = k / (ps * ps), r = k % (ps * ps), ky = r / ps, kx = r % ps;
+      v = pixels[(((long long)b * 3 + c) * image + (py * ps + ky)) * image + (px * ps + kx)];
+    }
+    if constexpr (sizeof(T) == 2) patches[prow * kpad + k] = f32_to_bf16(v);
+    else patches[prow * kpad + k] = v;
+  }
+}
+
+// x[b, 0] = cls + pos[0];  x[b, 1+p] = patch_out[b*P + p] + pos[1+p]
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch_out,
+                                                           const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, float* __restrict__ x,
+                                                           int tokens, int dim) {
+  const long long row = blockIdx.x;
+  const int b = (int)(row / tokens), s = (int)(row % tokens);
+  const float4* src = s == 0 ? reinterpret_cast<const float4*>(cls)
+                             : reinterpret_cast<const float4*>(patch_out + ((long long)b * (tokens - 1) + (s - 1)) * dim);
+  const float4* pp = reinterpret_cast<const float4*>(pos + (long long)s * dim);
+  float4* o = reinterpret_cast<float4*>(x + row * dim);
+  for (int c = threadIdx.x; c < (dim >> 2); c += 256) {
+    float4 v = src[c];
+    const float4 a = pp[c];
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    o[c] = v;
+  }
+}
+
+// dst[b, r, :] = src[r, :]
+__global__ __launch_bounds__(256) void rows_bcast_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         long long rows, int cols) {
+  const long long row = blockIdx.x;
+  const float4* s = reinterpret_cast<const float4*>(src + (row % rows) * cols);
+  float4* o = reinterpret_cast<float4*>(dst + row * cols);
+  for (int c = threadIdx.x; c < (cols >> 2); c += 256) o[c] = s[c];
+}
+
+}  // namespace
+
+extern "C" int kx_layernorm(const float* x, const float* pre_add, const float* gamma, const float* beta, void* y,
+                            kx_dtype ydt, int64_t rows, int64_t cols, float eps, int64_t rows_per_group,
+                            int64_t out_group_stride, int64_t out_row_offset, void* stream) {
+  KX_REQUIRE(x && gamma && beta && y, "kx_layernorm: null pointer");
+  KX_REQUIRE(rows > 0 && rows < (1ll << 31), "kx_layernorm: rows=%lld out of range", (long long)rows);
+  KX_REQUIRE(cols > 0 && cols % 4 == 0 && cols <= 8192, "kx_layernorm: cols=%lld must be a multiple of 4 and <= 8192",
+             (long long)cols);
+  KX_REQUIRE(rows_per_group > 0, "kx_layernorm: rows_per_group must be positive");
+  KX_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)pre_add) & 15) == 0,
+             "kx_layernorm: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_LAYERNORM, rows, cols, 0, s);
+  if (ydt == KX_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta, y,
+                       (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride,
+                       (long long)out_row_offset);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta, y,
+                       (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride,
+                       (long long)out_row_offset);
+  KX_CHECK_LAUNCH("kx_layernorm");
+  return KX_OK;
+}
+
+extern "C" int kx_embed_splice(const int64_t* tokens, const float* embed, const float* pos, const float* img,
+                               float* out, int64_t B, int64_t Tt, int64_t n_img, int64_t d, int64_t vocab,
+                               int64_t max_pos, int64_t splice_at, int32_t u1_alias, void* stream) {
+  KX_REQUIRE(embed && pos && out, "kx_embed_splice: null pointer");
+  KX_REQUIRE(B > 0 && Tt >= 0 && n_img >= 0 && Tt + n_img > 0 && d > 0 && d % 4 == 0,
+             "kx_embed_splice: bad shape B=%lld Tt=%lld n_img=%lld d=%lld", (long long)B, (long long)Tt,
+             (long long)n_img, (long long)d);
+  KX_REQUIRE(Tt == 0 || tokens != nullptr, "kx_embed_splice: Tt > 0 needs tokens");
+  KX_REQUIRE(n_img == 0 || img != nullptr, "kx_embed_splice: n_img > 0 needs img");
+  KX_REQUIRE(splice_at >= 0 && splice_at <= Tt, "kx_embed_splice: splice_at=%lld outside [0, Tt=%lld]",
+             (long long)splice_at, (long long)Tt);
+  KX_REQUIRE((((uintptr_t)embed | (uintptr_t)pos | (uintptr_t)img | (uintptr_t)out) & 15) == 0,
+             "kx_embed_splice: pointers must be 16-byte aligned");
+  // the reference raises IndexError from F.embedding here: positions run 2..T+1
+  KX_REQUIRE(Tt + n_img + 2 <= max_pos, "kx_embed_splice: position %lld out of range for a %lld-row table",
+             (long long)(Tt + n_img + 1), (long long)max_pos);
+  const long long rows = B * (Tt + n_img);
+  KxProfScope prof(KX_K_EMBED, rows, d, 0, (hipStream_t)stream);
+  hipLaunchKernelGGL(embed_splice_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)tokens, embed, pos, img, out, (int)Tt, (int)n_img, (int)d, (long long)vocab,
+                     (int)splice_at, (int)u1_alias);
+  KX_CHECK_LAUNCH("kx_embed_splice");
+  return KX_OK;
+}
+
+int kx_launch_rows_bcast(const float* src, float* dst, int64_t B, int64_t rows, int64_t cols, hipStream_t s) {
+  KxProfScope prof(KX_K_MISC, B * rows, cols, 0, s);
+  hipLaunchKernelGGL(rows_bcast_kernel, dim3((unsigned)(B * rows)), dim3(256), 0, s, src, dst, (long long)rows,
+                     (int)cols);
+  KX_CHECK_LAUNCH("rows_bcast");
+  return KX_OK;
+}
+
+int kx_launch_patchify(const float* pixels, void* patches, int64_t B, int image, int patch, int kpad, int prec,
+                       hipStream_t s) {
+  const int G = image / patch;
+  const unsigned rows = (unsigned)(B * G * G);
+  KxProfScope prof(KX_K_MISC, rows, kpad, 1, s);
+  if (prec == KX_PREC_BF16)
+    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, pixels, (bf16_t*)patches, image, patch,
+                       kpad);
+  else
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(rows), dim3(256), 0, s, pixels, (float*)patches, image, patch,
+                       kpad);
+  KX_CHECK_LAUNCH("patchify");
+  return KX_OK;
+}
+
+int kx_launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x, int64_t B,
+                           int tokens, int dim, hipStream_t s) {
+  KxProfScope prof(KX_K_MISC, B * tokens, dim, 2, s);
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3((unsigned)(B * tokens)), dim3(256), 0, s, patch_out, cls, pos, x,
+                     tokens, dim);
+  KX_CHECK_LAUNCH("vit_assemble");
+  return KX_OK;
+}

@@ -1,0 +1,159 @@
+"""ctypes binding of libkosmosx_hip.so (C ABI declared in include/kosmosx_hip.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing or a call
+fails, a RuntimeError is raised (after logging, mirroring the reference's log-and-re-raise
+convention, /root/reference/kosmosx/model.py:233-235).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
+_lib = None
+
+KX_PREC_BF16, KX_PREC_F32 = 0, 1
+KX_F32, KX_BF16 = 0, 1
+KX_ACT_NONE, KX_ACT_GELU, KX_ACT_QUICK_GELU = 0, 1, 2
+KX_ATTN_FULL, KX_ATTN_CAUSAL = 0, 1
+ACTS = {"none": KX_ACT_NONE, "gelu": KX_ACT_GELU, "quick_gelu": KX_ACT_QUICK_GELU}
+PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32}
+
+vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("lda", i64), ("W", vp), ("ldw", i64), ("C", vp), ("ldc", i64), ("cdt", i32),
+                ("bias", vp), ("residual", vp), ("ldr", i64), ("M", i64), ("N", i64), ("K", i64),
+                ("act", i32), ("qscale", f32), ("qcols", i64),
+                ("xq_cs", vp), ("xq_ss", vp), ("xk_cs", vp), ("xk_ss", vp), ("xpos_T", i64), ("xpos_dim", i64),
+                ("prec", i32), ("tile", i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", vp), ("q_batch_stride", i64), ("q_row_stride", i64),
+                ("k", vp), ("v", vp), ("kv_batch_stride", i64), ("kv_row_stride", i64),
+                ("out", vp), ("out_batch_stride", i64), ("out_row_stride", i64), ("odt", i32),
+                ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64), ("mask", i32), ("prec", i32)]
+
+
+class VitLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b",
+                                  "w1", "b1", "w2", "b2")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("image", i32), ("patch", i32), ("dim", i32), ("heads", i32), ("ffn", i32), ("layers", i32),
+                ("act", i32), ("eps", f32), ("kpad", i32),
+                ("wpatch", vp), ("cls", vp), ("pos", vp), ("pre_g", vp), ("pre_b", vp),
+                ("layer", C.POINTER(VitLayer))]
+
+
+class PerceiverLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("nm_g", "nm_b", "nl_g", "nl_b", "wq", "wkv", "wout", "ff_g", "ff_b", "w1", "w2")]
+
+
+class PerceiverWeights(C.Structure):
+    _fields_ = [("dim", i32), ("depth", i32), ("heads", i32), ("latents", i32), ("ff_mult", i32), ("out_dim", i32),
+                ("eps", f32), ("latents_p", vp), ("media_pos", vp), ("layer", C.POINTER(PerceiverLayer)),
+                ("norm_g", vp), ("norm_b", vp), ("wproj", vp)]
+
+
+class DecoderLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("sa_g", "sa_b", "wqkv", "bqkv", "in_g", "in_b", "wo", "bo", "fl_g", "fl_b",
+                                  "w1", "b1", "fn_g", "fn_b", "w2", "b2")]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("layers", i32), ("dim", i32), ("heads", i32), ("ffn", i32), ("vocab", i32), ("act", i32),
+                ("subln", i32), ("xpos", i32), ("eps", f32), ("layer", C.POINTER(DecoderLayer)),
+                ("ln_g", vp), ("ln_b", vp), ("wout", vp)]
+
+
+class ProfRecord(C.Structure):
+    _fields_ = [("kind", i32), ("reserved", i32), ("a", i64), ("b", i64), ("c", i64), ("ms", f32),
+                ("reserved2", f32)]
+
+
+KERNEL_KINDS = ["gemm_bf16_128", "gemm_bf16_64", "gemm_f32_128", "gemm_f32_64", "layernorm", "attn_bf16",
+                "attn_f32", "embed", "misc"]
+
+
+# every symbol include/kosmosx_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "kx_version": (C.c_int, []),
+    "kx_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "kx_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, i64, i64, f32, i64, i64, i64, vp]),
+    "kx_gemm": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "kx_attention": (C.c_int, [C.POINTER(AttnArgs), vp]),
+    "kx_embed_splice": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, vp]),
+    "kx_prof_enable": (C.c_int, [C.c_int]),
+    "kx_prof_collect": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),
+    "kx_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitWeights), i64, i32]),
+    "kx_vit_forward": (C.c_int, [C.POINTER(VitWeights), vp, i64, vp, vp, C.c_size_t, i32, vp]),
+    "kx_perceiver_workspace_bytes": (C.c_size_t, [C.POINTER(PerceiverWeights), i64, i64, i32]),
+    "kx_perceiver_forward": (C.c_int, [C.POINTER(PerceiverWeights), vp, i64, i64, vp, vp, vp, C.c_size_t, i32, vp]),
+    "kx_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderWeights), i64, i64, i32]),
+    "kx_decoder_forward": (C.c_int, [C.POINTER(DecoderWeights), vp, i64, i64, vp, vp, vp, vp, vp, i32, vp,
+                                     C.c_size_t, i32, vp]),
+}
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("KOSMOSX_HIP_LIB", str(_LIB_PATH)))
+
+
+def load():
+    """Load the HIP library or fail loudly (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        msg = (f"libkosmosx_hip.so not found at {path}: build it with `python kosmos-x_amd/build.py` "
+               "(hipcc --offload-arch=gfx950). The Kosmos-X MI355X path has no CPU fallback.")
+        logging.error(msg)
+        raise RuntimeError(msg)
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as e:  # missing ROCm runtime etc.
+        logging.error(f"Failed to load {path}: {e}")
+        raise RuntimeError(f"Failed to load {path}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.kx_version() != 1:
+        raise RuntimeError(f"libkosmosx_hip.so ABI version {lib.kx_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().kx_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = f"{what} failed (kx_status {rc}): {last_error()}"
+        logging.error(msg)
+        raise RuntimeError(msg)
+
+
+def prof_enable(on: bool):
+    load().kx_prof_enable(int(on))
+
+
+def prof_collect(max_records: int = 1 << 16) -> list:
+    """[(kind_name, a, b, c, ms)] for every launch since prof_enable(True)."""
+    buf = (ProfRecord * max_records)()
+    n = load().kx_prof_collect(buf, max_records)
+    return [(KERNEL_KINDS[buf[i].kind], buf[i].a, buf[i].b, buf[i].c, buf[i].ms) for i in range(n)]
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()

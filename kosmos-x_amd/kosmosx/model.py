@@ -1,0 +1,802 @@
+"""MI355X-native drop-in for ``kosmosx.model`` of kyegomez/Kosmos-X.
+
+Same module path, class names, constructor signatures, attribute names and state_dict key
+namespace as the reference (/root/reference/kosmosx/model.py:132-320; SURVEY.md §8b), but every
+tensor operation of the forward pass runs in hand-written gfx950 HIP kernels behind the C ABI of
+``libkosmosx_hip.so`` (include/kosmosx_hip.h).  PyTorch is used for parameter storage, device
+memory and the HIP stream only.  There is no CPU fallback: calling ``forward`` with CPU tensors or
+without the built library raises.
+
+Third-party classes the reference imports into this module's namespace (``Decoder``,
+``DecoderConfig``, ``PositionalEmbedding``, ``PerceiverResampler``) are re-created here as
+parameter containers with the upstream attribute/key names, so ``from kosmosx.model import
+Decoder`` (/root/reference/train.py:44) keeps working.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _hip as H
+from .config import DecoderConfig, KosmosConfig, PerceiverConfig, Switches, VitConfig
+
+# the reference configures the root logger at import (/root/reference/kosmosx/model.py:8-10)
+if not os.environ.get("KOSMOSX_NO_LOGGING_CONFIG"):
+    logging.basicConfig(level=logging.DEBUG, format="%(asctime)s - %(levelname)s - %(message)s")
+
+__all__ = ["Kosmos", "KosmosLanguage", "KosmosTokenizer", "Decoder", "DecoderConfig", "PositionalEmbedding",
+           "PerceiverResampler", "CLIPVisionTower"]
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _prec_dtype(prec: str):
+    return torch.bfloat16 if prec == "bf16" else torch.float32
+
+
+def _default_precision() -> str:
+    p = os.environ.get("KOSMOSX_PRECISION", "bf16")
+    if p not in H.PRECS:
+        raise ValueError(f"KOSMOSX_PRECISION must be one of {list(H.PRECS)}")
+    return p
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        msg = (f"{what} is on {t.device}: the Kosmos-X MI355X path runs on HIP devices only "
+               "(no CPU fallback); move the model and inputs to 'cuda'")
+        logging.error(msg)
+        raise RuntimeError(msg)
+
+
+class _Workspace:
+    """Grow-only device scratch shared by the three stages (they run back to back on one stream)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class _PackedMixin:
+    """Caches the operand-dtype copies / fused layouts of a module's weights per (device, precision).
+    Invalidated when the module is moved (``_apply``) or a state_dict is loaded; call
+    ``invalidate_packed()`` after mutating parameters in place."""
+
+    def _packed_init(self):
+        self._packed = {}
+
+    def invalidate_packed(self):
+        self._packed = {}
+        for m in self.children():
+            if isinstance(m, _PackedMixin):
+                m.invalidate_packed()
+
+    def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float() ...
+        out = super()._apply(fn, *a, **k)
+        self._packed = {}
+        return out
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = {}
+        return super()._load_from_state_dict(*a, **k)
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# CLIP ViT-L/14 vision tower (HF CLIPVisionTransformer key namespace)
+# ------------------------------------------------------------------------------------------------
+class _CLIPEmbeddings(nn.Module):
+    def __init__(self, c: VitConfig):
+        super().__init__()
+        self.class_embedding = nn.Parameter(torch.empty(c.dim))
+        self.patch_embedding = nn.Conv2d(3, c.dim, c.patch, c.patch, bias=False)
+        self.position_embedding = nn.Embedding(c.tokens, c.dim)
+
+
+class _CLIPAttention(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj, self.v_proj, self.q_proj, self.out_proj = (nn.Linear(d, d) for _ in range(4))
+
+
+class _CLIPMLP(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(d, f), nn.Linear(f, d)
+
+
+class _CLIPEncoderLayer(nn.Module):
+    def __init__(self, c: VitConfig):
+        super().__init__()
+        self.self_attn = _CLIPAttention(c.dim)
+        self.layer_norm1 = nn.LayerNorm(c.dim, eps=c.eps)
+        self.mlp = _CLIPMLP(c.dim, c.ffn)
+        self.layer_norm2 = nn.LayerNorm(c.dim, eps=c.eps)
+
+
+class _CLIPEncoder(nn.Module):
+    def __init__(self, c: VitConfig):
+        super().__init__()
+        self.layers = nn.ModuleList([_CLIPEncoderLayer(c) for _ in range(c.layers)])
+
+
+class CLIPVisionTower(_PackedMixin, nn.Module):
+    """``CLIPModel.from_pretrained(...).vision_model`` stand-in
+    (/root/reference/kosmosx/model.py:154-156).  ``tower(pixel_values=x)["last_hidden_state"]``."""
+
+    def __init__(self, c: VitConfig):
+        super().__init__()
+        self._packed_init()
+        self.cfg = c
+        self.embeddings = _CLIPEmbeddings(c)
+        self.pre_layrnorm = nn.LayerNorm(c.dim, eps=c.eps)  # (sic) HF key name
+        self.encoder = _CLIPEncoder(c)
+        self.post_layernorm = nn.LayerNorm(c.dim, eps=c.eps)
+
+    def _pack(self, prec: str):
+        dev = self.pre_layrnorm.weight.device
+        key = (dev, prec)
+        if key in self._packed:
+            return self._packed[key]
+        c, dt = self.cfg, _prec_dtype(prec)
+        keep = []
+
+        def op(t):  # GEMM operand in the compute dtype
+            t = t.detach().to(dt).contiguous(); keep.append(t); return t.data_ptr()
+
+        def v(t):   # fp32 vector / table
+            t = _f32(t); keep.append(t); return t.data_ptr()
+
+        kreal = 3 * c.patch * c.patch
+        kpad = (kreal + 63) // 64 * 64
+        wp = torch.zeros((c.dim, kpad), dtype=torch.float32, device=dev)
+        wp[:, :kreal] = self.embeddings.patch_embedding.weight.detach().reshape(c.dim, kreal)
+        layers = (H.VitLayer * c.layers)()
+        for i, L in enumerate(self.encoder.layers):
+            a = L.self_attn
+            wqkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)
+            bqkv = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)
+            e = layers[i]
+            e.ln1_g, e.ln1_b = v(L.layer_norm1.weight), v(L.layer_norm1.bias)
+            e.wqkv, e.bqkv = op(wqkv), v(bqkv)
+            e.wo, e.bo = op(a.out_proj.weight), v(a.out_proj.bias)
+            e.ln2_g, e.ln2_b = v(L.layer_norm2.weight), v(L.layer_norm2.bias)
+            e.w1, e.b1 = op(L.mlp.fc1.weight), v(L.mlp.fc1.bias)
+            e.w2, e.b2 = op(L.mlp.fc2.weight), v(L.mlp.fc2.bias)
+        w = H.VitWeights()
+        w.image, w.patch, w.dim, w.heads, w.ffn, w.layers = c.image, c.patch, c.dim, c.heads, c.ffn, c.layers
+        w.act, w.eps, w.kpad = H.ACTS[c.act], c.eps, kpad
+        w.wpatch = op(wp)
+        w.cls, w.pos = v(self.embeddings.class_embedding), v(self.embeddings.position_embedding.weight)
+        w.pre_g, w.pre_b = v(self.pre_layrnorm.weight), v(self.pre_layrnorm.bias)
+        w.layer = C.cast(layers, C.POINTER(H.VitLayer))
+        self._packed[key] = (w, layers, keep)
+        return self._packed[key]
+
+    def run(self, pixels: torch.Tensor, prec: str, ws: _Workspace) -> torch.Tensor:
+        """pixels [B,3,H,W] any real dtype (HF casts to the weight dtype; SURVEY H2) -> [B,tokens,dim] fp32."""
+        _require_cuda(pixels, "images")
+        c = self.cfg
+        if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != c.image or pixels.shape[3] != c.image:
+            raise ValueError(f"Input image size ({pixels.shape[-2]}*{pixels.shape[-1]}) doesn't match model "
+                             f"({c.image}*{c.image}).")
+        w, _, _ = self._pack(prec)
+        lib = H.load()
+        px = pixels.to(torch.float32).contiguous()
+        B = px.shape[0]
+        out = torch.empty((B, c.tokens, c.dim), dtype=torch.float32, device=px.device)
+        need = lib.kx_vit_workspace_bytes(C.byref(w), B, H.PRECS[prec])
+        buf = ws.get(need, px.device)
+        H.check(lib.kx_vit_forward(C.byref(w), px.data_ptr(), B, out.data_ptr(), buf.data_ptr(), buf.numel(),
+                                   H.PRECS[prec], _stream()), "kx_vit_forward")
+        return out
+
+    def forward(self, pixel_values: torch.Tensor = None, **kwargs):
+        from . import ops
+        h = self.run(pixel_values, getattr(self, "precision", _default_precision()), _Workspace())
+        pooled = ops.layernorm(h[:, 0, :].contiguous(), _f32(self.post_layernorm.weight),
+                               _f32(self.post_layernorm.bias), self.cfg.eps)
+        return {"last_hidden_state": h, "pooler_output": pooled}
+
+
+# ------------------------------------------------------------------------------------------------
+# PerceiverResampler (lucidrains flamingo-pytorch key namespace)
+# ------------------------------------------------------------------------------------------------
+class _PerceiverAttention(nn.Module):
+    def __init__(self, dim, dim_head, heads, eps):
+        super().__init__()
+        inner = dim_head * heads
+        self.norm_media = nn.LayerNorm(dim, eps=eps)
+        self.norm_latents = nn.LayerNorm(dim, eps=eps)
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(dim, inner * 2, bias=False)
+        self.to_out = nn.Linear(inner, dim, bias=False)
+
+
+def _feed_forward(dim, mult, eps):
+    return nn.Sequential(nn.LayerNorm(dim, eps=eps), nn.Linear(dim, dim * mult, bias=False), nn.GELU(),
+                         nn.Linear(dim * mult, dim, bias=False))
+
+
+class PerceiverResampler(_PackedMixin, nn.Module):
+    """flamingo_pytorch.PerceiverResampler stand-in (/root/reference/kosmosx/model.py:196-203)."""
+
+    def __init__(self, *, dim, depth, dim_head=64, heads=8, num_latents=64, num_media_embeds=4, ff_mult=4,
+                 eps=1e-5, switches: Switches | None = None):
+        super().__init__()
+        self._packed_init()
+        if dim_head != 64:
+            raise ValueError("the gfx950 attention kernels are specialised for dim_head == 64")
+        self.cfg = PerceiverConfig(dim, depth, dim_head, heads, num_latents, num_media_embeds, ff_mult, eps)
+        self.switches = switches or Switches()
+        self.latents = nn.Parameter(torch.empty(num_latents, dim))
+        self.media_pos_emb = nn.Parameter(torch.empty(num_media_embeds, 1, dim))
+        self.layers = nn.ModuleList([
+            nn.ModuleList([_PerceiverAttention(dim, dim_head, heads, eps), _feed_forward(dim, ff_mult, eps)])
+            for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=eps)
+
+    def _pack(self, prec: str, image_proj: torch.Tensor | None):
+        dev = self.latents.device
+        key = (dev, prec, None if image_proj is None else image_proj.data_ptr())
+        if key in self._packed:
+            return self._packed[key]
+        c, dt = self.cfg, _prec_dtype(prec)
+        if not self.switches.u6_media_pos_first_only:
+            raise NotImplementedError("per-token media_pos_emb is not a behaviour of the reference path")
+        keep = []
+
+        def op(t):
+            t = t.detach().to(dt).contiguous(); keep.append(t); return t.data_ptr()
+
+        def v(t):
+            t = _f32(t); keep.append(t); return t.data_ptr()
+
+        inner = c.heads * c.dim_head
+        layers = (H.PerceiverLayer * c.depth)()
+        for i, (att, ff) in enumerate(self.layers):
+            e = layers[i]
+            e.nm_g, e.nm_b = v(att.norm_media.weight), v(att.norm_media.bias)
+            e.nl_g, e.nl_b = v(att.norm_latents.weight), v(att.norm_latents.bias)
+            wkv = att.to_kv.weight.detach()
+            if not self.switches.u6_kv_k_first:
+                wkv = torch.cat([wkv[inner:], wkv[:inner]], 0)
+            e.wq, e.wkv, e.wout = op(att.to_q.weight), op(wkv), op(att.to_out.weight)
+            e.ff_g, e.ff_b = v(ff[0].weight), v(ff[0].bias)
+            e.w1, e.w2 = op(ff[1].weight), op(ff[3].weight)
+        w = H.PerceiverWeights()
+        w.dim, w.depth, w.heads, w.latents, w.ff_mult, w.eps = c.dim, c.depth, c.heads, c.latents, c.ff_mult, c.eps
+        w.out_dim = 0 if image_proj is None else image_proj.shape[0]
+        w.latents_p, w.media_pos = v(self.latents), v(self.media_pos_emb[0, 0])
+        w.layer = C.cast(layers, C.POINTER(H.PerceiverLayer))
+        w.norm_g, w.norm_b = v(self.norm.weight), v(self.norm.bias)
+        w.wproj = 0 if image_proj is None else op(image_proj)
+        self._packed[key] = (w, layers, keep)
+        return self._packed[key]
+
+    def run(self, x: torch.Tensor, prec: str, ws: _Workspace, image_proj: torch.Tensor | None = None,
+            want_latents: bool = False):
+        """x [B,m,dim] fp32 -> (projected [B,latents,out_dim] or None, latents [B,latents,dim] or None)."""
+        _require_cuda(x, "media")
+        w, _, _ = self._pack(prec, image_proj)
+        lib = H.load()
+        x = x.to(torch.float32).contiguous()
+        B, m, _ = x.shape
+        c = self.cfg
+        out = (torch.empty((B, c.latents, image_proj.shape[0]), dtype=torch.float32, device=x.device)
+               if image_proj is not None else None)
+        lat = torch.empty((B, c.latents, c.dim), dtype=torch.float32, device=x.device) if want_latents else None
+        need = lib.kx_perceiver_workspace_bytes(C.byref(w), B, m, H.PRECS[prec])
+        buf = ws.get(need, x.device)
+        H.check(lib.kx_perceiver_forward(C.byref(w), x.data_ptr(), B, m, H.ptr(out), H.ptr(lat), buf.data_ptr(),
+                                         buf.numel(), H.PRECS[prec], _stream()), "kx_perceiver_forward")
+        return out, lat
+
+    def forward(self, x: torch.Tensor):
+        if x.dim() == 4:
+            if x.shape[1] != 1:
+                raise NotImplementedError("only a single media time-step is on the Kosmos-X path")
+            x = x[:, 0]
+        _, lat = self.run(x, getattr(self, "precision", _default_precision()), _Workspace(), None, True)
+        return lat[:, None]  # b 1 n d, as upstream; the caller squeezes (/root/reference/kosmosx/model.py:231)
+
+
+# ------------------------------------------------------------------------------------------------
+# torchscale Decoder (Magneto sub-LN, XPos, multiway "A" branch) key namespace
+# ------------------------------------------------------------------------------------------------
+class PositionalEmbedding(nn.Embedding):
+    """torchscale.component.embedding.PositionalEmbedding: learned table, fairseq positions start at 2."""
+
+    def forward(self, x, positions=None, **kwargs):
+        raise RuntimeError("PositionalEmbedding is a parameter container here; positions are added inside "
+                           "the fused kx_embed_splice kernel")
+
+
+class MultiwayNetwork(nn.Module):
+    """torchscale MultiwayNetwork with split_position == -1: forward == A (SURVEY U7).  The B copy is never
+    allocated; it is emitted into / accepted from state_dicts as an alias of A (B = deepcopy(A) at init)."""
+
+    def __init__(self, module: nn.Module):
+        super().__init__()
+        self.A = module
+        self.split_position = -1
+        self._register_state_dict_hook(MultiwayNetwork._emit_b)
+        self._register_load_state_dict_pre_hook(MultiwayNetwork._drop_b, with_module=True)
+
+    @staticmethod
+    def _emit_b(module, state_dict, prefix, local_metadata):
+        for k in [k for k in state_dict if k.startswith(prefix + "A.")]:
+            state_dict[prefix + "B." + k[len(prefix) + 2:]] = state_dict[k]
+
+    @staticmethod
+    def _drop_b(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for k in [k for k in state_dict if k.startswith(prefix + "B.")]:
+            del state_dict[k]
+
+
+def _mw(multiway: bool, module: nn.Module) -> nn.Module:
+    return MultiwayNetwork(module) if multiway else module
+
+
+def _a(module: nn.Module) -> nn.Module:
+    return module.A if isinstance(module, MultiwayNetwork) else module
+
+
+class XPOS(nn.Module):
+    def __init__(self, head_dim, scale_base=512):
+        super().__init__()
+        self.head_dim, self.scale_base = head_dim, scale_base
+        self.register_buffer("scale", (torch.arange(0, head_dim, 2) + 0.4 * head_dim) / (1.4 * head_dim))
+
+    def tables(self, length: int, offset: int = 0, downscale: bool = False):
+        """(cos*scale, sin*scale) [length, head_dim/2] fp32 — torchscale XPOS.forward +
+        fixed_pos_embedding, same operation order, evaluated once per sequence length on the host."""
+        zeta = self.scale.detach().to("cpu", torch.float32)
+        min_pos = -(length + offset) // 2
+        max_pos = length + offset + min_pos
+        scale = zeta ** torch.arange(min_pos, max_pos, 1).to(zeta).div(self.scale_base)[:, None]
+        seq_len, dim = scale.shape
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, dim) / dim))
+        sinusoid = torch.einsum("i , j -> i j", torch.arange(0, seq_len, dtype=torch.float), inv_freq).to(scale)
+        sin, cos = torch.sin(sinusoid), torch.cos(sinusoid)
+        if scale.shape[0] > length:
+            scale, sin, cos = scale[-length:], sin[-length:], cos[-length:]
+        if downscale:
+            scale = 1 / scale
+        return (cos * scale).contiguous(), (sin * scale).contiguous()
+
+
+class MultiheadAttention(nn.Module):
+    def __init__(self, args: DecoderConfig):
+        super().__init__()
+        d, mw = args.decoder_embed_dim, args.multiway
+        self.embed_dim, self.num_heads = d, args.decoder_attention_heads
+        self.head_dim = d // self.num_heads
+        self.scaling = self.head_dim ** -0.5
+        self.k_proj, self.v_proj, self.q_proj, self.out_proj = (_mw(mw, nn.Linear(d, d, bias=True)) for _ in range(4))
+        self.inner_attn_ln = _mw(mw, nn.LayerNorm(d, eps=args.layernorm_eps)) if args.subln else None
+        self.xpos = XPOS(self.head_dim, args.xpos_scale_base) if args.xpos_rel_pos else None
+
+
+class FeedForwardNetwork(nn.Module):
+    def __init__(self, args: DecoderConfig):
+        super().__init__()
+        d, f = args.decoder_embed_dim, args.decoder_ffn_embed_dim
+        self.fc1, self.fc2 = nn.Linear(d, f), nn.Linear(f, d)
+        self.ffn_layernorm = nn.LayerNorm(f, eps=args.layernorm_eps) if args.subln else None
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, args: DecoderConfig):
+        super().__init__()
+        d, mw = args.decoder_embed_dim, args.multiway
+        self.self_attn = MultiheadAttention(args)
+        self.self_attn_layer_norm = _mw(mw, nn.LayerNorm(d, eps=args.layernorm_eps))
+        self.ffn = _mw(mw, FeedForwardNetwork(args))
+        self.final_layer_norm = _mw(mw, nn.LayerNorm(d, eps=args.layernorm_eps))
+        self.alpha = 1.0
+
+
+class Decoder(_PackedMixin, nn.Module):
+    """torchscale.architecture.decoder.Decoder stand-in with the ``passed_x`` patch
+    (/root/reference/README.md:179-193)."""
+
+    def __init__(self, args: DecoderConfig, embed_tokens=None, embed_positions=None, output_projection=None,
+                 switches: Switches | None = None, **kwargs):
+        super().__init__()
+        self._packed_init()
+        if args.decoder_embed_dim != 64 * args.decoder_attention_heads:
+            raise ValueError("the gfx950 attention kernels are specialised for head_dim == 64")
+        if args.activation_fn not in ("gelu",):
+            # torchscale get_activation_fn knows relu/gelu/swish; only gelu is on the reference path
+            raise NotImplementedError(f"activation_fn={args.activation_fn!r}: only 'gelu' is implemented")
+        self.args = args
+        self.switches = switches or Switches()
+        self.embed_scale = 1.0 if args.no_scale_embedding else math.sqrt(args.decoder_embed_dim)
+        self.embed_tokens, self.embed_positions, self.output_projection = embed_tokens, embed_positions, output_projection
+        self.layers = nn.ModuleList([DecoderLayer(args) for _ in range(args.decoder_layers)])
+        self.num_layers = len(self.layers)
+        self.layer_norm = nn.LayerNorm(args.decoder_embed_dim, eps=args.layernorm_eps)  # subln => normalize_before
+        self._xpos_cache = {}
+        self._ws = _Workspace()
+
+    # -- weights ----------------------------------------------------------------------------------
+    def _pack(self, prec: str):
+        dev = self.layer_norm.weight.device
+        key = (dev, prec)
+        if key in self._packed:
+            return self._packed[key]
+        a, dt = self.args, _prec_dtype(prec)
+        keep = []
+
+        def op(t):
+            t = t.detach().to(dt).contiguous(); keep.append(t); return t.data_ptr()
+
+        def v(t):
+            t = _f32(t); keep.append(t); return t.data_ptr()
+
+        layers = (H.DecoderLayer * self.num_layers)()
+        for i, L in enumerate(self.layers):
+            sa, ffn = L.self_attn, _a(L.ffn)
+            q, k, vv, o = _a(sa.q_proj), _a(sa.k_proj), _a(sa.v_proj), _a(sa.out_proj)
+            e = layers[i]
+            e.sa_g, e.sa_b = v(_a(L.self_attn_layer_norm).weight), v(_a(L.self_attn_layer_norm).bias)
+            e.wqkv = op(torch.cat([q.weight, k.weight, vv.weight], 0))
+            e.bqkv = v(torch.cat([q.bias, k.bias, vv.bias], 0))
+            if a.subln:
+                e.in_g, e.in_b = v(_a(sa.inner_attn_ln).weight), v(_a(sa.inner_attn_ln).bias)
+                e.fn_g, e.fn_b = v(ffn.ffn_layernorm.weight), v(ffn.ffn_layernorm.bias)
+            e.wo, e.bo = op(o.weight), v(o.bias)
+            e.fl_g, e.fl_b = v(_a(L.final_layer_norm).weight), v(_a(L.final_layer_norm).bias)
+            e.w1, e.b1 = op(ffn.fc1.weight), v(ffn.fc1.bias)
+            e.w2, e.b2 = op(ffn.fc2.weight), v(ffn.fc2.bias)
+        w = H.DecoderWeights()
+        w.layers, w.dim, w.heads, w.ffn = self.num_layers, a.decoder_embed_dim, a.decoder_attention_heads, a.decoder_ffn_embed_dim
+        w.vocab, w.act = self.output_projection.weight.shape[0], H.ACTS[a.activation_fn]
+        w.subln, w.xpos, w.eps = int(a.subln), int(a.xpos_rel_pos), a.layernorm_eps
+        w.layer = C.cast(layers, C.POINTER(H.DecoderLayer))
+        w.ln_g, w.ln_b = v(self.layer_norm.weight), v(self.layer_norm.bias)
+        w.wout = op(self.output_projection.weight)
+        emb, pos = _f32(self.embed_tokens.weight), _f32(self.embed_positions.weight)
+        keep += [emb, pos]
+        self._packed[key] = (w, layers, keep, emb, pos)
+        return self._packed[key]
+
+    def _xpos_tables(self, T: int, device):
+        key = (T, device)
+        if key not in self._xpos_cache:
+            x = self.layers[0].self_attn.xpos
+            qc, qs = x.tables(T, 0, False)
+            kc, ks = x.tables(T, 0, True)
+            self._xpos_cache[key] = tuple(t.to(device) for t in (qc, qs, kc, ks))
+        return self._xpos_cache[key]
+
+    # -- stages -----------------------------------------------------------------------------------
+    def embed(self, tokens: torch.Tensor | None, prec: str, img: torch.Tensor | None = None, splice_at: int = 2,
+              alias: bool | None = None) -> torch.Tensor:
+        """Fused forward_embedding/cat/forward_embedding of /root/reference/kosmosx/model.py:238-244
+        (img given) or the single forward_embedding of :319 (img None)."""
+        _, _, _, emb, pos = self._pack(prec)
+        lib = H.load()
+        if tokens is not None:
+            _require_cuda(tokens, "text_tokens")
+            if tokens.dtype != torch.int64:
+                tokens = tokens.long()  # F.embedding accepts int32/int64 indices
+            tokens = tokens.contiguous()
+            B, Tt = tokens.shape
+        else:
+            B, Tt = img.shape[0], 0
+        n_img = 0 if img is None else img.shape[1]
+        d = emb.shape[1]
+        out = torch.empty((B, Tt + n_img, d), dtype=torch.float32, device=emb.device)
+        alias = self.switches.u1_inplace_alias if alias is None else alias
+        rc = lib.kx_embed_splice(H.ptr(tokens), emb.data_ptr(), pos.data_ptr(), H.ptr(img), out.data_ptr(), B, Tt,
+                                 n_img, d, emb.shape[0], pos.shape[0], splice_at, int(alias), _stream())
+        if rc == 1 and "out of range" in H.last_error():
+            msg = H.last_error()
+            logging.error(msg)
+            raise IndexError("index out of range in self: " + msg)  # what F.embedding raises upstream (SURVEY H3)
+        H.check(rc, "kx_embed_splice")
+        return out
+
+    def run(self, x: torch.Tensor, prec: str, logits_dtype=torch.float32) -> torch.Tensor:
+        """x [B,T,dim] fp32 residual stream (CONSUMED) -> logits [B,T,vocab]."""
+        w, _, _, _, _ = self._pack(prec)
+        lib = H.load()
+        B, T, _ = x.shape
+        tabs = self._xpos_tables(T, x.device) if self.args.xpos_rel_pos else (None,) * 4
+        logits = torch.empty((B, T, w.vocab), dtype=logits_dtype, device=x.device)
+        need = lib.kx_decoder_workspace_bytes(C.byref(w), B, T, H.PRECS[prec])
+        buf = self._ws.get(need, x.device)
+        ldt = H.KX_F32 if logits_dtype == torch.float32 else H.KX_BF16
+        H.check(lib.kx_decoder_forward(C.byref(w), x.data_ptr(), B, T, *(H.ptr(t) for t in tabs), logits.data_ptr(),
+                                       ldt, buf.data_ptr(), buf.numel(), H.PRECS[prec], _stream()),
+                "kx_decoder_forward")
+        return logits
+
+    # -- torchscale-compatible surface ------------------------------------------------------------
+    def forward_embedding(self, tokens, token_embedding=None, incremental_state=None):
+        if incremental_state is not None:
+            raise NotImplementedError("incremental decoding is not on the reference forward path (SURVEY §8f)")
+        prec = getattr(self, "precision", _default_precision())
+        if token_embedding is None:
+            x = self.embed(tokens, prec)
+            return x, (x if self.switches.u1_inplace_alias else None)
+        _require_cuda(token_embedding, "token_embedding")
+        x = self.embed(None, prec, img=token_embedding.to(torch.float32).contiguous(), splice_at=0)
+        return x, x
+
+    def forward(self, prev_output_tokens, self_attn_padding_mask=None, encoder_out=None, incremental_state=None,
+                features_only=False, return_all_hiddens=False, token_embeddings=None, **kwargs):
+        if incremental_state is not None or encoder_out is not None or self_attn_padding_mask is not None \
+                or features_only:
+            raise NotImplementedError("only the full-sequence, decoder-only, logits path of the reference is built")
+        prec = getattr(self, "precision", _default_precision())
+        passed_x = kwargs.get("passed_x", None)
+        if passed_x is None:
+            x, _ = self.forward_embedding(prev_output_tokens, token_embeddings)
+        else:
+            _require_cuda(passed_x, "passed_x")
+            x = passed_x.to(torch.float32).clone(memory_format=torch.contiguous_format)  # run() consumes it
+        return self.run(x, prec), {"inner_states": None, "l_aux": None, "attn": None}
+
+
+# ------------------------------------------------------------------------------------------------
+# initialisation (a1, SURVEY.md §8a): the reference's distributions, seeded
+# ------------------------------------------------------------------------------------------------
+def _normal(t, std, g):
+    with torch.no_grad():
+        t.normal_(0.0, std, generator=g)
+
+
+def _uniform(t, bound, g):
+    with torch.no_grad():
+        t.uniform_(-bound, bound, generator=g)
+
+
+def _xavier_uniform(t, gain, g):
+    fan_out, fan_in = t.shape[0], t.shape[1]
+    _uniform(t, gain * math.sqrt(6.0 / (fan_in + fan_out)), g)
+
+
+def _linear_default(lin: nn.Linear, g):  # nn.Linear.reset_parameters: kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(in))
+    b = 1.0 / math.sqrt(lin.in_features)
+    _uniform(lin.weight, b, g)
+    if lin.bias is not None:
+        _uniform(lin.bias, b, g)
+
+
+def _ln_default(ln: nn.LayerNorm):
+    with torch.no_grad():
+        ln.weight.fill_(1.0)
+        ln.bias.zero_()
+
+
+def init_vit_(m: CLIPVisionTower, g):
+    """HF CLIPPreTrainedModel._init_weights (factor 1, initializer_range 0.02).  The reference loads
+    pretrained weights instead (/root/reference/kosmosx/model.py:154-156); there is no network here."""
+    c = m.cfg
+    _normal(m.embeddings.class_embedding, c.dim ** -0.5, g)
+    _normal(m.embeddings.patch_embedding.weight, 0.02, g)
+    _normal(m.embeddings.position_embedding.weight, 0.02, g)
+    in_std = (c.dim ** -0.5) * ((2 * c.layers) ** -0.5)
+    out_std = c.dim ** -0.5
+    fc_std = (2 * c.dim) ** -0.5
+    for L in m.encoder.layers:
+        for p in (L.self_attn.q_proj, L.self_attn.k_proj, L.self_attn.v_proj):
+            _normal(p.weight, in_std, g)
+        _normal(L.self_attn.out_proj.weight, out_std, g)
+        _normal(L.mlp.fc1.weight, fc_std, g)
+        _normal(L.mlp.fc2.weight, in_std, g)
+        with torch.no_grad():
+            for p in (L.self_attn.q_proj, L.self_attn.k_proj, L.self_attn.v_proj, L.self_attn.out_proj, L.mlp.fc1,
+                      L.mlp.fc2):
+                p.bias.zero_()
+        _ln_default(L.layer_norm1); _ln_default(L.layer_norm2)
+    _ln_default(m.pre_layrnorm); _ln_default(m.post_layernorm)
+
+
+def init_perceiver_(m: PerceiverResampler, g):
+    _normal(m.latents, 1.0, g)
+    _normal(m.media_pos_emb, 1.0, g)
+    for att, ff in m.layers:
+        _ln_default(att.norm_media); _ln_default(att.norm_latents)
+        for lin in (att.to_q, att.to_kv, att.to_out, ff[1], ff[3]):
+            _linear_default(lin, g)
+        _ln_default(ff[0])
+    _ln_default(m.norm)
+
+
+def init_decoder_(m: Decoder, g):
+    """torchscale MultiheadAttention.reset_parameters / FeedForwardNetwork.reset_parameters and the subln
+    init scale sqrt(log(2*layers)) applied to fc1, fc2, out_proj, v_proj (weights and biases)."""
+    a = m.args
+    init_scale = math.sqrt(math.log(a.decoder_layers * 2)) if a.subln else 1.0
+    for L in m.layers:
+        sa, ffn = L.self_attn, _a(L.ffn)
+        for p in (sa.q_proj, sa.k_proj, sa.v_proj):
+            _xavier_uniform(_a(p).weight, 1 / math.sqrt(2), g)
+            _uniform(_a(p).bias, 1.0 / math.sqrt(a.decoder_embed_dim), g)
+        _xavier_uniform(_a(sa.out_proj).weight, 1.0, g)
+        with torch.no_grad():
+            _a(sa.out_proj).bias.zero_()
+        _linear_default(ffn.fc1, g); _linear_default(ffn.fc2, g)
+        with torch.no_grad():
+            for p in (_a(sa.v_proj), _a(sa.out_proj), ffn.fc1, ffn.fc2):
+                p.weight.mul_(init_scale)
+                p.bias.mul_(init_scale)
+        for ln in (_a(L.self_attn_layer_norm), _a(L.final_layer_norm)):
+            _ln_default(ln)
+        if a.subln:
+            _ln_default(_a(sa.inner_attn_ln)); _ln_default(ffn.ffn_layernorm)
+    _ln_default(m.layer_norm)
+
+
+def init_embeddings_(embed: nn.Embedding, pos: nn.Embedding, g, padding_idx=1):
+    _xavier_uniform(embed.weight, 1.0, g)   # bitsandbytes Embedding.reset_parameters
+    _normal(pos.weight, 1.0, g)             # nn.Embedding default
+    with torch.no_grad():
+        embed.weight[padding_idx].zero_()
+        pos.weight[padding_idx].zero_()
+
+
+def perturb_(module: nn.Module, g, amount: float):
+    """Test helper: make every LayerNorm gain/bias and every Linear bias non-trivial so that parity tests
+    cannot pass with a forgotten bias or affine term."""
+    with torch.no_grad():
+        for mod in module.modules():
+            if isinstance(mod, nn.LayerNorm):
+                mod.weight.add_(torch.randn(mod.weight.shape, generator=g) * amount)
+                mod.bias.add_(torch.randn(mod.bias.shape, generator=g) * amount)
+            elif isinstance(mod, nn.Linear) and mod.bias is not None:
+                mod.bias.add_(torch.randn(mod.bias.shape, generator=g) * amount * 0.5)
+
+
+# ------------------------------------------------------------------------------------------------
+# the drop-in classes
+# ------------------------------------------------------------------------------------------------
+class Kosmos(nn.Module):
+    """The main Kosmos model class (/root/reference/kosmosx/model.py:132-253).
+
+    Attributes (same names as the reference): clip_model, embed, embed_positions, output_projection,
+    config, decoder, perceive, image_proj.
+    """
+
+    def __init__(self):
+        super().__init__()
+        self._build(KosmosConfig(decoder=DecoderConfig(vocab_size=64007)), seed=None, switches=None)
+
+    @classmethod
+    def _from_config(cls, cfg: KosmosConfig, seed: int | None = None, switches: Switches | None = None,
+                     perturb: float = 0.0):
+        """Reduced-size / seeded construction for tests and benchmarks (``Kosmos()`` itself takes no
+        arguments, as in the reference)."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self._build(cfg, seed, switches, perturb)
+        return self
+
+    def _build(self, cfg: KosmosConfig, seed, switches, perturb: float = 0.0):
+        self.cfg = cfg
+        self.switches = switches or Switches()
+        self.precision = _default_precision()
+        d = cfg.decoder.decoder_embed_dim
+        try:
+            self.clip_model = CLIPVisionTower(cfg.vit)
+        except Exception as e:
+            logging.error(f"Failed to initialize CLIP model: {e}")
+            raise
+        self.embed = nn.Embedding(cfg.vocab, d, padding_idx=cfg.padding_idx)   # bitsandbytes Embedding == F.embedding
+        self.embed_positions = PositionalEmbedding(cfg.max_positions, d, cfg.padding_idx)
+        self.output_projection = nn.Linear(d, cfg.vocab, bias=False)
+        self.config = cfg.decoder
+        try:
+            self.decoder = Decoder(self.config, embed_tokens=self.embed, embed_positions=self.embed_positions,
+                                   output_projection=self.output_projection, switches=self.switches)
+        except Exception as e:
+            logging.error(f"Failed to initialize Decoder: {e}")
+            raise
+        p = cfg.perceiver
+        self.perceive = PerceiverResampler(dim=p.dim, depth=p.depth, dim_head=p.dim_head, heads=p.heads,
+                                           num_latents=p.latents, num_media_embeds=p.media_embeds,
+                                           ff_mult=p.ff_mult, eps=p.eps, switches=self.switches)
+        self.image_proj = nn.Linear(p.dim, d, bias=False)
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        init_vit_(self.clip_model, g)
+        init_perceiver_(self.perceive, g)
+        init_embeddings_(self.embed, self.embed_positions, g, cfg.padding_idx)
+        _normal(self.output_projection.weight, d ** -0.5, g)   # /root/reference/kosmosx/model.py:166-167
+        init_decoder_(self.decoder, g)
+        _normal(self.image_proj.weight, d ** -0.5, g)          # :205-206
+        if perturb:
+            perturb_(self, g, perturb)
+        self._ws = _Workspace()
+
+    def forward(self, text_tokens: torch.Tensor, images: torch.Tensor, **kwargs):
+        """text_tokens [B,Tt] integer ids, images [B,3,224,224] any real dtype
+        -> logits [B, Tt+64, vocab] fp32.  kwargs are ignored, as in the reference."""
+        if not isinstance(text_tokens, torch.Tensor) or not isinstance(images, torch.Tensor):
+            raise TypeError("text_tokens and images must be instances of torch.Tensor")
+        prec = self.precision
+        try:
+            img = self.clip_model.run(images, prec, self._ws)                       # model.py:230
+            img, _ = self.perceive.run(img, prec, self._ws, self.image_proj.weight)  # :231-232
+        except Exception as e:
+            logging.error(f"Failed during image processing: {e}")
+            raise
+        try:
+            if text_tokens.dim() != 2 or text_tokens.shape[0] != img.shape[0]:
+                raise ValueError(f"text_tokens must be [batch, seq] with batch {img.shape[0]}, got "
+                                 f"{tuple(text_tokens.shape)}")
+            model_input = self.decoder.embed(text_tokens, prec, img=img)            # :238-244
+        except Exception as e:
+            logging.error(f"Failed during text processing: {e}")
+            raise
+        try:
+            return self.decoder.run(model_input, prec)                              # :250
+        except Exception as e:
+            logging.error(f"Failed during model forward pass: {e}")
+            raise
+
+
+class KosmosLanguage(nn.Module):
+    """Text-only variant (/root/reference/kosmosx/model.py:256-320)."""
+
+    def __init__(self, vocab_size: int = 64007, dim: int = 2048, depth: int = 24, ffn_dim: int = 8192,
+                 dropout: float = 0.1, multiway: bool = True, decoder_heads: int = 32, activation_fn: str = "gelu",
+                 subln: bool = True, alibi_pos_bias: bool = True, alibi_num_heads: int = 16,
+                 xpos_rel_pos: bool = True, max_rel_pos: int = 2048, *args, **kwargs):
+        super().__init__()
+        seed = kwargs.pop("_seed", None)
+        perturb = kwargs.pop("_perturb", 0.0)
+        self.precision = _default_precision()
+        self.embed = nn.Embedding(vocab_size, dim, padding_idx=1)
+        self.embed_positions = PositionalEmbedding(kwargs.pop("_max_positions", dim), dim, 1)  # (dim, dim, 1) upstream
+        self.output_projection = nn.Linear(dim, vocab_size, bias=False)
+        self.config = DecoderConfig(decoder_layers=depth, decoder_embed_dim=dim, decoder_ffn_embed_dim=ffn_dim,
+                                    decoder_attention_heads=decoder_heads, dropout=dropout,
+                                    activation_fn=activation_fn, attention_dropout=dropout, vocab_size=vocab_size,
+                                    subln=subln, xpos_rel_pos=xpos_rel_pos, multiway=multiway,
+                                    max_rel_pos=max_rel_pos, alibi_pos_bias=alibi_pos_bias,
+                                    alibi_num_heads=alibi_num_heads)
+        self.decoder = Decoder(self.config, embed_tokens=self.embed, embed_positions=self.embed_positions,
+                               output_projection=self.output_projection)
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        init_embeddings_(self.embed, self.embed_positions, g, 1)
+        _linear_default(self.output_projection, g)     # plain nn.Linear init upstream (:282)
+        init_decoder_(self.decoder, g)
+        if perturb:
+            perturb_(self, g, perturb)
+
+    def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor):
+            raise TypeError("x must be an instance of torch.Tensor")
+        model_input = self.decoder.embed(x, self.precision)         # :319
+        return self.decoder.run(model_input, self.precision)        # :320
+
+
+class KosmosTokenizer:
+    """Host-side pre-processing of the reference (/root/reference/kosmosx/model.py:23-129): CLIPProcessor +
+    GPT-NeoX tokenizer files fetched from the network.  It is not on the tensor->logits hot path
+    (SURVEY.md §8f, "next" row 3) and needs files that are unavailable offline."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("KosmosTokenizer is outside the MI355X hot-path scope (SURVEY.md §8f row 3); "
+                                  "feed token ids and pixel tensors directly to Kosmos.forward")

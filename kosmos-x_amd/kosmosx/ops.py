@@ -1,0 +1,104 @@
+"""Thin torch-tensor wrappers over the primitive C-ABI ops of libkosmosx_hip.so.
+
+PyTorch is plumbing here (device memory + the current HIP stream); the arithmetic runs in the
+hand-written gfx950 kernels.  Every wrapper requires CUDA tensors and raises otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _hip as H
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("kosmosx ops run on the MI355X HIP path only: tensor is not on a CUDA/HIP device")
+
+
+def _cdt(dtype) -> int:
+    if dtype == torch.float32:
+        return H.KX_F32
+    if dtype == torch.bfloat16:
+        return H.KX_BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, out=None,
+              rows_per_group=None, out_group_stride=0, out_row_offset=0):
+    """x [rows, cols] fp32 -> LN(x (+pre_add)) * gamma + beta."""
+    _need_cuda(x, gamma, beta, pre_add, out)
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
+    rc = H.load().kx_layernorm(H.ptr(x), H.ptr(pre_add), H.ptr(gamma), H.ptr(beta), H.ptr(out), _cdt(out.dtype),
+                               rows, cols, float(eps), rows_per_group or rows, out_group_stride, out_row_offset,
+                               _stream())
+    H.check(rc, "kx_layernorm")
+    return out
+
+
+def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
+         xpos=None, xpos_dim=0, tile=0, out=None):
+    """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32]."""
+    _need_cuda(a, w, bias, residual, out)
+    M, K = a.shape
+    N = w.shape[0]
+    prec = H.KX_PREC_BF16 if a.dtype == torch.bfloat16 else H.KX_PREC_F32
+    if a.dtype != w.dtype:
+        raise TypeError("gemm operands must share a dtype")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    g = H.GemmArgs()
+    g.A, g.lda, g.W, g.ldw = H.ptr(a), a.stride(0), H.ptr(w), w.stride(0)
+    g.C, g.ldc, g.cdt = H.ptr(out), out.stride(0), _cdt(out.dtype)
+    g.bias, g.residual, g.ldr = H.ptr(bias), H.ptr(residual), (residual.stride(0) if residual is not None else 0)
+    g.M, g.N, g.K = M, N, K
+    g.act, g.qscale, g.qcols = H.ACTS[act], float(qscale), qcols
+    if xpos is not None:
+        g.xq_cs, g.xq_ss, g.xk_cs, g.xk_ss = (H.ptr(t) for t in xpos)
+        g.xpos_T, g.xpos_dim = xpos[0].shape[0], xpos_dim
+    g.prec, g.tile = prec, tile
+    H.check(H.load().kx_gemm(C.byref(g), _stream()), "kx_gemm")
+    return out
+
+
+def attention(q, k, v, causal=False, out_dtype=None):
+    """q [B,Tq,H,64], k/v [B,Tk,H,64] (any row/batch strides, last two dims contiguous) -> [B,Tq,H*64]."""
+    _need_cuda(q, k, v)
+    B, Tq, Hh, hd = q.shape
+    Tk = k.shape[1]
+    assert hd == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and v.stride(2) == 64
+    assert k.stride(0) == v.stride(0) and k.stride(1) == v.stride(1)
+    prec = H.KX_PREC_BF16 if q.dtype == torch.bfloat16 else H.KX_PREC_F32
+    out = torch.empty((B, Tq, Hh * 64), dtype=out_dtype or q.dtype, device=q.device)
+    a = H.AttnArgs()
+    a.q, a.q_batch_stride, a.q_row_stride = H.ptr(q), q.stride(0), q.stride(1)
+    a.k, a.v, a.kv_batch_stride, a.kv_row_stride = H.ptr(k), H.ptr(v), k.stride(0), k.stride(1)
+    a.out, a.out_batch_stride, a.out_row_stride, a.odt = H.ptr(out), out.stride(0), out.stride(1), _cdt(out.dtype)
+    a.B, a.H, a.Tq, a.Tk = B, Hh, Tq, Tk
+    a.mask, a.prec = (H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL), prec
+    H.check(H.load().kx_attention(C.byref(a), _stream()), "kx_attention")
+    return out
+
+
+def embed_splice(tokens, embed, pos, img=None, u1_alias=True, splice_at=2):
+    """Decoder input assembly (see kx_embed_splice in include/kosmosx_hip.h)."""
+    _need_cuda(tokens, embed, pos, img)
+    if tokens is not None:
+        B, Tt = tokens.shape
+    else:
+        B, Tt = img.shape[0], 0
+    n_img = 0 if img is None else img.shape[1]
+    d = embed.shape[1]
+    out = torch.empty((B, Tt + n_img, d), dtype=torch.float32, device=embed.device)
+    rc = H.load().kx_embed_splice(H.ptr(tokens), H.ptr(embed), H.ptr(pos), H.ptr(img), H.ptr(out), B, Tt, n_img, d,
+                                  embed.shape[0], pos.shape[0], splice_at, int(u1_alias), _stream())
+    H.check(rc, "kx_embed_splice")
+    return out

@@ -1,0 +1,290 @@
+"""Per-kernel parity tests (GPU): every primitive C-ABI op against the CPU oracle's arithmetic.
+
+bf16 operands are exactly representable in fp32, so for the bf16 kernels the reference is the same
+fp32 arithmetic on the bf16-rounded operands: the only differences left are accumulation order and
+the final rounding, and the tolerances below are set for that (not for bf16 operand rounding).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from kosmosx import ops  # noqa: E402
+from oracle import kosmos_oracle as O  # noqa: E402
+from helpers import max_abs, rel_err  # noqa: E402
+
+DEV = "cuda"
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cols", [128, 256, 1024, 2048, 4096, 8192, 516])
+@pytest.mark.parametrize("rows", [1, 7, 114])
+def test_layernorm_f32(rows, cols):
+    g = _g(cols + rows)
+    x = torch.randn(rows, cols, generator=g) * 3 + 0.7
+    w = 1 + 0.2 * torch.randn(cols, generator=g)
+    b = 0.3 * torch.randn(cols, generator=g)
+    ref = F.layer_norm(x, (cols,), w, b, 1e-5)
+    out = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    assert max_abs(out, ref) < 2e-5
+    out16 = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out_dtype=torch.bfloat16)
+    # bf16 output: identical to rounding the fp32 result except where the fp32 values differ in the last ulp
+    assert max_abs(out16, ref.to(torch.bfloat16)) <= 2 ** -6 * float(ref.abs().max())
+
+
+def test_layernorm_properties():
+    """LN output has mean 0 / var 1 before the affine (SURVEY §8c analytic tests)."""
+    x = torch.randn(33, 2048, generator=_g(1)) * 5 + 2
+    out = ops.layernorm(x.to(DEV), torch.ones(2048, device=DEV), torch.zeros(2048, device=DEV), 1e-5).cpu()
+    assert out.mean(-1).abs().max() < 1e-5
+    assert (out.var(-1, unbiased=False) - 1).abs().max() < 1e-3
+
+
+def test_layernorm_preadd_and_row_remap():
+    """The Perceiver's cat(norm_media(x + media_pos), norm_latents(lat)) assembly."""
+    g = _g(5)
+    B, m, n, d = 3, 17, 8, 128
+    x, lat = torch.randn(B, m, d, generator=g), torch.randn(B, n, d, generator=g)
+    mp = torch.randn(d, generator=g)
+    w1, b1, w2, b2 = (torch.randn(d, generator=g) for _ in range(4))
+    ref = torch.cat([F.layer_norm(x + mp, (d,), w1, b1), F.layer_norm(lat, (d,), w2, b2)], dim=1)
+    out = torch.zeros(B * (m + n), d, device=DEV)
+    ops.layernorm(x.reshape(-1, d).to(DEV), w1.to(DEV), b1.to(DEV), pre_add=mp.to(DEV), out=out,
+                  rows_per_group=m, out_group_stride=m + n, out_row_offset=0)
+    ops.layernorm(lat.reshape(-1, d).to(DEV), w2.to(DEV), b2.to(DEV), out=out,
+                  rows_per_group=n, out_group_stride=m + n, out_row_offset=m)
+    assert max_abs(out.view(B, m + n, d), ref) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------
+def _gemm_ref(a, w, bias=None, residual=None, act="none", qscale=1.0, qcols=0):
+    y = a.double() @ w.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    if qcols:
+        y[:, :qcols] *= qscale
+    if act == "gelu":
+        y = F.gelu(y)
+    elif act == "quick_gelu":
+        y = y * torch.sigmoid(1.702 * y)
+    if residual is not None:
+        y = y + residual.double()
+    return y.float()
+
+
+SHAPES = [  # (M, N, K): tile edges in M and N, the awkward path dims (SURVEY §7 "awkward dims")
+    (128, 128, 64), (114, 2048, 2048), (257, 1024, 4096), (3, 136, 128), (64, 512, 1024),
+    (256, 1024, 640), (130, 258, 192), (114, 1002, 256), (1, 128, 64), (200, 130, 8192),
+]
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_bf16_plain(shape, tile):
+    M, N, K = shape
+    g = _g(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    ref = _gemm_ref(a.float(), w.float())
+    out = ops.gemm(a.to(DEV), w.to(DEV), tile=tile)
+    assert rel_err(out, ref) < 2e-5, (shape, tile)
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("shape", SHAPES[:7])
+def test_gemm_f32_plain(shape, tile):
+    M, N, K = shape
+    g = _g(M * 5 + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    ref = _gemm_ref(a, w)
+    out = ops.gemm(a.to(DEV), w.to(DEV), tile=tile)
+    assert rel_err(out, ref) < 2e-5, (shape, tile)
+
+
+def test_gemm_layout_is_not_transposed():
+    """A = I against an ASYMMETRIC W (guide rule 16: symmetric inputs hide operand/output transposes)."""
+    K = 128
+    a = torch.eye(K).to(torch.bfloat16)
+    w = (torch.arange(96 * K, dtype=torch.float32).reshape(96, K) % 251 - 125).to(torch.bfloat16)
+    out = ops.gemm(a.to(DEV), w.to(DEV))
+    assert torch.equal(out.cpu(), w.float().t().contiguous())
+
+
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("act", ["none", "gelu", "quick_gelu"])
+def test_gemm_epilogue_bias_act_residual(prec, act):
+    M, N, K = 150, 264, 256
+    g = _g(11)
+    a = torch.randn(M, K, generator=g).to(prec)
+    w = (torch.randn(N, K, generator=g) / 16).to(prec)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = _gemm_ref(a.float(), w.float(), bias, res, act, 0.125, 64)
+    out = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, act, qscale=0.125, qcols=64, out=out)  # residual aliases C
+    assert rel_err(out, ref) < 3e-5
+    out16 = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), act, out_dtype=torch.bfloat16,
+                     qscale=0.125, qcols=64)
+    assert rel_err(out16, ref) < 2 ** -7
+
+
+def test_gemm_unaligned_ldc_logits_edge():
+    """N = 32002 = 250*128 + 2: edge tile and a row pitch that is not 16-byte aligned."""
+    M, N, K = 20, 32002, 128
+    g = _g(3)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / 11).to(torch.bfloat16)
+    out = ops.gemm(a.to(DEV), w.to(DEV))
+    assert rel_err(out, _gemm_ref(a.float(), w.float())) < 2e-5
+
+
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("T", [1, 9, 114, 115])
+def test_gemm_xpos_epilogue(prec, T):
+    """Fused q-scale + XPos in the QKV GEMM epilogue vs torchscale's order of operations (oracle)."""
+    B, H, hd = 2, 4, 64
+    D = H * hd
+    g = _g(T)
+    a = torch.randn(B * T, D, generator=g).to(prec)
+    w = (torch.randn(3 * D, D, generator=g) / 16).to(prec)
+    bias = torch.randn(3 * D, generator=g) * 0.1
+    qc, qs = O.xpos_tables(T, hd, 512, 0, False)
+    kc, ks = O.xpos_tables(T, hd, 512, 0, True)
+    y = a.float() @ w.float().t() + bias
+    q, k, v = y[:, :D] * hd ** -0.5, y[:, D:2 * D], y[:, 2 * D:]
+
+    def heads(t):
+        return t.view(B, T, H, hd).transpose(1, 2).reshape(B * H, T, hd)
+
+    def unheads(t):
+        return t.view(B, H, T, hd).transpose(1, 2).reshape(B * T, D)
+
+    ref = torch.cat([unheads(O.apply_xpos(heads(q), qc, qs)), unheads(O.apply_xpos(heads(k), kc, ks)), v], 1)
+    tabs = tuple(t.contiguous().to(DEV) for t in (qc, qs, kc, ks))
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), qscale=hd ** -0.5, qcols=D, xpos=tabs, xpos_dim=D)
+    assert rel_err(out, ref) < 3e-5
+
+
+def test_gemm_rejects_bad_arguments():
+    a = torch.zeros(4, 100, device=DEV, dtype=torch.bfloat16)  # K not a multiple of 64
+    w = torch.zeros(8, 100, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple of"):
+        ops.gemm(a, w)
+    with pytest.raises(RuntimeError, match="not on a CUDA"):
+        ops.gemm(a.cpu(), w.cpu())
+
+
+# ---------------------------------------------------------------------------------------------
+# Attention
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, causal):
+    B, Tq, H, hd = q.shape
+    qh, kh, vh = (t.double().permute(0, 2, 1, 3) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2)
+    if causal:
+        s = s + torch.triu(torch.full((Tq, k.shape[1]), float("-inf"), dtype=torch.float64), 1)
+    o = torch.softmax(s, -1) @ vh
+    return o.permute(0, 2, 1, 3).reshape(B, Tq, H * hd).float()
+
+
+ATTN_CASES = [  # (B, H, Tq, Tk, causal): decoder T=114/115, ViT 257, perceiver 64x321, ragged/tiny
+    (2, 4, 114, 114, True), (1, 2, 115, 115, True), (2, 2, 257, 257, False), (2, 8, 64, 321, False),
+    (1, 1, 1, 1, True), (1, 2, 9, 9, True), (3, 2, 8, 25, False), (1, 2, 200, 200, True), (1, 1, 64, 64, True),
+    (1, 1, 65, 65, False),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_bf16(case):
+    B, H, Tq, Tk, causal = case
+    g = _g(Tq * 3 + Tk)
+    q = (torch.randn(B, Tq, H, 64, generator=g) * 0.35).to(torch.bfloat16)
+    k = torch.randn(B, Tk, H, 64, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, Tk, H, 64, generator=g).to(torch.bfloat16)
+    ref = _attn_ref(q.float(), k.float(), v.float(), causal)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), causal, out_dtype=torch.float32)
+    # P is rounded to bf16 before P·V (the only rounding the fp32 reference does not have)
+    assert rel_err(out, ref) < 1.5e-2, case
+    assert float((out.cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < 3e-3, case
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_f32(case):
+    B, H, Tq, Tk, causal = case
+    g = _g(Tq * 3 + Tk + 1)
+    q = torch.randn(B, Tq, H, 64, generator=g) * 0.35
+    k = torch.randn(B, Tk, H, 64, generator=g)
+    v = torch.randn(B, Tk, H, 64, generator=g)
+    ref = _attn_ref(q, k, v, causal)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), causal)
+    assert rel_err(out, ref) < 2e-5, case
+
+
+def test_attention_strided_qkv_views():
+    """q/k/v as column slices of one fused [B*T, 3*D] buffer — the layout the stage kernels use."""
+    B, T, H = 2, 50, 4
+    D = H * 64
+    qkv = (torch.randn(B, T, 3 * D, generator=_g(9)) * 0.5).to(torch.bfloat16).to(DEV)
+    q, k, v = (qkv[:, :, i * D:(i + 1) * D].unflatten(2, (H, 64)) for i in range(3))
+    out = ops.attention(q, k, v, True, out_dtype=torch.float32)
+    ref = _attn_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), True)
+    assert rel_err(out, ref) < 1.5e-2
+
+
+def test_attention_softmax_spike_forces_rescale():
+    """Online-softmax rescale branch (guide rule 26): a late key dominates after earlier tiles were summed."""
+    B, H, T = 1, 1, 200
+    g = _g(21)
+    q = (torch.randn(B, T, H, 64, generator=g) * 0.2).to(torch.bfloat16)
+    k = (torch.randn(B, T, H, 64, generator=g) * 0.2).to(torch.bfloat16)
+    v = torch.randn(B, T, H, 64, generator=g).to(torch.bfloat16)
+    k[0, 150, 0] = (q[0, 199, 0].float() * 40).to(torch.bfloat16)  # key 150 (3rd tile) spikes for query 199
+    ref = _attn_ref(q.float(), k.float(), v.float(), True)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), True, out_dtype=torch.float32)
+    assert rel_err(out, ref) < 1.5e-2
+
+
+# ---------------------------------------------------------------------------------------------
+# Decoder input assembly
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("alias", [True, False])
+def test_embed_splice_matches_reference_order(alias):
+    g = _g(2)
+    B, Tt, n, d, V, P = 3, 10, 8, 256, 1002, 64
+    tok = torch.randint(0, V, (B, Tt), generator=g)
+    emb, pos = torch.randn(V, d, generator=g), torch.randn(P, d, generator=g)
+    img = torch.randn(B, n, d, generator=g)
+    w = {"embed.weight": emb, "embed_positions.weight": pos}
+    cfg = O.DecoderCfg(vocab=V, max_pos=P, dim=d)
+    x, e = O.forward_embedding_tokens(w, tok, cfg)
+    first = x if alias else e
+    mi = torch.cat([first[:, 0:2], img, first[:, 2:]], dim=1)
+    ref = 1.0 * mi + pos[O.positions_for(Tt + n)][None]
+    out = ops.embed_splice(tok.to(DEV), emb.to(DEV), pos.to(DEV), img.to(DEV), alias)
+    assert torch.equal(out.cpu(), ref)                     # pure fp32 adds in the same order: bit-exact
+    # image tokens sit at decoder indices 2..2+n-1 (SURVEY §8c analytic test)
+    assert torch.equal(out.cpu()[:, 2:2 + n], img + pos[4:4 + n][None])
+    # text-only (KosmosLanguage): one position add
+    out_l = ops.embed_splice(tok.to(DEV), emb.to(DEV), pos.to(DEV))
+    assert torch.equal(out_l.cpu(), x)
+
+
+def test_embed_splice_position_overflow_is_an_error():
+    """positions run 2..T+1; a 64-row table admits T <= 62."""
+    V, d, P = 50, 128, 64
+    emb, pos = torch.randn(V, d, device=DEV), torch.randn(P, d, device=DEV)
+    ops.embed_splice(torch.zeros(1, 62, dtype=torch.long, device=DEV), emb, pos)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.embed_splice(torch.zeros(1, 63, dtype=torch.long, device=DEV), emb, pos)

@@ -1,0 +1,47 @@
+"""Micro-benchmark of kx_gemm on the shapes of the Kosmos-X forward (GPU box only).  Random operands
+(guide §5.4 rule 25: never zero-filled), interleaved rounds, median reported."""
+import os, sys, json, statistics
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "kosmos-x_amd")]
+os.environ.setdefault("KOSMOSX_NO_LOGGING_CONFIG", "1")
+import torch
+from kosmosx import ops
+
+SHAPES = {  # name: (M, N, K)
+    "dec_qkv_b32": (3648, 6144, 2048), "dec_out_b32": (3648, 2048, 2048), "dec_fc1_b32": (3648, 8192, 2048),
+    "dec_fc2_b32": (3648, 2048, 8192), "logits_b32": (3648, 32002, 2048),
+    "vit_qkv_b32": (8224, 3072, 1024), "vit_out_b32": (8224, 1024, 1024), "vit_fc1_b32": (8224, 4096, 1024),
+    "vit_fc2_b32": (8224, 1024, 4096), "sq4096": (4096, 4096, 4096), "sq8192": (8192, 8192, 8192),
+    "dec_qkv_b1": (114, 6144, 2048), "dec_fc1_b1": (114, 8192, 2048), "dec_fc2_b1": (114, 2048, 8192),
+    "c3_fc1": (65472, 8192, 2048),
+}
+
+def bench(name, M, N, K, tile, dtype=torch.bfloat16, iters=10, rounds=3):
+    a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dtype)
+    w = (torch.rand(N, K, device="cuda") * 2 - 1).to(dtype)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    for _ in range(2):
+        ops.gemm(a, w, out=out, tile=tile)
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.gemm(a, w, out=out, tile=tile)
+        e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters)
+    ms = statistics.median(ts)
+    return {"shape": name, "M": M, "N": N, "K": K, "tile": tile, "ms": round(ms, 4),
+            "tflops": round(2.0 * M * N * K / ms / 1e9, 1)}
+
+if __name__ == "__main__":
+    tiles = [int(t) for t in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["128", "64"])]
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+    for name, (M, N, K) in SHAPES.items():
+        if only and name not in only:
+            continue
+        for t in tiles:
+            if t == 64 and M * N > 5e7:
+                continue
+            print(json.dumps(bench(name, M, N, K, t)), flush=True)
