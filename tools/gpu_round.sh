@@ -6,8 +6,8 @@ export TMPDIR=/tmp KOSMOSX_NO_LOGGING_CONFIG=1
 mkdir -p gpurun_out
 WHAT="${1:-all}"
 if [[ "$WHAT" == all || "$WHAT" == tests ]]; then
-  timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider 2>&1 | tail -80 > gpurun_out/pytest_gpu.log
-  tail -30 gpurun_out/pytest_gpu.log
+  timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider -s > gpurun_out/pytest_gpu.log 2>&1
+  grep -E 'bf16:|fp32:|C1 ' gpurun_out/pytest_gpu.log | head -40; tail -25 gpurun_out/pytest_gpu.log
 fi
 if [[ "$WHAT" == all || "$WHAT" == bench ]]; then
   timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2> gpurun_out/bench.err
