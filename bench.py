@@ -47,13 +47,19 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3, help="instrumented steps for the roofline leg")
+    ap.add_argument("--gemm-tile", type=int, default=0, help="kernel-variant override (kx_set_tuning key 1), A/B only")
     return ap.parse_args()
 
 
 def kernel_report(records, steps):
     """Aggregate kx_prof records (one per kernel launch) into per-kernel totals per step."""
     agg = {}
+    shapes = {}
     for kind, a, b, c, ms in records:
+        if kind.startswith("gemm"):
+            se = shapes.setdefault((kind, a, b, c), [0, 0.0])
+            se[0] += 1
+            se[1] += ms
         e = agg.setdefault(kind, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         e["launches"] += 1
         e["ms"] += ms
@@ -68,6 +74,10 @@ def kernel_report(records, steps):
         e["ms"] /= steps
         e["flops"] /= steps
         e["bytes"] /= steps
+    top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:14]
+    agg["_gemm_shapes"] = [{"kernel": k[0], "M": k[1], "N": k[2], "K": k[3], "launches_per_step": v[0] / steps,
+                            "ms_per_step": round(v[1] / steps, 4),
+                            "tflops": round(2.0 * k[1] * k[2] * k[3] * v[0] / (v[1] * 1e-3) / 1e12, 1)} for k, v in top]
     return agg
 
 
@@ -102,6 +112,8 @@ def main():
         cpu_weights = oracle_weights(model)                     # shares the CPU storage, no copy
     model = model.to(dev)
     model.precision = args.precision
+    if args.gemm_tile:
+        _hip.load().kx_set_tuning(1, args.gemm_tile)
     t_build = time.time() - t_build
 
     g = torch.Generator().manual_seed(1000 + rank)              # per-rank synthetic shard
@@ -140,7 +152,7 @@ def main():
     assert out.shape[-1] == cfg.vocab and out.shape[-2] == Tt + cfg.perceiver.latents
 
     # ---- roofline leg: the same step, instrumented launch by launch with HIP events on the launch stream ----
-    roofline, breakdown = None, None
+    roofline, breakdown, gemm_shapes = None, None, None
     if rank == 0:
         _hip.prof_enable(True)
         for _ in range(args.prof_steps):
@@ -150,6 +162,7 @@ def main():
         recs = _hip.prof_collect()
         _hip.prof_enable(False)
         agg = kernel_report(recs, args.prof_steps)
+        gemm_shapes = agg.pop("_gemm_shapes")
         dom = max(agg, key=lambda k: agg[k]["ms"])
         e = agg[dom]
         if e["flops"] > 0:
@@ -208,6 +221,7 @@ def main():
             "model_tflops": round(fl["total"] * total / elapsed / 1e12, 2),
             "mfma_peak_frac_end_to_end": round(fl["total"] * total / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernel_breakdown": breakdown,
+            "gemm_shapes": gemm_shapes,
             "build_seconds": round(t_build, 1),
         }
         print(json.dumps(line), flush=True)

@@ -220,6 +220,11 @@ int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t B, int64_t
                        void* logits, int32_t ldt, void* workspace, size_t workspace_bytes,
                        int32_t prec, void* stream);
 
+/* Kernel-variant selection for in-process A/B measurement (tools/gemm_bench.py, tools/ln_bench.py).  Defaults (all 0) are the
+ * shipped configuration.  key 0: LayerNorm variant (0 wave-per-row, 1 workgroup-per-row);
+ * key 1: GEMM tile override used by the stage-level entry points (0 auto, else as kx_gemm_args.tile). */
+int kx_set_tuning(int key, int value);
+
 /* ------------------------------------------------------------------------------------------
  * In-process kernel timing (bench.py's roofline leg; the reference's own ad-hoc equivalents are the
  * wall-clock fences of /root/reference/tests/test_benchmarking.py:68-95,192-196).

@@ -35,6 +35,10 @@ void kx_set_error(const char* fmt, ...);
     if (rc__ != KX_OK) return rc__; \
   } while (0)
 
+// ---- runtime tuning knobs (kx_set_tuning) ----
+enum { KX_TUNE_LN_VARIANT = 0, KX_TUNE_GEMM_TILE = 1, KX_TUNE_COUNT = 8 };
+int kx_tuning_get(int key);
+
 // ---- in-process launch timing (kx_prof_*) ----
 bool kx_prof_on();
 void kx_prof_begin(int kind, int64_t a, int64_t b, int64_t c, hipStream_t s);
@@ -60,9 +64,27 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
-__device__ __forceinline__ float apply_act(float x, int act) {
-  return act == KX_ACT_GELU ? gelu_erf(x) : (act == KX_ACT_QUICK_GELU ? quick_gelu(x) : x);
+__device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
+// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + 5 fma instead of libm erff's two
+// divergent polynomial branches.  Used for GELU in bf16 mode only, where its error (<= 5e-7 on the GELU output
+// for |x| < 6) is three orders of magnitude below the bf16 operand rounding; fp32 mode keeps the exact erff.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // raw v_rcp_f32 (1 ulp), not an IEEE divide
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);   // erf(|x|/sqrt2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
+#define KX_ACT_GELU_FAST 3  /* internal: chosen by kx_gemm for KX_ACT_GELU when prec == bf16 */
+template <int ACT>
+__device__ __forceinline__ float apply_act(float x) {
+  if constexpr (ACT == KX_ACT_GELU) return gelu_erf(x);
+  else if constexpr (ACT == KX_ACT_GELU_FAST) return gelu_erf_fast(x);
+  else if constexpr (ACT == KX_ACT_QUICK_GELU) return quick_gelu(x);
+  else return x;
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

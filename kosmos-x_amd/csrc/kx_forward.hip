@@ -28,6 +28,20 @@ extern "C" int kx_last_error(char* buf, size_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// tuning knobs (kernel-variant A/B from one process; defaults are the shipped configuration)
+// ---------------------------------------------------------------------------------------------
+static int g_tuning[KX_TUNE_COUNT] = {0};
+int kx_tuning_get(int key) { return (key >= 0 && key < KX_TUNE_COUNT) ? g_tuning[key] : 0; }
+extern "C" int kx_set_tuning(int key, int value) {
+  if (key < 0 || key >= KX_TUNE_COUNT) {
+    kx_set_error("kx_set_tuning: unknown key %d", key);
+    return KX_ERR_INVALID_ARG;
+  }
+  g_tuning[key] = value;
+  return KX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch timing
 // ---------------------------------------------------------------------------------------------
 namespace {
@@ -92,7 +106,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   g.bias = bias; g.residual = residual; g.ldr = ldc; g.M = M; g.N = N; g.K = K;
   g.act = act; g.qscale = qscale; g.qcols = qcols;
   g.xq_cs = xq_cs; g.xq_ss = xq_ss; g.xk_cs = xk_cs; g.xk_ss = xk_ss; g.xpos_T = xT; g.xpos_dim = xdim;
-  g.prec = prec; g.tile = 0;
+  g.prec = prec; g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
   return kx_gemm(&g, (void*)s);
 }
 

@@ -29,6 +29,7 @@ struct GemmParams {
   int vec_ok;  // ldc % 4 == 0 (&& ldr % 4 == 0): 16-byte epilogue accesses are aligned
 };
 
+template <int ACT>
 __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32x4_t acc) {
   if (m >= p.M || n >= p.N) return;
   float x[4] = {acc[0], acc[1], acc[2], acc[3]};
@@ -57,7 +58,10 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
     const float y3 = x[3] * c.y + x[2] * s.y;
     x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;
   }
-  if (p.act) { for (int j = 0; j < 4; ++j) x[j] = apply_act(x[j], p.act); }
+  if constexpr (ACT != KX_ACT_NONE) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = apply_act<ACT>(x[j]);
+  }
   const long long off = (long long)m * p.ldc + n;
   if (p.residual) {
     const long long roff = (long long)m * p.ldr + n;
@@ -108,7 +112,7 @@ template <> struct Mma<float> {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int ROWB = 128;                 // bytes per staged tile row = one BK slice
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
@@ -206,23 +210,264 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
   }
 
-  // ---- epilogue: lane holds C[m][n..n+3] with m = frag row li, n = 4g.. ----
+  // ---- epilogue, staged through LDS ----
+  // The accumulator layout (lane = 1 row x 4 columns per fragment) would store 64-byte row segments and
+  // unroll the fused epilogue 16x (a >60 KB instruction stream executed cold once per tile).  Instead each
+  // wave parks its (BM/2)x(BN/2) fp32 sub-tile in its own slice of the (now idle) staging LDS — 16-B chunks
+  // XOR-swizzled by row so both the fragment-shaped writes and the row-shaped reads are conflict-free — and
+  // walks it back row-major: 16 lanes emit one full 256-B row segment per instruction and the epilogue body
+  // exists once, inside a rolled loop.
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int CH = WN / 4;          // 16-byte chunks per sub-tile row (16 or 8)
+  constexpr int RPI = 64 / CH;        // rows covered by one wave-wide access
+  __syncthreads();                    // every wave is done reading the last stage
+  float* cw = reinterpret_cast<float*>(smem) + wave * (WM * WN);
 #pragma unroll
   for (int a = 0; a < FN; ++a)
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
-      const int m = m0 + wm * (BM / 2) + b * 16 + li;
-      const int n = n0 + wn * (BN / 2) + a * 16 + 4 * g;
-      epilogue4(p, m, n, acc[a][b]);
+      const int ml = b * 16 + li, c = a * 4 + g;
+      *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][b];
     }
+  __syncthreads();
+  const int cl = lane % CH, rl = lane / CH;
+  const int mbase = m0 + wm * WM, nbase = n0 + wn * WN + cl * 4;
+#pragma unroll 2
+  for (int r = 0; r < WM; r += RPI) {
+    const int ml = r + rl;
+    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
+    epilogue4<ACT>(p, mbase + ml, nbase, v);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Deep-pipelined variant: 256(m) x 128(n) x 64 block tile, 8 waves (4 x 2, 64x64 each), 3-stage LDS ring
+// (3 x 48 KB = 144 of the CU's 160 KB), ONE raw s_barrier per K-tile and a COUNTED s_waitcnt vmcnt(6):
+// the six LDS-DMA instructions a wave issues for tile t+2 stay in flight across the barrier while tile t is
+// multiplied, so HBM/L2 latency is hidden behind a full tile of MFMA work instead of being drained at every
+// barrier (guide T3+T4).  The larger tile also halves the L2->LDS bytes per flop relative to 128x128
+// (85 vs 64 flop/B): the 128x128 kernel saturates the ~34 TB/s aggregate L2 near 1.0-1.1 PFLOP/s.
+// One workgroup per CU (2 waves per SIMD).
+// -------------------------------------------------------------------------------------------------
+template <typename T, int ACT, bool PHASED>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
+  constexpr int BM = 256, BN = 128, ROWB = 128;
+  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;   // 48 KB
+  constexpr int NST = 3;
+  constexpr int FM = 4, FN = 4;              // 64x64 per wave
+  constexpr int IA = 4, IW = 2;              // glds instructions per wave per stage (8 rows each)
+  constexpr int NLD = IA + IW;               // = the vmcnt distance of one tile
+  static_assert(NLD == 6, "the inline-asm vmcnt immediates below assume 6 loads per tile");
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GROUP = 4;
+  const int per_group = GROUP * p.tiles_n;
+  const int grp = wg / per_group;
+  const int first_m = grp * GROUP;
+  const int gsz = min(p.tiles_m - first_m, GROUP);
+  const int tm = first_m + (wg % per_group) % gsz;
+  const int tn = (wg % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int g = lane >> 4, li = lane & 15;
+
+  const int srow = lane >> 3, schunk = lane & 7;
+  const char* srcA[IA];
+  const char* srcW[IW];
+#pragma unroll
+  for (int j = 0; j < IA; ++j) {
+    const int row = wave * 32 + j * 8 + srow;
+    const int gm = min(m0 + row, p.M - 1);
+    srcA[j] = p.A + (long long)gm * p.lda_b + ((schunk ^ (row & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < IW; ++j) {
+    const int row = wave * 16 + j * 8 + srow;
+    const int gn = min(n0 + row, p.N - 1);
+    srcW[j] = p.W + (long long)gn * p.ldw_b + ((schunk ^ (row & 7)) << 4);
+  }
+  auto stage = [&](int slot, int kt) {
+    char* base = smem + slot * STAGE;
+    const long long koff = (long long)kt * ROWB;
+#pragma unroll
+    for (int j = 0; j < IA; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff), (lds_void_t*)(base + (wave * 32 + j * 8) * ROWB),
+                                       16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < IW; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcW[j] + koff),
+                                       (lds_void_t*)(base + A_BYTES + (wave * 16 + j * 8) * ROWB), 16, 0, 0);
+  };
+
+  f32x4_t acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  int offA[FM], offW[FN];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int row = wm * 64 + b * 16 + li;
+    offA[b] = row * ROWB + ((g ^ (row & 7)) << 4);
+  }
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    const int row = wn * 64 + a * 16 + li;
+    offW[a] = A_BYTES + row * ROWB + ((g ^ (row & 7)) << 4);
+  }
+
+  const int nk = p.K / (ROWB / (int)sizeof(T));
+  stage(0, 0);
+  if (nk > 1) {
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile 0 landed, tile 1 may still fly
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  int slot = 0;
+  if constexpr (!PHASED) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 2 < nk;
+      if (more) stage(slot == 0 ? 2 : slot - 1, kt + 2);   // (kt+2)%3: the slot tile kt-1 just vacated
+      const char* base = smem + slot * STAGE;
+  #pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4_t fa[FM], fw[FN];
+  #pragma unroll
+        for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ (ks << 6)));
+  #pragma unroll
+        for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ (ks << 6)));
+  #pragma unroll
+        for (int a = 0; a < FN; ++a)
+  #pragma unroll
+          for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
+      }
+      // tile kt+1 must be resident (all waves' pieces) before anyone reads it; tile kt+2 keeps flying
+      if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+
+  } else {
+    // Phased schedule (the guide's 8-phase idea, 4 phases per K-tile): each K-tile is split into
+    //   R0: [issue tile t+2's DMA] + ds_read the ks=0 fragments | M0: 16 MFMA | R1: ds_read ks=1 (+ the counted
+    //   vmcnt for tile t+1) | M1: 16 MFMA,   every phase closed by a raw s_barrier.
+    // Waves 4-7 (the second wave on each SIMD) run ONE PHASE BEHIND waves 0-3 (one extra barrier up front, one
+    // extra for waves 0-3 at the end), so on every SIMD one wave is in an MFMA phase while its partner is in a
+    // read phase: the matrix pipe never waits for LDS or for the barrier, and s_setprio has a role split to
+    // arbitrate.  Hazards: a slot is refilled (R0 of tile t+2... its previous tenant t-1) only after every wave's
+    // R1(t-1) reads retired before a barrier both groups have passed; tile t+1 is read only after every wave's
+    // vmcnt(6) in R1(t), which for the lagging group precedes the barrier the leading group passes into R0(t+1).
+    const bool lag = wave >= 4;
+    if (lag) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 2 < nk;
+      const char* base = smem + slot * STAGE;
+      u32x4_t fa[FM], fw[FN];
+      // ---- R0 ----
+      if (more) stage(slot == 0 ? 2 : slot - 1, kt + 2);
+#pragma unroll
+      for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + offA[b]);
+#pragma unroll
+      for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + offW[a]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- M0 ----
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- R1 ----
+#pragma unroll
+      for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ 64));
+#pragma unroll
+      for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ 64));
+      if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- M1 ----
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (!lag) __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue staged through LDS (see gemm_kernel) ----
+  constexpr int WM = 64, WN = 64, CH = WN / 4, RPI = 64 / CH;
+  float* cw = reinterpret_cast<float*>(smem) + wave * (WM * WN);
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      const int ml = b * 16 + li, c = a * 4 + g;
+      *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][b];
+    }
+  __syncthreads();
+  const int cl = lane % CH, rl = lane / CH;
+  const int mbase = m0 + wm * WM, nbase = n0 + wn * WN + cl * 4;
+#pragma unroll 2
+  for (int r = 0; r < WM; r += RPI) {
+    const int ml = r + rl;
+    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
+    epilogue4<ACT>(p, mbase + ml, nbase, v);
+  }
+}
+
+template <typename T, bool PHASED>
+int launch_p3(GemmParams& p, hipStream_t s) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 127) / 128;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+  switch (p.act) {
+    case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel_p3<T, KX_ACT_NONE, PHASED>), grid, block, 0, s, p); break;
+    case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel_p3<T, KX_ACT_GELU, PHASED>), grid, block, 0, s, p); break;
+    case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel_p3<T, KX_ACT_GELU_FAST, PHASED>), grid, block, 0, s, p); break;
+    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel_p3<T, KX_ACT_QUICK_GELU, PHASED>), grid, block, 0, s, p); break;
+    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+  }
+  KX_CHECK_LAUNCH("kx_gemm(p3)");
+  return KX_OK;
 }
 
 template <typename T, int BM, int BN>
 int launch(GemmParams& p, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  const int nwg = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN>), dim3(nwg), dim3(256), 0, s, p);
+  const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  // the activation is a compile-time property of the kernel: a runtime switch costs ~4 scalar branches per value
+  switch (p.act) {
+    case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p); break;
+    case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU>), grid, block, 0, s, p); break;
+    case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU_FAST>), grid, block, 0, s, p); break;
+    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU>), grid, block, 0, s, p); break;
+    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+  }
   KX_CHECK_LAUNCH("kx_gemm");
   return KX_OK;
 }
@@ -253,7 +498,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->cdt == KX_BF16;
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
-  p.act = a->act; p.qscale = a->qscale; p.qcols = (int)a->qcols;
+  p.act = (a->act == KX_ACT_GELU && a->prec == KX_PREC_BF16) ? KX_ACT_GELU_FAST : a->act;
+  p.qscale = a->qscale; p.qcols = (int)a->qcols;
   p.xq_cs = a->xq_cs; p.xq_ss = a->xq_ss; p.xk_cs = a->xk_cs; p.xk_ss = a->xk_ss;
   p.xpos_T = (int)a->xpos_T; p.xpos_dim = (int)a->xpos_dim;
   p.vec_ok = (a->ldc % 4 == 0) && (!a->residual || a->ldr % 4 == 0) &&
@@ -266,10 +512,12 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     const long long t128 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
     tile = t128 >= 192 ? 128 : 64;
   }
-  KxProfScope prof((a->prec == KX_PREC_BF16 ? 0 : 2) + (tile == 128 ? 0 : 1), a->M, a->N, a->K, s);
+  KxProfScope prof((a->prec == KX_PREC_BF16 ? 0 : 2) + (tile >= 128 ? 0 : 1), a->M, a->N, a->K, s);
   if (a->prec == KX_PREC_BF16) {
     if (tile == 128) return launch<bf16_t, 128, 128>(p, s);
     if (tile == 64) return launch<bf16_t, 64, 64>(p, s);
+    if (tile == 256) return launch_p3<bf16_t, true>(p, s);
+    if (tile == 257) return launch_p3<bf16_t, false>(p, s);   // A/B: same tile and ring, unphased
   } else {
     if (tile == 128) return launch<float, 128, 128>(p, s);
     if (tile == 64) return launch<float, 64, 64>(p, s);

@@ -18,11 +18,11 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
-// One workgroup (256 threads) per row; a thread owns up to 8 float4 (cols <= 8192).
+// Variant 1 (A/B reference): one workgroup (256 threads) per row; a thread owns up to 8 float4 (cols <= 8192).
 // Two-pass statistics on the register-resident row: mean, then centred variance (what
 // torch.nn.functional.layer_norm computes), eps inside the rsqrt.
 template <bool OUT_BF16>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ pre_add,
+__global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __restrict__ x, const float* __restrict__ pre_add,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ y,
                                                         int cols, float eps, long long rows_per_group,
@@ -77,6 +77,83 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       }
     }
   }
+}
+
+// Variant 0: one WAVE per row (4 rows per 256-thread workgroup): the row lives in registers (<= 32 float4 per lane for
+// cols <= 8192), statistics are pure wave-64 shuffles — no LDS, no barrier.  Two-pass statistics on the
+// register-resident row: mean, then centred variance (what torch.nn.functional.layer_norm computes).
+template <bool OUT_BF16, int NV>  // NV = float4 per lane (cols <= 256*NV)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ pre_add,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ y,
+                                                        long long rows, int cols, float eps, long long rows_per_group,
+                                                        long long out_group_stride, long long out_row_offset) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * (long long)cols);
+  const int nv = cols >> 2;  // float4 per row
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      v[i] = xr[c];
+      if (pre_add) {
+        const float4 a = reinterpret_cast<const float4*>(pre_add)[c];
+        v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+      }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float var = wave_sum(q) / (float)cols;
+  const float rstd = rsqrtf(var + eps);
+  const long long orow = (row / rows_per_group) * out_group_stride + out_row_offset + row % rows_per_group;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
+      const float4 bt = reinterpret_cast<const float4*>(beta)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+      o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+      o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+      o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+      if (OUT_BF16) {
+        uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
+        reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + orow * (long long)cols)[c] = pk;
+      } else {
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + orow * (long long)cols)[c] = o;
+      }
+    }
+  }
+}
+
+template <bool OUT_BF16, int NV>
+void launch_ln(const float* x, const float* pre_add, const float* gamma, const float* beta, void* y, int64_t rows,
+               int64_t cols, float eps, int64_t rpg, int64_t ogs, int64_t oro, hipStream_t s) {
+  hipLaunchKernelGGL((layernorm_kernel<OUT_BF16, NV>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, pre_add,
+                     gamma, beta, y, (long long)rows, (int)cols, eps, (long long)rpg, (long long)ogs, (long long)oro);
+}
+template <bool OUT_BF16>
+void dispatch_ln(const float* x, const float* pre_add, const float* gamma, const float* beta, void* y, int64_t rows,
+                 int64_t cols, float eps, int64_t rpg, int64_t ogs, int64_t oro, hipStream_t s) {
+  if (cols <= 1024) launch_ln<OUT_BF16, 4>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
+  else if (cols <= 2048) launch_ln<OUT_BF16, 8>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
+  else if (cols <= 4096) launch_ln<OUT_BF16, 16>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
+  else launch_ln<OUT_BF16, 32>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
 }
 
 // Decoder input assembly, one workgroup per output row (b, t), s = splice_at (2 on the Kosmos path):
@@ -183,14 +260,22 @@ extern "C" int kx_layernorm(const float* x, const float* pre_add, const float* g
              "kx_layernorm: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(KX_K_LAYERNORM, rows, cols, 0, s);
-  if (ydt == KX_BF16)
-    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta, y,
-                       (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride,
-                       (long long)out_row_offset);
+  // measured (tools/ln_bench.py): wave-per-row wins up to 2048 columns (3.6-5.1 vs 2.3-4.0 TB/s), workgroup-per-row
+  // wins on the 8192-wide ffn_layernorm rows (4.6 vs 3.2 TB/s: 204 VGPRs/lane cap the wave variant at 2 waves/SIMD)
+  const int variant = kx_tuning_get(KX_TUNE_LN_VARIANT);
+  if (variant == 1 || (variant == 0 && cols > 2048)) {
+    if (ydt == KX_BF16)
+      hipLaunchKernelGGL(layernorm_block_kernel<true>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta,
+                         y, (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride,
+                         (long long)out_row_offset);
+    else
+      hipLaunchKernelGGL(layernorm_block_kernel<false>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta,
+                         y, (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride,
+                         (long long)out_row_offset);
+  } else if (ydt == KX_BF16)
+    dispatch_ln<true>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
   else
-    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta, y,
-                       (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride,
-                       (long long)out_row_offset);
+    dispatch_ln<false>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
   KX_CHECK_LAUNCH("kx_layernorm");
   return KX_OK;
 }

@@ -89,6 +89,7 @@ SYMBOLS = {
     "kx_gemm": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "kx_attention": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "kx_embed_splice": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, vp]),
+    "kx_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "kx_prof_enable": (C.c_int, [C.c_int]),
     "kx_prof_collect": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),
     "kx_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitWeights), i64, i32]),

@@ -89,7 +89,7 @@ SHAPES = [  # (M, N, K): tile edges in M and N, the awkward path dims (SURVEY §
 ]
 
 
-@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("tile", [64, 128, 256, 257])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_bf16_plain(shape, tile):
     M, N, K = shape
@@ -122,9 +122,12 @@ def test_gemm_layout_is_not_transposed():
     assert torch.equal(out.cpu(), w.float().t().contiguous())
 
 
+@pytest.mark.parametrize("tile", [0, 256])
 @pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("act", ["none", "gelu", "quick_gelu"])
-def test_gemm_epilogue_bias_act_residual(prec, act):
+def test_gemm_epilogue_bias_act_residual(prec, act, tile):
+    if tile == 256 and prec == torch.float32:
+        pytest.skip("the 256x128 pipelined kernel is bf16-only")
     M, N, K = 150, 264, 256
     g = _g(11)
     a = torch.randn(M, K, generator=g).to(prec)
@@ -133,10 +136,10 @@ def test_gemm_epilogue_bias_act_residual(prec, act):
     res = torch.randn(M, N, generator=g)
     ref = _gemm_ref(a.float(), w.float(), bias, res, act, 0.125, 64)
     out = res.to(DEV).clone()
-    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, act, qscale=0.125, qcols=64, out=out)  # residual aliases C
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, act, qscale=0.125, qcols=64, out=out, tile=tile)  # residual aliases C
     assert rel_err(out, ref) < 3e-5
     out16 = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), act, out_dtype=torch.bfloat16,
-                     qscale=0.125, qcols=64)
+                     qscale=0.125, qcols=64, tile=tile)
     assert bool(((out16.float().cpu() - ref).abs() <= 2 ** -8 * ref.abs() + 1e-6).all())   # one bf16 rounding
 
 

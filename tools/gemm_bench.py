@@ -17,31 +17,50 @@ SHAPES = {  # name: (M, N, K)
     "c3_fc1": (65472, 8192, 2048),
 }
 
-def bench(name, M, N, K, tile, dtype=torch.bfloat16, iters=10, rounds=3):
+def bench(name, M, N, K, tiles, dtype=torch.bfloat16, iters=10, rounds=5, epi="plain"):
+    """Interleaved A/B over `tiles` (kernel variants) in one process; median of `rounds`."""
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dtype)
     w = (torch.rand(N, K, device="cuda") * 2 - 1).to(dtype)
-    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    for _ in range(2):
-        ops.gemm(a, w, out=out, tile=tile)
-    ts = []
+    kw = {}
+    if epi == "plain":
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    elif epi == "gelu_f32":      # decoder fc1: bias + GELU -> fp32
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        kw = dict(bias=torch.randn(N, device="cuda"), act="gelu")
+    elif epi == "gelu_bf16":     # ViT fc1: bias + GELU -> bf16
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        kw = dict(bias=torch.randn(N, device="cuda"), act="gelu")
+    elif epi == "resid":         # out_proj / fc2: bias + residual (in place, fp32)
+        out = torch.randn(M, N, device="cuda", dtype=torch.float32)
+        kw = dict(bias=torch.randn(N, device="cuda"), residual=out)
+    ts = {t: [] for t in tiles}
+    for t in tiles:
+        for _ in range(2):
+            ops.gemm(a, w, out=out, tile=t, **kw)
     for _ in range(rounds):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            ops.gemm(a, w, out=out, tile=tile)
-        e1.record(); e1.synchronize()
-        ts.append(e0.elapsed_time(e1) / iters)
-    ms = statistics.median(ts)
-    return {"shape": name, "M": M, "N": N, "K": K, "tile": tile, "ms": round(ms, 4),
-            "tflops": round(2.0 * M * N * K / ms / 1e9, 1)}
+        for t in tiles:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                ops.gemm(a, w, out=out, tile=t, **kw)
+            e1.record(); e1.synchronize()
+            ts[t].append(e0.elapsed_time(e1) / iters)
+    r = {"shape": name, "M": M, "N": N, "K": K, "epi": epi}
+    for t in tiles:
+        ms = statistics.median(ts[t])
+        r[f"t{t}_us"] = round(ms * 1e3, 1)
+        r[f"t{t}_tf"] = round(2.0 * M * N * K / ms / 1e9, 1)
+    return r
 
 if __name__ == "__main__":
     tiles = [int(t) for t in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["128", "64"])]
     only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+    EPI = {"dec_fc1_b32": "gelu_f32", "vit_fc1_b32": "gelu_bf16", "dec_out_b32": "resid", "dec_fc2_b32": "resid",
+           "vit_out_b32": "resid", "vit_fc2_b32": "resid", "c3_fc1": "gelu_f32"}
     for name, (M, N, K) in SHAPES.items():
         if only and name not in only:
             continue
-        for t in tiles:
-            if t == 64 and M * N > 5e7:
-                continue
-            print(json.dumps(bench(name, M, N, K, t)), flush=True)
+        ts = [t for t in tiles if not (t == 64 and M * N > 5e7)]
+        print(json.dumps(bench(name, M, N, K, ts)), flush=True)
+        if name in EPI:
+            print(json.dumps(bench(name, M, N, K, ts, epi=EPI[name])), flush=True)
