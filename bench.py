@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3, help="instrumented steps for the roofline leg")
+    ap.add_argument("--streams", type=int, default=1, help="micro-batch the shard over S HIP streams (overlaps kernel tails)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="kernel-variant override (kx_set_tuning key 1), A/B only")
     return ap.parse_args()
 
@@ -122,9 +123,28 @@ def main():
     img = torch.randn(B, 3, cfg.vit.image, cfg.vit.image, generator=g).to(dev)
     gatherer = LogitsGatherer(wire_dtype=torch.bfloat16) if (world > 1 and not args.no_gather) else None
 
+    S = max(1, args.streams)
+    side = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
+    toks, imgs = tok.chunk(S), img.chunk(S)
+    logits_buf = torch.empty((B, Tt + cfg.perceiver.latents, cfg.vocab), dtype=torch.float32, device=dev) if S > 1 else None
+
+    def forward_shard():
+        if S == 1:
+            return model(tok, img)
+        cur = torch.cuda.current_stream(dev)
+        lo = 0
+        for st, t_, i_ in zip(side, toks, imgs):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                logits_buf[lo:lo + t_.shape[0]].copy_(model(t_, i_))
+            lo += t_.shape[0]
+        for st in side:
+            cur.wait_stream(st)
+        return logits_buf
+
     def step():
         with torch.no_grad():
-            logits = model(tok, img)
+            logits = forward_shard()
             if gatherer is not None:
                 return gatherer.gather(logits)
             return logits
@@ -216,7 +236,8 @@ def main():
                                    "24L/2048d sub-LN XPos decoder, random-init weights (BASELINE.json configs[3] per-GPU share)",
                        "batch_per_gpu": B, "global_batch": world * B, "seq_len": Tt + cfg.perceiver.latents,
                        "text_len": Tt, "parallelism": f"dp{world}",
-                       "logits_gather": (None if gatherer is None else "RCCL all-gather, bf16 wire, overlapped")},
+                       "logits_gather": (None if gatherer is None else "RCCL all-gather, bf16 wire, overlapped"),
+                       "micro_batch_streams": S},
             "algorithmic_gflop_per_sample": round(fl["total"] / 1e9, 2),
             "model_tflops": round(fl["total"] * total / elapsed / 1e12, 2),
             "mfma_peak_frac_end_to_end": round(fl["total"] * total / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world), 4),

@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
   constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave (2x2 waves)
   constexpr int IA = BM / 32, IW = BN / 32;  // glds instructions per wave per stage (8 rows each)
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  constexpr int EPI_BYTES = BM * BN * 4;     // the epilogue parks the whole fp32 tile in LDS
+  constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU must fit the 160 KB LDS");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   // ---- XCD-aware, grouped tile mapping ----
   const int nwg = p.tiles_m * p.tiles_n;
@@ -506,16 +509,38 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
              (((uintptr_t)a->C & 15) == 0) && (!a->residual || ((uintptr_t)a->residual & 15) == 0);
   KX_REQUIRE(!a->bias || ((uintptr_t)a->bias & 15) == 0, "kx_gemm: bias must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  // tile choice: 128x128 unless the grid would leave most of the 256 CUs idle
+  // Kernel-variant choice (measured on MI355X with tools/gemm_bench.py and in situ with bench.py):
+  //   64x64    when 128x128 tiles would leave most of the 256 CUs idle (batch-1 shapes);
+  //   256x128 phased/pipelined (one workgroup per CU) when K is long enough to amortise its prologue and its grid
+  //            fills the chip evenly — the decoder's M = B*114 GEMMs;
+  //   160x128  when it removes a nearly empty trailing wave of 128x128 tiles — the ViT's M = B*257 = 64.25 x 128
+  //            GEMMs (520 tiles on 512 slots) — estimated with the cost model below;
+  //   128x128  otherwise.
   int tile = a->tile;
   if (tile == 0) {
-    const long long t128 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
-    tile = t128 >= 192 ? 128 : 64;
+    auto cdiv = [](long long x, long long y) { return (x + y - 1) / y; };
+    const long long t128 = cdiv(a->M, 128) * cdiv(a->N, 128);
+    if (t128 < 192) {
+      tile = 64;
+    } else if (a->prec != KX_PREC_BF16) {
+      tile = 128;
+    } else {
+      const long long t256 = cdiv(a->M, 256) * cdiv(a->N, 128);
+      const double eff256 = (double)t256 / (double)(cdiv(t256, 256) * 256);
+      auto cost = [&](int bm) {  // tile-time units: full waves of 512 resident tiles, cheaper trailing wave if <= 1 tile/CU
+        const long long t = cdiv(a->M, bm) * cdiv(a->N, 128);
+        const long long full = t / 512, rem = t % 512;
+        return bm * ((double)full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.62 : 1.0)));
+      };
+      if (a->K >= 2048 && eff256 >= 0.85 && a->N <= 16384) tile = 256;
+      else tile = cost(160) <= cost(128) ? 160 : 128;
+    }
   }
   KxProfScope prof((a->prec == KX_PREC_BF16 ? 0 : 2) + (tile >= 128 ? 0 : 1), a->M, a->N, a->K, s);
   if (a->prec == KX_PREC_BF16) {
     if (tile == 128) return launch<bf16_t, 128, 128>(p, s);
     if (tile == 64) return launch<bf16_t, 64, 64>(p, s);
+    if (tile == 160) return launch<bf16_t, 160, 128>(p, s);
     if (tile == 256) return launch_p3<bf16_t, true>(p, s);
     if (tile == 257) return launch_p3<bf16_t, false>(p, s);   // A/B: same tile and ring, unphased
   } else {

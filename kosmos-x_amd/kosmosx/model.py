@@ -60,15 +60,18 @@ def _require_cuda(t: torch.Tensor, what: str):
 
 
 class _Workspace:
-    """Grow-only device scratch shared by the three stages (they run back to back on one stream)."""
+    """Grow-only device scratch shared by the three stages (they run back to back on one stream).
+    One buffer per HIP stream: forwards issued on different streams (micro-batch overlap) never share scratch."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-        return self.buf
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self.bufs[key] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        return buf
 
 
 class _PackedMixin:

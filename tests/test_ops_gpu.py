@@ -89,7 +89,7 @@ SHAPES = [  # (M, N, K): tile edges in M and N, the awkward path dims (SURVEY §
 ]
 
 
-@pytest.mark.parametrize("tile", [64, 128, 256, 257])
+@pytest.mark.parametrize("tile", [0, 64, 128, 160, 256, 257])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_bf16_plain(shape, tile):
     M, N, K = shape
