@@ -1,0 +1,81 @@
+"""Generates the committed golden fixtures (run in the build container, where `transformers` is importable):
+
+    python tests/golden/make_golden.py
+
+  clip_tiny.npz    weights + input + last_hidden_state of the INSTALLED HF CLIPVisionModel (the only primary
+                   implementation on the path that can be imported) at a reduced config.
+  kosmos_tiny.npz  seeded inputs + stage outputs + logits of the CPU oracle for the tiny end-to-end model
+                   (weights are regenerated from the seed by the product's init; their checksum is stored so a
+                   change of the RNG stream is detected instead of mis-reported as a parity failure).
+  xpos_tables.npz  XPos cos*scale / sin*scale tables for T in {1, 2, 9, 114, 115}, q and k variants.
+Fixtures are data (inputs and expected outputs) — no reference source text is stored.
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+for p in (str(ROOT), str(ROOT / "kosmos-x_amd"), str(ROOT / "tests")):
+    sys.path.insert(0, p)
+os.environ.setdefault("KOSMOSX_NO_LOGGING_CONFIG", "1")
+
+from oracle import kosmos_oracle as O  # noqa: E402
+
+
+def weight_checksum(w: dict) -> float:
+    return float(sum(float(v.double().abs().sum()) for _, v in sorted(w.items())))
+
+
+def make_clip():
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    cfg = CLIPVisionConfig(hidden_size=128, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2,
+                           image_size=28, patch_size=14, hidden_act="gelu", layer_norm_eps=1e-5)
+    torch.manual_seed(0)
+    hf = CLIPVisionModel._from_config(cfg, attn_implementation="eager").eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+        x = torch.randn(2, 3, 28, 28, generator=g)
+        y = hf(pixel_values=x).last_hidden_state
+    sd = hf.state_dict()
+    pre = "vision_model." if any(k.startswith("vision_model.") for k in sd) else ""
+    out = {"w:" + k[len(pre):]: v.numpy() for k, v in sd.items() if k.startswith(pre) and v.dtype == torch.float32}
+    np.savez_compressed(HERE / "clip_tiny.npz", pixels=x.numpy(), last_hidden_state=y.numpy(), **out)
+
+
+def make_kosmos():
+    from helpers import oracle_cfg, oracle_weights, tiny_config
+    from kosmosx.model import Kosmos
+    m = Kosmos._from_config(tiny_config(), seed=1234, perturb=0.1).eval()
+    w, cfg = oracle_weights(m), oracle_cfg(m.cfg)
+    g = torch.Generator().manual_seed(5)
+    tok = torch.randint(0, m.cfg.vocab, (2, 11), generator=g)
+    img = torch.randn(2, 3, 56, 56, generator=g)
+    st = {}
+    logits = O.kosmos_forward(w, tok, img, cfg, O.Switches(), st)
+    np.savez_compressed(HERE / "kosmos_tiny.npz", seed=1234, perturb=0.1, tokens=tok.numpy(), images=img.numpy(),
+                        weight_checksum=weight_checksum(w), vit=st["vit"].numpy(), perceiver=st["perceiver"].numpy(),
+                        embed=st["embed"].numpy(), logits=logits.numpy())
+
+
+def make_xpos():
+    out = {}
+    for T in (1, 2, 9, 114, 115):
+        for name, down in (("q", False), ("k", True)):
+            cs, ss = O.xpos_tables(T, 64, 512, 0, down)
+            out[f"{name}_cs_{T}"] = cs.numpy()
+            out[f"{name}_ss_{T}"] = ss.numpy()
+    np.savez_compressed(HERE / "xpos_tables.npz", **out)
+
+
+if __name__ == "__main__":
+    make_clip()
+    make_kosmos()
+    make_xpos()
+    for f in sorted(HERE.glob("*.npz")):
+        print(f.name, f.stat().st_size)
