@@ -222,7 +222,8 @@ int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t B, int64_t
 
 /* Kernel-variant selection for in-process A/B measurement (tools/gemm_bench.py, tools/ln_bench.py).  Defaults (all 0) are the
  * shipped configuration.  key 0: LayerNorm variant (0 wave-per-row, 1 workgroup-per-row);
- * key 1: GEMM tile override used by the stage-level entry points (0 auto, else as kx_gemm_args.tile). */
+ * key 1: GEMM tile override used by the stage-level entry points (0 auto, else as kx_gemm_args.tile);
+ * key 2: bf16 attention variant (0 = v2: 32 queries/wave, transpose-read V, prefetched tiles; 1 = v1). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

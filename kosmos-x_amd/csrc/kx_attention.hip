@@ -152,6 +152,198 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// v2 (shipped): same transposed formulation, restructured for reuse and latency hiding
+//   * 32 queries per wave (two 16-query MFMA column blocks): every K / V fragment read from LDS feeds 2 MFMAs;
+//     one workgroup = 4 waves = 128 queries, KV tiles of 64 keys.
+//   * V stays ROW-MAJOR in LDS and is fed to the MFMA through ds_read_b64_tr_b16 (gfx950 transpose read; semantics
+//     probed on hardware by tools/probes/tr_probe.hip: lane (g,i) supplying &V[4g + (i>>2)][(i&3)*4] receives
+//     V[4g+j][i], j=0..3) — no 2-byte transposing stores.  Row pitch 160 B keeps the 8 rows a 32-lane service
+//     group touches on disjoint banks.  K rows are 128 B with the 16-B chunk XOR-swizzled by key&7.
+//   * K/V tiles are double-buffered in LDS and register-prefetched (guide T14): the global loads of tile t+1 are
+//     issued before tile t's MFMAs and written to the other buffer after them — one barrier per tile.
+//   * causal: tiles above the diagonal are never loaded; a wave skips the MFMA/softmax work of a tile that lies
+//     entirely above its own queries, and waves without a live query only help with the loads.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+constexpr int VSTR = 80;   // V tile row pitch in elements (160 B)
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bf16_v2_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * 64];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * VSTR];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  // Causal work grows linearly with the query-block index and the dispatcher does not rebalance it (measured:
+  // with one query block per workgroup a causal launch took as long as the unmasked one).  So a causal workgroup
+  // processes the PAIR (x, nx-1-x): every workgroup carries the same nx+1 tiles whatever the placement.
+  const int nx = (p.Tq + 127) >> 7;
+  const int qb_second = nx - 1 - (int)blockIdx.x;
+  const int npass = (CAUSAL && qb_second > (int)blockIdx.x) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qblk0 = (pass == 0 ? (int)blockIdx.x : qb_second) * 128;
+  const int qw0 = qblk0 + wave * 32;                        // first query of this wave
+  const bool wave_live = qw0 < p.Tq;
+  const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + (long long)b * p.qbs + (long long)h * 64;
+  const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + (long long)b * p.kbs + (long long)h * 64;
+  const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + (long long)b * p.kbs + (long long)h * 64;
+
+  u32x4_t qf[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const bf16_t* qr = qp + (long long)min(qw0 + qb * 16 + li, p.Tq - 1) * p.qrs + 8 * g;
+    qf[qb][0] = *reinterpret_cast<const u32x4_t*>(qr);
+    qf[qb][1] = *reinterpret_cast<const u32x4_t*>(qr + 32);
+  }
+  f32x4_t ot[2][4];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ot[qb][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+
+  int ntiles = (p.Tk + 63) >> 6;
+  if (CAUSAL) ntiles = min(ntiles, (min(qblk0 + 127, p.Tq - 1) >> 6) + 1);
+
+  // cooperative tile loads: thread owns chunks c = tid, tid+256 -> (row c>>3, 16-B part c&7)
+  u32x4_t kreg[2], vreg[2];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + 256 * j, row = c >> 3, part = c & 7;
+      const int key = t * 64 + row;
+      kreg[j] = (u32x4_t){0u, 0u, 0u, 0u};
+      vreg[j] = kreg[j];
+      if (key < p.Tk) {
+        kreg[j] = *reinterpret_cast<const u32x4_t*>(kp + (long long)key * p.krs + part * 8);
+        vreg[j] = *reinterpret_cast<const u32x4_t*>(vp + (long long)key * p.krs + part * 8);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + 256 * j, row = c >> 3, part = c & 7;
+      *reinterpret_cast<u32x4_t*>(&Ks[buf][row * 64 + ((part ^ (row & 7)) << 3)]) = kreg[j];
+      *reinterpret_cast<u32x4_t*>(&Vs[buf][row * VSTR + part * 8]) = vreg[j];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1, kv0 = t * 64;
+    if (t + 1 < ntiles) gload(t + 1);
+    const bool work = wave_live && (!CAUSAL || kv0 <= min(qw0 + 31, p.Tq - 1));
+    if (work) {
+      // ---- S^T = K Q^T : one K fragment feeds both query blocks ----
+      f32x4_t st[2][4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        st[0][kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        st[1][kb] = st[0][kb];
+        const int krow = kb * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4_t kf =
+              *reinterpret_cast<const u32x4_t*>(&Ks[buf][krow * 64 + (((ks * 4 + g) ^ (krow & 7)) << 3)]);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                                 __builtin_bit_cast(bf16x8_t, qf[qb][ks]), st[qb][kb],
+                                                                 0, 0, 0);
+        }
+      }
+      // ---- online softmax per query block (query = lane&15; its keys sit in 4 lanes x 16 registers) ----
+      u32x4_t pf[2][2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int qi = qw0 + qb * 16 + li;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kv0 + kb * 16 + 4 * g + r;
+            const bool ok = key < p.Tk && (!CAUSAL || key <= qi);
+            st[qb][kb][r] = ok ? st[qb][kb][r] : -INFINITY;
+            mloc = fmaxf(mloc, st[qb][kb][r]);
+          }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run[qb], mloc);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __expf(m_run[qb] - m_safe);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st[qb][kb][r] = __expf(st[qb][kb][r] - m_safe);
+            psum += st[qb][kb][r];
+          }
+        l_run[qb] = l_run[qb] * alpha + psum;
+        m_run[qb] = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ot[qb][d] *= alpha;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          pf[qb][c][0] = pack_bf16x2(st[qb][2 * c][0], st[qb][2 * c][1]);
+          pf[qb][c][1] = pack_bf16x2(st[qb][2 * c][2], st[qb][2 * c][3]);
+          pf[qb][c][2] = pack_bf16x2(st[qb][2 * c + 1][0], st[qb][2 * c + 1][1]);
+          pf[qb][c][3] = pack_bf16x2(st[qb][2 * c + 1][2], st[qb][2 * c + 1][3]);
+        }
+      }
+      // ---- O^T += V^T P^T : V fragment by transpose-read, k index (g,v) <-> key 32c + 16(v>>2) + 4g + (v&3) ----
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bf16_t* vr = &Vs[buf][(32 * c + 4 * g + (li >> 2)) * VSTR + d * 16 + (li & 3) * 4];
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)vr);
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vr + 16 * VSTR));
+          const u32x2_t lo2 = __builtin_bit_cast(u32x2_t, lo), hi2 = __builtin_bit_cast(u32x2_t, hi);
+          const u32x4_t vf = (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]};
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            ot[qb][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                                __builtin_bit_cast(bf16x8_t, pf[qb][c]), ot[qb][d],
+                                                                0, 0, 0);
+        }
+    }
+    if (t + 1 < ntiles) lstore(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l = l_run[qb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int qi = qw0 + qb * 16 + li;
+    if (qi < p.Tq) {
+      const long long ooff = (long long)b * p.obs + (long long)qi * p.ors + (long long)h * 64 + 4 * g;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const float o0 = ot[qb][d][0] * inv, o1 = ot[qb][d][1] * inv, o2 = ot[qb][d][2] * inv, o3 = ot[qb][d][3] * inv;
+        if (p.o_bf16) {
+          uint2 pk; pk.x = pack_bf16x2(o0, o1); pk.y = pack_bf16x2(o2, o3);
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + ooff + d * 16) = pk;
+        } else {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + ooff + d * 16) = make_float4(o0, o1, o2, o3);
+        }
+      }
+    }
+  }
+  }  // pass
+}
+
 // fp32 parity path: one wave per query, exact expf, scores in LDS.
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
@@ -228,10 +420,16 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(a->prec == KX_PREC_BF16 ? KX_K_ATTN_BF16 : KX_K_ATTN_F32, a->B * a->H, a->Tq, a->Tk, s);
-  if (a->prec == KX_PREC_BF16) {
+  if (a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1) {   // v1, kept for A/B
     dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, p);
+  } else if (a->prec == KX_PREC_BF16) {
+    const unsigned nx = (unsigned)((a->Tq + 127) / 128);
+    if (a->mask == KX_ATTN_CAUSAL)   // causal workgroups take query-block pairs (x, nx-1-x)
+      hipLaunchKernelGGL(attn_bf16_v2_kernel<true>, dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL(attn_bf16_v2_kernel<false>, dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
   } else {
     dim3 grid((unsigned)((a->Tq + 3) / 4), (unsigned)a->H, (unsigned)a->B);
     const size_t lds = 4 * (64 + (size_t)a->Tk) * sizeof(float);
