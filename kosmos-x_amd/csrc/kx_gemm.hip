@@ -458,6 +458,179 @@ int launch_p3(GemmParams& p, hipStream_t s) {
   return KX_OK;
 }
 
+// -------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 phased variant for the large problems (C3: M = 65,472): 8 waves (2 x 4), each owning a
+// 128(m) x 64(n) sub-tile = 8 x 4 fragments.  Why: at 64x64 per wave every MFMA needs 0.5 ds_read_b128 (1 KB) plus
+// its share of the LDS-DMA fill (256 B) = 768 B of LDS traffic per MFMA, i.e. 192 of the CU's 256 B/clk at full
+// MFMA rate — the 128x128 and 256x128 kernels are LDS-bandwidth bound near 1.0-1.1 PFLOP/s.  A 128x64 wave tile
+// needs 12 reads per 32 MFMAs (0.375 KB) and the 256x256 block halves the fill per flop (128 B): 512 B/MFMA.
+// Two LDS stages of 64 KB (128 of 160 KB), one workgroup per CU; the fill of tile t+1 is issued when tile t's
+// first phase starts and waited for (vmcnt(0)) in its third phase, so it has two MFMA phases to land.
+// Same 4-phase / lagging-half schedule as gemm_kernel_p3<PHASED>.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, ROWB = 128;
+  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;   // 64 KB
+  constexpr int FM = 8, FN = 4;              // 128(m) x 64(n) per wave
+  constexpr int IA = 4, IW = 4;              // glds instructions per wave per stage (8 rows each)
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GROUP = 4;
+  const int per_group = GROUP * p.tiles_n;
+  const int grp = wg / per_group;
+  const int first_m = grp * GROUP;
+  const int gsz = min(p.tiles_m - first_m, GROUP);
+  const int tm = first_m + (wg % per_group) % gsz;
+  const int tn = (wg % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int g = lane >> 4, li = lane & 15;
+
+  const int srow = lane >> 3, schunk = lane & 7;
+  const char* srcA[IA];
+  const char* srcW[IW];
+#pragma unroll
+  for (int j = 0; j < IA; ++j) {
+    const int row = wave * 32 + j * 8 + srow;
+    const int gm = min(m0 + row, p.M - 1);
+    srcA[j] = p.A + (long long)gm * p.lda_b + ((schunk ^ (row & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < IW; ++j) {
+    const int row = wave * 32 + j * 8 + srow;
+    const int gn = min(n0 + row, p.N - 1);
+    srcW[j] = p.W + (long long)gn * p.ldw_b + ((schunk ^ (row & 7)) << 4);
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE;
+    const long long koff = (long long)kt * ROWB;
+#pragma unroll
+    for (int j = 0; j < IA; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff), (lds_void_t*)(base + (wave * 32 + j * 8) * ROWB),
+                                       16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < IW; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcW[j] + koff),
+                                       (lds_void_t*)(base + A_BYTES + (wave * 32 + j * 8) * ROWB), 16, 0, 0);
+  };
+
+  f32x4_t acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  int offA[FM], offW[FN];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int row = wm * 128 + b * 16 + li;
+    offA[b] = row * ROWB + ((g ^ (row & 7)) << 4);
+  }
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    const int row = wn * 64 + a * 16 + li;
+    offW[a] = A_BYTES + row * ROWB + ((g ^ (row & 7)) << 4);
+  }
+
+  const int nk = p.K / (ROWB / (int)sizeof(T));
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const bool lag = wave >= 4;
+  if (lag) __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* base = smem + (kt & 1) * STAGE;
+    u32x4_t fa[FM], fw[FN];
+    // ---- R0 ----
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+#pragma unroll
+    for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + offW[a]);
+#pragma unroll
+    for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + offA[b]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M0 ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- R1 ----
+#pragma unroll
+    for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ 64));
+#pragma unroll
+    for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ 64));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed (this wave's pieces)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M1 ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!lag) __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue staged through LDS in two 64-row halves (8 waves x 64x64 fp32 = 128 KB) ----
+  constexpr int WN = 64, CH = WN / 4, RPI = 64 / CH;
+  float* cw = reinterpret_cast<float*>(smem) + wave * (64 * WN);
+  const int cl = lane % CH, rl = lane / CH;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();   // previous half's rows have been read back / the K loop is over
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ml = b * 16 + li, c = a * 4 + g;
+        *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][half * 4 + b];
+      }
+    __syncthreads();
+    const int mbase = m0 + wm * 128 + half * 64, nbase = n0 + wn * WN + cl * 4;
+#pragma unroll 2
+    for (int r = 0; r < 64; r += RPI) {
+      const int ml = r + rl;
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
+      epilogue4<ACT>(p, mbase + ml, nbase, v);
+    }
+  }
+}
+
+template <typename T>
+int launch_p5(GemmParams& p, hipStream_t s) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+  switch (p.act) {
+    case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE>), grid, block, 0, s, p); break;
+    case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU>), grid, block, 0, s, p); break;
+    case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST>), grid, block, 0, s, p); break;
+    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_QUICK_GELU>), grid, block, 0, s, p); break;
+    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+  }
+  KX_CHECK_LAUNCH("kx_gemm(p5)");
+  return KX_OK;
+}
+
 template <typename T, int BM, int BN>
 int launch(GemmParams& p, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -511,6 +684,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // Kernel-variant choice (measured on MI355X with tools/gemm_bench.py and in situ with bench.py):
   //   64x64    when 128x128 tiles would leave most of the 256 CUs idle (batch-1 shapes);
+  //   256x256 phased (one workgroup per CU, 128x64 per wave) when its grid fills the chip — C3, decoder fc1;
   //   256x128 phased/pipelined (one workgroup per CU) when K is long enough to amortise its prologue and its grid
   //            fills the chip evenly — the decoder's M = B*114 GEMMs;
   //   160x128  when it removes a nearly empty trailing wave of 128x128 tiles — the ViT's M = B*257 = 64.25 x 128
@@ -532,7 +706,12 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
         const long long full = t / 512, rem = t % 512;
         return bm * ((double)full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.62 : 1.0)));
       };
-      if (a->K >= 2048 && eff256 >= 0.85 && a->N <= 16384) tile = 256;
+      const long long t512 = cdiv(a->M, 256) * cdiv(a->N, 256);
+      const double eff512 = (double)t512 / (double)(cdiv(t512, 256) * 256);
+      // 256x256 (128x64 per wave) is the fastest main loop (1.37 vs 1.09 PFLOP/s at 8192^3: 512 vs 768 B of LDS
+      // traffic per MFMA) but needs >= ~0.85 of a 256-CU wave of tiles to pay: C3-sized problems, decoder fc1
+      if (a->K >= 1024 && eff512 >= 0.85) tile = 512;
+      else if (a->K >= 2048 && eff256 >= 0.85 && a->N <= 16384) tile = 256;
       else tile = cost(160) <= cost(128) ? 160 : 128;
     }
   }
@@ -543,6 +722,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     if (tile == 160) return launch<bf16_t, 160, 128>(p, s);
     if (tile == 256) return launch_p3<bf16_t, true>(p, s);
     if (tile == 257) return launch_p3<bf16_t, false>(p, s);   // A/B: same tile and ring, unphased
+    if (tile == 512) return launch_p5<bf16_t>(p, s);          // 256x256, 128x64 per wave
   } else {
     if (tile == 128) return launch<float, 128, 128>(p, s);
     if (tile == 64) return launch<float, 64, 64>(p, s);

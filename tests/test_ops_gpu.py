@@ -89,7 +89,7 @@ SHAPES = [  # (M, N, K): tile edges in M and N, the awkward path dims (SURVEY §
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 64, 128, 160, 256, 257])
+@pytest.mark.parametrize("tile", [0, 64, 128, 160, 256, 257, 512])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_bf16_plain(shape, tile):
     M, N, K = shape
@@ -122,11 +122,11 @@ def test_gemm_layout_is_not_transposed():
     assert torch.equal(out.cpu(), w.float().t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 256])
+@pytest.mark.parametrize("tile", [0, 256, 512])
 @pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("act", ["none", "gelu", "quick_gelu"])
 def test_gemm_epilogue_bias_act_residual(prec, act, tile):
-    if tile == 256 and prec == torch.float32:
+    if tile >= 256 and prec == torch.float32:
         pytest.skip("the 256x128 pipelined kernel is bf16-only")
     M, N, K = 150, 264, 256
     g = _g(11)
