@@ -96,6 +96,15 @@ typedef struct {
   int64_t xpos_T; int64_t xpos_dim;           /* 0 to disable */
   int32_t prec;                               /* kx_precision */
   int32_t tile;                               /* 0 = auto; kernel variant override for tests/bench */
+  /* Folded sub-LayerNorm (Magneto sub-LN: inner_attn_ln before out_proj, ffn_layernorm before fc2).
+   * Consumer side: with row_stats [M,2] = (mean, rstd) of each A row and colsum [N] = Σ_k W[n,k], and W holding
+   * γ ⊙ W_original, the epilogue starts with v = rstd·(acc − mean·colsum[n]); pass β·W_originalᵀ + b as `bias`.
+   * Then y = LN(A)·Wᵀ + b without a LayerNorm pass over A.
+   * Producer side: stats_out [M, N/32, 2] receives, per row and 32-column segment, (sum, Σ(x − segment mean)²)
+   * of the value after the activation (before any residual; N % 32 == 0) — kx_row_stats_finalize turns them
+   * into (mean, rstd). */
+  const float* row_stats; const float* colsum;
+  float* stats_out;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 
@@ -113,8 +122,16 @@ typedef struct {
   int64_t B, H, Tq, Tk;
   int32_t mask;                               /* kx_attn_mask */
   int32_t prec;
+  float* stats_out;                           /* optional [B*Tq, H, 2]: per row and head (sum, M2 about the head's mean)
+                                                 of the 64 output values, for the folded inner_attn_ln */
 } kx_attn_args;
 int kx_attention(const kx_attn_args* args, void* stream);
+
+/* (mean, rstd) per row from partial statistics: partials [rows, nseg, 2] = (sum, M2 about the segment mean) over
+ * segments of seg_size values each; combined with Chan's parallel-variance formula (what a two-pass LayerNorm
+ * computes, to fp32 rounding).  out [rows, 2] = (mean, 1/sqrt(var + eps)), var biased as in torch LayerNorm. */
+int kx_row_stats_finalize(const float* partials, int64_t rows, int64_t nseg, int64_t seg_size, float eps,
+                          float* out, void* stream);
 
 /* Decoder input assembly (a6-a8): token gather + learned positions (fairseq offset 2) +
  * image-token splice + second position add.
@@ -191,15 +208,21 @@ int kx_perceiver_forward(const kx_perceiver_weights* w, const float* x, int64_t 
                          float* out, float* lat_out, void* workspace, size_t workspace_bytes,
                          int32_t prec, void* stream);
 
+/* With subln != 0 the two sub-LayerNorms are FOLDED into the GEMMs that consume them (no LayerNorm pass, no fp32
+ * intermediate): the caller packs, with γ/β = the sub-LN's weight/bias and W/b = the following Linear,
+ *     w  := γ ⊙ W (column k scaled by γ_k, then cast to the operand dtype),
+ *     b  := W·β + b  (fp32),        w*_colsum[n] := Σ_k w[n,k]  (fp32 sum of the cast values)
+ * for (inner_attn_ln, out_proj) -> wo/bo/wo_colsum and (ffn_layernorm, fc2) -> w2/b2/w2_colsum.
+ * With subln == 0 wo/bo/w2/b2 are the plain weights and the colsum pointers are unused. */
 typedef struct {
   const float *sa_g, *sa_b;                   /* self_attn_layer_norm.A */
   const void* wqkv; const float* bqkv;        /* cat(q,k,v)_proj.A [3d,d] */
-  const float *in_g, *in_b;                   /* self_attn.inner_attn_ln.A (sub-LN) */
-  const void* wo;   const float* bo;          /* self_attn.out_proj.A */
+  const void* wo;   const float* bo;          /* self_attn.out_proj.A (sub-LN folded, see above) */
+  const float* wo_colsum;
   const float *fl_g, *fl_b;                   /* final_layer_norm.A */
   const void* w1;   const float* b1;          /* ffn.A.fc1 */
-  const float *fn_g, *fn_b;                   /* ffn.A.ffn_layernorm (sub-LN) */
-  const void* w2;   const float* b2;          /* ffn.A.fc2 */
+  const void* w2;   const float* b2;          /* ffn.A.fc2 (sub-LN folded) */
+  const float* w2_colsum;
 } kx_decoder_layer;
 
 typedef struct {

@@ -21,6 +21,7 @@ struct AttnParams {
   const char* k; const char* v; long long kbs, krs;
   void* out; long long obs, ors; int o_bf16;
   int B, H, Tq, Tk;
+  float* stats_out;   // [B*Tq, H, 2] partial LayerNorm statistics of the output rows (folded inner_attn_ln), or null
 };
 
 constexpr int KSTR = 72;  // LDS row stride (elements) for the 64-wide K / Vᵀ tiles: 144 B, 16-B aligned rows
@@ -327,6 +328,24 @@ __global__ __launch_bounds__(256) void attn_bf16_v2_kernel(const AttnParams p) {
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     const int qi = qw0 + qb * 16 + li;
+    if (p.stats_out) {   // (sum, M2 about the mean) of this query's 64 outputs for head h: 16 local values x 4 lanes
+      float sm = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) sm += (ot[qb][d][0] + ot[qb][d][1]) + (ot[qb][d][2] + ot[qb][d][3]);
+      sm *= inv;
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const float mu = sm * (1.0f / 64.0f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float dv = ot[qb][d][r] * inv - mu; m2 += dv * dv; }
+      m2 += __shfl_xor(m2, 16, 64);
+      m2 += __shfl_xor(m2, 32, 64);
+      if (g == 0 && qi < p.Tq)
+        *reinterpret_cast<float2*>(p.stats_out + 2 * (((long long)b * p.Tq + qi) * p.H + h)) = make_float2(sm, m2);
+    }
     if (qi < p.Tq) {
       const long long ooff = (long long)b * p.obs + (long long)qi * p.ors + (long long)h * 64 + 4 * g;
 #pragma unroll
@@ -390,6 +409,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
   float o = 0.f;
   for (int key = 0; key < kmax; ++key) o = fmaf(sc[key], vp[(long long)key * p.krs + lane], o);
   o /= sum;
+  if (p.stats_out) {
+    const float sm = wave_sum(o);
+    const float dv = o - sm * (1.0f / 64.0f);
+    const float m2 = wave_sum(dv * dv);
+    if (lane == 0 && qi < p.Tq)
+      *reinterpret_cast<float2*>(p.stats_out + 2 * (((long long)b * p.Tq + qi) * p.H + h)) = make_float2(sm, m2);
+  }
   if (qi < p.Tq) {
     const long long ooff = (long long)b * p.obs + (long long)qi * p.ors + (long long)h * 64 + lane;
     if (p.o_bf16) reinterpret_cast<bf16_t*>(p.out)[ooff] = f32_to_bf16(o);
@@ -418,6 +444,9 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.k = (const char*)a->k; p.v = (const char*)a->v; p.kbs = a->kv_batch_stride; p.krs = a->kv_row_stride;
   p.out = a->out; p.obs = a->out_batch_stride; p.ors = a->out_row_stride; p.o_bf16 = a->odt == KX_BF16;
   p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
+  p.stats_out = a->stats_out;
+  KX_REQUIRE(!a->stats_out || !(a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1),
+             "kx_attention: stats_out is not implemented by the v1 A/B kernel");
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(a->prec == KX_PREC_BF16 ? KX_K_ATTN_BF16 : KX_K_ATTN_F32, a->B * a->H, a->Tq, a->Tk, s);
   if (a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1) {   // v1, kept for A/B

@@ -99,7 +99,8 @@ inline int cdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : KX_F32; }
 int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t ldc, int cdtype, int64_t M, int64_t N,
          const float* bias, const float* residual, int act, float qscale, int64_t qcols, int prec, hipStream_t s,
          const float* xq_cs = nullptr, const float* xq_ss = nullptr, const float* xk_cs = nullptr,
-         const float* xk_ss = nullptr, int64_t xT = 0, int64_t xdim = 0) {
+         const float* xk_ss = nullptr, int64_t xT = 0, int64_t xdim = 0, const float* row_stats = nullptr,
+         const float* colsum = nullptr, float* stats_out = nullptr) {
   kx_gemm_args g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = ldc; g.cdt = cdtype;
@@ -107,6 +108,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   g.act = act; g.qscale = qscale; g.qcols = qcols;
   g.xq_cs = xq_cs; g.xq_ss = xq_ss; g.xk_cs = xk_cs; g.xk_ss = xk_ss; g.xpos_T = xT; g.xpos_dim = xdim;
   g.prec = prec; g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
+  g.row_stats = row_stats; g.colsum = colsum; g.stats_out = stats_out;
   return kx_gemm(&g, (void*)s);
 }
 
@@ -153,7 +155,7 @@ PerBufs per_plan(const kx_perceiver_weights* w, int64_t B, int64_t m, int prec, 
 }
 
 // ---------------- Decoder ----------------
-struct DecBufs { void *h, *qkv, *aln, *gln; float *att, *g; size_t total; };
+struct DecBufs { void *h, *qkv, *att, *g; float *partials, *stats; size_t total; };
 DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, char* base) {
   const int64_t M = B * T;
   const size_t es = esz(prec);
@@ -161,10 +163,11 @@ DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, ch
   DecBufs d;
   d.h = c.take((size_t)M * w->dim * es);
   d.qkv = c.take((size_t)M * 3 * w->dim * es);
-  d.att = (float*)c.take((size_t)M * w->dim * 4);
-  d.aln = c.take((size_t)M * w->dim * es);
-  d.g = (float*)c.take((size_t)M * w->ffn * 4);
-  d.gln = c.take((size_t)M * w->ffn * es);
+  d.att = c.take((size_t)M * w->dim * es);          // attention output, un-normalised (inner_attn_ln is folded)
+  d.g = c.take((size_t)M * w->ffn * es);            // gelu(fc1), un-normalised (ffn_layernorm is folded)
+  const int64_t nseg = w->ffn / 32 > w->heads ? w->ffn / 32 : w->heads;
+  d.partials = (float*)c.take((size_t)M * nseg * 2 * 4);
+  d.stats = (float*)c.take((size_t)M * 2 * 4);
   d.total = c.off;
   return d;
 }
@@ -280,6 +283,7 @@ extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t
   KX_REQUIRE(B > 0 && T > 0, "kx_decoder_forward: empty input");
   KX_REQUIRE(w->dim == w->heads * 64, "kx_decoder_forward: head_dim must be 64 (dim=%d heads=%d)", w->dim, w->heads);
   KX_REQUIRE(!w->xpos || (xq_cs && xq_ss && xk_cs && xk_ss), "kx_decoder_forward: XPos tables missing");
+  KX_REQUIRE(!w->subln || w->ffn % 32 == 0, "kx_decoder_forward: ffn must be a multiple of 32 for the folded sub-LN");
   KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_decoder_forward: workspace must be 256-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const DecBufs d = dec_plan(w, B, T, prec, (char*)workspace);
@@ -302,24 +306,32 @@ extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t
     a.k = (char*)d.qkv + D * es; a.v = (char*)d.qkv + 2 * D * es;
     a.kv_batch_stride = T * 3 * D; a.kv_row_stride = 3 * D;
     a.B = B; a.H = w->heads; a.Tq = T; a.Tk = T; a.mask = KX_ATTN_CAUSAL; a.prec = prec;
+    a.out = d.att; a.out_batch_stride = T * D; a.out_row_stride = D; a.odt = ct;
     if (w->subln) {
-      a.out = d.att; a.out_batch_stride = T * D; a.out_row_stride = D; a.odt = KX_F32;
+      // inner_attn_ln folded into out_proj: the attention kernel emits per-(row, head) partial statistics, the GEMM
+      // multiplies the un-normalised output by γ⊙Wo and applies rstd·(acc − mean·colsum) + (β·Woᵀ + bo) in its epilogue
+      a.stats_out = d.partials;
       KX_TRY(kx_attention(&a, stream));
-      KX_TRY(ln(d.att, nullptr, L.in_g, L.in_b, d.aln, ct, M, D, w->eps, s));
+      KX_TRY(kx_row_stats_finalize(d.partials, M, w->heads, 64, w->eps, d.stats, stream));
+      KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
+                  0, 0, d.stats, L.wo_colsum, nullptr));
     } else {
-      a.out = d.aln; a.out_batch_stride = T * D; a.out_row_stride = D; a.odt = ct;
       KX_TRY(kx_attention(&a, stream));
+      KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s));
     }
-    KX_TRY(gemm(d.aln, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s));
     // x = x + fc2(ffn_layernorm(gelu(fc1(final_layer_norm(x)))))
     KX_TRY(ln(x, nullptr, L.fl_g, L.fl_b, d.h, ct, M, D, w->eps, s));
     if (w->subln) {
-      KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, KX_F32, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s));
-      KX_TRY(ln(d.g, nullptr, L.fn_g, L.fn_b, d.gln, ct, M, F, w->eps, s));
+      // ffn_layernorm folded into fc2 the same way; fc1's epilogue emits the row statistics of gelu(fc1)
+      KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
+                  nullptr, 0, 0, nullptr, nullptr, d.partials));
+      KX_TRY(kx_row_stats_finalize(d.partials, M, F / 32, 32, w->eps, d.stats, stream));
+      KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
+                  0, 0, d.stats, L.w2_colsum, nullptr));
     } else {
-      KX_TRY(gemm(d.h, D, L.w1, D, d.gln, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s));
+      KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s));
+      KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s));
     }
-    KX_TRY(gemm(d.gln, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s));
   }
   KX_TRY(ln(x, nullptr, w->ln_g, w->ln_b, d.h, ct, M, D, w->eps, s));
   KX_TRY(gemm(d.h, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab, nullptr, nullptr, 0, 1.f, 0, prec, s));

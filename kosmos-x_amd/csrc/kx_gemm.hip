@@ -27,6 +27,9 @@ struct GemmParams {
   const float *xq_cs, *xq_ss, *xk_cs, *xk_ss; int xpos_T, xpos_dim;
   int tiles_m, tiles_n;
   int vec_ok;  // ldc % 4 == 0 (&& ldr % 4 == 0): 16-byte epilogue accesses are aligned
+  // folded sub-LayerNorm (see kx_gemm_args): consume per-row (mean, rstd) + column sums, produce partial statistics
+  const float* row_stats; const float* colsum;
+  float* stats_out; int stats_nseg;
 };
 
 template <int ACT>
@@ -34,6 +37,18 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   if (m >= p.M || n >= p.N) return;
   float x[4] = {acc[0], acc[1], acc[2], acc[3]};
   const bool full = (n + 3 < p.N);
+  if (p.row_stats) {
+    // y = LN(a)·Wᵀ with the LayerNorm folded out of the operand:  rstd·(a·W'ᵀ − mean·Σ_k W'[n,k]),  W' = γ ⊙ W;
+    // the β·Wᵀ term arrives through `bias`.
+    const float2 ms = *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)m);
+    if (full) {
+      const float4 c = *reinterpret_cast<const float4*>(p.colsum + n);
+      x[0] = ms.y * (x[0] - ms.x * c.x); x[1] = ms.y * (x[1] - ms.x * c.y);
+      x[2] = ms.y * (x[2] - ms.x * c.z); x[3] = ms.y * (x[3] - ms.x * c.w);
+    } else {
+      for (int j = 0; j < 4; ++j) if (n + j < p.N) x[j] = ms.y * (x[j] - ms.x * p.colsum[n + j]);
+    }
+  }
   if (p.bias) {
     if (full) {
       const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
@@ -61,6 +76,19 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   if constexpr (ACT != KX_ACT_NONE) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[j] = apply_act<ACT>(x[j]);
+  }
+  if (p.stats_out) {
+    // partial LayerNorm statistics of this row over the 32 columns held by the aligned 8-lane group (N % 32 == 0
+    // is enforced, rows are uniform per group): (sum, sum of squares about the segment mean) — combined exactly
+    // by kx_row_stats_finalize with Chan's formula, so no E[x²]−mean² cancellation.
+    float sm = (x[0] + x[1]) + (x[2] + x[3]);
+    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+    const float mu = sm * (1.0f / 32.0f);
+    const float d0 = x[0] - mu, d1 = x[1] - mu, d2 = x[2] - mu, d3 = x[3] - mu;
+    float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
+    if ((n & 31) == 0)
+      *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (n >> 5))) = make_float2(sm, m2);
   }
   const long long off = (long long)m * p.ldc + n;
   if (p.residual) {
@@ -678,6 +706,11 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   p.qscale = a->qscale; p.qcols = (int)a->qcols;
   p.xq_cs = a->xq_cs; p.xq_ss = a->xq_ss; p.xk_cs = a->xk_cs; p.xk_ss = a->xk_ss;
   p.xpos_T = (int)a->xpos_T; p.xpos_dim = (int)a->xpos_dim;
+  p.row_stats = a->row_stats; p.colsum = a->colsum; p.stats_out = a->stats_out; p.stats_nseg = (int)(a->N / 32);
+  KX_REQUIRE(!a->row_stats == !a->colsum, "kx_gemm: row_stats and colsum must be given together");
+  KX_REQUIRE(!a->colsum || ((uintptr_t)a->colsum & 15) == 0, "kx_gemm: colsum must be 16-byte aligned");
+  KX_REQUIRE(!a->stats_out || a->N % 32 == 0, "kx_gemm: stats_out needs N %% 32 == 0 (N=%lld)", (long long)a->N);
+  KX_REQUIRE(!a->stats_out || !a->residual, "kx_gemm: stats_out is taken before the residual add; pass one of them");
   p.vec_ok = (a->ldc % 4 == 0) && (!a->residual || a->ldr % 4 == 0) &&
              (((uintptr_t)a->C & 15) == 0) && (!a->residual || ((uintptr_t)a->residual & 15) == 0);
   KX_REQUIRE(!a->bias || ((uintptr_t)a->bias & 15) == 0, "kx_gemm: bias must be 16-byte aligned");

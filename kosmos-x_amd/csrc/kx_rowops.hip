@@ -237,6 +237,27 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restri
   }
 }
 
+// (mean, rstd) per row from per-segment (sum, M2): one wave per row, Chan's combination in the wave reduction.
+__global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float* __restrict__ partials,
+                                                                 float* __restrict__ out, long long rows, int nseg,
+                                                                 float seg_size, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float2* pr = reinterpret_cast<const float2*>(partials) + row * nseg;
+  float s = 0.f;
+  for (int i = lane; i < nseg; i += 64) s += pr[i].x;
+  const float mean = wave_sum(s) / (seg_size * (float)nseg);
+  float m2 = 0.f;
+  for (int i = lane; i < nseg; i += 64) {
+    const float2 v = pr[i];
+    const float d = v.x / seg_size - mean;
+    m2 += v.y + seg_size * d * d;
+  }
+  const float var = wave_sum(m2) / (seg_size * (float)nseg);
+  if (lane == 0) reinterpret_cast<float2*>(out)[row] = make_float2(mean, rsqrtf(var + eps));
+}
+
 // dst[b, r, :] = src[r, :]
 __global__ __launch_bounds__(256) void rows_bcast_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                          long long rows, int cols) {
@@ -302,6 +323,17 @@ extern "C" int kx_embed_splice(const int64_t* tokens, const float* embed, const 
                      (const long long*)tokens, embed, pos, img, out, (int)Tt, (int)n_img, (int)d, (long long)vocab,
                      (int)splice_at, (int)u1_alias);
   KX_CHECK_LAUNCH("kx_embed_splice");
+  return KX_OK;
+}
+
+extern "C" int kx_row_stats_finalize(const float* partials, int64_t rows, int64_t nseg, int64_t seg_size, float eps,
+                                     float* out, void* stream) {
+  KX_REQUIRE(partials && out, "kx_row_stats_finalize: null pointer");
+  KX_REQUIRE(rows > 0 && nseg > 0 && seg_size > 0 && nseg < (1 << 20), "kx_row_stats_finalize: bad shape");
+  KxProfScope prof(KX_K_MISC, rows, nseg, 3, (hipStream_t)stream);
+  hipLaunchKernelGGL(row_stats_finalize_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     partials, out, (long long)rows, (int)nseg, (float)seg_size, eps);
+  KX_CHECK_LAUNCH("kx_row_stats_finalize");
   return KX_OK;
 }
 

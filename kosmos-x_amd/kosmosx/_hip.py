@@ -29,14 +29,14 @@ class GemmArgs(C.Structure):
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("M", i64), ("N", i64), ("K", i64),
                 ("act", i32), ("qscale", f32), ("qcols", i64),
                 ("xq_cs", vp), ("xq_ss", vp), ("xk_cs", vp), ("xk_ss", vp), ("xpos_T", i64), ("xpos_dim", i64),
-                ("prec", i32), ("tile", i32)]
+                ("prec", i32), ("tile", i32), ("row_stats", vp), ("colsum", vp), ("stats_out", vp)]
 
 
 class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("q_batch_stride", i64), ("q_row_stride", i64),
                 ("k", vp), ("v", vp), ("kv_batch_stride", i64), ("kv_row_stride", i64),
                 ("out", vp), ("out_batch_stride", i64), ("out_row_stride", i64), ("odt", i32),
-                ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64), ("mask", i32), ("prec", i32)]
+                ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64), ("mask", i32), ("prec", i32), ("stats_out", vp)]
 
 
 class VitLayer(C.Structure):
@@ -62,8 +62,8 @@ class PerceiverWeights(C.Structure):
 
 
 class DecoderLayer(C.Structure):
-    _fields_ = [(n, vp) for n in ("sa_g", "sa_b", "wqkv", "bqkv", "in_g", "in_b", "wo", "bo", "fl_g", "fl_b",
-                                  "w1", "b1", "fn_g", "fn_b", "w2", "b2")]
+    _fields_ = [(n, vp) for n in ("sa_g", "sa_b", "wqkv", "bqkv", "wo", "bo", "wo_colsum", "fl_g", "fl_b",
+                                  "w1", "b1", "w2", "b2", "w2_colsum")]
 
 
 class DecoderWeights(C.Structure):
@@ -88,6 +88,7 @@ SYMBOLS = {
     "kx_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, i64, i64, f32, i64, i64, i64, vp]),
     "kx_gemm": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "kx_attention": (C.c_int, [C.POINTER(AttnArgs), vp]),
+    "kx_row_stats_finalize": (C.c_int, [vp, i64, i64, i64, f32, vp, vp]),
     "kx_embed_splice": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, vp]),
     "kx_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "kx_prof_enable": (C.c_int, [C.c_int]),

@@ -455,6 +455,14 @@ class Decoder(_PackedMixin, nn.Module):
         def v(t):
             t = _f32(t); keep.append(t); return t.data_ptr()
 
+        def fold(ln, lin):
+            """Fold a sub-LayerNorm into the Linear that consumes it (see kx_decoder_layer in the header):
+            W' = γ ⊙ W cast to the operand dtype, b' = W·β + b, colsum = Σ_k W'[n,k] of the cast values."""
+            wf, g_, b_ = lin.weight.detach().float(), ln.weight.detach().float(), ln.bias.detach().float()
+            wp = (wf * g_[None, :]).to(dt).contiguous()
+            keep.append(wp)
+            return wp.data_ptr(), v(wf @ b_ + lin.bias.detach().float()), v(wp.float().sum(1))
+
         layers = (H.DecoderLayer * self.num_layers)()
         for i, L in enumerate(self.layers):
             sa, ffn = L.self_attn, _a(L.ffn)
@@ -464,12 +472,13 @@ class Decoder(_PackedMixin, nn.Module):
             e.wqkv = op(torch.cat([q.weight, k.weight, vv.weight], 0))
             e.bqkv = v(torch.cat([q.bias, k.bias, vv.bias], 0))
             if a.subln:
-                e.in_g, e.in_b = v(_a(sa.inner_attn_ln).weight), v(_a(sa.inner_attn_ln).bias)
-                e.fn_g, e.fn_b = v(ffn.ffn_layernorm.weight), v(ffn.ffn_layernorm.bias)
-            e.wo, e.bo = op(o.weight), v(o.bias)
+                e.wo, e.bo, e.wo_colsum = fold(_a(sa.inner_attn_ln), o)
+                e.w2, e.b2, e.w2_colsum = fold(ffn.ffn_layernorm, ffn.fc2)
+            else:
+                e.wo, e.bo = op(o.weight), v(o.bias)
+                e.w2, e.b2 = op(ffn.fc2.weight), v(ffn.fc2.bias)
             e.fl_g, e.fl_b = v(_a(L.final_layer_norm).weight), v(_a(L.final_layer_norm).bias)
             e.w1, e.b1 = op(ffn.fc1.weight), v(ffn.fc1.bias)
-            e.w2, e.b2 = op(ffn.fc2.weight), v(ffn.fc2.bias)
         w = H.DecoderWeights()
         w.layers, w.dim, w.heads, w.ffn = self.num_layers, a.decoder_embed_dim, a.decoder_attention_heads, a.decoder_ffn_embed_dim
         w.vocab, w.act = self.output_projection.weight.shape[0], H.ACTS[a.activation_fn]

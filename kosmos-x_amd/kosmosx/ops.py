@@ -45,7 +45,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, o
 
 
 def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
-         xpos=None, xpos_dim=0, tile=0, out=None):
+         xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None):
     """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32]."""
     _need_cuda(a, w, bias, residual, out)
     M, K = a.shape
@@ -65,11 +65,22 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
         g.xq_cs, g.xq_ss, g.xk_cs, g.xk_ss = (H.ptr(t) for t in xpos)
         g.xpos_T, g.xpos_dim = xpos[0].shape[0], xpos_dim
     g.prec, g.tile = prec, tile
+    g.row_stats, g.colsum, g.stats_out = H.ptr(row_stats), H.ptr(colsum), H.ptr(stats_out)
     H.check(H.load().kx_gemm(C.byref(g), _stream()), "kx_gemm")
     return out
 
 
-def attention(q, k, v, causal=False, out_dtype=None):
+def row_stats_finalize(partials, seg_size, eps=1e-5):
+    """partials [rows, nseg, 2] (sum, M2 about the segment mean) -> [rows, 2] (mean, rstd)."""
+    _need_cuda(partials)
+    rows, nseg, _ = partials.shape
+    out = torch.empty((rows, 2), dtype=torch.float32, device=partials.device)
+    H.check(H.load().kx_row_stats_finalize(H.ptr(partials), rows, nseg, seg_size, float(eps), H.ptr(out), _stream()),
+            "kx_row_stats_finalize")
+    return out
+
+
+def attention(q, k, v, causal=False, out_dtype=None, stats_out=None):
     """q [B,Tq,H,64], k/v [B,Tk,H,64] (any row/batch strides, last two dims contiguous) -> [B,Tq,H*64]."""
     _need_cuda(q, k, v)
     B, Tq, Hh, hd = q.shape
@@ -84,6 +95,7 @@ def attention(q, k, v, causal=False, out_dtype=None):
     a.out, a.out_batch_stride, a.out_row_stride, a.odt = H.ptr(out), out.stride(0), out.stride(1), _cdt(out.dtype)
     a.B, a.H, a.Tq, a.Tk = B, Hh, Tq, Tk
     a.mask, a.prec = (H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL), prec
+    a.stats_out = H.ptr(stats_out)
     H.check(H.load().kx_attention(C.byref(a), _stream()), "kx_attention")
     return out
 

@@ -78,6 +78,11 @@ def test_version_and_error_plumbing(lib):
     a.q = a.k = a.v = a.out = 256
     a.B, a.H, a.Tq, a.Tk, a.mask = 1, 1, 4, 5, 1
     assert lib.kx_attention(C.byref(a), None) == 1 and "causal" in _hip.last_error()
+    g = _hip.GemmArgs()
+    g.A = g.W = g.C = g.row_stats = 256
+    g.M, g.N, g.K, g.lda, g.ldw, g.ldc = 4, 64, 64, 64, 64, 64
+    assert lib.kx_gemm(C.byref(g), None) == 1 and "together" in _hip.last_error()   # row_stats without colsum
+    assert lib.kx_row_stats_finalize(None, 4, 4, 32, 1e-5, None, None) == 1
 
 
 def test_workspace_queries_are_pure_host_arithmetic(lib):

@@ -291,3 +291,68 @@ def test_embed_splice_position_overflow_is_an_error():
     ops.embed_splice(torch.zeros(1, 62, dtype=torch.long, device=DEV), emb, pos)
     with pytest.raises(RuntimeError, match="out of range"):
         ops.embed_splice(torch.zeros(1, 63, dtype=torch.long, device=DEV), emb, pos)
+
+
+# ---------------------------------------------------------------------------------------------
+# Folded sub-LayerNorm: statistics produced by one epilogue, consumed by the next GEMM's epilogue
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [0, 64, 128, 256, 512])
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
+def test_gemm_partial_row_stats_and_finalize(prec, tile):
+    """fc1-style producer: stats of gelu(a·Wᵀ + b) per row == what LayerNorm would compute."""
+    if tile >= 256 and prec == torch.float32:
+        pytest.skip("pipelined kernels are bf16-only")
+    M, N, K = 150, 512, 256
+    g = _g(31)
+    a = torch.randn(M, K, generator=g).to(prec)
+    w = (torch.randn(N, K, generator=g) / 16).to(prec)
+    bias = torch.randn(N, generator=g)
+    bias = bias + 4.0                                   # large mean vs spread: E[x²]−mean² would cancel badly
+    y = F.gelu(a.double() @ w.double().t() + bias.double())
+    part = torch.zeros(M, N // 32, 2, device=DEV)
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), act="gelu", out_dtype=prec, stats_out=part, tile=tile)
+    st = ops.row_stats_finalize(part, 32, 1e-5).cpu().double()
+    assert (st[:, 0] - y.mean(1)).abs().max() < 2e-5
+    ref_rstd = 1.0 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
+    assert ((st[:, 1] - ref_rstd) / ref_rstd).abs().max() < 2e-5
+    assert rel_err(out.float(), y.float()) < (2e-5 if prec == torch.float32 else 2 ** -7)
+
+
+@pytest.mark.parametrize("tile", [0, 128, 512])
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
+def test_gemm_folded_layernorm_consumer(prec, tile):
+    """fc2-style consumer: rstd·(x·(γ⊙W)ᵀ − mean·colsum) + (W·β + b) + residual == LN(x)·Wᵀ + b + residual."""
+    if tile >= 256 and prec == torch.float32:
+        pytest.skip("pipelined kernels are bf16-only")
+    M, N, K = 130, 256, 512
+    g = _g(41)
+    x = (torch.randn(M, K, generator=g) * 2 + 0.7)
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    W, b = torch.randn(N, K, generator=g) / 20, torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = (F.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5) @ W.double().t() + b.double()
+           + res.double()).float()
+    xo = x.to(prec)                                       # the operand the GEMM sees
+    wp = (W * gamma[None]).to(prec)
+    colsum, bias = wp.float().sum(1), W @ beta + b
+    stats = torch.stack([x.mean(1), 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)], 1)
+    out = res.to(DEV).clone()
+    ops.gemm(xo.to(DEV), wp.to(DEV), bias.to(DEV), out, out=out, row_stats=stats.contiguous().to(DEV),
+             colsum=colsum.to(DEV), tile=tile)
+    tol = 3e-5 if prec == torch.float32 else 2e-2        # bf16: x and γ⊙W are rounded to bf16 (operand rounding)
+    assert rel_err(out, ref) < tol, rel_err(out, ref)
+
+
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
+def test_attention_partial_row_stats(prec):
+    B, H, T = 2, 4, 70
+    g = _g(51)
+    q = (torch.randn(B, T, H, 64, generator=g) * 0.3).to(prec)
+    k, v = torch.randn(B, T, H, 64, generator=g).to(prec), (torch.randn(B, T, H, 64, generator=g) + 0.5).to(prec)
+    part = torch.zeros(B * T, H, 2, device=DEV)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), True, out_dtype=torch.float32, stats_out=part)
+    st = ops.row_stats_finalize(part, 64, 1e-5).cpu()
+    o = out.cpu().reshape(B * T, H * 64)
+    assert (st[:, 0] - o.mean(1)).abs().max() < 2e-5
+    ref_rstd = 1 / torch.sqrt(o.var(1, unbiased=False) + 1e-5)
+    assert ((st[:, 1] - ref_rstd) / ref_rstd).abs().max() < 5e-5
