@@ -95,8 +95,14 @@ def main():
         sys.exit("bench.py needs an MI355X: the Kosmos-X HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("KOSMOSX_FORCE_DIST") == "1"     # exercise the RCCL path with a single rank (testing)
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     from kosmosx import _hip
@@ -121,7 +127,8 @@ def main():
     B, Tt = args.batch, args.text_len
     tok = torch.randint(0, cfg.vocab, (B, Tt), generator=g).to(dev)
     img = torch.randn(B, 3, cfg.vit.image, cfg.vit.image, generator=g).to(dev)
-    gatherer = LogitsGatherer(wire_dtype=torch.bfloat16) if (world > 1 and not args.no_gather) else None
+    gatherer = (LogitsGatherer(wire_dtype=torch.bfloat16, force=force_dist)
+                if ((world > 1 or force_dist) and not args.no_gather) else None)
 
     S = max(1, args.streams)
     side = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
@@ -153,7 +160,7 @@ def main():
         if gatherer is not None:
             gatherer.wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +180,7 @@ def main():
 
     # ---- roofline leg: the same step, instrumented launch by launch with HIP events on the launch stream ----
     roofline, breakdown, gemm_shapes = None, None, None
-    if rank == 0:
+    if rank == 0 and args.prof_steps > 0:
         _hip.prof_enable(True)
         for _ in range(args.prof_steps):
             with torch.no_grad():
@@ -197,6 +204,10 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                         "launches_per_step": e["launches"], "avg_launch_ms": round(e["ms"] / e["launches"], 5)}
+        fam = [v for k, v in agg.items() if k.startswith("gemm_bf16")]
+        if fam:
+            agg["gemm_bf16_all_variants"] = {"launches": sum(v["launches"] for v in fam), "ms": sum(v["ms"] for v in fam),
+                                              "flops": sum(v["flops"] for v in fam), "bytes": 0.0}
         breakdown = {k: {"ms_per_step": round(v["ms"], 4), "launches_per_step": v["launches"],
                          **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] else {}),
                          **({"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] else {})}
@@ -246,7 +257,7 @@ def main():
             "build_seconds": round(t_build, 1),
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

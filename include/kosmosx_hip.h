@@ -258,7 +258,8 @@ int kx_set_tuning(int key, int value);
  * ---------------------------------------------------------------------------------------- */
 typedef enum {
   KX_K_GEMM_BF16_128 = 0, KX_K_GEMM_BF16_64 = 1, KX_K_GEMM_F32_128 = 2, KX_K_GEMM_F32_64 = 3,
-  KX_K_LAYERNORM = 4, KX_K_ATTN_BF16 = 5, KX_K_ATTN_F32 = 6, KX_K_EMBED = 7, KX_K_MISC = 8
+  KX_K_LAYERNORM = 4, KX_K_ATTN_BF16 = 5, KX_K_ATTN_F32 = 6, KX_K_EMBED = 7, KX_K_MISC = 8,
+  KX_K_GEMM_BF16_160 = 9, KX_K_GEMM_BF16_256X128 = 10, KX_K_GEMM_BF16_256X256 = 11
 } kx_kernel_kind;
 typedef struct {
   int32_t kind;      /* kx_kernel_kind */

@@ -748,7 +748,12 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       else tile = cost(160) <= cost(128) ? 160 : 128;
     }
   }
-  KxProfScope prof((a->prec == KX_PREC_BF16 ? 0 : 2) + (tile >= 128 ? 0 : 1), a->M, a->N, a->K, s);
+  const int kind = a->prec != KX_PREC_BF16 ? (tile == 64 ? KX_K_GEMM_F32_64 : KX_K_GEMM_F32_128)
+                   : tile == 64 ? KX_K_GEMM_BF16_64
+                   : tile == 160 ? KX_K_GEMM_BF16_160
+                   : (tile == 256 || tile == 257) ? KX_K_GEMM_BF16_256X128
+                   : tile == 512 ? KX_K_GEMM_BF16_256X256 : KX_K_GEMM_BF16_128;
+  KxProfScope prof(kind, a->M, a->N, a->K, s);
   if (a->prec == KX_PREC_BF16) {
     if (tile == 128) return launch<bf16_t, 128, 128>(p, s);
     if (tile == 64) return launch<bf16_t, 64, 64>(p, s);

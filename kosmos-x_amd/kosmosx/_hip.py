@@ -77,8 +77,9 @@ class ProfRecord(C.Structure):
                 ("reserved2", f32)]
 
 
-KERNEL_KINDS = ["gemm_bf16_128", "gemm_bf16_64", "gemm_f32_128", "gemm_f32_64", "layernorm", "attn_bf16",
-                "attn_f32", "embed", "misc"]
+KERNEL_KINDS = ["gemm_bf16_128x128", "gemm_bf16_64x64", "gemm_f32_128x128", "gemm_f32_64x64", "layernorm",
+                "attn_bf16", "attn_f32", "embed", "misc", "gemm_bf16_160x128", "gemm_bf16_256x128_phased",
+                "gemm_bf16_256x256_phased"]
 
 
 # every symbol include/kosmosx_hip.h declares: name -> (restype, argtypes)

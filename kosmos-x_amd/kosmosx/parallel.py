@@ -29,8 +29,10 @@ class LogitsGatherer:
     configurable because xGMI is per-link bound (7 links x ~153 GB/s): bf16 halves the bytes on the wire.
     """
 
-    def __init__(self, group=None, wire_dtype: torch.dtype | None = torch.bfloat16, overlap: bool = True):
+    def __init__(self, group=None, wire_dtype: torch.dtype | None = torch.bfloat16, overlap: bool = True,
+                 force: bool = False):
         self.group = group
+        self.force = force          # run the collective even with a single rank (exercises the RCCL path in tests)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.wire_dtype = wire_dtype
         self.overlap = overlap
@@ -40,7 +42,7 @@ class LogitsGatherer:
         self._out = [None, None]
 
     def gather(self, local: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return local
         wire = local if self.wire_dtype is None else local.to(self.wire_dtype)
         wire = wire.contiguous()
