@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3, help="instrumented steps for the roofline leg")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (launch-bound batches)")
     ap.add_argument("--streams", type=int, default=1, help="micro-batch the shard over S HIP streams (overlaps kernel tails)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="kernel-variant override (kx_set_tuning key 1), A/B only")
     return ap.parse_args()
@@ -121,6 +122,7 @@ def main():
     model.precision = args.precision
     if args.gemm_tile:
         _hip.load().kx_set_tuning(1, args.gemm_tile)
+    model.use_hip_graphs = bool(args.graph)
     t_build = time.time() - t_build
 
     g = torch.Generator().manual_seed(1000 + rank)              # per-rank synthetic shard
@@ -181,6 +183,7 @@ def main():
     # ---- roofline leg: the same step, instrumented launch by launch with HIP events on the launch stream ----
     roofline, breakdown, gemm_shapes = None, None, None
     if rank == 0 and args.prof_steps > 0:
+        model.use_hip_graphs = False                        # per-launch events cannot be recorded under capture/replay
         _hip.prof_enable(True)
         for _ in range(args.prof_steps):
             with torch.no_grad():
@@ -248,7 +251,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "seq_len": Tt + cfg.perceiver.latents,
                        "text_len": Tt, "parallelism": f"dp{world}",
                        "logits_gather": (None if gatherer is None else "RCCL all-gather, bf16 wire, overlapped"),
-                       "micro_batch_streams": S},
+                       "micro_batch_streams": S, "hip_graph": bool(args.graph)},
             "algorithmic_gflop_per_sample": round(fl["total"] / 1e9, 2),
             "model_tflops": round(fl["total"] * total / elapsed / 1e12, 2),
             "mfma_peak_frac_end_to_end": round(fl["total"] * total / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world), 4),

@@ -105,6 +105,11 @@ typedef struct {
    * into (mean, rstd). */
   const float* row_stats; const float* colsum;
   float* stats_out;
+  /* Optional split-K scratch for skinny problems (the 64x64 variant): when given, K is sliced over up to 16
+   * workgroup rows so that the weights are streamed by ~512 workgroups instead of N/64; partial sums
+   * [splits, M, N] fp32 are combined in slice order (deterministic) by a reduce kernel that owns the epilogue.
+   * splitk: 0 = automatic, 1 = off, n = force n slices (tests). */
+  void* splitk_ws; size_t splitk_ws_bytes; int32_t splitk;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 

@@ -83,6 +83,15 @@ extern "C" int kx_prof_collect(kx_prof_record* out, int max_records) {
   return n;
 }
 
+// split-K scratch of the stage currently being launched (set by the stage entry points, read by gemm())
+thread_local void* g_splitk_ws = nullptr;
+thread_local size_t g_splitk_ws_bytes = 0;
+constexpr size_t KX_SPLITK_WS = 32u << 20;   // 32 MB: enough for 16 slices of every batch-1 GEMM on the path
+struct SplitkScope {
+  SplitkScope(void* p, size_t n) { g_splitk_ws = p; g_splitk_ws_bytes = n; }
+  ~SplitkScope() { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; }
+};
+
 namespace {
 
 struct Carver {
@@ -109,6 +118,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   g.xq_cs = xq_cs; g.xq_ss = xq_ss; g.xk_cs = xk_cs; g.xk_ss = xk_ss; g.xpos_T = xT; g.xpos_dim = xdim;
   g.prec = prec; g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
   g.row_stats = row_stats; g.colsum = colsum; g.stats_out = stats_out;
+  g.splitk_ws = g_splitk_ws; g.splitk_ws_bytes = g_splitk_ws_bytes; g.splitk = 0;
   return kx_gemm(&g, (void*)s);
 }
 
@@ -118,7 +128,7 @@ int ln(const float* x, const float* pre, const float* g, const float* b, void* y
 }
 
 // ---------------- ViT ----------------
-struct VitBufs { void *patches, *h, *qkv, *att, *ff; float *patch_out, *xpre; size_t total; };
+struct VitBufs { void *patches, *h, *qkv, *att, *ff, *splitk; float *patch_out, *xpre; size_t total; };
 VitBufs vit_plan(const kx_vit_weights* w, int64_t B, int prec, char* base) {
   const int64_t G = w->image / w->patch, P = G * G, S = P + 1, M = B * S, MP = B * P;
   const size_t es = esz(prec);
@@ -131,12 +141,13 @@ VitBufs vit_plan(const kx_vit_weights* w, int64_t B, int prec, char* base) {
   v.qkv = c.take((size_t)M * 3 * w->dim * es);
   v.att = c.take((size_t)M * w->dim * es);
   v.ff = c.take((size_t)M * w->ffn * es);
+  v.splitk = c.take(KX_SPLITK_WS);
   v.total = c.off;
   return v;
 }
 
 // ---------------- Perceiver ----------------
-struct PerBufs { float* lat; void *kvin, *lnq, *qb, *kvb, *att, *ffh, *fin; size_t total; };
+struct PerBufs { float* lat; void *kvin, *lnq, *qb, *kvb, *att, *ffh, *fin, *splitk; size_t total; };
 PerBufs per_plan(const kx_perceiver_weights* w, int64_t B, int64_t m, int prec, char* base) {
   const int64_t n = w->latents, inner = (int64_t)w->heads * 64, MQ = B * n, MK = B * (m + n);
   const size_t es = esz(prec);
@@ -150,12 +161,13 @@ PerBufs per_plan(const kx_perceiver_weights* w, int64_t B, int64_t m, int prec, 
   p.att = c.take((size_t)MQ * inner * es);
   p.ffh = c.take((size_t)MQ * w->dim * w->ff_mult * es);
   p.fin = c.take((size_t)MQ * w->dim * es);
+  p.splitk = c.take(KX_SPLITK_WS);
   p.total = c.off;
   return p;
 }
 
 // ---------------- Decoder ----------------
-struct DecBufs { void *h, *qkv, *att, *g; float *partials, *stats; size_t total; };
+struct DecBufs { void *h, *qkv, *att, *g, *splitk; float *partials, *stats; size_t total; };
 DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, char* base) {
   const int64_t M = B * T;
   const size_t es = esz(prec);
@@ -168,6 +180,7 @@ DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, ch
   const int64_t nseg = w->ffn / 32 > w->heads ? w->ffn / 32 : w->heads;
   d.partials = (float*)c.take((size_t)M * nseg * 2 * 4);
   d.stats = (float*)c.take((size_t)M * 2 * 4);
+  d.splitk = c.take(KX_SPLITK_WS);
   d.total = c.off;
   return d;
 }
@@ -193,6 +206,7 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
     return KX_ERR_WORKSPACE;
   }
   const int64_t G = w->image / w->patch, P = G * G, S = P + 1, M = B * S, MP = B * P, D = w->dim;
+  SplitkScope sk(v.splitk, KX_SPLITK_WS);
   const int ct = cdt(prec);
   const size_t es = esz(prec);
   KX_TRY(kx_launch_patchify(pixels, v.patches, B, w->image, w->patch, w->kpad, prec, s));
@@ -238,6 +252,7 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
     return KX_ERR_WORKSPACE;
   }
   const int64_t n = w->latents, D = w->dim, inner = (int64_t)w->heads * 64, MQ = B * n, MK = B * (m + n);
+  SplitkScope sk(p.splitk, KX_SPLITK_WS);
   const int64_t F = D * w->ff_mult;
   const int ct = cdt(prec);
   const size_t es = esz(prec);
@@ -292,6 +307,7 @@ extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t
     return KX_ERR_WORKSPACE;
   }
   const int64_t M = B * T, D = w->dim, F = w->ffn;
+  SplitkScope sk(d.splitk, KX_SPLITK_WS);
   const int ct = cdt(prec);
   const size_t es = esz(prec);
   for (int i = 0; i < w->layers; ++i) {

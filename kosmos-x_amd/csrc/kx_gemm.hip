@@ -30,6 +30,9 @@ struct GemmParams {
   // folded sub-LayerNorm (see kx_gemm_args): consume per-row (mean, rstd) + column sums, produce partial statistics
   const float* row_stats; const float* colsum;
   float* stats_out; int stats_nseg;
+  // split-K (skinny problems): blockIdx.y = K slice; raw fp32 partials go to `partial` [splitk][M][N], the fused
+  // epilogue runs in splitk_reduce_kernel, which sums the slices in a fixed order (deterministic)
+  int splitk; float* partial;
 };
 
 template <int ACT>
@@ -219,9 +222,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     offW[a] = A_BYTES + row * ROWB + ((g ^ (row & 7)) << 4);
   }
 
-  const int nk = p.K / (ROWB / (int)sizeof(T));
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
+  const int nk_all = p.K / (ROWB / (int)sizeof(T));
+  const int kchunk = (nk_all + p.splitk - 1) / p.splitk;
+  const int kt0 = (int)blockIdx.y * kchunk;
+  const int nk = min(nk_all, kt0 + kchunk);   // this block multiplies K-tiles [kt0, nk)
+  if (kt0 < nk) stage(kt0 & 1, kt0);
+  for (int kt = kt0; kt < nk; ++kt) {
     // stage kt has landed (this wave's DMA) and every wave is done reading the other buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -267,8 +273,38 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   for (int r = 0; r < WM; r += RPI) {
     const int ml = r + rl;
     const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
-    epilogue4<ACT>(p, mbase + ml, nbase, v);
+    if (p.splitk > 1) {
+      const int m = mbase + ml;
+      if (m < p.M && nbase < p.N) {
+        float* dst = p.partial + ((long long)blockIdx.y * p.M + m) * p.N + nbase;
+        if (nbase + 3 < p.N && (p.N & 3) == 0) *reinterpret_cast<f32x4_t*>(dst) = v;
+        else for (int j = 0; j < 4; ++j) if (nbase + j < p.N) dst[j] = v[j];
+      }
+    } else {
+      epilogue4<ACT>(p, mbase + ml, nbase, v);
+    }
   }
+}
+
+// Sums the K-slice partials of a split-K launch in slice order and runs the fused epilogue.  Thread = one row x 4
+// columns; consecutive threads walk a row, so the 8-lane groups of the LayerNorm-statistics epilogue still hold 32
+// consecutive columns of one row (N % 32 == 0 in that mode).
+template <int ACT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+  const int n4 = (p.N + 3) >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)p.M * n4) return;
+  const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bool vec = (n + 3 < p.N) && (p.N & 3) == 0;
+  for (int z = 0; z < p.splitk; ++z) {
+    const float* src = p.partial + ((long long)z * p.M + m) * p.N + n;
+    if (vec) acc += *reinterpret_cast<const f32x4_t*>(src);
+    else for (int j = 0; j < 4; ++j) if (n + j < p.N) acc[j] += src[j];
+  }
+  GemmParams q = p;
+  q.splitk = 1;
+  epilogue4<ACT>(q, m, n, acc);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -663,7 +699,23 @@ template <typename T, int BM, int BN>
 int launch(GemmParams& p, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  const dim3 grid(p.tiles_m * p.tiles_n, p.splitk), block(256);
+  if (p.splitk > 1) {
+    // skinny problem: the tile kernels only produce partials (activation-free), the reduce kernel owns the epilogue
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p);
+    KX_CHECK_LAUNCH("kx_gemm(split-K)");
+    const long long work = (long long)p.M * ((p.N + 3) / 4);
+    const dim3 rgrid((unsigned)((work + 255) / 256));
+    switch (p.act) {
+      case KX_ACT_NONE: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_NONE>, rgrid, block, 0, s, p); break;
+      case KX_ACT_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_GELU>, rgrid, block, 0, s, p); break;
+      case KX_ACT_GELU_FAST: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_GELU_FAST>, rgrid, block, 0, s, p); break;
+      case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_QUICK_GELU>, rgrid, block, 0, s, p); break;
+      default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+    }
+    KX_CHECK_LAUNCH("kx_gemm(split-K reduce)");
+    return KX_OK;
+  }
   // the activation is a compile-time property of the kernel: a runtime switch costs ~4 scalar branches per value
   switch (p.act) {
     case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p); break;
@@ -714,6 +766,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   p.vec_ok = (a->ldc % 4 == 0) && (!a->residual || a->ldr % 4 == 0) &&
              (((uintptr_t)a->C & 15) == 0) && (!a->residual || ((uintptr_t)a->residual & 15) == 0);
   KX_REQUIRE(!a->bias || ((uintptr_t)a->bias & 15) == 0, "kx_gemm: bias must be 16-byte aligned");
+  p.splitk = 1; p.partial = nullptr;
   hipStream_t s = (hipStream_t)stream;
   // Kernel-variant choice (measured on MI355X with tools/gemm_bench.py and in situ with bench.py):
   //   64x64    when 128x128 tiles would leave most of the 256 CUs idle (batch-1 shapes);
@@ -746,6 +799,23 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       if (a->K >= 1024 && eff512 >= 0.85) tile = 512;
       else if (a->K >= 2048 && eff256 >= 0.85 && a->N <= 16384) tile = 256;
       else tile = cost(160) <= cost(128) ? 160 : 128;
+    }
+  }
+  if (tile == 64 && a->splitk_ws) {
+    // Skinny problems (batch-1 shapes: M = 114 / 257 / 64) are weight-streaming bound and a 64x64 grid of N/64 x 2
+    // workgroups leaves most CUs idle while each one walks all of K serially.  Slice K so that ~512 workgroups
+    // stream the weights concurrently; partials are small ([splits][M][N] fp32, L2/MALL resident).
+    const long long tiles = ((a->M + 63) / 64) * ((a->N + 63) / 64);
+    const long long nk_all = a->K / bk;
+    long long sp = a->splitk > 0 ? a->splitk : (tiles >= 384 ? 1 : (512 + tiles - 1) / tiles);
+    if (sp > 16) sp = 16;
+    if (sp > nk_all / 2) sp = nk_all / 2;
+    while (sp > 1 && (size_t)sp * a->M * a->N * 4 > a->splitk_ws_bytes) --sp;
+    if (sp > 1) {
+      const long long kchunk = (nk_all + sp - 1) / sp;
+      sp = (nk_all + kchunk - 1) / kchunk;          // no empty slices
+      p.splitk = (int)sp;
+      p.partial = (float*)a->splitk_ws;
     }
   }
   const int kind = a->prec != KX_PREC_BF16 ? (tile == 64 ? KX_K_GEMM_F32_64 : KX_K_GEMM_F32_128)

@@ -29,7 +29,8 @@ class GemmArgs(C.Structure):
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("M", i64), ("N", i64), ("K", i64),
                 ("act", i32), ("qscale", f32), ("qcols", i64),
                 ("xq_cs", vp), ("xq_ss", vp), ("xk_cs", vp), ("xk_ss", vp), ("xpos_T", i64), ("xpos_dim", i64),
-                ("prec", i32), ("tile", i32), ("row_stats", vp), ("colsum", vp), ("stats_out", vp)]
+                ("prec", i32), ("tile", i32), ("row_stats", vp), ("colsum", vp), ("stats_out", vp),
+                ("splitk_ws", vp), ("splitk_ws_bytes", C.c_size_t), ("splitk", i32)]
 
 
 class AttnArgs(C.Structure):

@@ -740,12 +740,48 @@ class Kosmos(nn.Module):
         if perturb:
             perturb_(self, g, perturb)
         self._ws = _Workspace()
+        self.use_hip_graphs = os.environ.get("KOSMOSX_HIP_GRAPHS", "0") == "1"
+        self._graphs = {}
+
+    def invalidate_packed(self):
+        self._graphs = {}
+        for m in (self.clip_model, self.perceive, self.decoder):
+            m.invalidate_packed()
+
+    def _apply(self, fn, *a, **k):
+        self._graphs = {}
+        return super()._apply(fn, *a, **k)
 
     def forward(self, text_tokens: torch.Tensor, images: torch.Tensor, **kwargs):
         """text_tokens [B,Tt] integer ids, images [B,3,224,224] any real dtype
         -> logits [B, Tt+64, vocab] fp32.  kwargs are ignored, as in the reference."""
         if not isinstance(text_tokens, torch.Tensor) or not isinstance(images, torch.Tensor):
             raise TypeError("text_tokens and images must be instances of torch.Tensor")
+        if self.use_hip_graphs and text_tokens.is_cuda and images.is_cuda and text_tokens.dim() == 2:
+            return self._forward_graphed(text_tokens, images)
+        return self._forward_impl(text_tokens, images)
+
+    def _forward_graphed(self, text_tokens, images):
+        """Replay the ~420 kernel launches of one forward as a single hipGraph (the library never allocates or
+        synchronises, so the whole launch sequence is capturable).  Worth it when the forward is launch-bound
+        (small batches): one graph per (batch, text length, precision), inputs copied into static buffers."""
+        key = (tuple(text_tokens.shape), tuple(images.shape), images.dtype, self.precision, text_tokens.device)
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._forward_impl(text_tokens, images)          # warm-up: packs weights, sizes workspaces, uploads tables
+            torch.cuda.synchronize(text_tokens.device)
+            s_tok, s_img = text_tokens.clone(), images.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s_out = self._forward_impl(s_tok, s_img)
+            ent = self._graphs[key] = (g, s_tok, s_img, s_out)
+        g, s_tok, s_img, s_out = ent
+        s_tok.copy_(text_tokens)
+        s_img.copy_(images)
+        g.replay()
+        return s_out.clone()
+
+    def _forward_impl(self, text_tokens: torch.Tensor, images: torch.Tensor):
         prec = self.precision
         try:
             img = self.clip_model.run(images, prec, self._ws)                       # model.py:230

@@ -45,7 +45,8 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, o
 
 
 def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
-         xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None):
+         xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None, splitk_ws=None,
+         splitk=0):
     """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32]."""
     _need_cuda(a, w, bias, residual, out)
     M, K = a.shape
@@ -66,6 +67,8 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
         g.xpos_T, g.xpos_dim = xpos[0].shape[0], xpos_dim
     g.prec, g.tile = prec, tile
     g.row_stats, g.colsum, g.stats_out = H.ptr(row_stats), H.ptr(colsum), H.ptr(stats_out)
+    if splitk_ws is not None:
+        g.splitk_ws, g.splitk_ws_bytes, g.splitk = H.ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size(), splitk
     H.check(H.load().kx_gemm(C.byref(g), _stream()), "kx_gemm")
     return out
 

@@ -214,6 +214,17 @@ def test_full_size_c1_parity(full_model, full_reference):
     print(f"C1 bf16: vs bf16-oracle {e16:.3e}, vs fp32-oracle {e32:.3e}")
     assert e32 < BF16_VS_FP32_TOL
     assert torch.equal(out16, m(tok.to(DEV), img.to(DEV)))
-    # batch-32 rows equal the batch-1 result (what makes data-parallel sharding exact)
+    # Rows are independent of their batch mates.  Bit-equality holds between runs of the SAME shape (above, and
+    # test_properties_*): kernel variants are chosen by shape (batch-1 GEMMs are split-K), so a different batch size
+    # changes fp32 summation order and, through bf16 rounding flips, the logits at the bf16 error level.
     out_b = m(tok.to(DEV).expand(4, -1).contiguous(), img.to(DEV).expand(4, -1, -1, -1).contiguous())
-    assert torch.equal(out_b[3], out16[0])
+    assert torch.equal(out_b[3], out_b[0])
+    assert rel_err(out_b[3:4], out16) < BF16_VS_FP32_TOL
+    # hipGraph replay reproduces the eager launch sequence bit for bit
+    m.use_hip_graphs = True
+    try:
+        g1 = m(tok.to(DEV), img.to(DEV))
+        g2 = m(tok.to(DEV), img.to(DEV))
+        assert torch.equal(g1, out16) and torch.equal(g2, out16)
+    finally:
+        m.use_hip_graphs = False

@@ -356,3 +356,28 @@ def test_attention_partial_row_stats(prec):
     assert (st[:, 0] - o.mean(1)).abs().max() < 2e-5
     ref_rstd = 1 / torch.sqrt(o.var(1, unbiased=False) + 1e-5)
     assert ((st[:, 1] - ref_rstd) / ref_rstd).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("splitk", [0, 2, 7])
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
+def test_gemm_split_k_skinny(prec, splitk):
+    """Batch-1 shapes: K sliced over workgroup rows, partials reduced in slice order, epilogue in the reduce kernel."""
+    M, N, K = 114, 264, 2048
+    g = _g(61)
+    a = torch.randn(M, K, generator=g).to(prec)
+    w = (torch.randn(N, K, generator=g) / 40).to(prec)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = _gemm_ref(a.float(), w.float(), bias, res, "gelu")
+    ws = torch.empty(8 << 20, dtype=torch.uint8, device=DEV)
+    out = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, "gelu", out=out, tile=64, splitk_ws=ws, splitk=splitk)
+    assert rel_err(out, ref) < 3e-5
+    out2 = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out2, "gelu", out=out2, tile=64, splitk_ws=ws, splitk=splitk)
+    assert torch.equal(out, out2)                                   # slice-order reduction is deterministic
+    # statistics epilogue through the reduce kernel
+    part = torch.zeros(M, 256 // 32, 2, device=DEV)
+    w2 = (torch.randn(256, K, generator=g) / 40).to(prec)
+    y = ops.gemm(a.to(DEV), w2.to(DEV), act="gelu", stats_out=part, tile=64, splitk_ws=ws, splitk=splitk)
+    st = ops.row_stats_finalize(part, 32).cpu()
+    assert (st[:, 0] - y.cpu().mean(1)).abs().max() < 2e-5
