@@ -228,3 +228,60 @@ def test_full_size_c1_parity(full_model, full_reference):
         assert torch.equal(g1, out16) and torch.equal(g2, out16)
     finally:
         m.use_hip_graphs = False
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] (text-only, seq 2046 = the longest sequence the reference's 2048-row position table admits)
+# and the edge sizes of the multimodal path
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_lang():
+    return KosmosLanguage(vocab_size=32002, dim=2048, _seed=3, _perturb=0.05).eval()   # example_lang.py:9-12
+
+
+def test_language_full_size_max_length(full_lang):
+    lm = full_lang
+    g = torch.Generator().manual_seed(4)
+    tok = torch.randint(0, 32002, (1, 2046), generator=g)
+    cfg = O.DecoderCfg(vocab=32002)
+    ref = O.kosmos_language_forward(oracle_weights(lm), tok, cfg)
+    lm = lm.to(DEV)
+    lm.precision = "fp32"
+    out = lm(tok.to(DEV))
+    assert out.shape == (1, 2046, 32002)
+    e = rel_err(out, ref)
+    print(f"C3-shape (B=1,T=2046) fp32: max|d|/rms = {e:.3e}")
+    assert e < 2e-4
+    lm.precision = "bf16"
+    out16 = lm(tok.to(DEV))
+    e16 = rel_err(out16, ref)
+    print(f"C3-shape (B=1,T=2046) bf16: max|d|/rms = {e16:.3e}")
+    assert e16 < BF16_VS_FP32_TOL
+    # causality at full length: changing the last 100 tokens leaves the first 1946 positions bit-identical
+    tok2 = tok.clone()
+    tok2[:, 1946:] = (tok2[:, 1946:] + 7) % 32002
+    out2 = lm(tok2.to(DEV))
+    assert torch.equal(out16[:, :1946], out2[:, :1946]) and not torch.equal(out16[:, 1946:], out2[:, 1946:])
+    # batch rows are independent: a batch of 2 reproduces each row (same shapes => same kernels => bit equality)
+    both = lm(torch.cat([tok, tok2]).to(DEV))
+    both2 = lm(torch.cat([tok2, tok]).to(DEV))
+    assert torch.equal(both[0], both2[1]) and torch.equal(both[1], both2[0])
+    # one token more overflows the position table exactly like the reference (example_lang.py's 2048 raises)
+    with pytest.raises(IndexError):
+        lm(torch.zeros(1, 2047, dtype=torch.long, device=DEV))
+
+
+@pytest.mark.parametrize("Tt", [2, 1982])
+def test_full_size_text_length_edges(full_model, Tt):
+    """Shortest (T_text = 2: the splice needs '<s> <image>') and longest (T = 2046) multimodal sequences."""
+    tok, img = _inputs(1, Tt, full_model.cfg, seed=Tt)
+    ref = O.kosmos_forward(oracle_weights(full_model.cpu()), tok, img, oracle_cfg(full_model.cfg), O.Switches())
+    m = full_model.to(DEV)
+    m.precision = "fp32"
+    out = m(tok.to(DEV), img.to(DEV))
+    assert out.shape == (1, Tt + 64, 32002)
+    e = rel_err(out, ref)
+    print(f"multimodal Tt={Tt} fp32: max|d|/rms = {e:.3e}")
+    assert e < 2e-4
+    with pytest.raises(IndexError):
+        m(torch.zeros(1, 1983, dtype=torch.long, device=DEV), img.to(DEV))
