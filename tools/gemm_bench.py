@@ -15,6 +15,8 @@ SHAPES = {  # name: (M, N, K)
     "vit_fc2_b32": (8224, 1024, 4096), "sq4096": (4096, 4096, 4096), "sq8192": (8192, 8192, 8192),
     "dec_qkv_b1": (114, 6144, 2048), "dec_fc1_b1": (114, 8192, 2048), "dec_fc2_b1": (114, 2048, 8192),
     "c3_fc1": (65472, 8192, 2048),
+    "vitp_qkv": (8192, 3072, 1024), "vitp_out": (8192, 1024, 1024), "vitp_fc1": (8192, 4096, 1024),
+    "vitp_fc2": (8192, 1024, 4096),
 }
 
 def bench(name, M, N, K, tiles, dtype=torch.bfloat16, iters=10, rounds=5, epi="plain"):
@@ -56,7 +58,8 @@ if __name__ == "__main__":
     tiles = [int(t) for t in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["128", "64"])]
     only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
     EPI = {"dec_fc1_b32": "gelu_f32", "vit_fc1_b32": "gelu_bf16", "dec_out_b32": "resid", "dec_fc2_b32": "resid",
-           "vit_out_b32": "resid", "vit_fc2_b32": "resid", "c3_fc1": "gelu_f32"}
+           "vit_out_b32": "resid", "vit_fc2_b32": "resid", "c3_fc1": "gelu_f32",
+           "vitp_fc1": "gelu_bf16", "vitp_out": "resid", "vitp_fc2": "resid"}
     for name, (M, N, K) in SHAPES.items():
         if only and name not in only:
             continue
