@@ -531,6 +531,8 @@ int launch_p3(GemmParams& p, hipStream_t s) {
 // Two LDS stages of 64 KB (128 of 160 KB), one workgroup per CU; the fill of tile t+1 is issued when tile t's
 // first phase starts and waited for (vmcnt(0)) in its third phase, so it has two MFMA phases to land.
 // Same 4-phase / lagging-half schedule as gemm_kernel_p3<PHASED>.
+// (A v_mfma_f32_32x32x16_bf16 version of this kernel — same LDS traffic, half the MFMA instructions — measured
+// 1.16 vs 1.36 PFLOP/s at 8192^3 and was dropped.)
 // -------------------------------------------------------------------------------------------------
 template <typename T, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {

@@ -32,6 +32,13 @@ def bench(name, M, N, K, tiles, dtype=torch.bfloat16, iters=10, rounds=5, epi="p
     elif epi == "gelu_bf16":     # ViT fc1: bias + GELU -> bf16
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         kw = dict(bias=torch.randn(N, device="cuda"), act="gelu")
+    elif epi == "gelu_bf16_stats":   # decoder fc1 with the folded ffn_layernorm: bias + GELU -> bf16 + row statistics
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        kw = dict(bias=torch.randn(N, device="cuda"), act="gelu", stats_out=torch.empty(M, N // 32, 2, device="cuda"))
+    elif epi == "resid_fold":        # decoder fc2 / out_proj with folded LN: rstd*(acc-mean*colsum) + bias + residual
+        out = torch.randn(M, N, device="cuda", dtype=torch.float32)
+        kw = dict(bias=torch.randn(N, device="cuda"), residual=out, row_stats=torch.rand(M, 2, device="cuda"),
+                  colsum=torch.randn(N, device="cuda"))
     elif epi == "resid":         # out_proj / fc2: bias + residual (in place, fp32)
         out = torch.randn(M, N, device="cuda", dtype=torch.float32)
         kw = dict(bias=torch.randn(N, device="cuda"), residual=out)
@@ -67,3 +74,8 @@ if __name__ == "__main__":
         print(json.dumps(bench(name, M, N, K, ts)), flush=True)
         if name in EPI:
             print(json.dumps(bench(name, M, N, K, ts, epi=EPI[name])), flush=True)
+        if name in ("dec_fc1_b32", "c3_fc1"):
+            print(json.dumps(bench(name, M, N, K, ts, epi="gelu_bf16")), flush=True)
+            print(json.dumps(bench(name, M, N, K, ts, epi="gelu_bf16_stats")), flush=True)
+        if name in ("dec_fc2_b32", "dec_out_b32"):
+            print(json.dumps(bench(name, M, N, K, ts, epi="resid_fold")), flush=True)
