@@ -100,9 +100,9 @@ typedef struct {
    * Consumer side: with row_stats [M,2] = (mean, rstd) of each A row and colsum [N] = Σ_k W[n,k], and W holding
    * γ ⊙ W_original, the epilogue starts with v = rstd·(acc − mean·colsum[n]); pass β·W_originalᵀ + b as `bias`.
    * Then y = LN(A)·Wᵀ + b without a LayerNorm pass over A.
-   * Producer side: stats_out [M, N/32, 2] receives, per row and 32-column segment, (sum, Σ(x − segment mean)²)
-   * of the value after the activation (before any residual; N % 32 == 0) — kx_row_stats_finalize turns them
-   * into (mean, rstd). */
+   * Producer side: stats_out [M, N/64, 2] receives, per row and 64-column segment, (sum, Σ(x − segment mean)²)
+   * of act(acc + bias) (N % 64 == 0; combines with bias and activation only) — kx_row_stats_finalize(seg_size 64)
+   * turns them into (mean, rstd). */
   const float* row_stats; const float* colsum;
   float* stats_out;
   /* Optional split-K scratch for skinny problems (the 64x64 variant): when given, K is sliced over up to 16

@@ -177,7 +177,7 @@ DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, ch
   d.qkv = c.take((size_t)M * 3 * w->dim * es);
   d.att = c.take((size_t)M * w->dim * es);          // attention output, un-normalised (inner_attn_ln is folded)
   d.g = c.take((size_t)M * w->ffn * es);            // gelu(fc1), un-normalised (ffn_layernorm is folded)
-  const int64_t nseg = w->ffn / 32 > w->heads ? w->ffn / 32 : w->heads;
+  const int64_t nseg = w->ffn / 64 > w->heads ? w->ffn / 64 : w->heads;
   d.partials = (float*)c.take((size_t)M * nseg * 2 * 4);
   d.stats = (float*)c.take((size_t)M * 2 * 4);
   d.splitk = c.take(KX_SPLITK_WS);
@@ -298,7 +298,7 @@ extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t
   KX_REQUIRE(B > 0 && T > 0, "kx_decoder_forward: empty input");
   KX_REQUIRE(w->dim == w->heads * 64, "kx_decoder_forward: head_dim must be 64 (dim=%d heads=%d)", w->dim, w->heads);
   KX_REQUIRE(!w->xpos || (xq_cs && xq_ss && xk_cs && xk_ss), "kx_decoder_forward: XPos tables missing");
-  KX_REQUIRE(!w->subln || w->ffn % 32 == 0, "kx_decoder_forward: ffn must be a multiple of 32 for the folded sub-LN");
+  KX_REQUIRE(!w->subln || w->ffn % 64 == 0, "kx_decoder_forward: ffn must be a multiple of 64 for the folded sub-LN");
   KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_decoder_forward: workspace must be 256-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const DecBufs d = dec_plan(w, B, T, prec, (char*)workspace);
@@ -341,7 +341,7 @@ extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t
       // ffn_layernorm folded into fc2 the same way; fc1's epilogue emits the row statistics of gelu(fc1)
       KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
                   nullptr, 0, 0, nullptr, nullptr, d.partials));
-      KX_TRY(kx_row_stats_finalize(d.partials, M, F / 32, 32, w->eps, d.stats, stream));
+      KX_TRY(kx_row_stats_finalize(d.partials, M, F / 64, 64, w->eps, d.stats, stream));
       KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
                   0, 0, d.stats, L.w2_colsum, nullptr));
     } else {

@@ -27,6 +27,7 @@ struct GemmParams {
   const float *xq_cs, *xq_ss, *xk_cs, *xk_ss; int xpos_T, xpos_dim;
   int tiles_m, tiles_n;
   int vec_ok;  // ldc % 4 == 0 (&& ldr % 4 == 0): 16-byte epilogue accesses are aligned
+  int vec8_ok; // additionally ldc % 8 == 0: 8 bf16 outputs per lane can go out as one 16-byte store
   // folded sub-LayerNorm (see kx_gemm_args): consume per-row (mean, rstd) + column sums, produce partial statistics
   const float* row_stats; const float* colsum;
   float* stats_out; int stats_nseg;
@@ -35,10 +36,10 @@ struct GemmParams {
   int splitk; float* partial;
 };
 
+// Everything of the fused epilogue except the store: x[0..3] = columns n..n+3 of row m (in range: m < M, n < N).
 template <int ACT>
-__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32x4_t acc) {
-  if (m >= p.M || n >= p.N) return;
-  float x[4] = {acc[0], acc[1], acc[2], acc[3]};
+__device__ __forceinline__ void epilogue_compute4(const GemmParams& p, int m, int n, f32x4_t acc, float (&x)[4]) {
+  x[0] = acc[0]; x[1] = acc[1]; x[2] = acc[2]; x[3] = acc[3];
   const bool full = (n + 3 < p.N);
   if (p.row_stats) {
     // y = LN(a)·Wᵀ with the LayerNorm folded out of the operand:  rstd·(a·W'ᵀ − mean·Σ_k W'[n,k]),  W' = γ ⊙ W;
@@ -81,19 +82,19 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
     for (int j = 0; j < 4; ++j) x[j] = apply_act<ACT>(x[j]);
   }
   if (p.stats_out) {
-    // partial LayerNorm statistics of this row over the 32 columns held by the aligned 8-lane group (N % 32 == 0
+    // (split-K reduce kernel only; the tile kernels take statistics at accumulator level, prepass_bias_act_stats)
+    // partial LayerNorm statistics of this row over the 64 columns held by the aligned 16-lane group (N % 64 == 0
     // is enforced, rows are uniform per group): (sum, sum of squares about the segment mean) — combined exactly
     // by kx_row_stats_finalize with Chan's formula, so no E[x²]−mean² cancellation.
     float sm = (x[0] + x[1]) + (x[2] + x[3]);
-    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
-    const float mu = sm * (1.0f / 32.0f);
+    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
+    const float mu = sm * (1.0f / 64.0f);
     const float d0 = x[0] - mu, d1 = x[1] - mu, d2 = x[2] - mu, d3 = x[3] - mu;
     float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
-    if ((n & 31) == 0)
-      *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (n >> 5))) = make_float2(sm, m2);
+    m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64); m2 += __shfl_xor(m2, 8, 64);
+    if ((n & 63) == 0)
+      *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (n >> 6))) = make_float2(sm, m2);
   }
-  const long long off = (long long)m * p.ldc + n;
   if (p.residual) {
     const long long roff = (long long)m * p.ldr + n;
     if (full && p.vec_ok) {
@@ -103,6 +104,15 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
       for (int j = 0; j < 4; ++j) if (n + j < p.N) x[j] += p.residual[roff + j];
     }
   }
+}
+
+template <int ACT>
+__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32x4_t acc) {
+  if (m >= p.M || n >= p.N) return;
+  float x[4];
+  epilogue_compute4<ACT>(p, m, n, acc, x);
+  const bool full = (n + 3 < p.N);
+  const long long off = (long long)m * p.ldc + n;
   if (p.c_bf16) {
     bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
     if (full && p.vec_ok) {
@@ -118,6 +128,96 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
     } else {
       for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = x[j];
     }
+  }
+}
+
+// bf16 outputs: 8 columns per lane -> one 16-byte store.  With 4 columns per lane the 8-byte stores are issue-bound
+// (a bf16 store loop measured slower than the fp32 one that moves twice the bytes).  Needs vec_ok, N % 8 == 0 rows.
+template <int ACT>
+__device__ __forceinline__ void epilogue8_bf16(const GemmParams& p, int m, int n, f32x4_t lo, f32x4_t hi) {
+  if (m >= p.M || n >= p.N) return;
+  if (n + 7 < p.N) {
+    float x[4], y[4];
+    epilogue_compute4<ACT>(p, m, n, lo, x);
+    epilogue_compute4<ACT>(p, m, n + 4, hi, y);
+    uint4 o;
+    o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]);
+    o.z = pack_bf16x2(y[0], y[1]); o.w = pack_bf16x2(y[2], y[3]);
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n) = o;
+  } else {
+    epilogue4<ACT>(p, m, n, lo);
+    epilogue4<ACT>(p, m, n + 4, hi);
+  }
+}
+
+// The store loop every tile kernel runs over its LDS-parked fp32 sub-tile (`rows` x WN, 16-B chunks XOR-swizzled by
+// row): row-major walk, fused epilogue, coalesced row segments.
+template <int ACT, int WN>
+__device__ __forceinline__ void store_loop(const GemmParams& p, const float* cw, int rows, int lane, int mbase,
+                                           int nwave) {
+  constexpr int CH = WN / 4;
+  if (p.c_bf16 && p.vec8_ok) {
+    constexpr int L8 = WN / 8, RPI8 = 64 / L8;          // lanes per row, rows per wave-wide pass
+    const int cl = lane % L8, rl = lane / L8;
+#pragma unroll 2
+    for (int r = 0; r < rows; r += RPI8) {
+      const int ml = r + rl;
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + (((2 * cl) ^ (ml & (CH - 1))) << 2));
+      const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + (((2 * cl + 1) ^ (ml & (CH - 1))) << 2));
+      epilogue8_bf16<ACT>(p, mbase + ml, nwave + cl * 8, lo, hi);
+    }
+  } else {
+    constexpr int RPI = 64 / CH;
+    const int cl = lane % CH, rl = lane / CH;
+#pragma unroll 2
+    for (int r = 0; r < rows; r += RPI) {
+      const int ml = r + rl;
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
+      epilogue4<ACT>(p, mbase + ml, nwave + cl * 4, v);
+    }
+  }
+}
+
+// Producer side of the folded sub-LayerNorm, at ACCUMULATOR level (before the LDS staging): bias + activation are
+// applied in place and the row statistics of the wave's 64 columns are reduced where they are cheapest — a lane of
+// the 16x16 accumulator layout already holds 16 of a row's 64 values (4 fragments x 4 columns), the other 48 sit
+// in the lanes +16/+32/+48.  2 shuffles per value instead of 6 per float4 in the store loop (measured: −12 us of a
+// 149 us fc1 launch).  The store loop then runs without bias/activation.
+template <int ACT, int FM, int FN>
+__device__ __forceinline__ void prepass_bias_act_stats(const GemmParams& p, f32x4_t (&acc)[FN][FM], int mrow0,
+                                                       int ncol0, int g, int li) {
+  static_assert(FN == 4, "a wave must own exactly one 64-column statistics segment");
+  if (ncol0 >= p.N) return;                       // whole segment outside (N % 64 == 0)
+  float4 bias[FN];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+    bias[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + ncol0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    float sm = 0.f;
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      f32x4_t v = acc[a][b];
+      v[0] = apply_act<ACT>(v[0] + bias[a].x); v[1] = apply_act<ACT>(v[1] + bias[a].y);
+      v[2] = apply_act<ACT>(v[2] + bias[a].z); v[3] = apply_act<ACT>(v[3] + bias[a].w);
+      acc[a][b] = v;
+      sm += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    sm += __shfl_xor(sm, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    const float mu = sm * (1.0f / 64.0f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const f32x4_t v = acc[a][b];
+      const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
+      m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    m2 += __shfl_xor(m2, 16, 64);
+    m2 += __shfl_xor(m2, 32, 64);
+    const int m = mrow0 + b * 16 + li;
+    if (g == 0 && m < p.M)
+      *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (ncol0 >> 6))) = make_float2(sm, m2);
   }
 }
 
@@ -257,6 +357,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int CH = WN / 4;          // 16-byte chunks per sub-tile row (16 or 8)
   constexpr int RPI = 64 / CH;        // rows covered by one wave-wide access
+  const bool pre = p.stats_out != nullptr && p.splitk == 1;   // folded sub-LN producer: see prepass_bias_act_stats
+  if constexpr (FN == 4) {
+    if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, g, li);
+  }
+  GemmParams q = p;                   // what is left for the store loop after the pre-pass
+  q.bias = nullptr; q.stats_out = nullptr;
   __syncthreads();                    // every wave is done reading the last stage
   float* cw = reinterpret_cast<float*>(smem) + wave * (WM * WN);
 #pragma unroll
@@ -267,28 +373,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][b];
     }
   __syncthreads();
-  const int cl = lane % CH, rl = lane / CH;
-  const int mbase = m0 + wm * WM, nbase = n0 + wn * WN + cl * 4;
-#pragma unroll 2
-  for (int r = 0; r < WM; r += RPI) {
-    const int ml = r + rl;
-    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
-    if (p.splitk > 1) {
-      const int m = mbase + ml;
+  if (p.splitk > 1) {                 // split-K: raw fp32 partials, the reduce kernel owns the epilogue
+    const int cl = lane % CH, rl = lane / CH;
+    const int mbase = m0 + wm * WM, nbase = n0 + wn * WN + cl * 4;
+    for (int r = 0; r < WM; r += RPI) {
+      const int ml = r + rl, m = mbase + ml;
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
       if (m < p.M && nbase < p.N) {
         float* dst = p.partial + ((long long)blockIdx.y * p.M + m) * p.N + nbase;
         if (nbase + 3 < p.N && (p.N & 3) == 0) *reinterpret_cast<f32x4_t*>(dst) = v;
         else for (int j = 0; j < 4; ++j) if (nbase + j < p.N) dst[j] = v[j];
       }
-    } else {
-      epilogue4<ACT>(p, mbase + ml, nbase, v);
     }
+  } else if (pre) {
+    store_loop<KX_ACT_NONE, WN>(q, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);
+  } else {
+    store_loop<ACT, WN>(p, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);
   }
 }
 
 // Sums the K-slice partials of a split-K launch in slice order and runs the fused epilogue.  Thread = one row x 4
-// columns; consecutive threads walk a row, so the 8-lane groups of the LayerNorm-statistics epilogue still hold 32
-// consecutive columns of one row (N % 32 == 0 in that mode).
+// columns; consecutive threads walk a row, so the 16-lane groups of the LayerNorm-statistics epilogue hold 64
+// consecutive columns of one row (N % 64 == 0 in that mode).
 template <int ACT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
   const int n4 = (p.N + 3) >> 2;
@@ -486,7 +592,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
   }
 
   // ---- epilogue staged through LDS (see gemm_kernel) ----
-  constexpr int WM = 64, WN = 64, CH = WN / 4, RPI = 64 / CH;
+  constexpr int WM = 64, WN = 64, CH = WN / 4;
+  const bool pre = p.stats_out != nullptr;
+  if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, g, li);
+  GemmParams q = p;
+  q.bias = nullptr; q.stats_out = nullptr;
   float* cw = reinterpret_cast<float*>(smem) + wave * (WM * WN);
 #pragma unroll
   for (int a = 0; a < FN; ++a)
@@ -496,14 +606,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
       *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][b];
     }
   __syncthreads();
-  const int cl = lane % CH, rl = lane / CH;
-  const int mbase = m0 + wm * WM, nbase = n0 + wn * WN + cl * 4;
-#pragma unroll 2
-  for (int r = 0; r < WM; r += RPI) {
-    const int ml = r + rl;
-    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
-    epilogue4<ACT>(p, mbase + ml, nbase, v);
-  }
+  if (pre) store_loop<KX_ACT_NONE, WN>(q, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);
+  else store_loop<ACT, WN>(p, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);
 }
 
 template <typename T, bool PHASED>
@@ -657,9 +761,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   if (!lag) __builtin_amdgcn_s_barrier();
 
   // ---- epilogue staged through LDS in two 64-row halves (8 waves x 64x64 fp32 = 128 KB) ----
-  constexpr int WN = 64, CH = WN / 4, RPI = 64 / CH;
+  constexpr int WN = 64, CH = WN / 4;
+  const bool pre = p.stats_out != nullptr;
+  if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * 128, n0 + wn * WN, g, li);
+  GemmParams q = p;
+  q.bias = nullptr; q.stats_out = nullptr;
   float* cw = reinterpret_cast<float*>(smem) + wave * (64 * WN);
-  const int cl = lane % CH, rl = lane / CH;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();   // previous half's rows have been read back / the K loop is over
@@ -671,13 +778,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
         *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][half * 4 + b];
       }
     __syncthreads();
-    const int mbase = m0 + wm * 128 + half * 64, nbase = n0 + wn * WN + cl * 4;
-#pragma unroll 2
-    for (int r = 0; r < 64; r += RPI) {
-      const int ml = r + rl;
-      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
-      epilogue4<ACT>(p, mbase + ml, nbase, v);
-    }
+    if (pre) store_loop<KX_ACT_NONE, WN>(q, cw, 64, lane, m0 + wm * 128 + half * 64, n0 + wn * WN);
+    else store_loop<ACT, WN>(p, cw, 64, lane, m0 + wm * 128 + half * 64, n0 + wn * WN);
   }
 }
 
@@ -760,13 +862,16 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   p.qscale = a->qscale; p.qcols = (int)a->qcols;
   p.xq_cs = a->xq_cs; p.xq_ss = a->xq_ss; p.xk_cs = a->xk_cs; p.xk_ss = a->xk_ss;
   p.xpos_T = (int)a->xpos_T; p.xpos_dim = (int)a->xpos_dim;
-  p.row_stats = a->row_stats; p.colsum = a->colsum; p.stats_out = a->stats_out; p.stats_nseg = (int)(a->N / 32);
+  p.row_stats = a->row_stats; p.colsum = a->colsum; p.stats_out = a->stats_out; p.stats_nseg = (int)(a->N / 64);
   KX_REQUIRE(!a->row_stats == !a->colsum, "kx_gemm: row_stats and colsum must be given together");
   KX_REQUIRE(!a->colsum || ((uintptr_t)a->colsum & 15) == 0, "kx_gemm: colsum must be 16-byte aligned");
-  KX_REQUIRE(!a->stats_out || a->N % 32 == 0, "kx_gemm: stats_out needs N %% 32 == 0 (N=%lld)", (long long)a->N);
+  KX_REQUIRE(!a->stats_out || a->N % 64 == 0, "kx_gemm: stats_out needs N %% 64 == 0 (N=%lld)", (long long)a->N);
+  KX_REQUIRE(!a->stats_out || (!a->row_stats && a->qcols == 0 && a->xpos_dim == 0),
+             "kx_gemm: stats_out combines with bias and activation only");
   KX_REQUIRE(!a->stats_out || !a->residual, "kx_gemm: stats_out is taken before the residual add; pass one of them");
   p.vec_ok = (a->ldc % 4 == 0) && (!a->residual || a->ldr % 4 == 0) &&
              (((uintptr_t)a->C & 15) == 0) && (!a->residual || ((uintptr_t)a->residual & 15) == 0);
+  p.vec8_ok = p.vec_ok && (a->ldc % 8 == 0) && (a->N % 8 == 0);
   KX_REQUIRE(!a->bias || ((uintptr_t)a->bias & 15) == 0, "kx_gemm: bias must be 16-byte aligned");
   p.splitk = 1; p.partial = nullptr;
   hipStream_t s = (hipStream_t)stream;
@@ -803,6 +908,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       else tile = cost(160) <= cost(128) ? 160 : 128;
     }
   }
+  if (tile == 64 && a->stats_out && !(a->splitk_ws && a->splitk != 1)) tile = 128;   // 64x64 waves own 32 columns only
   if (tile == 64 && a->splitk_ws) {
     // Skinny problems (batch-1 shapes: M = 114 / 257 / 64) are weight-streaming bound and a 64x64 grid of N/64 x 2
     // workgroups leaves most CUs idle while each one walks all of K serially.  Slice K so that ~512 workgroups

@@ -34,7 +34,7 @@ def bench(name, M, N, K, tiles, dtype=torch.bfloat16, iters=10, rounds=5, epi="p
         kw = dict(bias=torch.randn(N, device="cuda"), act="gelu")
     elif epi == "gelu_bf16_stats":   # decoder fc1 with the folded ffn_layernorm: bias + GELU -> bf16 + row statistics
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        kw = dict(bias=torch.randn(N, device="cuda"), act="gelu", stats_out=torch.empty(M, N // 32, 2, device="cuda"))
+        kw = dict(bias=torch.randn(N, device="cuda"), act="gelu", stats_out=torch.empty(M, N // 64, 2, device="cuda"))
     elif epi == "resid_fold":        # decoder fc2 / out_proj with folded LN: rstd*(acc-mean*colsum) + bias + residual
         out = torch.randn(M, N, device="cuda", dtype=torch.float32)
         kw = dict(bias=torch.randn(N, device="cuda"), residual=out, row_stats=torch.rand(M, 2, device="cuda"),
