@@ -171,7 +171,7 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 constexpr int VSTR = 80;   // V tile row pitch in elements (160 B)
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bf16_v2_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * VSTR];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -262,37 +262,50 @@ __global__ __launch_bounds__(256) void attn_bf16_v2_kernel(const AttnParams p) {
         }
       }
       // ---- online softmax per query block (query = lane&15; its keys sit in 4 lanes x 16 registers) ----
+      // Masking is needed only on the tile that holds the sequence end or crosses this wave's diagonal (wave-uniform).
+      const bool need_mask = (kv0 + 63 >= p.Tk) || (CAUSAL && kv0 + 63 > qw0);
       u32x4_t pf[2][2];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int qi = qw0 + qb * 16 + li;
         float mloc = -INFINITY;
+        if (need_mask) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+          for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kv0 + kb * 16 + 4 * g + r;
-            const bool ok = key < p.Tk && (!CAUSAL || key <= qi);
-            st[qb][kb][r] = ok ? st[qb][kb][r] : -INFINITY;
-            mloc = fmaxf(mloc, st[qb][kb][r]);
-          }
+            for (int r = 0; r < 4; ++r) {
+              const int key = kv0 + kb * 16 + 4 * g + r;
+              const bool ok = key < p.Tk && (!CAUSAL || key <= qi);
+              st[qb][kb][r] = ok ? st[qb][kb][r] : -INFINITY;
+              mloc = fmaxf(mloc, st[qb][kb][r]);
+            }
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+            mloc = fmaxf(fmaxf(mloc, fmaxf(st[qb][kb][0], st[qb][kb][1])), fmaxf(st[qb][kb][2], st[qb][kb][3]));
+        }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run[qb], mloc);
         const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = __expf(m_run[qb] - m_safe);
+        // exp(s - m) as one FMA + v_exp_f32 (2^x): exp2(s*log2e - m*log2e)
+        constexpr float LOG2E = 1.44269504088896340736f;
+        const float mneg = -m_safe * LOG2E;
+        const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qb], LOG2E, mneg));
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            st[qb][kb][r] = __expf(st[qb][kb][r] - m_safe);
+            st[qb][kb][r] = __builtin_amdgcn_exp2f(fmaf(st[qb][kb][r], LOG2E, mneg));
             psum += st[qb][kb][r];
           }
         l_run[qb] = l_run[qb] * alpha + psum;
         m_run[qb] = m_new;
+        if (!__all(alpha == 1.0f)) {      // the running max moved for some query of the wave: rescale O
 #pragma unroll
-        for (int d = 0; d < 4; ++d) ot[qb][d] *= alpha;
+          for (int d = 0; d < 4; ++d) ot[qb][d] *= alpha;
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           pf[qb][c][0] = pack_bf16x2(st[qb][2 * c][0], st[qb][2 * c][1]);
