@@ -152,10 +152,11 @@ int kx_row_stats_finalize(const float* partials, int64_t rows, int64_t nseg, int
  *   already contains positions (in-place `x += positions`), so text rows get positions
  *   twice.  Returns KX_ERR_INVALID_ARG ("position ... out of range") when Tt+n_img+2 > max_pos —
  *   the condition under which the reference's F.embedding raises IndexError.
- *   Token ids are clamped to [0, vocab) for memory safety. */
+ *   Token ids are clamped to [0, vocab) for memory safety.  pos_offset shifts every position index (0 on the
+ *   forward path; the number of cached tokens when embedding the next token of an incremental decode). */
 int kx_embed_splice(const int64_t* tokens, const float* embed, const float* pos, const float* img,
                     float* out, int64_t B, int64_t Tt, int64_t n_img, int64_t d, int64_t vocab,
-                    int64_t max_pos, int64_t splice_at, int32_t u1_alias, void* stream);
+                    int64_t max_pos, int64_t splice_at, int32_t u1_alias, int64_t pos_offset, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stage-level entry points (what kosmosx.model calls).  Weight structs hold device pointers
@@ -247,6 +248,33 @@ int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t B, int64_t
                        const float* xq_cs, const float* xq_ss, const float* xk_cs, const float* xk_ss,
                        void* logits, int32_t ldt, void* workspace, size_t workspace_bytes,
                        int32_t prec, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Incremental decoding (torchscale Decoder.forward(..., incremental_state=...),
+ * MultiheadAttention's prev_key / prev_value path).  Not exercised by the reference's own call
+ * (/root/reference/kosmosx/model.py:250 passes no incremental_state); built as the next row after the forward.
+ *
+ * Caches: kcache / vcache [layers, B, Tmax, dim] in the operand dtype of `prec`.  Keys are stored AFTER the XPos
+ * rotation/scale (torchscale stores them before and re-rotates the whole cache every step; the score only depends
+ * on i − m and the centring constant cancels), so the tables passed to the prefill and to every
+ * decode step must share ONE centring: build [Tmax, 32] tables once with min_pos of the prefill length.
+ *
+ * kx_decoder_prefill  = kx_decoder_forward that also fills rows [0, T) of the caches.
+ * kx_decoder_decode_step: x [B, 1, dim] fp32 = embedding of the ONE new token at position t (consumed);
+ *   xq_*, xk_* point at ROW t of the tables ([32] floats each); appends row t to the caches, attends over rows
+ *   [0, t], returns logits [B, 1, vocab].  Workspace: kx_decoder_workspace_bytes(w, B, 1, prec).
+ * kx_attention_decode: the single-query attention + cache append used by the step (qkv [B, 3*dim] rows of the new
+ *   token; stats_out [B, H, 2] optional, as kx_attn_args.stats_out). */
+int kx_decoder_prefill(const kx_decoder_weights* w, float* x, int64_t B, int64_t T,
+                       const float* xq_cs, const float* xq_ss, const float* xk_cs, const float* xk_ss,
+                       void* logits, int32_t ldt, void* kcache, void* vcache, int64_t Tmax,
+                       void* workspace, size_t workspace_bytes, int32_t prec, void* stream);
+int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int64_t B, int64_t t,
+                           const float* xq_cs, const float* xq_ss, const float* xk_cs, const float* xk_ss,
+                           void* kcache, void* vcache, int64_t Tmax, void* logits, int32_t ldt,
+                           void* workspace, size_t workspace_bytes, int32_t prec, void* stream);
+int kx_attention_decode(const void* qkv, void* kcache, void* vcache, void* out, int32_t odt, float* stats_out,
+                        int64_t B, int64_t H, int64_t t, int64_t Tmax, int32_t prec, void* stream);
 
 /* Kernel-variant selection for in-process A/B measurement (tools/gemm_bench.py, tools/ln_bench.py).  Defaults (all 0) are the
  * shipped configuration.  key 0: LayerNorm variant (0 wave-per-row, 1 workgroup-per-row);

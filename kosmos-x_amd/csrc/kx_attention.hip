@@ -482,3 +482,149 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   KX_CHECK_LAUNCH("kx_attention");
   return KX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Incremental decoding: one new query per (batch, head) against the KV cache.
+// HBM-bound: the work is streaming (t+1) x 64 keys and values per head once.  A 16-lane group owns one key
+// (4 head dims per lane, 8-byte loads -> a wave-instruction covers 4 whole 128-B key rows), scores need 4
+// shuffles, every group keeps its own online-softmax state and the groups / waves are merged once at the end.
+// The block also appends the new token's (XPos-rotated) key and value to the cache.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct DecodeParams {
+  const char* qkv; long long qkv_row;        // [B, 3*D] rows: q | k | v of the new token (elements)
+  char* kcache; char* vcache;                // [B, Tmax, D]
+  long long cache_batch, cache_row;          // element strides
+  void* out; long long out_row; int o_bf16;  // [B, D]
+  float* stats_out;                          // [B, H, 2] or null
+  int H, D, t;                               // t = number of tokens already cached (the new one goes to row t)
+};
+
+template <typename T> struct Ld4;
+template <> struct Ld4<bf16_t> {
+  static __device__ __forceinline__ void load(const char* p, float (&x)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xffff0000u);
+    x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+};
+template <> struct Ld4<float> {
+  static __device__ __forceinline__ void load(const char* p, float (&x)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) {
+  __shared__ float sm_m[16], sm_l[16], sm_o[16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, li = lane & 15;              // 16-lane group = one key at a time; lane = dims 4li..4li+3
+  const int h = blockIdx.x, b = blockIdx.y;
+  const long long es = sizeof(T);
+  const char* qrow = p.qkv + ((long long)b * p.qkv_row + (long long)h * 64) * es;
+  char* kc = p.kcache + ((long long)b * p.cache_batch + (long long)h * 64) * es;
+  char* vc = p.vcache + ((long long)b * p.cache_batch + (long long)h * 64) * es;
+  // append the new token (row t): 64 k + 64 v elements per head, 16 lanes x 4 elements each
+  if (wave == 0 && grp < 2) {
+    const char* src = qrow + ((long long)(grp + 1) * p.D + 4 * li) * es;
+    char* dst = (grp == 0 ? kc : vc) + ((long long)p.t * p.cache_row + 4 * li) * es;
+    if (sizeof(T) == 2) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
+    else *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+  }
+  __syncthreads();
+  float q[4];
+  Ld4<T>::load(qrow + 4 * li * es, q);
+  float m = -INFINITY, l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nkeys = p.t + 1;
+  for (int j = wave * 4 + grp; j < nkeys; j += 16) {
+    float k[4], v[4];
+    Ld4<T>::load(kc + ((long long)j * p.cache_row + 4 * li) * es, k);
+    Ld4<T>::load(vc + ((long long)j * p.cache_row + 4 * li) * es, v);
+    float s = (q[0] * k[0] + q[1] * k[1]) + (q[2] * k[2] + q[3] * k[3]);
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+    const float mn = fmaxf(m, s);
+    const float a = __expf(m - mn), pj = __expf(s - mn);
+    l = l * a + pj;
+    o[0] = o[0] * a + pj * v[0]; o[1] = o[1] * a + pj * v[1];
+    o[2] = o[2] * a + pj * v[2]; o[3] = o[3] * a + pj * v[3];
+    m = mn;
+  }
+  // merge the 16 (wave, group) partial states
+  const int slot = wave * 4 + grp;
+  if (li == 0) { sm_m[slot] = m; sm_l[slot] = l; }
+  sm_o[slot][4 * li + 0] = o[0]; sm_o[slot][4 * li + 1] = o[1];
+  sm_o[slot][4 * li + 2] = o[2]; sm_o[slot][4 * li + 3] = o[3];
+  __syncthreads();
+  if (wave == 0) {
+    float M = -INFINITY;
+    for (int s2 = 0; s2 < 16; ++s2) M = fmaxf(M, sm_m[s2]);
+    float L = 0.f, acc = 0.f;
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const float w = sm_m[s2] == -INFINITY ? 0.f : __expf(sm_m[s2] - M);
+      L += w * sm_l[s2];
+      acc += w * sm_o[s2][lane];
+    }
+    const float ov = acc / L;                                  // lane = head dim
+    if (p.stats_out) {
+      const float sm = wave_sum(ov);
+      const float dv = ov - sm * (1.0f / 64.0f);
+      const float m2 = wave_sum(dv * dv);
+      if (lane == 0) *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)b * p.H + h)) = make_float2(sm, m2);
+    }
+    const long long ooff = (long long)b * p.out_row + (long long)h * 64 + lane;
+    if (p.o_bf16) reinterpret_cast<bf16_t*>(p.out)[ooff] = f32_to_bf16(ov);
+    else reinterpret_cast<float*>(p.out)[ooff] = ov;
+  }
+}
+
+// prefill: copy the k and v column blocks of the fused qkv rows [B*T, 3D] into the caches [B, Tmax, D]
+template <typename T>
+__global__ __launch_bounds__(256) void kv_prefill_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                         int Tlen, int D, long long cache_batch) {
+  const long long row = blockIdx.x;                       // b*T + t
+  const long long b = row / Tlen, t = row % Tlen;
+  const uint4* src = reinterpret_cast<const uint4*>(qkv + row * 3 * D);
+  constexpr int EPV = 16 / sizeof(T);
+  const int nv = D / EPV;
+  uint4* dk = reinterpret_cast<uint4*>(kc + b * cache_batch + t * D);
+  uint4* dv = reinterpret_cast<uint4*>(vc + b * cache_batch + t * D);
+  for (int c = threadIdx.x; c < nv; c += 256) { dk[c] = src[nv + c]; dv[c] = src[2 * nv + c]; }
+}
+
+}  // namespace
+
+int kx_launch_kv_prefill(const void* qkv, void* kc, void* vc, int64_t B, int64_t T, int64_t D, int64_t Tmax, int prec,
+                         hipStream_t s) {
+  KxProfScope prof(KX_K_MISC, B * T, D, 4, s);
+  if (prec == KX_PREC_BF16)
+    hipLaunchKernelGGL(kv_prefill_kernel<bf16_t>, dim3((unsigned)(B * T)), dim3(256), 0, s, (const bf16_t*)qkv,
+                       (bf16_t*)kc, (bf16_t*)vc, (int)T, (int)D, (long long)(Tmax * D));
+  else
+    hipLaunchKernelGGL(kv_prefill_kernel<float>, dim3((unsigned)(B * T)), dim3(256), 0, s, (const float*)qkv, (float*)kc,
+                       (float*)vc, (int)T, (int)D, (long long)(Tmax * D));
+  KX_CHECK_LAUNCH("kv_prefill");
+  return KX_OK;
+}
+
+extern "C" int kx_attention_decode(const void* qkv, void* kcache, void* vcache, void* out, int32_t odt, float* stats_out,
+                                   int64_t B, int64_t H, int64_t t, int64_t Tmax, int32_t prec, void* stream) {
+  KX_REQUIRE(qkv && kcache && vcache && out, "kx_attention_decode: null pointer");
+  KX_REQUIRE(B > 0 && H > 0 && t >= 0 && t < Tmax, "kx_attention_decode: position %lld outside the cache of %lld rows",
+             (long long)t, (long long)Tmax);
+  KX_REQUIRE(prec == KX_PREC_BF16 || prec == KX_PREC_F32, "kx_attention_decode: bad precision");
+  KX_REQUIRE(B < 65536 && H < 65536, "kx_attention_decode: B/H exceed the grid limits");
+  DecodeParams p;
+  const int64_t D = H * 64;
+  p.qkv = (const char*)qkv; p.qkv_row = 3 * D;
+  p.kcache = (char*)kcache; p.vcache = (char*)vcache; p.cache_batch = Tmax * D; p.cache_row = D;
+  p.out = out; p.out_row = D; p.o_bf16 = odt == KX_BF16; p.stats_out = stats_out;
+  p.H = (int)H; p.D = (int)D; p.t = (int)t;
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(prec == KX_PREC_BF16 ? KX_K_ATTN_BF16 : KX_K_ATTN_F32, B * H, 1, t + 1, s);
+  if (prec == KX_PREC_BF16) hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, dim3((unsigned)H, (unsigned)B), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(attn_decode_kernel<float>, dim3((unsigned)H, (unsigned)B), dim3(256), 0, s, p);
+  KX_CHECK_LAUNCH("kx_attention_decode");
+  return KX_OK;
+}

@@ -102,5 +102,7 @@ __device__ __forceinline__ float wave_max(float v) {
 int kx_launch_rows_bcast(const float* src, float* dst, int64_t B, int64_t rows, int64_t cols, hipStream_t s);
 int kx_launch_patchify(const float* pixels, void* patches, int64_t B, int image, int patch, int kpad, int prec,
                        hipStream_t s);
+int kx_launch_kv_prefill(const void* qkv, void* kc, void* vc, int64_t B, int64_t T, int64_t D, int64_t Tmax, int prec,
+                         hipStream_t s);
 int kx_launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x, int64_t B,
                            int tokens, int dim, hipStream_t s);

@@ -291,10 +291,14 @@ extern "C" size_t kx_decoder_workspace_bytes(const kx_decoder_weights* w, int64_
   return w ? dec_plan(w, B, T, prec, nullptr).total : 0;
 }
 
-extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t B, int64_t T, const float* xq_cs,
-                                  const float* xq_ss, const float* xk_cs, const float* xk_ss, void* logits,
-                                  int32_t ldt, void* workspace, size_t workspace_bytes, int32_t prec, void* stream) {
+static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B, int64_t T, const float* xq_cs,
+                                const float* xq_ss, const float* xk_cs, const float* xk_ss, void* logits, int32_t ldt,
+                                void* workspace, size_t workspace_bytes, int32_t prec, void* stream, void* kcache,
+                                void* vcache, int64_t Tmax) {
   KX_REQUIRE(w && x && logits && workspace, "kx_decoder_forward: null pointer");
+  KX_REQUIRE(!kcache == !vcache, "kx_decoder_prefill: kcache and vcache must be given together");
+  KX_REQUIRE(!kcache || T <= Tmax, "kx_decoder_prefill: %lld tokens do not fit a %lld-row cache", (long long)T,
+             (long long)Tmax);
   KX_REQUIRE(B > 0 && T > 0, "kx_decoder_forward: empty input");
   KX_REQUIRE(w->dim == w->heads * 64, "kx_decoder_forward: head_dim must be 64 (dim=%d heads=%d)", w->dim, w->heads);
   KX_REQUIRE(!w->xpos || (xq_cs && xq_ss && xk_cs && xk_ss), "kx_decoder_forward: XPos tables missing");
@@ -316,6 +320,11 @@ extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t
     KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
     KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
                 w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? T : 0, w->xpos ? D : 0));
+    if (kcache) {   // incremental decoding: keep this layer's (XPos-rotated) keys and values
+      const size_t layer_bytes = (size_t)B * Tmax * D * es;
+      KX_TRY(kx_launch_kv_prefill(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, B, T, D, Tmax,
+                                  prec, s));
+    }
     kx_attn_args a;
     memset(&a, 0, sizeof(a));
     a.q = d.qkv; a.q_batch_stride = T * 3 * D; a.q_row_stride = 3 * D;
@@ -339,6 +348,75 @@ extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t
     KX_TRY(ln(x, nullptr, L.fl_g, L.fl_b, d.h, ct, M, D, w->eps, s));
     if (w->subln) {
       // ffn_layernorm folded into fc2 the same way; fc1's epilogue emits the row statistics of gelu(fc1)
+      KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
+                  nullptr, 0, 0, nullptr, nullptr, d.partials));
+      KX_TRY(kx_row_stats_finalize(d.partials, M, F / 64, 64, w->eps, d.stats, stream));
+      KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
+                  0, 0, d.stats, L.w2_colsum, nullptr));
+    } else {
+      KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s));
+      KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s));
+    }
+  }
+  KX_TRY(ln(x, nullptr, w->ln_g, w->ln_b, d.h, ct, M, D, w->eps, s));
+  KX_TRY(gemm(d.h, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab, nullptr, nullptr, 0, 1.f, 0, prec, s));
+  return KX_OK;
+}
+
+extern "C" int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t B, int64_t T, const float* xq_cs,
+                                  const float* xq_ss, const float* xk_cs, const float* xk_ss, void* logits,
+                                  int32_t ldt, void* workspace, size_t workspace_bytes, int32_t prec, void* stream) {
+  return decoder_forward_impl(w, x, B, T, xq_cs, xq_ss, xk_cs, xk_ss, logits, ldt, workspace, workspace_bytes, prec,
+                              stream, nullptr, nullptr, 0);
+}
+
+extern "C" int kx_decoder_prefill(const kx_decoder_weights* w, float* x, int64_t B, int64_t T, const float* xq_cs,
+                                  const float* xq_ss, const float* xk_cs, const float* xk_ss, void* logits,
+                                  int32_t ldt, void* kcache, void* vcache, int64_t Tmax, void* workspace,
+                                  size_t workspace_bytes, int32_t prec, void* stream) {
+  KX_REQUIRE(kcache && vcache && Tmax > 0, "kx_decoder_prefill: cache missing");
+  return decoder_forward_impl(w, x, B, T, xq_cs, xq_ss, xk_cs, xk_ss, logits, ldt, workspace, workspace_bytes, prec,
+                              stream, kcache, vcache, Tmax);
+}
+
+extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int64_t B, int64_t t, const float* xq_cs,
+                                      const float* xq_ss, const float* xk_cs, const float* xk_ss, void* kcache,
+                                      void* vcache, int64_t Tmax, void* logits, int32_t ldt, void* workspace,
+                                      size_t workspace_bytes, int32_t prec, void* stream) {
+  KX_REQUIRE(w && x && logits && workspace && kcache && vcache, "kx_decoder_decode_step: null pointer");
+  KX_REQUIRE(B > 0 && t >= 0 && t < Tmax, "kx_decoder_decode_step: position %lld outside the cache of %lld rows",
+             (long long)t, (long long)Tmax);
+  KX_REQUIRE(w->dim == w->heads * 64, "kx_decoder_decode_step: head_dim must be 64");
+  KX_REQUIRE(!w->xpos || (xq_cs && xq_ss && xk_cs && xk_ss), "kx_decoder_decode_step: XPos rows for position t missing");
+  KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_decoder_decode_step: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const DecBufs d = dec_plan(w, B, 1, prec, (char*)workspace);
+  if (d.total > workspace_bytes) {
+    kx_set_error("kx_decoder_decode_step: workspace %zu < required %zu", workspace_bytes, d.total);
+    return KX_ERR_WORKSPACE;
+  }
+  const int64_t M = B, D = w->dim, F = w->ffn;
+  SplitkScope sk(d.splitk, KX_SPLITK_WS);
+  const int ct = cdt(prec);
+  const size_t es = esz(prec);
+  const size_t layer_bytes = (size_t)B * Tmax * D * es;
+  for (int i = 0; i < w->layers; ++i) {
+    const kx_decoder_layer& L = w->layer[i];
+    KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
+    // XPos rows of absolute position t (xpos_T = 1: every batch row is the same position)
+    KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
+                w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? 1 : 0, w->xpos ? D : 0));
+    KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, ct,
+                               w->subln ? d.partials : nullptr, B, w->heads, t, Tmax, prec, stream));
+    if (w->subln) {
+      KX_TRY(kx_row_stats_finalize(d.partials, M, w->heads, 64, w->eps, d.stats, stream));
+      KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
+                  0, 0, d.stats, L.wo_colsum, nullptr));
+    } else {
+      KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s));
+    }
+    KX_TRY(ln(x, nullptr, L.fl_g, L.fl_b, d.h, ct, M, D, w->eps, s));
+    if (w->subln) {
       KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
                   nullptr, 0, 0, nullptr, nullptr, d.partials));
       KX_TRY(kx_row_stats_finalize(d.partials, M, F / 64, 64, w->eps, d.stats, stream));

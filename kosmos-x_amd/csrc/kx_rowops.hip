@@ -166,13 +166,13 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const long long* __re
                                                            const float* __restrict__ pos,
                                                            const float* __restrict__ img, float* __restrict__ out,
                                                            int Tt, int n_img, int d, long long vocab, int splice_at,
-                                                           int u1_alias) {
+                                                           int u1_alias, int pos_offset) {
   const int T = Tt + n_img;
   const long long row = blockIdx.x;
   const int b = (int)(row / T), t = (int)(row % T);
   const float4* src;
   const float4* p1 = nullptr;  // first-call positions (text rows only)
-  const float4* p2 = reinterpret_cast<const float4*>(pos + (long long)(2 + t) * d);
+  const float4* p2 = reinterpret_cast<const float4*>(pos + (long long)(2 + pos_offset + t) * d);
   bool text = true;
   int tt = t;
   if (n_img > 0) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const long long* __re
     long long id = tokens[(long long)b * Tt + tt];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // memory safety only; the boundary validates ids
     src = reinterpret_cast<const float4*>(embed + id * d);
-    if (n_img > 0 && u1_alias) p1 = reinterpret_cast<const float4*>(pos + (long long)(2 + tt) * d);
+    if (n_img > 0 && u1_alias) p1 = reinterpret_cast<const float4*>(pos + (long long)(2 + pos_offset + tt) * d);
   } else {
     src = reinterpret_cast<const float4*>(img + ((long long)b * n_img + (t - splice_at)) * d);
   }
@@ -303,25 +303,26 @@ extern "C" int kx_layernorm(const float* x, const float* pre_add, const float* g
 
 extern "C" int kx_embed_splice(const int64_t* tokens, const float* embed, const float* pos, const float* img,
                                float* out, int64_t B, int64_t Tt, int64_t n_img, int64_t d, int64_t vocab,
-                               int64_t max_pos, int64_t splice_at, int32_t u1_alias, void* stream) {
+                               int64_t max_pos, int64_t splice_at, int32_t u1_alias, int64_t pos_offset, void* stream) {
   KX_REQUIRE(embed && pos && out, "kx_embed_splice: null pointer");
   KX_REQUIRE(B > 0 && Tt >= 0 && n_img >= 0 && Tt + n_img > 0 && d > 0 && d % 4 == 0,
              "kx_embed_splice: bad shape B=%lld Tt=%lld n_img=%lld d=%lld", (long long)B, (long long)Tt,
              (long long)n_img, (long long)d);
   KX_REQUIRE(Tt == 0 || tokens != nullptr, "kx_embed_splice: Tt > 0 needs tokens");
   KX_REQUIRE(n_img == 0 || img != nullptr, "kx_embed_splice: n_img > 0 needs img");
-  KX_REQUIRE(splice_at >= 0 && splice_at <= Tt, "kx_embed_splice: splice_at=%lld outside [0, Tt=%lld]",
+  KX_REQUIRE(n_img == 0 || (splice_at >= 0 && splice_at <= Tt), "kx_embed_splice: splice_at=%lld outside [0, Tt=%lld]",
              (long long)splice_at, (long long)Tt);
   KX_REQUIRE((((uintptr_t)embed | (uintptr_t)pos | (uintptr_t)img | (uintptr_t)out) & 15) == 0,
              "kx_embed_splice: pointers must be 16-byte aligned");
   // the reference raises IndexError from F.embedding here: positions run 2..T+1
-  KX_REQUIRE(Tt + n_img + 2 <= max_pos, "kx_embed_splice: position %lld out of range for a %lld-row table",
-             (long long)(Tt + n_img + 1), (long long)max_pos);
+  KX_REQUIRE(pos_offset >= 0 && pos_offset + Tt + n_img + 2 <= max_pos,
+             "kx_embed_splice: position %lld out of range for a %lld-row table",
+             (long long)(pos_offset + Tt + n_img + 1), (long long)max_pos);
   const long long rows = B * (Tt + n_img);
   KxProfScope prof(KX_K_EMBED, rows, d, 0, (hipStream_t)stream);
   hipLaunchKernelGGL(embed_splice_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
                      (const long long*)tokens, embed, pos, img, out, (int)Tt, (int)n_img, (int)d, (long long)vocab,
-                     (int)splice_at, (int)u1_alias);
+                     (int)splice_at, (int)u1_alias, (int)pos_offset);
   KX_CHECK_LAUNCH("kx_embed_splice");
   return KX_OK;
 }

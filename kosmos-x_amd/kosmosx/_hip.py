@@ -91,7 +91,7 @@ SYMBOLS = {
     "kx_gemm": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "kx_attention": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "kx_row_stats_finalize": (C.c_int, [vp, i64, i64, i64, f32, vp, vp]),
-    "kx_embed_splice": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, vp]),
+    "kx_embed_splice": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i64, vp]),
     "kx_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "kx_prof_enable": (C.c_int, [C.c_int]),
     "kx_prof_collect": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),
@@ -100,6 +100,11 @@ SYMBOLS = {
     "kx_perceiver_workspace_bytes": (C.c_size_t, [C.POINTER(PerceiverWeights), i64, i64, i32]),
     "kx_perceiver_forward": (C.c_int, [C.POINTER(PerceiverWeights), vp, i64, i64, vp, vp, vp, C.c_size_t, i32, vp]),
     "kx_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderWeights), i64, i64, i32]),
+    "kx_decoder_prefill": (C.c_int, [C.POINTER(DecoderWeights), vp, i64, i64, vp, vp, vp, vp, vp, i32, vp, vp, i64, vp,
+                                     C.c_size_t, i32, vp]),
+    "kx_decoder_decode_step": (C.c_int, [C.POINTER(DecoderWeights), vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, i32,
+                                         vp, C.c_size_t, i32, vp]),
+    "kx_attention_decode": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i64, i64, i64, i32, vp]),
     "kx_decoder_forward": (C.c_int, [C.POINTER(DecoderWeights), vp, i64, i64, vp, vp, vp, vp, vp, i32, vp,
                                      C.c_size_t, i32, vp]),
 }

@@ -368,6 +368,21 @@ class XPOS(nn.Module):
         self.head_dim, self.scale_base = head_dim, scale_base
         self.register_buffer("scale", (torch.arange(0, head_dim, 2) + 0.4 * head_dim) / (1.4 * head_dim))
 
+    def tables_centred(self, n_pos: int, centre_len: int, downscale: bool = False):
+        """Rows for absolute positions 0..n_pos-1 with the centring constant of a `centre_len`-token sequence
+        (min_pos = -(centre_len)//2).  For n_pos == centre_len this is `tables(centre_len)`; incremental decoding
+        keeps the prefill's centring for every later position (the constant cancels in q·k)."""
+        zeta = self.scale.detach().to("cpu", torch.float32)
+        min_pos = -(centre_len) // 2
+        scale = zeta ** torch.arange(min_pos, min_pos + n_pos, 1).to(zeta).div(self.scale_base)[:, None]
+        seq_len, dim = scale.shape
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, dim) / dim))
+        sinusoid = torch.einsum("i , j -> i j", torch.arange(0, seq_len, dtype=torch.float), inv_freq).to(scale)
+        sin, cos = torch.sin(sinusoid), torch.cos(sinusoid)
+        if downscale:
+            scale = 1 / scale
+        return (cos * scale).contiguous(), (sin * scale).contiguous()
+
     def tables(self, length: int, offset: int = 0, downscale: bool = False):
         """(cos*scale, sin*scale) [length, head_dim/2] fp32 — torchscale XPOS.forward +
         fixed_pos_embedding, same operation order, evaluated once per sequence length on the host."""
@@ -502,7 +517,7 @@ class Decoder(_PackedMixin, nn.Module):
 
     # -- stages -----------------------------------------------------------------------------------
     def embed(self, tokens: torch.Tensor | None, prec: str, img: torch.Tensor | None = None, splice_at: int = 2,
-              alias: bool | None = None) -> torch.Tensor:
+              alias: bool | None = None, pos_offset: int = 0) -> torch.Tensor:
         """Fused forward_embedding/cat/forward_embedding of /root/reference/kosmosx/model.py:238-244
         (img given) or the single forward_embedding of :319 (img None)."""
         _, _, _, emb, pos = self._pack(prec)
@@ -520,7 +535,7 @@ class Decoder(_PackedMixin, nn.Module):
         out = torch.empty((B, Tt + n_img, d), dtype=torch.float32, device=emb.device)
         alias = self.switches.u1_inplace_alias if alias is None else alias
         rc = lib.kx_embed_splice(H.ptr(tokens), emb.data_ptr(), pos.data_ptr(), H.ptr(img), out.data_ptr(), B, Tt,
-                                 n_img, d, emb.shape[0], pos.shape[0], splice_at, int(alias), _stream())
+                                 n_img, d, emb.shape[0], pos.shape[0], splice_at, int(alias), pos_offset, _stream())
         if rc == 1 and "out of range" in H.last_error():
             msg = H.last_error()
             logging.error(msg)
@@ -543,6 +558,66 @@ class Decoder(_PackedMixin, nn.Module):
                 "kx_decoder_forward")
         return logits
 
+    # -- incremental decoding ---------------------------------------------------
+    def _forward_incremental(self, tokens, state: dict, passed_x, prec: str) -> torch.Tensor:
+        """torchscale's incremental_state protocol: the first call runs the whole prefix and fills the KV cache,
+        every later call is given the token history (only its last token and its length are used, as upstream's
+        `tokens[:, -1:]`) and appends one position.  ``state`` is an opaque dict owned by the caller."""
+        w, _, _, emb, pos = self._pack(prec)
+        lib = H.load()
+        D, L = self.args.decoder_embed_dim, self.num_layers
+        if "len" not in state:                                             # ---- first step: prefill ----
+            if passed_x is not None:
+                _require_cuda(passed_x, "passed_x")
+                x = passed_x.to(torch.float32).clone(memory_format=torch.contiguous_format)
+            else:
+                x = self.embed(tokens, prec)
+            B, T, _ = x.shape
+            Tmax = int(state.get("max_len", pos.shape[0] - 2))
+            if T > Tmax:
+                raise IndexError(f"index out of range in self: {T} tokens exceed the {Tmax}-row cache")
+            dt = _prec_dtype(prec)
+            state["kcache"] = torch.empty((L, B, Tmax, D), dtype=dt, device=x.device)
+            state["vcache"] = torch.empty((L, B, Tmax, D), dtype=dt, device=x.device)
+            xp = self.layers[0].self_attn.xpos
+            if xp is not None:
+                q = xp.tables_centred(Tmax, T, False)
+                k = xp.tables_centred(Tmax, T, True)
+                state["xpos"] = tuple(t.to(x.device) for t in (*q, *k))
+            else:
+                state["xpos"] = (None,) * 4
+            logits = torch.empty((B, T, w.vocab), dtype=torch.float32, device=x.device)
+            need = lib.kx_decoder_workspace_bytes(C.byref(w), B, T, H.PRECS[prec])
+            buf = self._ws.get(need, x.device)
+            H.check(lib.kx_decoder_prefill(C.byref(w), x.data_ptr(), B, T, *(H.ptr(t) for t in state["xpos"]),
+                                           logits.data_ptr(), H.KX_F32, state["kcache"].data_ptr(),
+                                           state["vcache"].data_ptr(), Tmax, buf.data_ptr(), buf.numel(),
+                                           H.PRECS[prec], _stream()), "kx_decoder_prefill")
+            state.update(len=T, max_len=Tmax, batch=B, prec=prec)
+            return logits
+        t, Tmax, B = state["len"], state["max_len"], state["batch"]           # ---- later steps: one token ----
+        if state["prec"] != prec:
+            raise RuntimeError("precision changed between incremental steps")
+        if t >= Tmax or t + 2 >= pos.shape[0]:
+            raise IndexError(f"index out of range in self: position {t + 2} exceeds the table / cache")  # SURVEY H3
+        if passed_x is not None:
+            _require_cuda(passed_x, "passed_x")
+            x = passed_x[:, -1:].to(torch.float32).clone(memory_format=torch.contiguous_format)
+        else:
+            x = self.embed(tokens[:, -1:], prec, pos_offset=t)
+        if x.shape[0] != B:
+            raise ValueError("batch size changed between incremental steps")
+        rows = tuple(None if tb is None else tb[t] for tb in state["xpos"])   # views: row t of each [Tmax, 32] table
+        logits = torch.empty((B, 1, w.vocab), dtype=torch.float32, device=x.device)
+        need = lib.kx_decoder_workspace_bytes(C.byref(w), B, 1, H.PRECS[prec])
+        buf = self._ws.get(need, x.device)
+        H.check(lib.kx_decoder_decode_step(C.byref(w), x.data_ptr(), B, t, *(H.ptr(r) for r in rows),
+                                           state["kcache"].data_ptr(), state["vcache"].data_ptr(), Tmax,
+                                           logits.data_ptr(), H.KX_F32, buf.data_ptr(), buf.numel(), H.PRECS[prec],
+                                           _stream()), "kx_decoder_decode_step")
+        state["len"] = t + 1
+        return logits
+
     # -- torchscale-compatible surface ------------------------------------------------------------
     def forward_embedding(self, tokens, token_embedding=None, incremental_state=None):
         if incremental_state is not None:
@@ -557,11 +632,13 @@ class Decoder(_PackedMixin, nn.Module):
 
     def forward(self, prev_output_tokens, self_attn_padding_mask=None, encoder_out=None, incremental_state=None,
                 features_only=False, return_all_hiddens=False, token_embeddings=None, **kwargs):
-        if incremental_state is not None or encoder_out is not None or self_attn_padding_mask is not None \
-                or features_only:
-            raise NotImplementedError("only the full-sequence, decoder-only, logits path of the reference is built")
+        if encoder_out is not None or self_attn_padding_mask is not None or features_only:
+            raise NotImplementedError("only the decoder-only logits path of the reference is built")
         prec = getattr(self, "precision", _default_precision())
         passed_x = kwargs.get("passed_x", None)
+        if incremental_state is not None:
+            return self._forward_incremental(prev_output_tokens, incremental_state, passed_x, prec), \
+                {"inner_states": None, "l_aux": None, "attn": None}
         if passed_x is None:
             x, _ = self.forward_embedding(prev_output_tokens, token_embeddings)
         else:
@@ -836,6 +913,9 @@ class KosmosLanguage(nn.Module):
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         if not isinstance(x, torch.Tensor):
             raise TypeError("x must be an instance of torch.Tensor")
+        inc = kwargs.get("incremental_state", None)
+        if inc is not None:     # torchscale's incremental protocol; kwargs reach forward_embedding upstream
+            return self.decoder._forward_incremental(x, inc, None, self.precision)
         model_input = self.decoder.embed(x, self.precision)         # :319
         return self.decoder.run(model_input, self.precision)        # :320
 

@@ -103,7 +103,7 @@ def attention(q, k, v, causal=False, out_dtype=None, stats_out=None):
     return out
 
 
-def embed_splice(tokens, embed, pos, img=None, u1_alias=True, splice_at=2):
+def embed_splice(tokens, embed, pos, img=None, u1_alias=True, splice_at=2, pos_offset=0):
     """Decoder input assembly (see kx_embed_splice in include/kosmosx_hip.h)."""
     _need_cuda(tokens, embed, pos, img)
     if tokens is not None:
@@ -114,6 +114,6 @@ def embed_splice(tokens, embed, pos, img=None, u1_alias=True, splice_at=2):
     d = embed.shape[1]
     out = torch.empty((B, Tt + n_img, d), dtype=torch.float32, device=embed.device)
     rc = H.load().kx_embed_splice(H.ptr(tokens), H.ptr(embed), H.ptr(pos), H.ptr(img), H.ptr(out), B, Tt, n_img, d,
-                                  embed.shape[0], pos.shape[0], splice_at, int(u1_alias), _stream())
+                                  embed.shape[0], pos.shape[0], splice_at, int(u1_alias), pos_offset, _stream())
     H.check(rc, "kx_embed_splice")
     return out

@@ -324,6 +324,62 @@ def decoder_forward(w: dict, x: torch.Tensor, cfg: DecoderCfg, sw: Switches, pre
     return linear(x, w["output_projection.weight"], None, sw)
 
 
+def decoder_incremental(w: dict, x: torch.Tensor, cfg: DecoderCfg, sw: Switches, prefix="decoder.", mw=".A",
+                        first: int | None = None) -> torch.Tensor:
+    """torchscale's incremental_state path, restated (MultiheadAttention.forward with prev_key/prev_value,
+    Decoder.forward's `is_first_step`): the first `first` positions are processed as one block (causal mask, XPos
+    offset 0), every later position one at a time with the cache of PRE-XPos keys: k of the whole cache is re-rotated
+    with offset 0 (min_pos = -(src_len)//2) and q with offset src_len-1; no mask.  Returns logits for all positions.
+    x [B,T,D] = embedded inputs (forward_embedding already applied)."""
+    B, T, D = x.shape
+    H = cfg.heads
+    hd = D // H
+    first = T if first is None else first
+    caches = [dict() for _ in range(cfg.layers)]
+    outs = []
+    steps = [(0, first)] + [(t, t + 1) for t in range(first, T)]
+    for (lo, hi) in steps:
+        h = x[:, lo:hi]
+        n = hi - lo
+        for i in range(cfg.layers):
+            p = f"{prefix}layers.{i}."
+            r = h
+            y = layer_norm(h, w[p + f"self_attn_layer_norm{mw}.weight"], w[p + f"self_attn_layer_norm{mw}.bias"], cfg.eps)
+            q = linear(y, w[p + f"self_attn.q_proj{mw}.weight"], w[p + f"self_attn.q_proj{mw}.bias"], sw) * (hd ** -0.5)
+            k = linear(y, w[p + f"self_attn.k_proj{mw}.weight"], w[p + f"self_attn.k_proj{mw}.bias"], sw)
+            v = linear(y, w[p + f"self_attn.v_proj{mw}.weight"], w[p + f"self_attn.v_proj{mw}.bias"], sw)
+            sp = lambda t_: t_.view(B, n, H, hd).transpose(1, 2).reshape(B * H, n, hd)
+            q, k, v = sp(q), sp(k), sp(v)
+            c = caches[i]
+            if "k" in c:
+                k, v = torch.cat([c["k"], k], 1), torch.cat([c["v"], v], 1)
+            c["k"], c["v"] = k, v
+            src = k.shape[1]
+            if cfg.xpos:
+                off = src - 1 if lo > 0 else 0
+                kc, ks = xpos_tables(src, hd, cfg.xpos_scale_base, 0, True, sw.u3b_xpos_scale)
+                qc, qs = xpos_tables(n, hd, cfg.xpos_scale_base, off, False, sw.u3b_xpos_scale)
+                k = apply_xpos(k, kc, ks)
+                q = apply_xpos(q, qc, qs)
+            a = torch.bmm(_r(q, sw), _r(k, sw).transpose(1, 2))
+            if lo == 0:
+                a = torch.nan_to_num(a) + torch.triu(torch.zeros([n, n]).fill_(float("-inf")), 1)[None]
+            a = F.softmax(a, dim=-1, dtype=torch.float32)
+            o = torch.bmm(_r(a, sw), _r(v, sw)).transpose(0, 1).reshape(n, B, D).transpose(0, 1)
+            if cfg.subln:
+                o = layer_norm(o, w[p + f"self_attn.inner_attn_ln{mw}.weight"], w[p + f"self_attn.inner_attn_ln{mw}.bias"], cfg.eps)
+            h = r + linear(o, w[p + f"self_attn.out_proj{mw}.weight"], w[p + f"self_attn.out_proj{mw}.bias"], sw)
+            r = h
+            y = layer_norm(h, w[p + f"final_layer_norm{mw}.weight"], w[p + f"final_layer_norm{mw}.bias"], cfg.eps)
+            y = act_fn(linear(y, w[p + f"ffn{mw}.fc1.weight"], w[p + f"ffn{mw}.fc1.bias"], sw), cfg.act)
+            if cfg.subln:
+                y = layer_norm(y, w[p + f"ffn{mw}.ffn_layernorm.weight"], w[p + f"ffn{mw}.ffn_layernorm.bias"], cfg.eps)
+            h = r + linear(y, w[p + f"ffn{mw}.fc2.weight"], w[p + f"ffn{mw}.fc2.bias"], sw)
+        h = layer_norm(h, w[prefix + "layer_norm.weight"], w[prefix + "layer_norm.bias"], cfg.eps)
+        outs.append(linear(h, w["output_projection.weight"], None, sw))
+    return torch.cat(outs, dim=1)
+
+
 def positions_for(T: int) -> torch.Tensor:
     """PositionalEmbedding.forward: fairseq convention, positions start at 2."""
     return torch.arange(2, T + 2).long()

@@ -72,7 +72,7 @@ def test_version_and_error_plumbing(lib):
     assert lib.kx_layernorm(256, None, 256, 256, 256, 0, 3, 6, 1e-5, 3, 0, 0, None) == 1   # cols % 4
     assert "cols" in _hip.last_error()
     # H3: position overflow is reported before any launch
-    rc = lib.kx_embed_splice(256, 256, 256, None, 256, 1, 2047, 0, 2048, 32002, 2048, 2, 1, None)
+    rc = lib.kx_embed_splice(256, 256, 256, None, 256, 1, 2047, 0, 2048, 32002, 2048, 2, 1, 0, None)
     assert rc == 1 and "out of range" in _hip.last_error()
     a = _hip.AttnArgs()
     a.q = a.k = a.v = a.out = 256

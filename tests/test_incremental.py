@@ -1,0 +1,59 @@
+"""Incremental decoding.
+
+CPU: the oracle's restatement of torchscale's incremental_state path (pre-XPos key cache, whole-cache re-rotation,
+q offset = src_len-1) reproduces the full forward position by position — the property that lets the HIP path cache
+POST-XPos keys with one fixed centring.  GPU: prefill + decode steps against the oracle's full forward."""
+import pytest
+import torch
+
+from oracle import kosmos_oracle as O
+from helpers import oracle_weights, rel_err
+from kosmosx.model import KosmosLanguage
+
+
+def _lm(seed=5):
+    return KosmosLanguage(vocab_size=502, dim=256, depth=2, ffn_dim=512, decoder_heads=4, _seed=seed, _perturb=0.1,
+                          _max_positions=64).eval()
+
+
+CFG = O.DecoderCfg(layers=2, dim=256, ffn=512, heads=4, vocab=502, max_pos=64)
+
+
+def test_oracle_incremental_equals_full_forward():
+    lm = _lm()
+    w = oracle_weights(lm)
+    tok = torch.randint(0, 502, (2, 23), generator=torch.Generator().manual_seed(1))
+    x, _ = O.forward_embedding_tokens(w, tok, CFG)
+    full = O.decoder_forward(w, x, CFG, O.Switches())
+    for first in (1, 7, 22):     # odd and even prefix lengths: the XPos centring changes every step upstream
+        inc = O.decoder_incremental(w, x, CFG, O.Switches(), first=first)
+        assert (inc - full).abs().max() < 3e-5, first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+def test_hip_prefill_and_decode_steps_match_full_forward(prec, tol):
+    lm = _lm(seed=6)
+    w = oracle_weights(lm)
+    g = torch.Generator().manual_seed(2)
+    tok = torch.randint(0, 502, (3, 40), generator=g)
+    ref = O.kosmos_language_forward(w, tok, CFG)              # [3, 40, V]: position t's logits = the decode step's
+    lm = lm.to("cuda")
+    lm.precision = prec
+    tokd = tok.cuda()
+    P = 9                                                     # prefix length
+    state = {}
+    out = lm(tokd[:, :P], incremental_state=state)
+    assert out.shape == (3, P, 502) and rel_err(out, ref[:, :P]) < tol
+    for t in range(P, 40):
+        step = lm(tokd[:, : t + 1], incremental_state=state)  # full history in, one position out (fairseq protocol)
+        assert step.shape == (3, 1, 502)
+        assert rel_err(step, ref[:, t:t + 1]) < tol, t
+    assert state["len"] == 40
+    # the cache is exhausted at max_positions - 2 rows, like the reference's position table
+    state2 = {"max_len": 12}
+    lm(tokd[:, :12], incremental_state=state2)
+    with pytest.raises(IndexError):
+        lm(tokd[:, :13], incremental_state=state2)
+    with pytest.raises(IndexError):
+        lm(tokd[:, :13], incremental_state={"max_len": 12})
