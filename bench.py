@@ -290,6 +290,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
+        dist.barrier()                      # rank 0 finishes its instrumented leg before anyone tears down
         dist.destroy_process_group()
 
 
