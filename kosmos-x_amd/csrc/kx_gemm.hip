@@ -638,12 +638,13 @@ int launch_p3(GemmParams& p, hipStream_t s) {
 // (A v_mfma_f32_32x32x16_bf16 version of this kernel — same LDS traffic, half the MFMA instructions — measured
 // 1.16 vs 1.36 PFLOP/s at 8192^3 and was dropped.)
 // -------------------------------------------------------------------------------------------------
-template <typename T, int ACT>
+template <typename T, int ACT, int BM>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
-  constexpr int BM = 256, BN = 256, ROWB = 128;
+  constexpr int BN = 256, ROWB = 128;
+  static_assert(BM % 64 == 0, "BM must split into 2 wave rows of whole 16-row fragments and 8 staging waves");
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;   // 64 KB
-  constexpr int FM = 8, FN = 4;              // 128(m) x 64(n) per wave
-  constexpr int IA = 4, IW = 4;              // glds instructions per wave per stage (8 rows each)
+  constexpr int FM = BM / 32, FN = 4;        // (BM/2)(m) x 64(n) per wave
+  constexpr int IA = BM / 64, IW = 4;        // glds instructions per wave per stage (8 rows each)
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int nwg = p.tiles_m * p.tiles_n;
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const char* srcW[IW];
 #pragma unroll
   for (int j = 0; j < IA; ++j) {
-    const int row = wave * 32 + j * 8 + srow;
+    const int row = wave * (BM / 8) + j * 8 + srow;
     const int gm = min(m0 + row, p.M - 1);
     srcA[j] = p.A + (long long)gm * p.lda_b + ((schunk ^ (row & 7)) << 4);
   }
@@ -684,8 +685,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     const long long koff = (long long)kt * ROWB;
 #pragma unroll
     for (int j = 0; j < IA; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff), (lds_void_t*)(base + (wave * 32 + j * 8) * ROWB),
-                                       16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff),
+                                       (lds_void_t*)(base + (wave * (BM / 8) + j * 8) * ROWB), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < IW; ++j)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcW[j] + koff),
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   int offA[FM], offW[FN];
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
-    const int row = wm * 128 + b * 16 + li;
+    const int row = wm * (BM / 2) + b * 16 + li;
     offA[b] = row * ROWB + ((g ^ (row & 7)) << 4);
   }
 #pragma unroll
@@ -763,36 +764,37 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   // ---- epilogue staged through LDS in two 64-row halves (8 waves x 64x64 fp32 = 128 KB) ----
   constexpr int WN = 64, CH = WN / 4;
   const bool pre = p.stats_out != nullptr;
-  if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * 128, n0 + wn * WN, g, li);
+  if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
   GemmParams q = p;
   q.bias = nullptr; q.stats_out = nullptr;
-  float* cw = reinterpret_cast<float*>(smem) + wave * (64 * WN);
+  constexpr int HR = BM / 4;                 // rows per epilogue half per wave
+  float* cw = reinterpret_cast<float*>(smem) + wave * (HR * WN);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();   // previous half's rows have been read back / the K loop is over
 #pragma unroll
     for (int a = 0; a < FN; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < FM / 2; ++b) {
         const int ml = b * 16 + li, c = a * 4 + g;
-        *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][half * 4 + b];
+        *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][half * (FM / 2) + b];
       }
     __syncthreads();
-    if (pre) store_loop<KX_ACT_NONE, WN>(q, cw, 64, lane, m0 + wm * 128 + half * 64, n0 + wn * WN);
-    else store_loop<ACT, WN>(p, cw, 64, lane, m0 + wm * 128 + half * 64, n0 + wn * WN);
+    if (pre) store_loop<KX_ACT_NONE, WN>(q, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
+    else store_loop<ACT, WN>(p, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
   }
 }
 
-template <typename T>
+template <typename T, int BM>
 int launch_p5(GemmParams& p, hipStream_t s) {
-  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + 255) / 256;
   const dim3 grid(p.tiles_m * p.tiles_n), block(512);
   switch (p.act) {
-    case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE>), grid, block, 0, s, p); break;
-    case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU>), grid, block, 0, s, p); break;
-    case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST>), grid, block, 0, s, p); break;
-    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_QUICK_GELU>), grid, block, 0, s, p); break;
+    case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM>), grid, block, 0, s, p); break;
+    case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU, BM>), grid, block, 0, s, p); break;
+    case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM>), grid, block, 0, s, p); break;
+    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_QUICK_GELU, BM>), grid, block, 0, s, p); break;
     default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
   }
   KX_CHECK_LAUNCH("kx_gemm(p5)");
@@ -906,6 +908,15 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       if (a->K >= 1024 && eff512 >= 0.85) tile = 512;
       else if (a->K >= 2048 && eff256 >= 0.85 && a->N <= 16384) tile = 256;
       else tile = cost(160) <= cost(128) ? 160 : 128;
+      // 192x256 (96x64 per wave, same kernel): M = 32*114 = 19 x 192 exactly, and the decoder qkv GEMM (N = 6144)
+      // then needs 456 tiles = 2 rounds instead of 360 256x256 tiles (also 2 rounds, each 1/0.83 longer) or 720
+      // 256x128 tiles (3 rounds).  Relative round times measured with tools/gemm_bench.py: 1.0 / 0.83 / 0.6.
+      if ((tile == 512 || tile == 256) && a->K >= 1024) {
+        const long long t384 = cdiv(a->M, 192) * cdiv(a->N, 256);
+        const double c384 = 0.83 * (double)cdiv(t384, 256);
+        const double cur = tile == 512 ? (double)cdiv(t512, 256) : 0.6 * (double)cdiv(t256, 256);
+        if (c384 < 0.97 * cur) tile = 384;
+      }
     }
   }
   if (tile == 64 && a->stats_out && !(a->splitk_ws && a->splitk != 1)) tile = 128;   // 64x64 waves own 32 columns only
@@ -930,7 +941,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
                    : tile == 64 ? KX_K_GEMM_BF16_64
                    : tile == 160 ? KX_K_GEMM_BF16_160
                    : (tile == 256 || tile == 257) ? KX_K_GEMM_BF16_256X128
-                   : tile == 512 ? KX_K_GEMM_BF16_256X256 : KX_K_GEMM_BF16_128;
+                   : (tile == 512 || tile == 384) ? KX_K_GEMM_BF16_256X256 : KX_K_GEMM_BF16_128;
   KxProfScope prof(kind, a->M, a->N, a->K, s);
   if (a->prec == KX_PREC_BF16) {
     if (tile == 128) return launch<bf16_t, 128, 128>(p, s);
@@ -938,7 +949,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     if (tile == 160) return launch<bf16_t, 160, 128>(p, s);
     if (tile == 256) return launch_p3<bf16_t, true>(p, s);
     if (tile == 257) return launch_p3<bf16_t, false>(p, s);   // A/B: same tile and ring, unphased
-    if (tile == 512) return launch_p5<bf16_t>(p, s);          // 256x256, 128x64 per wave
+    if (tile == 512) return launch_p5<bf16_t, 256>(p, s);     // 256x256, 128x64 per wave
+    if (tile == 384) return launch_p5<bf16_t, 192>(p, s);     // 192x256,  96x64 per wave
   } else {
     if (tile == 128) return launch<float, 128, 128>(p, s);
     if (tile == 64) return launch<float, 64, 64>(p, s);

@@ -89,7 +89,7 @@ SHAPES = [  # (M, N, K): tile edges in M and N, the awkward path dims (SURVEY §
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 64, 128, 160, 256, 257, 512])
+@pytest.mark.parametrize("tile", [0, 64, 128, 160, 256, 257, 384, 512])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_bf16_plain(shape, tile):
     M, N, K = shape
@@ -122,7 +122,7 @@ def test_gemm_layout_is_not_transposed():
     assert torch.equal(out.cpu(), w.float().t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 256, 512])
+@pytest.mark.parametrize("tile", [0, 256, 384, 512])
 @pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("act", ["none", "gelu", "quick_gelu"])
 def test_gemm_epilogue_bias_act_residual(prec, act, tile):
@@ -296,7 +296,7 @@ def test_embed_splice_position_overflow_is_an_error():
 # ---------------------------------------------------------------------------------------------
 # Folded sub-LayerNorm: statistics produced by one epilogue, consumed by the next GEMM's epilogue
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [0, 64, 128, 256, 512])
+@pytest.mark.parametrize("tile", [0, 64, 128, 256, 384, 512])
 @pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
 def test_gemm_partial_row_stats_and_finalize(prec, tile):
     """fc1-style producer: stats of gelu(a·Wᵀ + b) per row == what LayerNorm would compute."""
@@ -318,7 +318,7 @@ def test_gemm_partial_row_stats_and_finalize(prec, tile):
     assert rel_err(out.float(), y.float()) < (2e-5 if prec == torch.float32 else 2 ** -7)
 
 
-@pytest.mark.parametrize("tile", [0, 128, 512])
+@pytest.mark.parametrize("tile", [0, 128, 384, 512])
 @pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
 def test_gemm_folded_layernorm_consumer(prec, tile):
     """fc2-style consumer: rstd·(x·(γ⊙W)ᵀ − mean·colsum) + (W·β + b) + residual == LN(x)·Wᵀ + b + residual."""
