@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (launch-bound batches)")
     ap.add_argument("--streams", type=int, default=1, help="micro-batch the shard over S HIP streams (overlaps kernel tails)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="kernel-variant override (kx_set_tuning key 1), A/B only")
+    ap.add_argument("--tune", default="", help="A/B only: comma list of kx_set_tuning key=value pairs, e.g. 4=1")
     return ap.parse_args()
 
 
@@ -125,6 +126,9 @@ def main():
     model.precision = args.precision
     if args.gemm_tile:
         _hip.load().kx_set_tuning(1, args.gemm_tile)
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        _hip.load().kx_set_tuning(int(k), int(v))
     model.use_hip_graphs = bool(args.graph)
     t_build = time.time() - t_build
 

@@ -14,10 +14,17 @@ SHAPES = {  # name: (M, N, K)
     "vit_qkv_b32": (8224, 3072, 1024), "vit_out_b32": (8224, 1024, 1024), "vit_fc1_b32": (8224, 4096, 1024),
     "vit_fc2_b32": (8224, 1024, 4096), "sq4096": (4096, 4096, 4096), "sq8192": (8192, 8192, 8192),
     "dec_qkv_b1": (114, 6144, 2048), "dec_fc1_b1": (114, 8192, 2048), "dec_fc2_b1": (114, 2048, 8192),
-    "c3_fc1": (65472, 8192, 2048),
+    "c3_fc1": (65472, 8192, 2048), "c3_qkv": (65472, 6144, 2048), "c3_out": (65472, 2048, 2048),
+    "c3_fc2": (65472, 2048, 8192),
     "vitp_qkv": (8192, 3072, 1024), "vitp_out": (8192, 1024, 1024), "vitp_fc1": (8192, 4096, 1024),
     "vitp_fc2": (8192, 1024, 4096),
 }
+
+def _set_variant(t):
+    """Tile codes >= 1000: rolled per-pass store loop (tuning key 4 = 1) on tile t - 1000; below: prefetching loop (2)."""
+    from kosmosx import _hip
+    _hip.load().kx_set_tuning(4, 1 if t >= 1000 else 2)
+    return t - 1000 if t >= 1000 else t
 
 def bench(name, M, N, K, tiles, dtype=torch.bfloat16, iters=10, rounds=5, epi="plain"):
     """Interleaved A/B over `tiles` (kernel variants) in one process; median of `rounds`."""
@@ -39,19 +46,25 @@ def bench(name, M, N, K, tiles, dtype=torch.bfloat16, iters=10, rounds=5, epi="p
         out = torch.randn(M, N, device="cuda", dtype=torch.float32)
         kw = dict(bias=torch.randn(N, device="cuda"), residual=out, row_stats=torch.rand(M, 2, device="cuda"),
                   colsum=torch.randn(N, device="cuda"))
+    elif epi == "qkv_xpos":      # decoder qkv: bias + q-scale + XPos rotate/scale of q and k -> bf16
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        T = 114 if M % 114 == 0 else 2046
+        kw = dict(bias=torch.randn(N, device="cuda"), qscale=0.125, qcols=N // 3, xpos_dim=N // 3,
+                  xpos=tuple(torch.rand(T, 32, device="cuda") for _ in range(4)))
     elif epi == "resid":         # out_proj / fc2: bias + residual (in place, fp32)
         out = torch.randn(M, N, device="cuda", dtype=torch.float32)
         kw = dict(bias=torch.randn(N, device="cuda"), residual=out)
     ts = {t: [] for t in tiles}
     for t in tiles:
         for _ in range(2):
-            ops.gemm(a, w, out=out, tile=t, **kw)
+            ops.gemm(a, w, out=out, tile=_set_variant(t), **kw)
     for _ in range(rounds):
         for t in tiles:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tt = _set_variant(t)
             e0.record()
             for _ in range(iters):
-                ops.gemm(a, w, out=out, tile=t, **kw)
+                ops.gemm(a, w, out=out, tile=tt, **kw)
             e1.record(); e1.synchronize()
             ts[t].append(e0.elapsed_time(e1) / iters)
     r = {"shape": name, "M": M, "N": N, "K": K, "epi": epi}
@@ -64,8 +77,12 @@ def bench(name, M, N, K, tiles, dtype=torch.bfloat16, iters=10, rounds=5, epi="p
 if __name__ == "__main__":
     tiles = [int(t) for t in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["128", "64"])]
     only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+    if os.environ.get("KX_STAGGER"):          # 256x256 kernel: start stagger per phase group, 10 ns ticks
+        from kosmosx import _hip
+        _hip.load().kx_set_tuning(3, int(os.environ["KX_STAGGER"]))
     EPI = {"dec_fc1_b32": "gelu_f32", "vit_fc1_b32": "gelu_bf16", "dec_out_b32": "resid", "dec_fc2_b32": "resid",
-           "vit_out_b32": "resid", "vit_fc2_b32": "resid", "c3_fc1": "gelu_f32",
+           "vit_out_b32": "resid", "vit_fc2_b32": "resid", "c3_fc1": "gelu_f32", "c3_out": "resid_fold",
+           "c3_fc2": "resid_fold", "c3_qkv": "qkv_xpos", "dec_qkv_b32": "qkv_xpos",
            "vitp_fc1": "gelu_bf16", "vitp_out": "resid", "vitp_fc2": "resid"}
     for name, (M, N, K) in SHAPES.items():
         if only and name not in only:
