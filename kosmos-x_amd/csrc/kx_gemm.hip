@@ -286,38 +286,42 @@ __device__ __forceinline__ void store_loop(const GemmParams& p, const float* cw,
 template <int ACT, int FM, int FN>
 __device__ __forceinline__ void prepass_bias_act_stats(const GemmParams& p, f32x4_t (&acc)[FN][FM], int mrow0,
                                                        int ncol0, int g, int li) {
-  static_assert(FN == 4, "a wave must own exactly one 64-column statistics segment");
-  if (ncol0 >= p.N) return;                       // whole segment outside (N % 64 == 0)
-  float4 bias[FN];
+  static_assert(FN % 4 == 0, "a wave must own whole 64-column statistics segments");
 #pragma unroll
-  for (int a = 0; a < FN; ++a)
-    bias[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + ncol0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sg = 0; sg < FN / 4; ++sg) {
+    const int nseg0 = ncol0 + sg * 64;
+    if (nseg0 >= p.N) return;                     // whole segment outside (N % 64 == 0)
+    float4 bias[4];
 #pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    float sm = 0.f;
+    for (int a = 0; a < 4; ++a)
+      bias[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nseg0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int a = 0; a < FN; ++a) {
-      f32x4_t v = acc[a][b];
-      v[0] = apply_act<ACT>(v[0] + bias[a].x); v[1] = apply_act<ACT>(v[1] + bias[a].y);
-      v[2] = apply_act<ACT>(v[2] + bias[a].z); v[3] = apply_act<ACT>(v[3] + bias[a].w);
-      acc[a][b] = v;
-      sm += (v[0] + v[1]) + (v[2] + v[3]);
+    for (int b = 0; b < FM; ++b) {
+      float sm = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        f32x4_t v = acc[sg * 4 + a][b];
+        v[0] = apply_act<ACT>(v[0] + bias[a].x); v[1] = apply_act<ACT>(v[1] + bias[a].y);
+        v[2] = apply_act<ACT>(v[2] + bias[a].z); v[3] = apply_act<ACT>(v[3] + bias[a].w);
+        acc[sg * 4 + a][b] = v;
+        sm += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const float mu = sm * (1.0f / 64.0f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const f32x4_t v = acc[sg * 4 + a][b];
+        const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
+        m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+      m2 += __shfl_xor(m2, 16, 64);
+      m2 += __shfl_xor(m2, 32, 64);
+      const int m = mrow0 + b * 16 + li;
+      if (g == 0 && m < p.M)
+        *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (nseg0 >> 6))) = make_float2(sm, m2);
     }
-    sm += __shfl_xor(sm, 16, 64);
-    sm += __shfl_xor(sm, 32, 64);
-    const float mu = sm * (1.0f / 64.0f);
-    float m2 = 0.f;
-#pragma unroll
-    for (int a = 0; a < FN; ++a) {
-      const f32x4_t v = acc[a][b];
-      const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
-      m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-    m2 += __shfl_xor(m2, 16, 64);
-    m2 += __shfl_xor(m2, 32, 64);
-    const int m = mrow0 + b * 16 + li;
-    if (g == 0 && m < p.M)
-      *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (ncol0 >> 6))) = make_float2(sm, m2);
   }
 }
 
@@ -736,7 +740,10 @@ int launch_p3(GemmParams& p, hipStream_t s) {
 // first phase starts and waited for (vmcnt(0)) in its third phase, so it has two MFMA phases to land.
 // Same 4-phase / lagging-half schedule as gemm_kernel_p3<PHASED>.
 // (A v_mfma_f32_32x32x16_bf16 version of this kernel — same LDS traffic, half the MFMA instructions — measured
-// 1.16 vs 1.36 PFLOP/s at 8192^3 and was dropped.)
+// 1.16 vs 1.36 PFLOP/s at 8192^3 and was dropped.  So was a 4-wave version with 128x128 per wave, accumulators
+// pinned to all 256 AGPRs and a hand-interleaved read/DMA/MFMA stream (384 instead of 512 B of LDS traffic per
+// MFMA): 1.34 vs 1.37 PFLOP/s.  Sustained, this kernel holds the board at its 1400 W cap at ~2.04 GHz
+// (profiles/r01_h_power_*.log): the limit left is power, not LDS or issue slots.)
 // -------------------------------------------------------------------------------------------------
 template <typename T, int ACT, int BM>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
