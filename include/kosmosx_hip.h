@@ -281,7 +281,8 @@ int kx_attention_decode(const void* qkv, void* kcache, void* vcache, void* out, 
  * key 1: GEMM tile override used by the stage-level entry points (0 auto, else as kx_gemm_args.tile);
  * key 2: bf16 attention variant (0 = v2: 32 queries/wave, transpose-read V, prefetched tiles; 1 = v1);
  * key 3: 256x256 GEMM start stagger per phase group in 10 ns ticks (0 = none; measured useless, kept for A/B);
- * key 4: GEMM store loop (0 auto, 1 rolled per-pass loads, 2 prefetching). */
+ * key 4: GEMM store loop (0 auto, 1 rolled per-pass loads, 2 prefetching);
+ * key 5: phased GEMM kernels skip the MFMAs of waves whose rows are all beyond M (0 on, 1 off). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

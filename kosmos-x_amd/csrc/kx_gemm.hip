@@ -39,6 +39,7 @@ struct GemmParams {
   // wall-clock ticks) late, so the CUs' epilogues (HBM bursts) stop coinciding — see launch_p5
   int stagger_ticks;
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
+  int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
 };
 
 // Everything of the fused epilogue except the store: x[0..3] = columns n..n+3 of row m (in range: m < M, n < N).
@@ -645,6 +646,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
     // R1(t-1) reads retired before a barrier both groups have passed; tile t+1 is read only after every wave's
     // vmcnt(6) in R1(t), which for the lagging group precedes the barrier the leading group passes into R0(t+1).
     const bool lag = wave >= 4;
+    // a wave whose 64 rows all lie beyond M (M = 3648 = 14.25 x 256: three of the last tile's four wave rows) only
+    // stages and keeps the barrier cadence — under the board's power cap wasted MFMAs cost clock, not just slots
+    const bool work = !p.skip_idle_waves || m0 + wm * 64 < p.M;
     if (lag) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
       const bool more = kt + 2 < nk;
@@ -652,41 +656,49 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
       u32x4_t fa[FM], fw[FN];
       // ---- R0 ----
       if (more) stage(slot == 0 ? 2 : slot - 1, kt + 2);
+      if (work) {
 #pragma unroll
       for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + offA[b]);
 #pragma unroll
       for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + offW[a]);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---- M0 ----
+      if (work) {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
       __builtin_amdgcn_s_setprio(0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---- R1 ----
+      if (work) {
 #pragma unroll
       for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ 64));
 #pragma unroll
       for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ 64));
+      }
       if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---- M1 ----
+      if (work) {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
       __builtin_amdgcn_s_setprio(0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -829,46 +841,55 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const bool lag = wave >= 4;
+  const bool work = !p.skip_idle_waves || m0 + wm * (BM / 2) < p.M;   // see gemm_kernel_p3
   if (lag) __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const char* base = smem + (kt & 1) * STAGE;
     u32x4_t fa[FM], fw[FN];
     // ---- R0 ----
     if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    if (work) {
 #pragma unroll
     for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + offW[a]);
 #pragma unroll
     for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + offA[b]);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- M0 ----
+    if (work) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int a = 0; a < FN; ++a)
 #pragma unroll
       for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
     __builtin_amdgcn_s_setprio(0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- R1 ----
+    if (work) {
 #pragma unroll
     for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ 64));
 #pragma unroll
     for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ 64));
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed (this wave's pieces)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- M1 ----
+    if (work) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int a = 0; a < FN; ++a)
 #pragma unroll
       for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
     __builtin_amdgcn_s_setprio(0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -997,6 +1018,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     // The prefetching store loop pays where the epilogue has per-row global operands to wait for (residual, folded-LN
     // statistics, XPos tables); bias-only bf16 epilogues measured ~5 % faster on the plain rolled loop.
     const int mode = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE);   // 0 auto, 1 never, 2 always (A/B)
+    p.skip_idle_waves = kx_tuning_get(KX_TUNE_GEMM_IDLE_SKIP) != 1;   // A/B: 1 = off
     p.fast_epilogue = mode == 2 || (mode == 0 && (a->residual || a->row_stats || a->xpos_dim > 0));
   }
   hipStream_t s = (hipStream_t)stream;
