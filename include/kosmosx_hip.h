@@ -276,13 +276,49 @@ int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int64_t B, int
 int kx_attention_decode(const void* qkv, void* kcache, void* vcache, void* out, int32_t odt, float* stats_out,
                         int64_t B, int64_t H, int64_t t, int64_t Tmax, int32_t prec, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Host pre-processing, tensor half: what KosmosTokenizer does to images and token ids before
+ * Kosmos.forward, on the device.  Integer / byte work; results are bit-identical to the HF processor.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Resampling plan of one source size (H, W): Pillow ImagingResample's precomputed taps for the centre-crop window
+ * only.  All arrays are DEVICE pointers to int32; built by the host binding (kosmosx/preprocess.py) in Pillow's
+ * double arithmetic and fixed-point rounding (22 fractional bits).
+ *   hbounds [crop][2]  (first source column, tap count) of output column left+xo;  hcoef [crop][hk] its taps
+ *   vbounds [crop][2]  (first source row,    tap count) of output row    top+yo;   vcoef [crop][vk]
+ *   y_first, rows_needed : union of the vertical windows  (source rows the horizontal pass must produce)
+ *   x_first, span_px     : union of the horizontal windows (source columns staged per row) */
+typedef struct {
+  int32_t crop, hk, vk;
+  int32_t y_first, rows_needed, x_first, span_px;
+  const int32_t *hbounds, *hcoef, *vbounds, *vcoef;
+} kx_resample_plan;
+
+/* KosmosTokenizer.tokenize_images (/root/reference/kosmosx/model.py:88-104) -> HF CLIPProcessor(images=...)
+ * .pixel_values: resize(shortest edge = crop, PIL BICUBIC) -> center_crop(crop) -> rescale(1/255) -> normalize.
+ * src: B packed-RGB uint8 images of one size [B][H][W][3] (row_pitch / img_stride in bytes, 16-byte aligned base);
+ * lut [3][256] float = rescale+normalize of every byte value per channel; out [B,3,crop,crop] float32;
+ * out_u8 (optional, may be NULL) [B,crop,crop,3]: the uint8 image after resize + crop (the processor's
+ * intermediate, for parity tests).  workspace: kx_clip_preprocess_workspace_bytes(B, plan->rows_needed, crop). */
+size_t kx_clip_preprocess_workspace_bytes(int64_t B, int32_t rows_needed, int32_t crop);
+int kx_clip_preprocess(const uint8_t* src, int64_t B, int32_t H, int32_t W, int64_t img_stride, int64_t row_pitch,
+                       const kx_resample_plan* plan, const float* lut, float* out, uint8_t* out_u8,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* KosmosTokenizer.tokenize_texts / tokenize, tensor half (/root/reference/kosmosx/model.py:72-82, 114-127):
+ * texts [B,L] int64 (tokenizer output, column 0 = <s>) -> tokens [B,L+2] = [<s>, im_idx, im_end_idx, texts[:,1:]],
+ * mask [B, n_img+L+2] float32 = [ones(n_img) | tokens != pad_id]. */
+int kx_token_splice(const int64_t* texts, int64_t B, int64_t L, int64_t im_idx, int64_t im_end_idx, int64_t pad_id,
+                    int64_t n_img, int64_t* tokens, float* mask, void* stream);
+
 /* Kernel-variant selection for in-process A/B measurement (tools/gemm_bench.py, tools/ln_bench.py).  Defaults (all 0) are the
  * shipped configuration.  key 0: LayerNorm variant (0 wave-per-row, 1 workgroup-per-row);
  * key 1: GEMM tile override used by the stage-level entry points (0 auto, else as kx_gemm_args.tile);
  * key 2: bf16 attention variant (0 = v2: 32 queries/wave, transpose-read V, prefetched tiles; 1 = v1);
  * key 3: 256x256 GEMM start stagger per phase group in 10 ns ticks (0 = none; measured useless, kept for A/B);
  * key 4: GEMM store loop (0 auto, 1 rolled per-pass loads, 2 prefetching);
- * key 5: phased GEMM kernels skip the MFMAs of waves whose rows are all beyond M (0 on, 1 off). */
+ * key 5: phased GEMM kernels skip the MFMAs of waves whose rows are all beyond M (0 on, 1 off);
+ * key 6: kx_clip_preprocess reads its taps from global memory instead of the LDS-staged row (0 auto, 1 force). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -78,6 +78,11 @@ class ProfRecord(C.Structure):
                 ("reserved2", f32)]
 
 
+class ResamplePlan(C.Structure):
+    _fields_ = [("crop", i32), ("hk", i32), ("vk", i32), ("y_first", i32), ("rows_needed", i32), ("x_first", i32),
+                ("span_px", i32), ("hbounds", vp), ("hcoef", vp), ("vbounds", vp), ("vcoef", vp)]
+
+
 KERNEL_KINDS = ["gemm_bf16_128x128", "gemm_bf16_64x64", "gemm_f32_128x128", "gemm_f32_64x64", "layernorm",
                 "attn_bf16", "attn_f32", "embed", "misc", "gemm_bf16_160x128", "gemm_bf16_256x128_phased",
                 "gemm_bf16_256x256_phased"]
@@ -107,6 +112,10 @@ SYMBOLS = {
     "kx_attention_decode": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i64, i64, i64, i32, vp]),
     "kx_decoder_forward": (C.c_int, [C.POINTER(DecoderWeights), vp, i64, i64, vp, vp, vp, vp, vp, i32, vp,
                                      C.c_size_t, i32, vp]),
+    "kx_clip_preprocess_workspace_bytes": (C.c_size_t, [i64, i32, i32]),
+    "kx_clip_preprocess": (C.c_int, [vp, i64, i32, i32, i64, i64, C.POINTER(ResamplePlan), vp, vp, vp, vp,
+                                     C.c_size_t, vp]),
+    "kx_token_splice": (C.c_int, [vp, i64, i64, i64, i64, i64, i64, vp, vp, vp]),
 }
 
 

@@ -921,10 +921,66 @@ class KosmosLanguage(nn.Module):
 
 
 class KosmosTokenizer:
-    """Host-side pre-processing of the reference (/root/reference/kosmosx/model.py:23-129): CLIPProcessor +
-    GPT-NeoX tokenizer files fetched from the network.  It is not on the tensor->logits hot path
-    ("next" row 3) and needs files that are unavailable offline."""
+    """The reference's host pre-processing (/root/reference/kosmosx/model.py:23-129) with its tensor half on the
+    device: `tokenize_images` = CLIP resize / centre-crop / rescale / normalize in
+    csrc/kx_preprocess.hip, bit-identical to the HF CLIPProcessor; `tokenize_texts` / `tokenize` = the
+    `<s> <image> </image> text` id splice and attention mask in `kx_token_splice`.
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("KosmosTokenizer is outside the MI355X hot-path scope (SURVEY.md §8f row 3); "
-                                  "feed token ids and pixel tensors directly to Kosmos.forward")
+    The text tokenizer itself (GPT-NeoX vocabulary files) is host string processing and stays the HF object: pass one
+    in (`tokenizer=`), or leave it None to load "EleutherAI/gpt-neox-20b" exactly as the reference does (:41-48) —
+    which needs the hub or a local cache and otherwise fails with the reference's log-and-re-raise (:49-51).  The
+    image half needs no files: the CLIP processor constants are built in."""
+
+    def __init__(self, tokenizer=None, device=None):
+        try:
+            if tokenizer is None:
+                from transformers import AutoTokenizer
+                tokenizer = AutoTokenizer.from_pretrained(
+                    "EleutherAI/gpt-neox-20b", additional_special_tokens=["<image>", "</image>"], eos_token="<eos>",
+                    pad_token="<pad>", extra_ids=0, model_max_length=8192)
+            self.tokenizer = tokenizer
+        except Exception as e:
+            logging.error(f"Failed to initialize KosmosTokenizer: {e}")
+            raise
+        self.device = torch.device(device) if device is not None else None
+        self.im_idx, self.im_end_idx = self.tokenizer.convert_tokens_to_ids(["<image>", "</image>"])
+
+    def _dev(self):
+        return self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def tokenize_texts(self, texts):
+        """-> (text_tokens [B,L+2] with the image tokens spliced in after <s>, only_text_tokens [B,L]), on the device."""
+        try:
+            ids = self.tokenizer(texts, return_tensors="pt", padding=True, truncation=True).input_ids
+            ids = ids.to(self._dev(), dtype=torch.int64)
+            from .preprocess import token_splice
+            tok, self._last_mask = token_splice(ids, self.im_idx, self.im_end_idx, self.tokenizer.pad_token_id)
+            return tok, ids
+        except Exception as e:
+            logging.error(f"Failed to tokenize texts: {e}")
+            raise
+
+    def tokenize_images(self, images):
+        """-> pixel_values float32 [B,3,224,224] on the device (CLIPProcessor(images=...).pixel_values)."""
+        try:
+            from .preprocess import clip_preprocess
+            return clip_preprocess(images, device=self._dev())
+        except Exception as e:
+            logging.error(f"Failed to tokenize images: {e}")
+            raise
+
+    def tokenize(self, sample):
+        """{"text_tokens", "images", "labels", "attention_mask"} as the reference builds them (:106-129)."""
+        try:
+            text_tokens, only_text_tokens = self.tokenize_texts(sample["target_text"])
+            return {
+                "text_tokens": text_tokens,
+                "images": self.tokenize_images(sample["image"]),
+                "labels": only_text_tokens,
+                "attention_mask": self._last_mask,      # [64 ones | text_tokens != pad], from the same kernel
+            }
+        except Exception as e:
+            logging.error(f"Failed to tokenize sample: {e}")
+            raise
+
+

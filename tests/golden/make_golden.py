@@ -8,6 +8,9 @@
                    (weights are regenerated from the seed by the product's init; their checksum is stored so a
                    change of the RNG stream is detected instead of mis-reported as a parity failure).
   xpos_tables.npz  XPos cos*scale / sin*scale tables for T in {1, 2, 9, 114, 115}, q and k variants.
+  preprocess.npz   seeded uint8 images of five sizes + the uint8 resize/centre-crop result and the normalisation
+                   table recovered from the INSTALLED HF CLIPImageProcessor's pixel_values (Pillow resampler
+                   underneath), and the float pixel_values of image 0.
 Fixtures are data (inputs and expected outputs) — no reference source text is stored.
 """
 import os
@@ -28,6 +31,25 @@ from oracle import kosmos_oracle as O  # noqa: E402
 
 def weight_checksum(w: dict) -> float:
     return float(sum(float(v.double().abs().sum()) for _, v in sorted(w.items())))
+
+
+def make_preprocess():
+    from transformers import CLIPImageProcessor
+    proc = CLIPImageProcessor()
+    rng = np.random.default_rng(2024)
+    sizes = [(97, 131), (300, 200), (224, 224), (180, 411), (40, 33)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    pv = proc(images=imgs, return_tensors="np")["pixel_values"]                    # [5,3,224,224] float32
+    # every byte value -> float, per channel, as the processor maps it (ramp image through rescale + normalize only)
+    ramp = np.tile(np.arange(256, dtype=np.uint8)[None, :, None], (8, 1, 3))         # [8,256,3]
+    lut = proc(images=[ramp], do_resize=False, do_center_crop=False, return_tensors="np")["pixel_values"][0, :, 0, :]
+    out = {"n": np.int64(len(imgs)), "lut": lut.astype(np.float32), "pixel_values0": pv[0]}
+    for i, im in enumerate(imgs):
+        # invert the (strictly monotonic) table to recover the uint8 crop the processor produced
+        crop = np.stack([np.searchsorted(lut[c], pv[i, c]) for c in range(3)], -1).astype(np.uint8)
+        assert all(np.array_equal(lut[c][crop[:, :, c]], pv[i, c]) for c in range(3))
+        out[f"img{i}"], out[f"crop{i}"] = im, crop
+    np.savez_compressed(HERE / "preprocess.npz", **out)
 
 
 def make_clip():
@@ -74,8 +96,9 @@ def make_xpos():
 
 
 if __name__ == "__main__":
-    make_clip()
-    make_kosmos()
-    make_xpos()
+    only = sys.argv[1:]            # e.g. `make_golden.py preprocess` regenerates one fixture
+    for name, fn in (("clip", make_clip), ("kosmos", make_kosmos), ("xpos", make_xpos), ("preprocess", make_preprocess)):
+        if not only or name in only:
+            fn()
     for f in sorted(HERE.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -45,7 +45,7 @@ def test_struct_layouts_match_the_header_field_order():
                        ("kx_vit_layer", _hip.VitLayer), ("kx_vit_weights", _hip.VitWeights),
                        ("kx_perceiver_layer", _hip.PerceiverLayer), ("kx_perceiver_weights", _hip.PerceiverWeights),
                        ("kx_decoder_layer", _hip.DecoderLayer), ("kx_decoder_weights", _hip.DecoderWeights),
-                       ("kx_prof_record", _hip.ProfRecord)]:
+                       ("kx_prof_record", _hip.ProfRecord), ("kx_resample_plan", _hip.ResamplePlan)]:
         m = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + r"\s*;", body, flags=re.S)
         assert m, cname
         names = []
@@ -110,11 +110,15 @@ def test_no_cpu_fallback():
         lm(torch.zeros(1, 4, dtype=torch.long))
     with pytest.raises(RuntimeError, match="not on a CUDA"):
         ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8))
-    with pytest.raises(NotImplementedError):
-        KosmosTokenizer()
+    from kosmosx import preprocess
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        preprocess.clip_preprocess_same_size(torch.zeros(1, 8, 8, 3, dtype=torch.uint8))
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        preprocess.token_splice(torch.zeros(1, 4, dtype=torch.long), 5, 6, 1)
+    assert KosmosTokenizer.tokenize_images and KosmosTokenizer.tokenize_texts and KosmosTokenizer.tokenize
     import kosmosx.model as km
     import inspect
-    src = inspect.getsource(km) + inspect.getsource(ops)
+    src = inspect.getsource(km) + inspect.getsource(ops) + inspect.getsource(preprocess)
     assert "oracle" not in src.replace("the oracle", "")        # the product never imports the test oracle
 
 
