@@ -110,6 +110,19 @@ typedef struct {
    * [splits, M, N] fp32 are combined in slice order (deterministic) by a reduce kernel that owns the epilogue.
    * splitk: 0 = automatic, 1 = off, n = force n slices (tests). */
   void* splitk_ws; size_t splitk_ws_bytes; int32_t splitk;
+  /* Weight-streaming variant, tile = 16 (bf16, M <= 16: incremental decoding, one token per sequence).  One launch
+   * per GEMM: a workgroup owns 16 output columns, its waves split K and stream their weight rows straight into
+   * MFMA fragments, the partial sums meet in LDS (fixed order) and wave 0 runs the epilogue above.  It takes three
+   * extra inputs that remove the small kernels around a decode-step GEMM (all optional, this variant only):
+   *   ln_gamma/ln_beta/ln_eps : A is then the raw fp32 rows [M,K] (lda in floats) and LayerNorm(A)*gamma+beta, rounded
+   *       to bf16 exactly as kx_layernorm does, is the operand (M*(2K+16) <= 128 KB);
+   *   stats_partials [M, stats_in_nseg, 2] + stats_in_seg + stats_eps : the consumer side of the folded sub-LayerNorm
+   *       takes the producer's partial statistics directly (what kx_row_stats_finalize would turn into row_stats);
+   *   stats_out_seg : the producer side emits its statistics per 16-column segment ([M, N/16, 2]; must be 16 here,
+   *       0 or 64 for every other variant). */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  const float* stats_partials; int64_t stats_in_nseg; int64_t stats_in_seg; float stats_eps;
+  int32_t stats_out_seg;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 

@@ -538,18 +538,32 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
   Ld4<T>::load(qrow + 4 * li * es, q);
   float m = -INFINITY, l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
   const int nkeys = p.t + 1;
-  for (int j = wave * 4 + grp; j < nkeys; j += 16) {
-    float k[4], v[4];
-    Ld4<T>::load(kc + ((long long)j * p.cache_row + 4 * li) * es, k);
-    Ld4<T>::load(vc + ((long long)j * p.cache_row + 4 * li) * es, v);
-    float s = (q[0] * k[0] + q[1] * k[1]) + (q[2] * k[2] + q[3] * k[3]);
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-    const float mn = fmaxf(m, s);
-    const float a = __expf(m - mn), pj = __expf(s - mn);
-    l = l * a + pj;
-    o[0] = o[0] * a + pj * v[0]; o[1] = o[1] * a + pj * v[1];
-    o[2] = o[2] * a + pj * v[2]; o[3] = o[3] * a + pj * v[3];
-    m = mn;
+  // eight keys of this slot in flight per round: the loop is a chain of dependent cache reads (~1 us each at
+  // batch 1 — ten of them for a 150-token context when issued one key at a time)
+  constexpr int UK = 8;
+  for (int j0 = wave * 4 + grp; j0 < nkeys; j0 += 16 * UK) {
+    float k[UK][4], v[UK][4];
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      const int j = j0 + 16 * u;
+      if (j < nkeys) {
+        Ld4<T>::load(kc + ((long long)j * p.cache_row + 4 * li) * es, k[u]);
+        Ld4<T>::load(vc + ((long long)j * p.cache_row + 4 * li) * es, v[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      if (j0 + 16 * u < nkeys) {
+        float s = (q[0] * k[u][0] + q[1] * k[u][1]) + (q[2] * k[u][2] + q[3] * k[u][3]);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        const float mn = fmaxf(m, s);
+        const float a = __expf(m - mn), pj = __expf(s - mn);
+        l = l * a + pj;
+        o[0] = o[0] * a + pj * v[u][0]; o[1] = o[1] * a + pj * v[u][1];
+        o[2] = o[2] * a + pj * v[u][2]; o[3] = o[3] * a + pj * v[u][3];
+        m = mn;
+      }
+    }
   }
   // merge the 16 (wave, group) partial states
   const int slot = wave * 4 + grp;

@@ -122,6 +122,30 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   return kx_gemm(&g, (void*)s);
 }
 
+// tile 16 (weight streaming, bf16, M <= 16) with its prologues — see kx_gemm_args in the header
+struct Gemv16 {
+  const void* A; int64_t lda; const void* W; int64_t K; void* C; int64_t ldc; int cdt; int64_t M, N;
+  const float* bias = nullptr; const float* residual = nullptr; int act = 0; float qscale = 1.f; int64_t qcols = 0;
+  const float *xq_cs = nullptr, *xq_ss = nullptr, *xk_cs = nullptr, *xk_ss = nullptr; int64_t xT = 0, xdim = 0;
+  const float *ln_g = nullptr, *ln_b = nullptr; float eps = 0.f;
+  const float* partials_in = nullptr; int64_t nseg_in = 0, seg_in = 0; const float* colsum = nullptr;
+  float* stats_out = nullptr;
+};
+int gemv16(const Gemv16& v, hipStream_t s) {
+  kx_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  g.A = v.A; g.lda = v.lda; g.W = v.W; g.ldw = v.K; g.C = v.C; g.ldc = v.ldc; g.cdt = v.cdt;
+  g.bias = v.bias; g.residual = v.residual; g.ldr = v.ldc; g.M = v.M; g.N = v.N; g.K = v.K;
+  g.act = v.act; g.qscale = v.qscale; g.qcols = v.qcols;
+  g.xq_cs = v.xq_cs; g.xq_ss = v.xq_ss; g.xk_cs = v.xk_cs; g.xk_ss = v.xk_ss; g.xpos_T = v.xT; g.xpos_dim = v.xdim;
+  g.prec = KX_PREC_BF16; g.tile = 16;
+  g.ln_gamma = v.ln_g; g.ln_beta = v.ln_b; g.ln_eps = v.eps;
+  g.stats_partials = v.partials_in; g.stats_in_nseg = v.nseg_in; g.stats_in_seg = v.seg_in; g.stats_eps = v.eps;
+  g.colsum = v.colsum;
+  g.stats_out = v.stats_out; g.stats_out_seg = v.stats_out ? 16 : 0;
+  return kx_gemm(&g, (void*)s);
+}
+
 int ln(const float* x, const float* pre, const float* g, const float* b, void* y, int ydt, int64_t rows, int64_t cols,
        float eps, hipStream_t s, int64_t rpg = 0, int64_t ogs = 0, int64_t oro = 0) {
   return kx_layernorm(x, pre, g, b, y, (kx_dtype)ydt, rows, cols, eps, rpg ? rpg : rows, ogs, oro, (void*)s);
@@ -177,7 +201,9 @@ DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, ch
   d.qkv = c.take((size_t)M * 3 * w->dim * es);
   d.att = c.take((size_t)M * w->dim * es);          // attention output, un-normalised (inner_attn_ln is folded)
   d.g = c.take((size_t)M * w->ffn * es);            // gelu(fc1), un-normalised (ffn_layernorm is folded)
-  const int64_t nseg = w->ffn / 64 > w->heads ? w->ffn / 64 : w->heads;
+  // per-segment statistics: 64 columns per segment from the tile kernels and attention (heads), 16 from the
+  // weight-streaming decode path
+  const int64_t nseg = w->ffn / 16 > w->heads ? w->ffn / 16 : w->heads;
   d.partials = (float*)c.take((size_t)M * nseg * 2 * 4);
   d.stats = (float*)c.take((size_t)M * 2 * 4);
   d.splitk = c.take(KX_SPLITK_WS);
@@ -400,6 +426,36 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
   const int ct = cdt(prec);
   const size_t es = esz(prec);
   const size_t layer_bytes = (size_t)B * Tmax * D * es;
+  // One token per sequence in bf16, up to 16 sequences: the step is 120 dependent launches of weight-streaming work,
+  // and launches are what it costs (~6 us each) — tile 16 does each GEMM in one launch and takes the LayerNorm and
+  // statistics-finalize kernels in as prologues: 5 launches per layer instead of 13.
+  if (prec == KX_PREC_BF16 && M <= 16 && kx_tuning_get(KX_TUNE_GEMM_TILE) == 0 && D % 16 == 0 && F % 16 == 0 &&
+      (size_t)M * (2 * D + 16) <= 128 * 1024) {
+    for (int i = 0; i < w->layers; ++i) {
+      const kx_decoder_layer& L = w->layer[i];
+      Gemv16 q{x, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D};
+      q.bias = L.bqkv; q.qscale = 0.125f; q.qcols = D; q.ln_g = L.sa_g; q.ln_b = L.sa_b; q.eps = w->eps;
+      if (w->xpos) { q.xq_cs = xq_cs; q.xq_ss = xq_ss; q.xk_cs = xk_cs; q.xk_ss = xk_ss; q.xT = 1; q.xdim = D; }
+      KX_TRY(gemv16(q, s));
+      KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, ct,
+                                 w->subln ? d.partials : nullptr, B, w->heads, t, Tmax, prec, stream));
+      Gemv16 o{d.att, D, L.wo, D, x, D, KX_F32, M, D};
+      o.bias = L.bo; o.residual = x; o.eps = w->eps;
+      if (w->subln) { o.partials_in = d.partials; o.nseg_in = w->heads; o.seg_in = 64; o.colsum = L.wo_colsum; }
+      KX_TRY(gemv16(o, s));
+      Gemv16 f1{x, D, L.w1, D, d.g, F, ct, M, F};
+      f1.bias = L.b1; f1.act = w->act; f1.ln_g = L.fl_g; f1.ln_b = L.fl_b; f1.eps = w->eps;
+      if (w->subln) f1.stats_out = d.partials;
+      KX_TRY(gemv16(f1, s));
+      Gemv16 f2{d.g, F, L.w2, F, x, D, KX_F32, M, D};
+      f2.bias = L.b2; f2.residual = x; f2.eps = w->eps;
+      if (w->subln) { f2.partials_in = d.partials; f2.nseg_in = F / 16; f2.seg_in = 16; f2.colsum = L.w2_colsum; }
+      KX_TRY(gemv16(f2, s));
+    }
+    Gemv16 lo{x, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab};
+    lo.ln_g = w->ln_g; lo.ln_b = w->ln_b; lo.eps = w->eps;
+    return gemv16(lo, s);
+  }
   for (int i = 0; i < w->layers; ++i) {
     const kx_decoder_layer& L = w->layer[i];
     KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));

@@ -40,6 +40,9 @@ struct GemmParams {
   int stagger_ticks;
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
   int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
+  // weight-streaming variant (gemv_fused_kernel) only
+  const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
+  const float* stats_partials; int stats_in_nseg; float stats_in_seg, stats_eps;
 };
 
 // Everything of the fused epilogue except the store: x[0..3] = columns n..n+3 of row m (in range: m < M, n < N).
@@ -938,6 +941,181 @@ int launch_p5(GemmParams& p, hipStream_t s) {
   return KX_OK;
 }
 
+int launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
+  const long long work = (long long)p.M * ((p.N + 3) / 4);
+  const dim3 rgrid((unsigned)((work + 255) / 256)), block(256);
+  switch (p.act) {
+    case KX_ACT_NONE: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_NONE>, rgrid, block, 0, s, p); break;
+    case KX_ACT_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_GELU>, rgrid, block, 0, s, p); break;
+    case KX_ACT_GELU_FAST: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_GELU_FAST>, rgrid, block, 0, s, p); break;
+    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_QUICK_GELU>, rgrid, block, 0, s, p); break;
+    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+  }
+  KX_CHECK_LAUNCH("kx_gemm(split-K reduce)");
+  return KX_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Weight-streaming kernel for M <= 16 rows (incremental decoding: one token per sequence), ONE launch per GEMM.
+// A decode step is a read-once stream of each W (8-131 MB) against a few KB of activations, and what it costs on
+// this machine is dependent kernel launches (~6 us each: a split-K GEMM + its reduce kernel took 12-16 us whatever
+// the bytes), so this kernel does the whole GEMM and absorbs its neighbours:
+//   * a workgroup owns 16 output columns; its S waves (8 or 16) split K, each streaming its slice of the 16 weight rows
+//     straight from global memory into MFMA A-fragments (lane (g,i): 16 B of row i at k-chunk g, 8 k-steps = 8 KB
+//     per wave in flight; N/16 x S waves per launch keep 8-30 MB in flight).  Nothing of W touches LDS;
+//   * the S partial accumulators meet in LDS and are summed in wave order (deterministic) by wave 0, which runs the
+//     usual fused epilogue (folded-LN consume, bias, q-scale, XPos, activation, residual, fp32/bf16 store) and, as the
+//     producer of a folded sub-LN, emits per-16-column statistics;
+//   * optional LayerNorm prologue (ln_g): the raw fp32 rows are normalised into LDS as bf16 with kx_layernorm's
+//     arithmetic (same lane/column walk, same rounding) — the decode step's separate LayerNorm launches disappear;
+//   * optional statistics prologue (stats_partials): (mean, rstd) of each row from the producer's partials, the
+//     kx_row_stats_finalize arithmetic — those launches disappear too.
+// -------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(1024) void gemv_fused_kernel(const GemmParams p, int S, int kw, int x_pitch) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  float* red = reinterpret_cast<float*>(lds);                    // [S][64] float4
+  float* st = reinterpret_cast<float*>(lds + S * 1024);          // [16][2] (mean, rstd)
+  char* xn = lds + S * 1024 + 128;                               // [M][x_pitch] bf16 (LayerNorm prologue)
+  // The weight stream does not depend on the prologues: put this wave's first 8 KB in flight before them (the
+  // LayerNorm / statistics prologues are three dependent L2 round trips; serialised in front of the loads they
+  // cost more than the stream itself: 17 -> ~9 us per launch at batch 1).
+  constexpr int U = 8;
+  const int n0 = blockIdx.x * 16;
+  const int k0 = wave * kw, klen = min(kw, p.K - k0);           // may be <= 0 for trailing waves of a short K
+  const int nrow = min(n0 + i, p.N - 1);                         // columns past N re-read the last row; never stored
+  const char* wp = p.W + (long long)nrow * p.ldw_b + ((long long)(k0 + 8 * g) << 1);
+  u32x4_t wf[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (32 * u < klen) wf[u] = *reinterpret_cast<const u32x4_t*>(wp + ((32 * u) << 1));
+  if (p.stats_partials) {
+    for (int m = wave; m < p.M; m += S) {
+      const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
+      float sm = 0.f;
+      for (int j = lane; j < p.stats_in_nseg; j += 64) sm += pr[j].x;
+      const float mean = wave_sum(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
+      float m2 = 0.f;
+      for (int j = lane; j < p.stats_in_nseg; j += 64) {
+        const float2 v = pr[j];
+        const float d = v.x / p.stats_in_seg - mean;
+        m2 += v.y + p.stats_in_seg * d * d;
+      }
+      const float var = wave_sum(m2) / (p.stats_in_seg * (float)p.stats_in_nseg);
+      if (lane == 0) { st[2 * m] = mean; st[2 * m + 1] = rsqrtf(var + p.stats_eps); }
+    }
+  }
+  if (p.ln_g) {
+    const int nv = p.K >> 2;                                     // float4 per row
+    // (a register-resident row — one load round trip instead of three — was slower: with 16 waves per workgroup
+    // the 32 extra VGPRs spill)
+    for (int m = wave; m < p.M; m += S) {
+      const float4* xr = reinterpret_cast<const float4*>(p.A + (long long)m * p.lda_b);
+      float sm = 0.f;
+      for (int c = lane; c < nv; c += 64) { const float4 v = xr[c]; sm += (v.x + v.y) + (v.z + v.w); }
+      const float mean = wave_sum(sm) / (float)p.K;
+      float q = 0.f;
+      for (int c = lane; c < nv; c += 64) {
+        const float4 v = xr[c];
+        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+      const float rstd = rsqrtf(wave_sum(q) / (float)p.K + p.ln_eps);
+      for (int c = lane; c < nv; c += 64) {
+        const float4 v = xr[c];
+        const float4 gm = reinterpret_cast<const float4*>(p.ln_g)[c];
+        const float4 bt = reinterpret_cast<const float4*>(p.ln_b)[c];
+        uint2 o;
+        o.x = pack_bf16x2((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y);
+        o.y = pack_bf16x2((v.z - mean) * rstd * gm.z + bt.z, (v.w - mean) * rstd * gm.w + bt.w);
+        *reinterpret_cast<uint2*>(xn + m * x_pitch + c * 8) = o;
+      }
+    }
+  }
+  if (p.ln_g || p.stats_partials) __syncthreads();
+
+  const int xrow = min(i, p.M - 1);                              // fragment columns m >= M: any finite-or-not data,
+  const char* xg = p.ln_g ? xn + xrow * x_pitch + ((k0 + 8 * g) << 1)   //   they only reach outputs that are dropped
+                          : p.A + (long long)xrow * p.lda_b + ((long long)(k0 + 8 * g) << 1);
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int kk = 0; kk < klen; kk += 32 * U) {
+    u32x4_t xf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kk + 32 * u < klen) {
+        if (kk > 0) wf[u] = *reinterpret_cast<const u32x4_t*>(wp + ((kk + 32 * u) << 1));   // first batch: in flight
+        xf[u] = *reinterpret_cast<const u32x4_t*>(xg + ((kk + 32 * u) << 1));
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kk + 32 * u < klen) acc = Mma<bf16_t>::step(wf[u], xf[u], acc);
+  }
+  *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < S; ++w) acc += *reinterpret_cast<const f32x4_t*>(red + (w * 64 + lane) * 4);
+
+  const int m = i, n = n0 + 4 * g;                               // lane: row m, columns n..n+3
+  const bool live = m < p.M && n < p.N;
+  GemmParams q = p;
+  q.stats_out = nullptr;
+  if (p.stats_partials) q.row_stats = st;                        // LDS through a generic pointer
+  float x[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) epilogue_compute4<ACT>(q, m, n, acc, x);
+  if (p.stats_out) {
+    // producer of a folded sub-LN: (sum, M2 about the segment mean) of this row's 16 columns — the four lanes
+    // i, i+16, i+32, i+48 hold them (N % 16 == 0, no residual in this mode: enforced on the host)
+    float sm = (x[0] + x[1]) + (x[2] + x[3]);
+    sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+    const float mu = sm * (1.0f / 16.0f);
+    const float d0 = x[0] - mu, d1 = x[1] - mu, d2 = x[2] - mu, d3 = x[3] - mu;
+    float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    m2 += __shfl_xor(m2, 16, 64); m2 += __shfl_xor(m2, 32, 64);
+    if (live && g == 0)
+      *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (n0 >> 4))) = make_float2(sm, m2);
+  }
+  if (!live) return;
+  const bool full = n + 3 < p.N && p.vec_ok;
+  const long long off = (long long)m * p.ldc + n;
+  if (p.c_bf16) {
+    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
+    if (full) { uint2 o; o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); *reinterpret_cast<uint2*>(c) = o; }
+    else for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = f32_to_bf16(x[j]);
+  } else {
+    float* c = reinterpret_cast<float*>(p.C) + off;
+    if (full) *reinterpret_cast<float4*>(c) = make_float4(x[0], x[1], x[2], x[3]);
+    else for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = x[j];
+  }
+}
+
+int launch_gemv_fused(GemmParams& p, hipStream_t s) {
+  const int S = p.K <= 4096 ? 8 : 16;
+  const int kw = ((p.K + S - 1) / S + 31) / 32 * 32;
+  const int x_pitch = p.ln_g ? p.K * 2 + 16 : 0;
+  const size_t lds = (size_t)S * 1024 + 128 + (size_t)(p.ln_g ? p.M : 0) * x_pitch;
+  const dim3 grid((unsigned)((p.N + 15) / 16)), block(64 * S);
+  static bool attr_set = false;
+  if (!attr_set) {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_QUICK_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  switch (p.act) {
+    case KX_ACT_NONE: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_NONE>, grid, block, lds, s, p, S, kw, x_pitch); break;
+    case KX_ACT_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;
+    case KX_ACT_GELU_FAST: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU_FAST>, grid, block, lds, s, p, S, kw, x_pitch); break;
+    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_QUICK_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;
+    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+  }
+  KX_CHECK_LAUNCH("kx_gemm(weight streaming)");
+  return KX_OK;
+}
+
 template <typename T, int BM, int BN>
 int launch(GemmParams& p, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -947,17 +1125,7 @@ int launch(GemmParams& p, hipStream_t s) {
     // skinny problem: the tile kernels only produce partials (activation-free), the reduce kernel owns the epilogue
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p);
     KX_CHECK_LAUNCH("kx_gemm(split-K)");
-    const long long work = (long long)p.M * ((p.N + 3) / 4);
-    const dim3 rgrid((unsigned)((work + 255) / 256));
-    switch (p.act) {
-      case KX_ACT_NONE: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_NONE>, rgrid, block, 0, s, p); break;
-      case KX_ACT_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_GELU>, rgrid, block, 0, s, p); break;
-      case KX_ACT_GELU_FAST: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_GELU_FAST>, rgrid, block, 0, s, p); break;
-      case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_QUICK_GELU>, rgrid, block, 0, s, p); break;
-      default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
-    }
-    KX_CHECK_LAUNCH("kx_gemm(split-K reduce)");
-    return KX_OK;
+    return launch_splitk_reduce(p, s);
   }
   // the activation is a compile-time property of the kernel: a runtime switch costs ~4 scalar branches per value
   switch (p.act) {
@@ -1002,9 +1170,10 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   p.xq_cs = a->xq_cs; p.xq_ss = a->xq_ss; p.xk_cs = a->xk_cs; p.xk_ss = a->xk_ss;
   p.xpos_T = (int)a->xpos_T; p.xpos_dim = (int)a->xpos_dim;
   p.row_stats = a->row_stats; p.colsum = a->colsum; p.stats_out = a->stats_out; p.stats_nseg = (int)(a->N / 64);
-  KX_REQUIRE(!a->row_stats == !a->colsum, "kx_gemm: row_stats and colsum must be given together");
+  KX_REQUIRE((!a->row_stats && !a->stats_partials) == !a->colsum, "kx_gemm: row_stats and colsum must be given together");
   KX_REQUIRE(!a->colsum || ((uintptr_t)a->colsum & 15) == 0, "kx_gemm: colsum must be 16-byte aligned");
-  KX_REQUIRE(!a->stats_out || a->N % 64 == 0, "kx_gemm: stats_out needs N %% 64 == 0 (N=%lld)", (long long)a->N);
+  KX_REQUIRE(!a->stats_out || a->stats_out_seg == 16 || a->N % 64 == 0, "kx_gemm: stats_out needs N %% 64 == 0 (N=%lld)",
+             (long long)a->N);
   KX_REQUIRE(!a->stats_out || (!a->row_stats && a->qcols == 0 && a->xpos_dim == 0),
              "kx_gemm: stats_out combines with bias and activation only");
   KX_REQUIRE(!a->stats_out || !a->residual, "kx_gemm: stats_out is taken before the residual add; pass one of them");
@@ -1014,6 +1183,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   KX_REQUIRE(!a->bias || ((uintptr_t)a->bias & 15) == 0, "kx_gemm: bias must be 16-byte aligned");
   p.splitk = 1; p.partial = nullptr;
   p.stagger_ticks = 0;
+  p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
+  p.stats_partials = nullptr; p.stats_in_nseg = 0; p.stats_in_seg = p.stats_eps = 0.f;
   {
     // The prefetching store loop pays where the epilogue has per-row global operands to wait for (residual, folded-LN
     // statistics, XPos tables); bias-only bf16 epilogues measured ~5 % faster on the plain rolled loop.
@@ -1065,6 +1236,23 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     }
   }
   if (tile == 64 && a->stats_out && !(a->splitk_ws && a->splitk != 1)) tile = 128;   // 64x64 waves own 32 columns only
+  const bool gemv_extras = a->ln_gamma || a->stats_partials || (a->stats_out_seg != 0 && a->stats_out_seg != 64);
+  if (tile == 16) {
+    KX_REQUIRE(a->prec == KX_PREC_BF16 && a->M <= 16, "kx_gemm: tile 16 (weight streaming) is bf16, M <= 16 only");
+    KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * 2 + 16) <= 128 * 1024 && a->K % 4 == 0),
+               "kx_gemm: LayerNorm prologue needs beta and M*(2K+16) <= 128 KB");
+    KX_REQUIRE(!a->stats_partials || (a->colsum && !a->row_stats && a->stats_in_nseg > 0 && a->stats_in_seg > 0),
+               "kx_gemm: stats_partials needs colsum, nseg, seg size and excludes row_stats");
+    KX_REQUIRE(!a->stats_out || (a->stats_out_seg == 16 && a->N % 16 == 0 && !a->residual),
+               "kx_gemm: tile 16 emits statistics per 16-column segment (stats_out_seg = 16, N %% 16 == 0, no residual)");
+    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps;
+    if (a->ln_gamma) p.lda_b = a->lda * 4;              // A holds fp32 rows in this mode
+    p.stats_partials = a->stats_partials; p.stats_in_nseg = (int)a->stats_in_nseg;
+    p.stats_in_seg = (float)a->stats_in_seg; p.stats_eps = a->stats_eps;
+    if (a->stats_out) p.stats_nseg = (int)(a->N / 16);
+  } else {
+    KX_REQUIRE(!gemv_extras, "kx_gemm: ln_gamma / stats_partials / stats_out_seg = 16 belong to tile 16 (weight streaming)");
+  }
   if (tile == 64 && a->splitk_ws) {
     // Skinny problems (batch-1 shapes: M = 114 / 257 / 64) are weight-streaming bound and a 64x64 grid of N/64 x 2
     // workgroups leaves most CUs idle while each one walks all of K serially.  Slice K so that ~512 workgroups
@@ -1083,12 +1271,13 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     }
   }
   const int kind = a->prec != KX_PREC_BF16 ? (tile == 64 ? KX_K_GEMM_F32_64 : KX_K_GEMM_F32_128)
-                   : tile == 64 ? KX_K_GEMM_BF16_64
+                   : (tile == 64 || tile == 16) ? KX_K_GEMM_BF16_64
                    : tile == 160 ? KX_K_GEMM_BF16_160
                    : (tile == 256 || tile == 257) ? KX_K_GEMM_BF16_256X128
                    : (tile == 512 || tile == 384) ? KX_K_GEMM_BF16_256X256 : KX_K_GEMM_BF16_128;
   KxProfScope prof(kind, a->M, a->N, a->K, s);
   if (a->prec == KX_PREC_BF16) {
+    if (tile == 16) return launch_gemv_fused(p, s);
     if (tile == 128) return launch<bf16_t, 128, 128>(p, s);
     if (tile == 64) return launch<bf16_t, 64, 64>(p, s);
     if (tile == 160) return launch<bf16_t, 160, 128>(p, s);

@@ -30,7 +30,10 @@ class GemmArgs(C.Structure):
                 ("act", i32), ("qscale", f32), ("qcols", i64),
                 ("xq_cs", vp), ("xq_ss", vp), ("xk_cs", vp), ("xk_ss", vp), ("xpos_T", i64), ("xpos_dim", i64),
                 ("prec", i32), ("tile", i32), ("row_stats", vp), ("colsum", vp), ("stats_out", vp),
-                ("splitk_ws", vp), ("splitk_ws_bytes", C.c_size_t), ("splitk", i32)]
+                ("splitk_ws", vp), ("splitk_ws_bytes", C.c_size_t), ("splitk", i32),
+                ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
+                ("stats_partials", vp), ("stats_in_nseg", i64), ("stats_in_seg", i64), ("stats_eps", f32),
+                ("stats_out_seg", i32)]
 
 
 class AttnArgs(C.Structure):

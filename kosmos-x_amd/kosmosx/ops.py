@@ -46,13 +46,15 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, o
 
 def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
          xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None, splitk_ws=None,
-         splitk=0):
-    """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32]."""
+         splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0):
+    """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32].
+    tile=16 (weight streaming, bf16, M <= 16) extras: ln = (gamma, beta, eps) with `a` the raw fp32 rows;
+    stats_partials [M,nseg,2] instead of row_stats; stats_out_seg=16."""
     _need_cuda(a, w, bias, residual, out)
     M, K = a.shape
     N = w.shape[0]
-    prec = H.KX_PREC_BF16 if a.dtype == torch.bfloat16 else H.KX_PREC_F32
-    if a.dtype != w.dtype:
+    prec = H.KX_PREC_BF16 if w.dtype == torch.bfloat16 else H.KX_PREC_F32
+    if a.dtype != w.dtype and ln is None:
         raise TypeError("gemm operands must share a dtype")
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
@@ -69,6 +71,12 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
     g.row_stats, g.colsum, g.stats_out = H.ptr(row_stats), H.ptr(colsum), H.ptr(stats_out)
     if splitk_ws is not None:
         g.splitk_ws, g.splitk_ws_bytes, g.splitk = H.ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size(), splitk
+    if ln is not None:
+        g.ln_gamma, g.ln_beta, g.ln_eps = H.ptr(ln[0]), H.ptr(ln[1]), float(ln[2])
+    if stats_partials is not None:
+        g.stats_partials, g.stats_in_nseg = H.ptr(stats_partials), stats_partials.shape[1]
+        g.stats_in_seg, g.stats_eps = stats_in_seg, float(stats_eps)
+    g.stats_out_seg = stats_out_seg
     H.check(H.load().kx_gemm(C.byref(g), _stream()), "kx_gemm")
     return out
 

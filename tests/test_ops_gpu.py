@@ -381,3 +381,64 @@ def test_gemm_split_k_skinny(prec, splitk):
     y = ops.gemm(a.to(DEV), w2.to(DEV), act="gelu", stats_out=part, tile=64, splitk_ws=ws, splitk=splitk)
     st = ops.row_stats_finalize(part, 64).cpu()
     assert (st[:, 0] - y.cpu().mean(1)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("M", [1, 5, 16])
+@pytest.mark.parametrize("N,K", [(264, 2048), (2048, 8192), (1002, 320), (6144, 2048)])
+def test_gemm_weight_streaming_decode_shapes(M, N, K):
+    """tile 16, M <= 16 (one token per sequence): one launch, weights streamed straight into MFMA fragments, the waves'
+    K slices summed in wave order.  fp32-accumulated products: tight tolerance, deterministic, ragged N and K tails."""
+    g = _g(7 * M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / 40).to(torch.bfloat16)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = _gemm_ref(a.float(), w.float(), bias, res, "gelu")
+    out = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, "gelu", out=out, tile=16)
+    assert rel_err(out, ref) < 3e-5
+    again = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), again, "gelu", out=again, tile=16)
+    assert torch.equal(out, again)
+    ob = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), act="gelu", tile=16, out_dtype=torch.bfloat16)   # bf16 store
+    refb = _gemm_ref(a.float(), w.float(), bias, None, "gelu")
+    assert ((ob.float().cpu() - refb).abs() <= refb.abs() * 2 ** -8 + 1e-6).all()
+    with pytest.raises(RuntimeError, match="tile 16"):
+        ops.gemm(torch.zeros(17, K, device=DEV, dtype=torch.bfloat16), w.to(DEV), tile=16)
+
+
+@pytest.mark.parametrize("M", [1, 7, 16])
+def test_gemm_weight_streaming_prologues(M):
+    """The three things the decode step folds into tile 16: LayerNorm of the raw rows (bit-identical operand to
+    kx_layernorm), folded-LN statistics taken from the producer's partials, per-16-column statistics out."""
+    N, K = 512, 2048
+    g = _g(100 + M)
+    x = torch.randn(M, K, generator=g) * 3 + 0.5
+    gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    w = (torch.randn(N, K, generator=g) / 40).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    # (a) LN prologue == separate kx_layernorm + tile 16, bit for bit
+    h = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out_dtype=torch.bfloat16)
+    two = ops.gemm(h, w.to(DEV), bias.to(DEV), act="gelu", tile=16)
+    one = ops.gemm(x.to(DEV), w.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5))
+    assert torch.equal(one, two)
+    # (b) producer statistics per 16 columns -> finalize == statistics of the stored values
+    part = torch.zeros(M, N // 16, 2, device=DEV)
+    y = ops.gemm(h, w.to(DEV), bias.to(DEV), act="gelu", tile=16, stats_out=part, stats_out_seg=16)
+    assert torch.equal(y, two)
+    st = ops.row_stats_finalize(part, 16).cpu()
+    assert (st[:, 0] - y.cpu().mean(1)).abs().max() < 2e-5
+    ref_rstd = 1 / torch.sqrt(y.cpu().var(1, unbiased=False) + 1e-5)
+    assert ((st[:, 1] - ref_rstd) / ref_rstd).abs().max() < 5e-5
+    # (c) consumer: partials in == finalize + row_stats
+    yb = y.to(torch.bfloat16)
+    w2 = (torch.randn(256, N, generator=g) / 20).to(torch.bfloat16).to(DEV)
+    cs = w2.float().sum(1)
+    res = torch.randn(M, 256, generator=g).to(DEV)
+    via_stats = ops.gemm(yb, w2, bias[:256].to(DEV).contiguous(), res.clone(), tile=16, row_stats=ops.row_stats_finalize(part, 16),
+                         colsum=cs)
+    via_part = ops.gemm(yb, w2, bias[:256].to(DEV).contiguous(), res.clone(), tile=16, stats_partials=part, stats_in_seg=16,
+                        colsum=cs)
+    assert torch.equal(via_stats, via_part)
+    lnref = torch.nn.functional.layer_norm(yb.float().cpu(), (N,), eps=1e-5)
+    ref = lnref @ w2.float().cpu().T + bias[:256] + res.cpu()
+    assert rel_err(via_part, ref) < 2e-3          # statistics are of the fp32 values, the operand is their bf16 rounding

@@ -14,7 +14,10 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--prefix", type=int, default=114)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--max-len", type=int, default=512)
+ap.add_argument("--tune", default="", help="A/B: kx_set_tuning key=value pairs, e.g. 1=64 (tile kernels instead of tile 16)")
 a = ap.parse_args()
+for kv in filter(None, a.tune.split(",")):
+    _hip.load().kx_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 dev = torch.device("cuda", 0)
 m = KosmosLanguage(vocab_size=32002, dim=2048, _seed=0).eval().to(dev)
 tok = torch.randint(0, 32002, (a.batch, a.prefix + a.steps + 8), generator=torch.Generator().manual_seed(0)).to(dev)
@@ -28,6 +31,7 @@ with torch.no_grad():
         t0 = time.perf_counter()
         for t in range(a.prefix + 4, a.prefix + 4 + a.steps):
             out = m(tok[:, : t + 1], incremental_state=state)
+        host_dt = (time.perf_counter() - t0) / a.steps      # time to ISSUE a step (host side), before the sync
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
     _hip.prof_enable(True)
@@ -43,7 +47,7 @@ agg = {}
 for kind, x, y, z, ms in recs:
     e = agg.setdefault(kind, [0, 0.0]); e[0] += 1; e[1] += ms
 print(json.dumps({"workload": f"KosmosLanguage decode step, B={a.batch}, context ~{int(tavg)} tokens, bf16",
-                  "ms_per_token_step": round(dt * 1e3, 3), "tokens_per_s": round(a.batch / dt, 1),
+                  "ms_per_token_step": round(dt * 1e3, 3), "host_issue_ms": round(host_dt * 1e3, 3), "tokens_per_s": round(a.batch / dt, 1),
                   "bytes_per_step_GB": round((wbytes + kvbytes) / 1e9, 3),
                   "achieved_GBs": round((wbytes + kvbytes) / dt / 1e9, 1),
                   "frac_of_8TBs": round((wbytes + kvbytes) / dt / 8e12, 4),
