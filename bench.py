@@ -57,6 +57,28 @@ def parse():
     return ap.parse_args()
 
 
+_PMC_KEYS = {"gemm_bf16_160x128": "gemm_kernel<bf16,160,128", "gemm_bf16_128x128": "gemm_kernel<bf16,128,128",
+             "gemm_bf16_64x64": "gemm_kernel<bf16,64,64", "gemm_bf16_256x128_phased": "gemm_kernel_p3<bf16",
+             "gemm_bf16_256x256_phased": "gemm_kernel_p5<bf16", "attn_bf16": "attn_bf16_v2_kernel"}
+
+
+def pmc_traffic(kernel, args):
+    """roofline.traffic: HBM-side bytes per launch of the dominant kernel.  PMC counters need rocprofv3 around the
+    process, so they are not collected here: the value comes from the committed PMC pass of this same command
+    (tools/pmc_round.sh -> tools/pmc_summary.py -> profiles/r01_j_pmc.json; FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950
+    correction) and is only reported for the default workload it was measured on; otherwise null."""
+    f = Path(__file__).resolve().parent / "profiles" / "r01_j_pmc.json"
+    key = _PMC_KEYS.get(kernel)
+    if not (f.exists() and key and args.batch == 32 and args.text_len == 50 and args.precision == "bf16"):
+        return {"traffic": None}
+    rows = [v for k, v in json.loads(f.read_text()).items() if k.startswith(key)]
+    n = sum(v["launches"] for v in rows)
+    if not n:
+        return {"traffic": None}
+    t = sum(v["launches"] * (v["fetch_bytes_x2"] + v["write_bytes"]) for v in rows) / n
+    return {"traffic": round(t), "traffic_unit": "bytes/launch", "traffic_source": "profiles/r01_j_pmc_summary.md"}
+
+
 def kernel_report(records, steps):
     """Aggregate kx_prof records (one per kernel launch) into per-kernel totals per step."""
     agg = {}
@@ -219,7 +241,7 @@ def main():
             peak = PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS
             ach = e["flops"] / (e["ms"] * 1e-3) / 1e12
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None,
+                        "frac": round(ach / peak, 4), **pmc_traffic(dom, args),
                         "launches_per_step": e["launches"], "avg_launch_ms": round(e["ms"] / e["launches"], 5),
                         "algorithmic_flops_per_step": e["flops"]}
         else:
