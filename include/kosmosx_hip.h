@@ -327,7 +327,8 @@ int kx_token_splice(const int64_t* texts, int64_t B, int64_t L, int64_t im_idx, 
 /* Kernel-variant selection for in-process A/B measurement (tools/gemm_bench.py, tools/ln_bench.py).  Defaults (all 0) are the
  * shipped configuration.  key 0: LayerNorm variant (0 wave-per-row, 1 workgroup-per-row);
  * key 1: GEMM tile override used by the stage-level entry points (0 auto, else as kx_gemm_args.tile);
- * key 2: bf16 attention variant (0 = v2: 32 queries/wave, transpose-read V, prefetched tiles; 1 = v1);
+ * key 2: attention variant (0 = bf16 v2: 32 queries/wave, transpose-read V, prefetched tiles / fp32 on the matrix
+ *        cores; 1 = the first versions: bf16 v1 / fp32 wave-per-query VALU kernel);
  * key 3: 256x256 GEMM start stagger per phase group in 10 ns ticks (0 = none; measured useless, kept for A/B);
  * key 4: GEMM store loop (0 auto, 1 rolled per-pass loads, 2 prefetching);
  * key 5: phased GEMM kernels skip the MFMAs of waves whose rows are all beyond M (0 on, 1 off);

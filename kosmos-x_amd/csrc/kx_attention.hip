@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
   }  // pass
 }
 
-// fp32 parity path: one wave per query, exact expf, scores in LDS.
+// fp32 parity path, first version (tuning key 2 = 1): one wave per query on the VALU, exact expf, scores in LDS.
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -436,6 +436,146 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
   }
 }
 
+// fp32 parity path on the matrix cores: flash-style tiles of 64 keys, exact-f32 MFMA (v_mfma_f32_16x16x4_f32) for
+// both products, operands never leave fp32 (P stays in the accumulator registers: the C layout of S^T — lane (g,i)
+// holds keys 4g..4g+3 of query i — is the B-operand layout of four k-slices, one per register), libm expf.
+// 16 queries per wave, 64 per workgroup.  k-slice map of S^T = K Q^T: slice g <-> head dims 16g + s (s = MFMA step),
+// so a lane's 16 operand values are contiguous: 4 x 16-byte reads of its key row / query row.
+// Replaces the wave-per-query VALU kernel below as the default (36 -> a few ms of a 150 ms fp32-mode step).
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const AttnParams p) {
+  constexpr int PITCH = 68;                                  // floats per LDS row (272 B: 16-byte aligned, bank-skewed)
+  __shared__ __attribute__((aligned(16))) float Ks[64 * PITCH];
+  __shared__ __attribute__((aligned(16))) float Vs[64 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int nqb = (p.Tq + 63) >> 6;
+  const int qblk0 = (CAUSAL ? nqb - 1 - (int)blockIdx.x : (int)blockIdx.x) * 64;   // causal: long blocks first
+  const int qw0 = qblk0 + wave * 16, qi = qw0 + li;
+  const bool wave_live = qw0 < p.Tq;
+  const float* qp = reinterpret_cast<const float*>(p.q) + (long long)b * p.qbs + (long long)h * 64;
+  const float* kp = reinterpret_cast<const float*>(p.k) + (long long)b * p.kbs + (long long)h * 64;
+  const float* vp = reinterpret_cast<const float*>(p.v) + (long long)b * p.kbs + (long long)h * 64;
+
+  float qf[16];
+  {
+    const float4* qr = reinterpret_cast<const float4*>(qp + (long long)min(qi, p.Tq - 1) * p.qrs + 16 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float4 v = qr[j]; qf[4 * j] = v.x; qf[4 * j + 1] = v.y; qf[4 * j + 2] = v.z; qf[4 * j + 3] = v.w; }
+  }
+  f32x4_t ot[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) ot[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  int ntiles = (p.Tk + 63) >> 6;
+  if (CAUSAL) ntiles = min(ntiles, (min(qblk0 + 63, p.Tq - 1) >> 6) + 1);
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * 64;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = tid + 256 * j, row = c >> 4, part = c & 15;
+      const int key = kv0 + row;
+      float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+      if (key < p.Tk) {
+        kk = *reinterpret_cast<const float4*>(kp + (long long)key * p.krs + part * 4);
+        vv = *reinterpret_cast<const float4*>(vp + (long long)key * p.krs + part * 4);
+      }
+      *reinterpret_cast<float4*>(&Ks[row * PITCH + part * 4]) = kk;
+      *reinterpret_cast<float4*>(&Vs[row * PITCH + part * 4]) = vv;
+    }
+    __syncthreads();
+    if (!wave_live || (CAUSAL && kv0 > min(qw0 + 15, p.Tq - 1))) continue;   // wave-uniform; barriers stay aligned
+
+    // ---- S^T = K Q^T ----
+    f32x4_t st[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      st[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const float4* kr = reinterpret_cast<const float4*>(&Ks[(kb * 16 + li) * PITCH + 16 * g]);
+      float kf[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float4 v = kr[j]; kf[4 * j] = v.x; kf[4 * j + 1] = v.y; kf[4 * j + 2] = v.z; kf[4 * j + 3] = v.w; }
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) st[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s2], qf[s2], st[kb], 0, 0, 0);
+    }
+    // ---- mask + online softmax (query = lane&15, its 64 keys: 16 registers x the 4 lane groups) ----
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kv0 + kb * 16 + 4 * g + r;
+        const bool ok = key < p.Tk && (!CAUSAL || key <= qi);
+        st[kb][r] = ok ? st[kb][r] : -INFINITY;
+        mloc = fmaxf(mloc, st[kb][r]);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = expf(m_run - m_safe);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[kb][r] = expf(st[kb][r] - m_safe);
+        psum += st[kb][r];
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ot[d] *= alpha;
+    // ---- O^T += V^T P^T : k-slice g of step (kb, r) <-> key kb*16 + 4g + r on both operands ----
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* vr = &Vs[(kb * 16 + 4 * g + r) * PITCH + li];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ot[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[d * 16], st[kb][r], ot[d], 0, 0, 0);
+      }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { ot[d][0] *= inv; ot[d][1] *= inv; ot[d][2] *= inv; ot[d][3] *= inv; }
+  if (p.stats_out) {
+    // (sum, M2 about the head mean) of this query's 64 output values: 16 in this lane, the rest in lanes +16/+32/+48
+    float sm = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) sm += (ot[d][0] + ot[d][1]) + (ot[d][2] + ot[d][3]);
+    sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+    const float mu = sm * (1.0f / 64.0f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float dv = ot[d][r] - mu; m2 += dv * dv; }
+    m2 += __shfl_xor(m2, 16, 64); m2 += __shfl_xor(m2, 32, 64);
+    if (g == 0 && qi < p.Tq)
+      *reinterpret_cast<float2*>(p.stats_out + 2 * (((long long)b * p.Tq + qi) * p.H + h)) = make_float2(sm, m2);
+  }
+  if (qi < p.Tq) {
+    const long long ooff = (long long)b * p.obs + (long long)qi * p.ors + (long long)h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (p.o_bf16) {
+        uint2 pk; pk.x = pack_bf16x2(ot[d][0], ot[d][1]); pk.y = pack_bf16x2(ot[d][2], ot[d][3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + ooff + d * 16) = pk;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + ooff + d * 16) =
+            make_float4(ot[d][0], ot[d][1], ot[d][2], ot[d][3]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
@@ -472,7 +612,11 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
       hipLaunchKernelGGL(attn_bf16_v2_kernel<true>, dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
     else
       hipLaunchKernelGGL(attn_bf16_v2_kernel<false>, dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
-  } else {
+  } else if (kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1) {
+    dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
+    if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_f32_mfma_kernel<true>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_f32_mfma_kernel<false>, grid, dim3(256), 0, s, p);
+  } else {                                                                      // wave-per-query VALU kernel, kept for A/B
     dim3 grid((unsigned)((a->Tq + 3) / 4), (unsigned)a->H, (unsigned)a->B);
     const size_t lds = 4 * (64 + (size_t)a->Tk) * sizeof(float);
     KX_REQUIRE(lds <= 64 * 1024, "kx_attention(f32): Tk=%lld exceeds the LDS score buffer", (long long)a->Tk);

@@ -235,6 +235,29 @@ def test_attention_f32(case):
     assert rel_err(out, ref) < 2e-5, case
 
 
+def test_attention_f32_rescale_long_causal_and_first_version():
+    """fp32 on the matrix cores: the online-softmax rescale (a late key dominates), a multi-tile causal case beyond
+    the first version's LDS score buffer class (T = 700), bf16 output, and agreement with the VALU kernel (key 2 = 1)."""
+    from kosmosx import _hip
+    g = _g(33)
+    B, H, T = 2, 3, 700
+    q = torch.randn(B, T, H, 64, generator=g) * 0.3
+    k = torch.randn(B, T, H, 64, generator=g)
+    v = torch.randn(B, T, H, 64, generator=g)
+    k[0, 150, 0] = q[0, 650, 0] * 40
+    ref = _attn_ref(q, k, v, True)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), True)
+    assert rel_err(out, ref) < 2e-5
+    ob = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), True, out_dtype=torch.bfloat16)
+    assert ((ob.float().cpu() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-5).all()
+    _hip.load().kx_set_tuning(2, 1)
+    try:
+        old = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), True)
+    finally:
+        _hip.load().kx_set_tuning(2, 0)
+    assert rel_err(out, old.cpu()) < 2e-5
+
+
 def test_attention_strided_qkv_views():
     """q/k/v as column slices of one fused [B*T, 3*D] buffer — the layout the stage kernels use."""
     B, T, H = 2, 50, 4
