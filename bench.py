@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--text-len", type=int, default=50)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--no-gather", action="store_true", help="skip the logits all-gather (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
@@ -285,7 +285,19 @@ def main():
             O.kosmos_forward(cpu_weights, ctok, cimg, ocfg)
             t_cpu += time.perf_counter() - t1
             n += 1
+        # parity of every precision mode against that same CPU forward, measured here and now (sample 0 of the shard):
+        # max|logit difference| / rms(logits), the figure the tests bound (1e-5 class fp32, 1e-3 bf16x3, 6e-2 bf16)
+        ref_logits = O.kosmos_forward(cpu_weights, ctok, cimg, ocfg)
+        parity = {}
+        for mode in ("bf16", "bf16x3", "fp32"):
+            model.precision = mode
+            with torch.no_grad():
+                got = model(tok[:1], img[:1]).float().cpu()
+            parity[mode] = float((got - ref_logits).abs().max() / ref_logits.pow(2).mean().sqrt())
+            model.invalidate_packed()                 # drop this mode's operand copies (3-10 GB each)
+        model.precision = args.precision
         cpu_baseline = {"value": round(n / t_cpu, 4), "unit": "samples/s", "cores": best_n,
+                        "parity_max_abs_over_rms": {k: float(f"{v:.3e}") for k, v in parity.items()},
                         "host_threads_available": ncpu, "kind": "port",
                         "sample": f"{n} x (1 image + {Tt} tokens) forward, fp32 torch CPU oracle (oracle/kosmos_oracle.py), "
                                   f"batch 1, {t_cpu:.1f} s"}

@@ -43,8 +43,13 @@ typedef enum {
   KX_ERR_UNSUPPORTED = 4
 } kx_status;
 
-typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1 } kx_precision;
-typedef enum { KX_F32 = 0, KX_BF16 = 1 } kx_dtype;
+/* KX_PREC_BF16X3 (stage-level entry points only): bf16 MFMA arithmetic on split operands.  Every GEMM operand value v
+ * travels as hi = bf16(v), lo = bf16(v - hi); an activation row is stored as [hi(K) | hi(K) | lo(K)] (dtype
+ * KX_BF16X3, 3K bf16 per row) and the matching weight row as [hi | lo | hi], so an ordinary bf16 GEMM over 3K
+ * accumulates a_hi*w_hi + a_hi*w_lo + a_lo*w_hi in fp32 — 16 mantissa bits per operand at 3x the bf16 MFMA work.
+ * Attention and the residual stream stay fp32.  ~1e-4 parity with the fp32 reference (bf16: ~4e-2, fp32: ~1e-5). */
+typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2 } kx_precision;
+typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2 } kx_dtype;
 typedef enum { KX_ACT_NONE = 0, KX_ACT_GELU = 1, KX_ACT_QUICK_GELU = 2 } kx_act;
 typedef enum { KX_ATTN_FULL = 0, KX_ATTN_CAUSAL = 1 } kx_attn_mask;
 

@@ -19,7 +19,7 @@ namespace {
 struct AttnParams {
   const char* q; long long qbs, qrs;          // element strides
   const char* k; const char* v; long long kbs, krs;
-  void* out; long long obs, ors; int o_bf16;
+  void* out; long long obs, ors; int o_bf16, o_x3;
   int B, H, Tq, Tk;
   float* stats_out;   // [B*Tq, H, 2] partial LayerNorm statistics of the output rows (folded inner_attn_ln), or null
 };
@@ -565,7 +565,15 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const AttnParams p) 
     const long long ooff = (long long)b * p.obs + (long long)qi * p.ors + (long long)h * 64 + 4 * g;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      if (p.o_bf16) {
+      if (p.o_x3) {                               // KX_BF16X3 row [hi(D) | hi(D) | lo(D)], D = H*64 (ors >= 3D)
+        uint2 hh, ll;
+        split_bf16x2(ot[d][0], ot[d][1], hh.x, ll.x); split_bf16x2(ot[d][2], ot[d][3], hh.y, ll.y);
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.out) + ooff + d * 16;
+        const long long D = (long long)p.H * 64;
+        *reinterpret_cast<uint2*>(c) = hh;
+        *reinterpret_cast<uint2*>(c + D) = hh;
+        *reinterpret_cast<uint2*>(c + 2 * D) = ll;
+      } else if (p.o_bf16) {
         uint2 pk; pk.x = pack_bf16x2(ot[d][0], ot[d][1]); pk.y = pack_bf16x2(ot[d][2], ot[d][3]);
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + ooff + d * 16) = pk;
       } else {
@@ -596,6 +604,10 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.q = (const char*)a->q; p.qbs = a->q_batch_stride; p.qrs = a->q_row_stride;
   p.k = (const char*)a->k; p.v = (const char*)a->v; p.kbs = a->kv_batch_stride; p.krs = a->kv_row_stride;
   p.out = a->out; p.obs = a->out_batch_stride; p.ors = a->out_row_stride; p.o_bf16 = a->odt == KX_BF16;
+  p.o_x3 = a->odt == KX_BF16X3;
+  KX_REQUIRE(!p.o_x3 || (a->prec == KX_PREC_F32 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1 &&
+                         a->out_row_stride >= 3 * a->H * 64),
+             "kx_attention: a KX_BF16X3 output is produced by the fp32 matrix-core kernel only (row stride >= 3*H*64)");
   p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
   p.stats_out = a->stats_out;
   KX_REQUIRE(!a->stats_out || !(a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1),

@@ -64,6 +64,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
+// bf16x3 operand format (KX_BF16X3): a value v travels as hi = bf16(v) and lo = bf16(v - hi) (16 mantissa bits together);
+// an operand row of K values is stored as [hi(K) | hi(K) | lo(K)] and the matching weight row as [hi | lo | hi], so
+// one ordinary bf16 GEMM over 3K accumulates  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi  in fp32 (everything but a_lo*w_lo).
+__device__ __forceinline__ void split_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
+  const bf16_t ah = f32_to_bf16(a), bh = f32_to_bf16(b);
+  hi = (unsigned)ah | ((unsigned)bh << 16);
+  lo = pack_bf16x2(a - bf16_to_f32(ah), b - bf16_to_f32(bh));
+}
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 // erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + 5 fma instead of libm erff's two

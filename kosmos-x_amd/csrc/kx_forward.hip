@@ -102,8 +102,14 @@ struct Carver {
     return p;
   }
 };
-inline size_t esz(int prec) { return prec == KX_PREC_BF16 ? 2 : 4; }
-inline int cdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : KX_F32; }
+// GEMM-operand activations: bf16 (2 B), fp32 (4 B) or bf16x3 (3 x 2 B per value: [hi | hi | lo] rows, kx_precision doc)
+inline size_t esz(int prec) { return prec == KX_PREC_BF16 ? 2 : prec == KX_PREC_BF16X3 ? 6 : 4; }
+inline int cdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : prec == KX_PREC_BF16X3 ? KX_BF16X3 : KX_F32; }
+// q/k/v (attention inputs) and the attention arithmetic: bf16x3 keeps them in fp32 on the exact-f32 matrix instruction
+inline size_t qes(int prec) { return prec == KX_PREC_BF16 ? 2 : 4; }
+inline int qdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : KX_F32; }
+inline int aprec(int prec) { return prec == KX_PREC_BF16 ? KX_PREC_BF16 : KX_PREC_F32; }
+inline int64_t kmul(int prec) { return prec == KX_PREC_BF16X3 ? 3 : 1; }
 
 int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t ldc, int cdtype, int64_t M, int64_t N,
          const float* bias, const float* residual, int act, float qscale, int64_t qcols, int prec, hipStream_t s,
@@ -112,11 +118,13 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
          const float* colsum = nullptr, float* stats_out = nullptr) {
   kx_gemm_args g;
   memset(&g, 0, sizeof(g));
-  g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = ldc; g.cdt = cdtype;
-  g.bias = bias; g.residual = residual; g.ldr = ldc; g.M = M; g.N = N; g.K = K;
+  // bf16x3: the same bf16 kernels over the 3K-wide split operands ([hi|hi|lo] activations x [hi|lo|hi] weights)
+  const int64_t km = kmul(prec);
+  g.A = A; g.lda = lda * km; g.W = W; g.ldw = K * km; g.C = C; g.ldc = cdtype == KX_BF16X3 ? 3 * ldc : ldc; g.cdt = cdtype;
+  g.bias = bias; g.residual = residual; g.ldr = ldc; g.M = M; g.N = N; g.K = K * km;
   g.act = act; g.qscale = qscale; g.qcols = qcols;
   g.xq_cs = xq_cs; g.xq_ss = xq_ss; g.xk_cs = xk_cs; g.xk_ss = xk_ss; g.xpos_T = xT; g.xpos_dim = xdim;
-  g.prec = prec; g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
+  g.prec = km == 3 ? KX_PREC_BF16 : prec; g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
   g.row_stats = row_stats; g.colsum = colsum; g.stats_out = stats_out;
   g.splitk_ws = g_splitk_ws; g.splitk_ws_bytes = g_splitk_ws_bytes; g.splitk = 0;
   return kx_gemm(&g, (void*)s);
@@ -162,7 +170,7 @@ VitBufs vit_plan(const kx_vit_weights* w, int64_t B, int prec, char* base) {
   v.patch_out = (float*)c.take((size_t)MP * w->dim * 4);
   v.xpre = (float*)c.take((size_t)M * w->dim * 4);
   v.h = c.take((size_t)M * w->dim * es);
-  v.qkv = c.take((size_t)M * 3 * w->dim * es);
+  v.qkv = c.take((size_t)M * 3 * w->dim * qes(prec));
   v.att = c.take((size_t)M * w->dim * es);
   v.ff = c.take((size_t)M * w->ffn * es);
   v.splitk = c.take(KX_SPLITK_WS);
@@ -180,8 +188,8 @@ PerBufs per_plan(const kx_perceiver_weights* w, int64_t B, int64_t m, int prec, 
   p.lat = (float*)c.take((size_t)MQ * w->dim * 4);
   p.kvin = c.take((size_t)MK * w->dim * es);
   p.lnq = c.take((size_t)MQ * w->dim * es);
-  p.qb = c.take((size_t)MQ * inner * es);
-  p.kvb = c.take((size_t)MK * 2 * inner * es);
+  p.qb = c.take((size_t)MQ * inner * qes(prec));
+  p.kvb = c.take((size_t)MK * 2 * inner * qes(prec));
   p.att = c.take((size_t)MQ * inner * es);
   p.ffh = c.take((size_t)MQ * w->dim * w->ff_mult * es);
   p.fin = c.take((size_t)MQ * w->dim * es);
@@ -198,7 +206,7 @@ DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, ch
   Carver c{base, 0};
   DecBufs d;
   d.h = c.take((size_t)M * w->dim * es);
-  d.qkv = c.take((size_t)M * 3 * w->dim * es);
+  d.qkv = c.take((size_t)M * 3 * w->dim * qes(prec));
   d.att = c.take((size_t)M * w->dim * es);          // attention output, un-normalised (inner_attn_ln is folded)
   d.g = c.take((size_t)M * w->ffn * es);            // gelu(fc1), un-normalised (ffn_layernorm is folded)
   // per-segment statistics: 64 columns per segment from the tile kernels and attention (heads), 16 from the
@@ -243,14 +251,14 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
   for (int i = 0; i < w->layers; ++i) {
     const kx_vit_layer& L = w->layer[i];
     KX_TRY(ln(out, nullptr, L.ln1_g, L.ln1_b, v.h, ct, M, D, w->eps, s));
-    KX_TRY(gemm(v.h, D, L.wqkv, D, v.qkv, 3 * D, ct, M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s));
+    KX_TRY(gemm(v.h, D, L.wqkv, D, v.qkv, 3 * D, qdt(prec), M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s));
     kx_attn_args a;
     memset(&a, 0, sizeof(a));
     a.q = v.qkv; a.q_batch_stride = S * 3 * D; a.q_row_stride = 3 * D;
-    a.k = (char*)v.qkv + D * es; a.v = (char*)v.qkv + 2 * D * es;
+    a.k = (char*)v.qkv + D * qes(prec); a.v = (char*)v.qkv + 2 * D * qes(prec);
     a.kv_batch_stride = S * 3 * D; a.kv_row_stride = 3 * D;
-    a.out = v.att; a.out_batch_stride = S * D; a.out_row_stride = D; a.odt = ct;
-    a.B = B; a.H = w->heads; a.Tq = S; a.Tk = S; a.mask = KX_ATTN_FULL; a.prec = prec;
+    a.out = v.att; a.out_batch_stride = S * D * kmul(prec); a.out_row_stride = D * kmul(prec); a.odt = ct;
+    a.B = B; a.H = w->heads; a.Tq = S; a.Tk = S; a.mask = KX_ATTN_FULL; a.prec = aprec(prec);
     KX_TRY(kx_attention(&a, stream));
     KX_TRY(gemm(v.att, D, L.wo, D, out, D, KX_F32, M, D, L.bo, out, 0, 1.f, 0, prec, s));
     KX_TRY(ln(out, nullptr, L.ln2_g, L.ln2_b, v.h, ct, M, D, w->eps, s));
@@ -289,15 +297,15 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
     KX_TRY(ln(x, w->media_pos, L.nm_g, L.nm_b, p.kvin, ct, B * m, D, w->eps, s, m, m + n, 0));
     KX_TRY(ln(p.lat, nullptr, L.nl_g, L.nl_b, p.kvin, ct, MQ, D, w->eps, s, n, m + n, m));
     KX_TRY(ln(p.lat, nullptr, L.nl_g, L.nl_b, p.lnq, ct, MQ, D, w->eps, s));
-    KX_TRY(gemm(p.lnq, D, L.wq, D, p.qb, inner, ct, MQ, inner, nullptr, nullptr, 0, 0.125f, inner, prec, s));
-    KX_TRY(gemm(p.kvin, D, L.wkv, D, p.kvb, 2 * inner, ct, MK, 2 * inner, nullptr, nullptr, 0, 1.f, 0, prec, s));
+    KX_TRY(gemm(p.lnq, D, L.wq, D, p.qb, inner, qdt(prec), MQ, inner, nullptr, nullptr, 0, 0.125f, inner, prec, s));
+    KX_TRY(gemm(p.kvin, D, L.wkv, D, p.kvb, 2 * inner, qdt(prec), MK, 2 * inner, nullptr, nullptr, 0, 1.f, 0, prec, s));
     kx_attn_args a;
     memset(&a, 0, sizeof(a));
     a.q = p.qb; a.q_batch_stride = n * inner; a.q_row_stride = inner;
-    a.k = p.kvb; a.v = (char*)p.kvb + inner * es;
+    a.k = p.kvb; a.v = (char*)p.kvb + inner * qes(prec);
     a.kv_batch_stride = (m + n) * 2 * inner; a.kv_row_stride = 2 * inner;
-    a.out = p.att; a.out_batch_stride = n * inner; a.out_row_stride = inner; a.odt = ct;
-    a.B = B; a.H = w->heads; a.Tq = n; a.Tk = m + n; a.mask = KX_ATTN_FULL; a.prec = prec;
+    a.out = p.att; a.out_batch_stride = n * inner * kmul(prec); a.out_row_stride = inner * kmul(prec); a.odt = ct;
+    a.B = B; a.H = w->heads; a.Tq = n; a.Tk = m + n; a.mask = KX_ATTN_FULL; a.prec = aprec(prec);
     KX_TRY(kx_attention(&a, stream));
     KX_TRY(gemm(p.att, inner, L.wout, inner, p.lat, D, KX_F32, MQ, D, nullptr, p.lat, 0, 1.f, 0, prec, s));
     KX_TRY(ln(p.lat, nullptr, L.ff_g, L.ff_b, p.lnq, ct, MQ, D, w->eps, s));
@@ -323,6 +331,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
                                 void* vcache, int64_t Tmax) {
   KX_REQUIRE(w && x && logits && workspace, "kx_decoder_forward: null pointer");
   KX_REQUIRE(!kcache == !vcache, "kx_decoder_prefill: kcache and vcache must be given together");
+  KX_REQUIRE(!kcache || prec != KX_PREC_BF16X3, "kx_decoder_prefill: incremental decoding is offered in bf16 and fp32");
   KX_REQUIRE(!kcache || T <= Tmax, "kx_decoder_prefill: %lld tokens do not fit a %lld-row cache", (long long)T,
              (long long)Tmax);
   KX_REQUIRE(B > 0 && T > 0, "kx_decoder_forward: empty input");
@@ -344,7 +353,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     const kx_decoder_layer& L = w->layer[i];
     // x = x + out_proj(inner_attn_ln(attn(xpos(q), xpos(k), v)))   on self_attn_layer_norm(x)
     KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
-    KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
+    KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, qdt(prec), M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
                 w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? T : 0, w->xpos ? D : 0));
     if (kcache) {   // incremental decoding: keep this layer's (XPos-rotated) keys and values
       const size_t layer_bytes = (size_t)B * Tmax * D * es;
@@ -354,10 +363,10 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     kx_attn_args a;
     memset(&a, 0, sizeof(a));
     a.q = d.qkv; a.q_batch_stride = T * 3 * D; a.q_row_stride = 3 * D;
-    a.k = (char*)d.qkv + D * es; a.v = (char*)d.qkv + 2 * D * es;
+    a.k = (char*)d.qkv + D * qes(prec); a.v = (char*)d.qkv + 2 * D * qes(prec);
     a.kv_batch_stride = T * 3 * D; a.kv_row_stride = 3 * D;
-    a.B = B; a.H = w->heads; a.Tq = T; a.Tk = T; a.mask = KX_ATTN_CAUSAL; a.prec = prec;
-    a.out = d.att; a.out_batch_stride = T * D; a.out_row_stride = D; a.odt = ct;
+    a.B = B; a.H = w->heads; a.Tq = T; a.Tk = T; a.mask = KX_ATTN_CAUSAL; a.prec = aprec(prec);
+    a.out = d.att; a.out_batch_stride = T * D * kmul(prec); a.out_row_stride = D * kmul(prec); a.odt = ct;
     if (w->subln) {
       // inner_attn_ln folded into out_proj: the attention kernel emits per-(row, head) partial statistics, the GEMM
       // multiplies the un-normalised output by γ⊙Wo and applies rstd·(acc − mean·colsum) + (β·Woᵀ + bo) in its epilogue
@@ -410,6 +419,7 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
                                       void* vcache, int64_t Tmax, void* logits, int32_t ldt, void* workspace,
                                       size_t workspace_bytes, int32_t prec, void* stream) {
   KX_REQUIRE(w && x && logits && workspace && kcache && vcache, "kx_decoder_decode_step: null pointer");
+  KX_REQUIRE(prec != KX_PREC_BF16X3, "kx_decoder_decode_step: incremental decoding is offered in bf16 and fp32");
   KX_REQUIRE(B > 0 && t >= 0 && t < Tmax, "kx_decoder_decode_step: position %lld outside the cache of %lld rows",
              (long long)t, (long long)Tmax);
   KX_REQUIRE(w->dim == w->heads * 64, "kx_decoder_decode_step: head_dim must be 64");

@@ -22,6 +22,7 @@ struct GemmParams {
   const char* A; const char* W;
   long long lda_b, ldw_b;  // row pitch in BYTES
   void* C; long long ldc; int c_bf16;
+  int c_x3;   // KX_BF16X3 output: [hi(N) | hi(N) | lo(N)] per row (c_bf16 is set too)
   const float* bias; const float* residual; long long ldr;
   int M, N, K;
   int act; float qscale; int qcols;
@@ -122,7 +123,14 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   epilogue_compute4<ACT>(p, m, n, acc, x);
   const bool full = (n + 3 < p.N);
   const long long off = (long long)m * p.ldc + n;
-  if (p.c_bf16) {
+  if (p.c_x3) {                                   // N % 8 == 0 and aligned rows are enforced on the host
+    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
+    uint2 h, l;
+    split_bf16x2(x[0], x[1], h.x, l.x); split_bf16x2(x[2], x[3], h.y, l.y);
+    *reinterpret_cast<uint2*>(c) = h;
+    *reinterpret_cast<uint2*>(c + p.N) = h;
+    *reinterpret_cast<uint2*>(c + 2 * (long long)p.N) = l;
+  } else if (p.c_bf16) {
     bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
     if (full && p.vec_ok) {
       uint2 o; o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]);
@@ -149,10 +157,20 @@ __device__ __forceinline__ void epilogue8_bf16(const GemmParams& p, int m, int n
     float x[4], y[4];
     epilogue_compute4<ACT>(p, m, n, lo, x);
     epilogue_compute4<ACT>(p, m, n + 4, hi, y);
-    uint4 o;
-    o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]);
-    o.z = pack_bf16x2(y[0], y[1]); o.w = pack_bf16x2(y[2], y[3]);
-    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n) = o;
+    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n;
+    if (p.c_x3) {
+      uint4 h, l;
+      split_bf16x2(x[0], x[1], h.x, l.x); split_bf16x2(x[2], x[3], h.y, l.y);
+      split_bf16x2(y[0], y[1], h.z, l.z); split_bf16x2(y[2], y[3], h.w, l.w);
+      *reinterpret_cast<uint4*>(c) = h;
+      *reinterpret_cast<uint4*>(c + p.N) = h;
+      *reinterpret_cast<uint4*>(c + 2 * (long long)p.N) = l;
+    } else {
+      uint4 o;
+      o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]);
+      o.z = pack_bf16x2(y[0], y[1]); o.w = pack_bf16x2(y[2], y[3]);
+      *reinterpret_cast<uint4*>(c) = o;
+    }
   } else {
     epilogue4<ACT>(p, m, n, lo);
     epilogue4<ACT>(p, m, n + 4, hi);
@@ -237,10 +255,20 @@ __device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float
       }
       if (m < p.M) {
         if constexpr (CPL == 8) {
-          uint4 o;
-          o.x = pack_bf16x2(x[0][0], x[0][1]); o.y = pack_bf16x2(x[0][2], x[0][3]);
-          o.z = pack_bf16x2(x[1][0], x[1][1]); o.w = pack_bf16x2(x[1][2], x[1][3]);
-          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n) = o;
+          bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n;
+          if (p.c_x3) {
+            uint4 h, l;
+            split_bf16x2(x[0][0], x[0][1], h.x, l.x); split_bf16x2(x[0][2], x[0][3], h.y, l.y);
+            split_bf16x2(x[1][0], x[1][1], h.z, l.z); split_bf16x2(x[1][2], x[1][3], h.w, l.w);
+            *reinterpret_cast<uint4*>(c) = h;
+            *reinterpret_cast<uint4*>(c + p.N) = h;
+            *reinterpret_cast<uint4*>(c + 2 * (long long)p.N) = l;
+          } else {
+            uint4 o;
+            o.x = pack_bf16x2(x[0][0], x[0][1]); o.y = pack_bf16x2(x[0][2], x[0][3]);
+            o.z = pack_bf16x2(x[1][0], x[1][1]); o.w = pack_bf16x2(x[1][2], x[1][3]);
+            *reinterpret_cast<uint4*>(c) = o;
+          }
         } else {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long long)m * p.ldc + n) =
               make_float4(x[0][0], x[0][1], x[0][2], x[0][3]);
@@ -1162,7 +1190,10 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   GemmParams p;
   p.A = (const char*)a->A; p.W = (const char*)a->W;
   p.lda_b = a->lda * es; p.ldw_b = a->ldw * es;
-  p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->cdt == KX_BF16;
+  p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->cdt == KX_BF16 || a->cdt == KX_BF16X3; p.c_x3 = a->cdt == KX_BF16X3;
+  KX_REQUIRE(a->cdt != KX_BF16X3 || (a->N % 8 == 0 && a->ldc >= 3 * a->N && a->ldc % 8 == 0 && a->tile != 16 &&
+                                      ((uintptr_t)a->C & 15) == 0),
+             "kx_gemm: a KX_BF16X3 output needs N %% 8 == 0, ldc >= 3N, ldc %% 8 == 0 (and is not offered by tile 16)");
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
   p.act = (a->act == KX_ACT_GELU && a->prec == KX_PREC_BF16) ? KX_ACT_GELU_FAST : a->act;

@@ -21,7 +21,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // Variant 1 (A/B reference): one workgroup (256 threads) per row; a thread owns up to 8 float4 (cols <= 8192).
 // Two-pass statistics on the register-resident row: mean, then centred variance (what
 // torch.nn.functional.layer_norm computes), eps inside the rsqrt.
-template <bool OUT_BF16>
+template <int OUT>   // kx_dtype of y
 __global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __restrict__ x, const float* __restrict__ pre_add,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ y,
@@ -69,7 +69,14 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __res
       o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
       o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
       o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
-      if (OUT_BF16) {
+      if (OUT == KX_BF16X3) {                      // [hi(cols) | hi(cols) | lo(cols)] per row, see split_bf16x2
+        uint2 hh, ll;
+        split_bf16x2(o.x, o.y, hh.x, ll.x); split_bf16x2(o.z, o.w, hh.y, ll.y);
+        bf16_t* yr = reinterpret_cast<bf16_t*>(y) + orow * 3ll * cols;
+        reinterpret_cast<uint2*>(yr)[c] = hh;
+        reinterpret_cast<uint2*>(yr + cols)[c] = hh;
+        reinterpret_cast<uint2*>(yr + 2ll * cols)[c] = ll;
+      } else if (OUT == KX_BF16) {
         uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
         reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + orow * (long long)cols)[c] = pk;
       } else {
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __res
 // Variant 0: one WAVE per row (4 rows per 256-thread workgroup): the row lives in registers (<= 32 float4 per lane for
 // cols <= 8192), statistics are pure wave-64 shuffles — no LDS, no barrier.  Two-pass statistics on the
 // register-resident row: mean, then centred variance (what torch.nn.functional.layer_norm computes).
-template <bool OUT_BF16, int NV>  // NV = float4 per lane (cols <= 256*NV)
+template <int OUT, int NV>  // OUT = kx_dtype of y, NV = float4 per lane (cols <= 256*NV)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ pre_add,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ y,
@@ -131,7 +138,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
       o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
       o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
-      if (OUT_BF16) {
+      if (OUT == KX_BF16X3) {                      // [hi(cols) | hi(cols) | lo(cols)] per row, see split_bf16x2
+        uint2 hh, ll;
+        split_bf16x2(o.x, o.y, hh.x, ll.x); split_bf16x2(o.z, o.w, hh.y, ll.y);
+        bf16_t* yr = reinterpret_cast<bf16_t*>(y) + orow * 3ll * cols;
+        reinterpret_cast<uint2*>(yr)[c] = hh;
+        reinterpret_cast<uint2*>(yr + cols)[c] = hh;
+        reinterpret_cast<uint2*>(yr + 2ll * cols)[c] = ll;
+      } else if (OUT == KX_BF16) {
         uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
         reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + orow * (long long)cols)[c] = pk;
       } else {
@@ -141,19 +155,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
-template <bool OUT_BF16, int NV>
+template <int OUT, int NV>
 void launch_ln(const float* x, const float* pre_add, const float* gamma, const float* beta, void* y, int64_t rows,
                int64_t cols, float eps, int64_t rpg, int64_t ogs, int64_t oro, hipStream_t s) {
-  hipLaunchKernelGGL((layernorm_kernel<OUT_BF16, NV>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, pre_add,
+  hipLaunchKernelGGL((layernorm_kernel<OUT, NV>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, pre_add,
                      gamma, beta, y, (long long)rows, (int)cols, eps, (long long)rpg, (long long)ogs, (long long)oro);
 }
-template <bool OUT_BF16>
+template <int OUT>
 void dispatch_ln(const float* x, const float* pre_add, const float* gamma, const float* beta, void* y, int64_t rows,
                  int64_t cols, float eps, int64_t rpg, int64_t ogs, int64_t oro, hipStream_t s) {
-  if (cols <= 1024) launch_ln<OUT_BF16, 4>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
-  else if (cols <= 2048) launch_ln<OUT_BF16, 8>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
-  else if (cols <= 4096) launch_ln<OUT_BF16, 16>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
-  else launch_ln<OUT_BF16, 32>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
+  if (cols <= 1024) launch_ln<OUT, 4>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
+  else if (cols <= 2048) launch_ln<OUT, 8>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
+  else if (cols <= 4096) launch_ln<OUT, 16>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
+  else launch_ln<OUT, 32>(x, pre_add, gamma, beta, y, rows, cols, eps, rpg, ogs, oro, s);
 }
 
 // Decoder input assembly, one workgroup per output row (b, t), s = splice_at (2 on the Kosmos path):
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const long long* __re
 // pixels[b][c][py*ps+ky][px*ps+kx]; columns >= 3*ps*ps are zero padding up to kpad.
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ pixels, T* __restrict__ patches,
-                                                       int image, int ps, int kpad) {
+                                                       int image, int ps, int kpad, int x3) {
   const int G = image / ps;
   const long long prow = blockIdx.x;  // b*G*G + py*G + px
   const int b = (int)(prow / (G * G)), pp = (int)(prow % (G * G));
@@ -213,8 +227,17 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
       const int c = k / (ps * ps), r = k % (ps * ps), ky = r / ps, kx = r % ps;
       v = pixels[(((long long)b * 3 + c) * image + (py * ps + ky)) * image + (px * ps + kx)];
     }
-    if constexpr (sizeof(T) == 2) patches[prow * kpad + k] = f32_to_bf16(v);
-    else patches[prow * kpad + k] = v;
+    if constexpr (sizeof(T) == 2) {
+      if (x3) {                                   // KX_BF16X3 row: [hi(kpad) | hi(kpad) | lo(kpad)]
+        const bf16_t hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
+        T* pr = patches + prow * 3ll * kpad;
+        pr[k] = hi; pr[kpad + k] = hi; pr[2 * kpad + k] = lo;
+      } else {
+        patches[prow * kpad + k] = f32_to_bf16(v);
+      }
+    } else {
+      patches[prow * kpad + k] = v;
+    }
   }
 }
 
@@ -285,18 +308,19 @@ extern "C" int kx_layernorm(const float* x, const float* pre_add, const float* g
   // wins on the 8192-wide ffn_layernorm rows (4.6 vs 3.2 TB/s: 204 VGPRs/lane cap the wave variant at 2 waves/SIMD)
   const int variant = kx_tuning_get(KX_TUNE_LN_VARIANT);
   if (variant == 1 || (variant == 0 && cols > 2048)) {
-    if (ydt == KX_BF16)
-      hipLaunchKernelGGL(layernorm_block_kernel<true>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta,
-                         y, (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride,
-                         (long long)out_row_offset);
-    else
-      hipLaunchKernelGGL(layernorm_block_kernel<false>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta,
-                         y, (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride,
-                         (long long)out_row_offset);
-  } else if (ydt == KX_BF16)
-    dispatch_ln<true>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
+#define KX_LN_BLOCK(OUT)                                                                                             \
+  hipLaunchKernelGGL(layernorm_block_kernel<OUT>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta, y,  \
+                     (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride, (long long)out_row_offset)
+    if (ydt == KX_BF16X3) KX_LN_BLOCK(KX_BF16X3);
+    else if (ydt == KX_BF16) KX_LN_BLOCK(KX_BF16);
+    else KX_LN_BLOCK(KX_F32);
+#undef KX_LN_BLOCK
+  } else if (ydt == KX_BF16X3)
+    dispatch_ln<KX_BF16X3>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
+  else if (ydt == KX_BF16)
+    dispatch_ln<KX_BF16>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
   else
-    dispatch_ln<false>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
+    dispatch_ln<KX_F32>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
   KX_CHECK_LAUNCH("kx_layernorm");
   return KX_OK;
 }
@@ -351,12 +375,12 @@ int kx_launch_patchify(const float* pixels, void* patches, int64_t B, int image,
   const int G = image / patch;
   const unsigned rows = (unsigned)(B * G * G);
   KxProfScope prof(KX_K_MISC, rows, kpad, 1, s);
-  if (prec == KX_PREC_BF16)
+  if (prec == KX_PREC_BF16 || prec == KX_PREC_BF16X3)
     hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, pixels, (bf16_t*)patches, image, patch,
-                       kpad);
+                       kpad, prec == KX_PREC_BF16X3 ? 1 : 0);
   else
     hipLaunchKernelGGL(patchify_kernel<float>, dim3(rows), dim3(256), 0, s, pixels, (float*)patches, image, patch,
-                       kpad);
+                       kpad, 0);
   KX_CHECK_LAUNCH("patchify");
   return KX_OK;
 }

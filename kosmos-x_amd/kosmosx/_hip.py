@@ -14,12 +14,12 @@ from pathlib import Path
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
 
-KX_PREC_BF16, KX_PREC_F32 = 0, 1
-KX_F32, KX_BF16 = 0, 1
+KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3 = 0, 1, 2
+KX_F32, KX_BF16, KX_BF16X3 = 0, 1, 2
 KX_ACT_NONE, KX_ACT_GELU, KX_ACT_QUICK_GELU = 0, 1, 2
 KX_ATTN_FULL, KX_ATTN_CAUSAL = 0, 1
 ACTS = {"none": KX_ACT_NONE, "gelu": KX_ACT_GELU, "quick_gelu": KX_ACT_QUICK_GELU}
-PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32}
+PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32, "bf16x3": KX_PREC_BF16X3}
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 

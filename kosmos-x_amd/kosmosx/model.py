@@ -41,7 +41,28 @@ def _stream() -> int:
 
 
 def _prec_dtype(prec: str):
-    return torch.bfloat16 if prec == "bf16" else torch.float32
+    return torch.float32 if prec == "fp32" else torch.bfloat16
+
+
+def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
+    """A weight matrix [N,K] as the GEMM operand of `prec`: bf16 / fp32 cast, or for "bf16x3" the split rows
+    [hi(K) | lo(K) | hi(K)] in bf16 (hi = bf16(w), lo = bf16(w - hi)) that pair with [hi | hi | lo] activation rows —
+    see kx_precision in include/kosmosx_hip.h."""
+    t = t.detach()
+    if prec != "bf16x3":
+        return t.to(_prec_dtype(prec)).contiguous()
+    f = t.float()
+    hi = f.to(torch.bfloat16)
+    lo = (f - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo, hi], dim=1).contiguous()
+
+
+def _operand_colsum(wp: torch.Tensor, prec: str) -> torch.Tensor:
+    """Sum over k of the values a packed operand row represents (what the folded-LayerNorm epilogue subtracts)."""
+    if prec != "bf16x3":
+        return wp.float().sum(1)
+    K = wp.shape[1] // 3
+    return (wp[:, :K].float() + wp[:, K:2 * K].float()).sum(1)
 
 
 def _default_precision() -> str:
@@ -162,7 +183,7 @@ class CLIPVisionTower(_PackedMixin, nn.Module):
         keep = []
 
         def op(t):  # GEMM operand in the compute dtype
-            t = t.detach().to(dt).contiguous(); keep.append(t); return t.data_ptr()
+            t = _operand(t, prec); keep.append(t); return t.data_ptr()
 
         def v(t):   # fp32 vector / table
             t = _f32(t); keep.append(t); return t.data_ptr()
@@ -267,7 +288,7 @@ class PerceiverResampler(_PackedMixin, nn.Module):
         keep = []
 
         def op(t):
-            t = t.detach().to(dt).contiguous(); keep.append(t); return t.data_ptr()
+            t = _operand(t, prec); keep.append(t); return t.data_ptr()
 
         def v(t):
             t = _f32(t); keep.append(t); return t.data_ptr()
@@ -465,7 +486,7 @@ class Decoder(_PackedMixin, nn.Module):
         keep = []
 
         def op(t):
-            t = t.detach().to(dt).contiguous(); keep.append(t); return t.data_ptr()
+            t = _operand(t, prec); keep.append(t); return t.data_ptr()
 
         def v(t):
             t = _f32(t); keep.append(t); return t.data_ptr()
@@ -474,9 +495,9 @@ class Decoder(_PackedMixin, nn.Module):
             """Fold a sub-LayerNorm into the Linear that consumes it (see kx_decoder_layer in the header):
             W' = γ ⊙ W cast to the operand dtype, b' = W·β + b, colsum = Σ_k W'[n,k] of the cast values."""
             wf, g_, b_ = lin.weight.detach().float(), ln.weight.detach().float(), ln.bias.detach().float()
-            wp = (wf * g_[None, :]).to(dt).contiguous()
+            wp = _operand(wf * g_[None, :], prec)
             keep.append(wp)
-            return wp.data_ptr(), v(wf @ b_ + lin.bias.detach().float()), v(wp.float().sum(1))
+            return wp.data_ptr(), v(wf @ b_ + lin.bias.detach().float()), v(_operand_colsum(wp, prec))
 
         layers = (H.DecoderLayer * self.num_layers)()
         for i, L in enumerate(self.layers):

@@ -31,13 +31,14 @@ def _cdt(dtype) -> int:
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, out=None,
-              rows_per_group=None, out_group_stride=0, out_row_offset=0):
-    """x [rows, cols] fp32 -> LN(x (+pre_add)) * gamma + beta."""
+              rows_per_group=None, out_group_stride=0, out_row_offset=0, x3=False):
+    """x [rows, cols] fp32 -> LN(x (+pre_add)) * gamma + beta.  x3: KX_BF16X3 rows [hi | hi | lo] ([rows, 3*cols] bf16)."""
     _need_cuda(x, gamma, beta, pre_add, out)
     rows, cols = x.shape
     if out is None:
-        out = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
-    rc = H.load().kx_layernorm(H.ptr(x), H.ptr(pre_add), H.ptr(gamma), H.ptr(beta), H.ptr(out), _cdt(out.dtype),
+        out = torch.empty((rows, 3 * cols if x3 else cols), dtype=torch.bfloat16 if x3 else out_dtype, device=x.device)
+    rc = H.load().kx_layernorm(H.ptr(x), H.ptr(pre_add), H.ptr(gamma), H.ptr(beta), H.ptr(out),
+                               H.KX_BF16X3 if x3 else _cdt(out.dtype),
                                rows, cols, float(eps), rows_per_group or rows, out_group_stride, out_row_offset,
                                _stream())
     H.check(rc, "kx_layernorm")
@@ -46,7 +47,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, o
 
 def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
          xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None, splitk_ws=None,
-         splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0):
+         splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0, out_x3=False):
     """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32].
     tile=16 (weight streaming, bf16, M <= 16) extras: ln = (gamma, beta, eps) with `a` the raw fp32 rows;
     stats_partials [M,nseg,2] instead of row_stats; stats_out_seg=16."""
@@ -57,10 +58,10 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
     if a.dtype != w.dtype and ln is None:
         raise TypeError("gemm operands must share a dtype")
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+        out = torch.empty((M, 3 * N if out_x3 else N), dtype=torch.bfloat16 if out_x3 else out_dtype, device=a.device)
     g = H.GemmArgs()
     g.A, g.lda, g.W, g.ldw = H.ptr(a), a.stride(0), H.ptr(w), w.stride(0)
-    g.C, g.ldc, g.cdt = H.ptr(out), out.stride(0), _cdt(out.dtype)
+    g.C, g.ldc, g.cdt = H.ptr(out), out.stride(0), (H.KX_BF16X3 if out_x3 else _cdt(out.dtype))
     g.bias, g.residual, g.ldr = H.ptr(bias), H.ptr(residual), (residual.stride(0) if residual is not None else 0)
     g.M, g.N, g.K = M, N, K
     g.act, g.qscale, g.qcols = H.ACTS[act], float(qscale), qcols
@@ -91,19 +92,22 @@ def row_stats_finalize(partials, seg_size, eps=1e-5):
     return out
 
 
-def attention(q, k, v, causal=False, out_dtype=None, stats_out=None):
-    """q [B,Tq,H,64], k/v [B,Tk,H,64] (any row/batch strides, last two dims contiguous) -> [B,Tq,H*64]."""
+def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=False):
+    """q [B,Tq,H,64], k/v [B,Tk,H,64] (any row/batch strides, last two dims contiguous) -> [B,Tq,H*64]
+    (out_x3, fp32 inputs only: KX_BF16X3 rows [hi | hi | lo], [B,Tq,3*H*64] bf16)."""
     _need_cuda(q, k, v)
     B, Tq, Hh, hd = q.shape
     Tk = k.shape[1]
     assert hd == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and v.stride(2) == 64
     assert k.stride(0) == v.stride(0) and k.stride(1) == v.stride(1)
     prec = H.KX_PREC_BF16 if q.dtype == torch.bfloat16 else H.KX_PREC_F32
-    out = torch.empty((B, Tq, Hh * 64), dtype=out_dtype or q.dtype, device=q.device)
+    out = (torch.empty((B, Tq, 3 * Hh * 64), dtype=torch.bfloat16, device=q.device) if out_x3 else
+           torch.empty((B, Tq, Hh * 64), dtype=out_dtype or q.dtype, device=q.device))
     a = H.AttnArgs()
     a.q, a.q_batch_stride, a.q_row_stride = H.ptr(q), q.stride(0), q.stride(1)
     a.k, a.v, a.kv_batch_stride, a.kv_row_stride = H.ptr(k), H.ptr(v), k.stride(0), k.stride(1)
-    a.out, a.out_batch_stride, a.out_row_stride, a.odt = H.ptr(out), out.stride(0), out.stride(1), _cdt(out.dtype)
+    a.out, a.out_batch_stride, a.out_row_stride = H.ptr(out), out.stride(0), out.stride(1)
+    a.odt = H.KX_BF16X3 if out_x3 else _cdt(out.dtype)
     a.B, a.H, a.Tq, a.Tk = B, Hh, Tq, Tk
     a.mask, a.prec = (H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL), prec
     a.stats_out = H.ptr(stats_out)

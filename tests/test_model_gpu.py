@@ -24,6 +24,7 @@ DEV = "cuda"
 FP32_TOL = 1e-5          # north star, fp32
 BF16_KERNEL_TOL = 1e-3   # north star, bf16: vs the oracle with identical operand rounding
 BF16_VS_FP32_TOL = 6e-2  # bf16 operands vs un-rounded fp32 oracle (max-abs / rms), documented bound
+BF16X3_TOL = 1e-3        # north star's bf16 figure, met by "bf16x3": bf16 MFMA arithmetic on split (hi, lo) operands
 
 
 def _tiny(seed=0, switches=None):
@@ -52,6 +53,21 @@ def test_tiny_fp32_matches_oracle(B, Tt):
     assert out.shape == (B, Tt + m.cfg.perceiver.latents, m.cfg.vocab) and out.dtype == torch.float32
     assert rel_err(out, ref) < FP32_TOL * 20, rel_err(out, ref)  # tiny model: few-ulp noise over a small rms
     assert max_abs(out, ref) < 5e-5
+
+
+@pytest.mark.parametrize("B,Tt", [(1, 10), (3, 2), (2, 50)])
+def test_tiny_bf16x3_meets_the_bf16_north_star(B, Tt):
+    """bf16 MFMA arithmetic, operands carried as hi + lo bf16 pairs: within 1e-3 of the un-rounded fp32 CPU path."""
+    m = _tiny()
+    tok, img = _inputs(B, Tt, m.cfg, seed=20 + B)
+    ref = O.kosmos_forward(oracle_weights(m), tok, img, oracle_cfg(m.cfg), O.Switches())
+    m.precision = "bf16x3"
+    m = m.to(DEV)
+    out = m(tok.to(DEV), img.to(DEV))
+    e = rel_err(out, ref)
+    print(f"tiny bf16x3 B={B} Tt={Tt}: max|d|/rms vs fp32 oracle = {e:.3e}")
+    assert out.dtype == torch.float32 and e < BF16X3_TOL, e
+    assert torch.equal(out, m(tok.to(DEV), img.to(DEV)))
 
 
 @pytest.mark.parametrize("B,Tt", [(1, 10), (2, 50)])
@@ -166,7 +182,7 @@ def test_properties_causality_batch_independence_determinism():
     assert torch.isfinite(out).all()
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", BF16_VS_FP32_TOL)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", BF16_VS_FP32_TOL), ("bf16x3", BF16X3_TOL)])
 def test_kosmos_language_tiny(prec, tol):
     lm = KosmosLanguage(vocab_size=1002, dim=256, depth=2, ffn_dim=512, decoder_heads=4, _seed=1, _perturb=0.1,
                         _max_positions=128).eval()
@@ -214,6 +230,12 @@ def test_full_size_c1_parity(full_model, full_reference):
     print(f"C1 bf16: vs bf16-oracle {e16:.3e}, vs fp32-oracle {e32:.3e}")
     assert e32 < BF16_VS_FP32_TOL
     assert torch.equal(out16, m(tok.to(DEV), img.to(DEV)))
+    m.precision = "bf16x3"
+    outx3 = m(tok.to(DEV), img.to(DEV))
+    ex3 = rel_err(outx3, ref32)
+    print(f"C1 bf16x3: max|d|/rms vs fp32 oracle = {ex3:.3e}")
+    assert ex3 < BF16X3_TOL, ex3
+    m.precision = "bf16"
     # Rows are independent of their batch mates.  Bit-equality holds between runs of the SAME shape (above, and
     # test_properties_*): kernel variants are chosen by shape (batch-1 GEMMs are split-K), so a different batch size
     # changes fp32 summation order and, through bf16 rounding flips, the logits at the bf16 error level.

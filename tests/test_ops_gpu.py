@@ -465,3 +465,48 @@ def test_gemm_weight_streaming_prologues(M):
     lnref = torch.nn.functional.layer_norm(yb.float().cpu(), (N,), eps=1e-5)
     ref = lnref @ w2.float().cpu().T + bias[:256] + res.cpu()
     assert rel_err(via_part, ref) < 2e-3          # statistics are of the fp32 values, the operand is their bf16 rounding
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16x3: bf16 MFMA arithmetic on (hi, lo) split operands — the format and what it buys
+# ---------------------------------------------------------------------------------------------
+def _split3(t, order):
+    """fp32 [M,K] -> bf16 [M,3K]: activations 'hhl' = [hi|hi|lo], weights 'hlh' = [hi|lo|hi]."""
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return torch.cat([{"h": hi, "l": lo}[c] for c in order], dim=1).contiguous()
+
+
+def test_bf16x3_producers_write_the_split_format_bit_exactly():
+    """LayerNorm, GEMM epilogue and fp32 attention with a KX_BF16X3 output == split of their own fp32 output."""
+    g = _g(77)
+    x = torch.randn(70, 512, generator=g) * 2 + 0.3
+    gam, bet = torch.randn(512, generator=g).to(DEV), torch.randn(512, generator=g).to(DEV)
+    y32 = ops.layernorm(x.to(DEV), gam, bet)
+    y3 = ops.layernorm(x.to(DEV), gam, bet, x3=True)
+    assert torch.equal(y3, _split3(y32, "hhl"))
+    a = torch.randn(150, 256, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(264, 256, generator=g) / 16).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(264, generator=g).to(DEV)
+    for tile in (0, 64, 128, 160, 256, 384, 512):
+        c32 = ops.gemm(a, w, bias, act="gelu", tile=tile)
+        c3 = ops.gemm(a, w, bias, act="gelu", tile=tile, out_x3=True)
+        assert torch.equal(c3, _split3(c32, "hhl")), tile
+    q = torch.randn(2, 70, 3, 64, generator=g).to(DEV) * 0.3
+    k, v = torch.randn(2, 70, 3, 64, generator=g).to(DEV), torch.randn(2, 70, 3, 64, generator=g).to(DEV)
+    o32 = ops.attention(q, k, v, True)
+    o3 = ops.attention(q, k, v, True, out_x3=True)
+    assert torch.equal(o3.reshape(140, -1), _split3(o32.reshape(140, -1), "hhl"))
+
+
+def test_bf16x3_gemm_is_two_orders_closer_to_fp32_than_bf16():
+    """One bf16 GEMM over [hi|hi|lo] x [hi|lo|hi] = a_hi w_hi + a_hi w_lo + a_lo w_hi: everything but a_lo w_lo."""
+    g = _g(78)
+    M, N, K = 300, 520, 1024
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 32
+    ref = (a.double() @ w.double().T).float()
+    plain = ops.gemm(a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV))
+    x3 = ops.gemm(_split3(a, "hhl").to(DEV), _split3(w, "hlh").to(DEV))
+    e_plain, e_x3 = rel_err(plain, ref), rel_err(x3, ref)
+    print(f"GEMM K={K}: bf16 {e_plain:.2e}, bf16x3 {e_x3:.2e}")
+    assert e_x3 < 5e-5 and e_x3 * 100 < e_plain
