@@ -258,6 +258,25 @@ def main():
                          **({"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] else {})}
                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
 
+    # ---- the same step in the other precision modes (single-GPU run only; reported next to the headline, never as it) ----
+    other_modes = None
+    if rank == 0 and world == 1 and not force_dist and not args.no_cpu_baseline:
+        other_modes = {}
+        for mode in [m for m in ("bf16x3", "fp32") if m != args.precision]:
+            model.precision = mode
+            k = max(3, min(args.steps, 8))
+            for _ in range(2):
+                step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                step()
+            fence()
+            dt_m = (time.perf_counter() - t1) / k
+            other_modes[mode] = {"samples_per_s": round(B / dt_m, 1), "ms_per_step": round(dt_m * 1e3, 3), "steps": k}
+            model.invalidate_packed()
+        model.precision = args.precision
+
     # ---- cpu_baseline: the oracle (a port — the reference's third-party stack is absent) on the host cores ----
     cpu_baseline = None
     if cpu_weights is not None:
@@ -322,7 +341,8 @@ def main():
             "algorithmic_gflop_per_sample": round(fl["total"] / 1e9, 2),
             "model_tflops": round(fl["total"] * total / elapsed / 1e12, 2),
             "mfma_peak_frac_end_to_end": round(fl["total"] * total / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernel_breakdown": breakdown,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "other_precision_modes": other_modes,
+            "kernel_breakdown": breakdown,
             "gemm_shapes": gemm_shapes,
             "build_seconds": round(t_build, 1),
         }
