@@ -279,6 +279,11 @@ def test_language_full_size_max_length(full_lang):
     e16 = rel_err(out16, ref)
     print(f"C3-shape (B=1,T=2046) bf16: max|d|/rms = {e16:.3e}")
     assert e16 < BF16_VS_FP32_TOL
+    lm.precision = "bf16x3"
+    ex3 = rel_err(lm(tok.to(DEV)), ref)
+    print(f"C3-shape (B=1,T=2046) bf16x3: max|d|/rms = {ex3:.3e}")
+    assert ex3 < BF16X3_TOL
+    lm.precision = "bf16"
     # causality at full length: changing the last 100 tokens leaves the first 1946 positions bit-identical
     tok2 = tok.clone()
     tok2[:, 1946:] = (tok2[:, 1946:] + 7) % 32002
@@ -305,5 +310,10 @@ def test_full_size_text_length_edges(full_model, Tt):
     e = rel_err(out, ref)
     print(f"multimodal Tt={Tt} fp32: max|d|/rms = {e:.3e}")
     assert e < 2e-4
+    m.precision = "bf16x3"
+    ex3 = rel_err(m(tok.to(DEV), img.to(DEV)), ref)
+    print(f"multimodal Tt={Tt} bf16x3: max|d|/rms = {ex3:.3e}")
+    assert ex3 < BF16X3_TOL
+    m.precision = "fp32"
     with pytest.raises(IndexError):
         m(torch.zeros(1, 1983, dtype=torch.long, device=DEV), img.to(DEV))
