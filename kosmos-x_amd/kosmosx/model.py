@@ -863,17 +863,22 @@ class Kosmos(nn.Module):
         """Replay the ~420 kernel launches of one forward as a single hipGraph (the library never allocates or
         synchronises, so the whole launch sequence is capturable).  Worth it when the forward is launch-bound
         (small batches): one graph per (batch, text length, precision), inputs copied into static buffers."""
-        key = (tuple(text_tokens.shape), tuple(images.shape), images.dtype, self.precision, text_tokens.device)
+        # one graph per issuing stream as well: graphs replayed concurrently on different streams (independent
+        # requests) must not share static buffers or scratch — each capture runs on its own stream, which is what keys
+        # the library workspace (_Workspace), and allocates from its own graph memory pool
+        key = (tuple(text_tokens.shape), tuple(images.shape), images.dtype, self.precision, text_tokens.device,
+               torch.cuda.current_stream(text_tokens.device).cuda_stream)
         ent = self._graphs.get(key)
         if ent is None:
             self._forward_impl(text_tokens, images)          # warm-up: packs weights, sizes workspaces, uploads tables
             torch.cuda.synchronize(text_tokens.device)
             s_tok, s_img = text_tokens.clone(), images.clone()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            cap = torch.cuda.Stream(device=text_tokens.device)
+            with torch.cuda.graph(g, stream=cap):
                 s_out = self._forward_impl(s_tok, s_img)
-            ent = self._graphs[key] = (g, s_tok, s_img, s_out)
-        g, s_tok, s_img, s_out = ent
+            ent = self._graphs[key] = (g, s_tok, s_img, s_out, cap)
+        g, s_tok, s_img, s_out = ent[:4]
         s_tok.copy_(text_tokens)
         s_img.copy_(images)
         g.replay()

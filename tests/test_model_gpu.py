@@ -317,3 +317,28 @@ def test_full_size_text_length_edges(full_model, Tt):
     m.precision = "fp32"
     with pytest.raises(IndexError):
         m(torch.zeros(1, 1983, dtype=torch.long, device=DEV), img.to(DEV))
+
+
+def test_concurrent_graph_replays_on_separate_streams_do_not_interfere():
+    """Independent requests replayed as hipGraphs on different streams (bench.py --graph --pipeline N): every stream
+    has its own graph, static buffers and library scratch, so each result equals the eager forward bit for bit."""
+    m = _tiny().to(DEV)
+    m.precision = "bf16"
+    reqs = [_inputs(1, 10, m.cfg, seed=50 + i) for i in range(4)]
+    eager = [m(t.to(DEV), i.to(DEV)).clone() for t, i in reqs]
+    m.use_hip_graphs = True
+    try:
+        streams = [torch.cuda.Stream() for _ in reqs]
+        for rep in range(3):                       # rep 0 captures, later reps replay concurrently
+            outs = []
+            for st, (t, i) in zip(streams, reqs):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    outs.append(m(t.to(DEV), i.to(DEV)))
+            for st in streams:
+                torch.cuda.current_stream().wait_stream(st)
+            torch.cuda.synchronize()
+            for o, e in zip(outs, eager):
+                assert torch.equal(o, e), rep
+    finally:
+        m.use_hip_graphs = False
