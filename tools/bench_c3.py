@@ -17,9 +17,11 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--gemm-tile", type=int, default=0)
 ap.add_argument("--tune", default="")
+ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 m = KosmosLanguage(vocab_size=32002, dim=2048, _seed=0).eval().to(dev)     # /root/reference/example_lang.py:9-12
+m.precision = a.precision
 if a.gemm_tile:
     _hip.load().kx_set_tuning(1, a.gemm_tile)
 for kv in filter(None, a.tune.split(",")):
@@ -46,7 +48,7 @@ for kind, x, y, z, ms in recs:
     e = agg.setdefault(kind, [0, 0.0]); e[0] += 1; e[1] += ms
     if "gemm" in str(kind):
         e = shapes.setdefault(f"{kind}:{x}x{y}x{z}", [0, 0.0, 2.0 * x * y * z]); e[0] += 1; e[1] += ms
-print(json.dumps({"workload": f"KosmosLanguage forward B={B} T={T} bf16 (configs[2])", "ms_per_forward": round(dt * 1e3, 2),
+print(json.dumps({"workload": f"KosmosLanguage forward B={B} T={T} {a.precision} (configs[2])", "ms_per_forward": round(dt * 1e3, 2),
                   "tokens_per_s": round(B * T / dt, 1), "algorithmic_tflop": round(flops / 1e12, 2),
                   "tflops": round(flops / dt / 1e12, 1), "frac_of_2.5PF": round(flops / dt / 2.5e15, 4),
                   "logits_shape": list(out.shape),
