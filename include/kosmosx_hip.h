@@ -147,6 +147,8 @@ typedef struct {
   int32_t prec;
   float* stats_out;                           /* optional [B*Tq, H, 2]: per row and head (sum, M2 about the head's mean)
                                                  of the 64 output values, for the folded inner_attn_ln */
+  float* lse_out;                             /* optional [B,H,Tq] fp32: log-sum-exp of each query's scores (fp32 matrix-core
+                                                 kernel only): what kx_attention_backward needs to rebuild P */
 } kx_attn_args;
 int kx_attention(const kx_attn_args* args, void* stream);
 
@@ -328,6 +330,51 @@ int kx_clip_preprocess(const uint8_t* src, int64_t B, int32_t H, int32_t W, int6
  * mask [B, n_img+L+2] float32 = [ones(n_img) | tokens != pad_id]. */
 int kx_token_splice(const int64_t* texts, int64_t B, int64_t L, int64_t im_idx, int64_t im_end_idx, int64_t pad_id,
                     int64_t n_img, int64_t* tokens, float* mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training step, first slice (/root/reference/train.py:642-656: loss, backward,
+ * clip_grad_norm_(1.0), AdamW step).  fp32 activations / gradients; the matrix products of the backward pass are
+ * kx_gemm on transposed operands (dX = kx_gemm(dY, W^T), dW = kx_gemm(dY^T, X^T)).  Deterministic reductions.
+ * The step itself is orchestrated by kosmosx/training.py over these entry points.
+ * ------------------------------------------------------------------------------------------ */
+/* dst[c][r] = src[r][c]; dt = KX_F32 or KX_BF16 */
+int kx_transpose(const void* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, int32_t dt,
+                 void* stream);
+/* out[c] (+)= sum_r x[r][c] (bias gradients) */
+size_t kx_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int kx_colsum(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, int32_t accumulate, void* workspace,
+              size_t workspace_bytes, void* stream);
+/* torch.nn.LayerNorm backward: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) (+ dres, the residual branch's gradient,
+ * may be NULL), g = dy*gamma; dgamma = sum_r dy*xhat, dbeta = sum_r dy (both NULL to skip). */
+size_t kx_layernorm_backward_workspace_bytes(int64_t rows, int64_t cols);
+int kx_layernorm_backward(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
+                          float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps, void* workspace,
+                          size_t workspace_bytes, void* stream);
+/* exact (erf) GELU: dpre = dg * (Phi(pre) + pre*phi(pre)) */
+int kx_gelu_backward(const float* pre, const float* dg, float* dpre, int64_t n, void* stream);
+/* F.cross_entropy rows: loss_rows[r] = logsumexp(logits[r]) - logits[r][target[r]] (0 for targets outside [0,V):
+ * ignore_index); dlogits (optional) = (softmax - onehot) * scale. */
+int kx_cross_entropy(const float* logits, int64_t rows, int64_t V, int64_t ld, const int64_t* target, float scale,
+                     float* loss_rows, float* dlogits, int64_t ldd, void* stream);
+/* out[0] (+)= sum x[i] (squares != 0: sum x[i]^2 — the gradient norm); workspace >= 4 KB */
+int kx_reduce_sum(const float* x, int64_t n, int32_t squares, float* out, int32_t accumulate, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* backward of the qkv epilogue (q *= qscale, XPos rotate/scale of q and k), in place on the fused [M,3D] gradient */
+int kx_xpos_backward(float* dqkv, int64_t M, int64_t D, int64_t T, const float* xq_cs, const float* xq_ss,
+                     const float* xk_cs, const float* xk_ss, float qscale, void* stream);
+/* dembed[v] = sum of dx rows whose token is v (overwrites all vocab rows); dpos[2+pos_offset+t] = sum_b dx[b,t] */
+int kx_embed_backward(const int64_t* tokens, const float* dx, int64_t B, int64_t T, int64_t d, int64_t vocab,
+                      int64_t pos_offset, float* dembed, float* dpos, void* stream);
+/* torch.optim.AdamW step on one flat fp32 tensor; grad_norm_sq (optional, device scalar) + max_norm apply
+ * clip_grad_norm_'s factor min(1, max_norm / (norm + 1e-6)) to the gradient on the fly. */
+int kx_adamw(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, int64_t step, const float* grad_norm_sq, float max_norm, void* stream);
+/* Attention backward (fp32, head_dim 64): q/k/v/dq/dk/dv are column blocks of fused [B*T, 3D] buffers (row / batch
+ * strides in elements), out/dout [B,T,D]; lse [B,H,T] from kx_attention (lse_out); delta [B,H,T] scratch. */
+int kx_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                          const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B, int64_t H, int64_t T,
+                          int64_t qkv_row_stride, int64_t qkv_batch_stride, int64_t out_row_stride,
+                          int64_t out_batch_stride, int32_t mask, void* stream);
 
 /* Kernel-variant selection for in-process A/B measurement (tools/gemm_bench.py, tools/ln_bench.py).  Defaults (all 0) are the
  * shipped configuration.  key 0: LayerNorm variant (0 wave-per-row, 1 workgroup-per-row);

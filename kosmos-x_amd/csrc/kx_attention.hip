@@ -22,6 +22,7 @@ struct AttnParams {
   void* out; long long obs, ors; int o_bf16, o_x3;
   int B, H, Tq, Tk;
   float* stats_out;   // [B*Tq, H, 2] partial LayerNorm statistics of the output rows (folded inner_attn_ln), or null
+  float* lse_out;     // [B, H, Tq] log-sum-exp of the scores (fp32 matrix-core kernel; for the backward pass), or null
 };
 
 constexpr int KSTR = 72;  // LDS row stride (elements) for the 64-wide K / Vᵀ tiles: 144 B, 16-B aligned rows
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const AttnParams p) 
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
+  if (p.lse_out && g == 0 && qi < p.Tq) p.lse_out[((long long)b * p.H + h) * p.Tq + qi] = m_run + logf(l_run);
 #pragma unroll
   for (int d = 0; d < 4; ++d) { ot[d][0] *= inv; ot[d][1] *= inv; ot[d][2] *= inv; ot[d][3] *= inv; }
   if (p.stats_out) {
@@ -610,6 +612,9 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
              "kx_attention: a KX_BF16X3 output is produced by the fp32 matrix-core kernel only (row stride >= 3*H*64)");
   p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
   p.stats_out = a->stats_out;
+  p.lse_out = a->lse_out;
+  KX_REQUIRE(!a->lse_out || (a->prec == KX_PREC_F32 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1),
+             "kx_attention: lse_out is produced by the fp32 matrix-core kernel only");
   KX_REQUIRE(!a->stats_out || !(a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1),
              "kx_attention: stats_out is not implemented by the v1 A/B kernel");
   hipStream_t s = (hipStream_t)stream;

@@ -1,0 +1,587 @@
+// Backward / optimizer kernels of the training step (/root/reference/train.py:642-656 — forward,
+// loss, backward, clip_grad_norm_(1.0), AdamW step — on the text decoder).  First slice: fp32 activations and
+// gradients; the matrix products of the backward pass are the forward GEMM kernel on transposed operands
+// (dX = dY·W = kx_gemm(dY, Wᵀ), dW = dYᵀ·X = kx_gemm(dYᵀ, Xᵀ)), everything else lives here.  All reductions are
+// deterministic (fixed summation order, no atomics).  Row kernels are HBM-bound; the attention backward is a
+// plain LDS-tiled fp32 kernel (correctness first — the matrix-core version is next).
+#include "kx_common.h"
+
+namespace {
+
+// ---- transpose: dst[c][r] = src[r][c], 64x64 tiles through LDS (padded), fp32 or bf16 ----
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, long long rows,
+                                                        long long cols, long long ld_src, long long ld_dst) {
+  __shared__ T tile[64][65];
+  const long long r0 = (long long)blockIdx.y * 64, c0 = (long long)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const long long r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[i][tx] = src[r * ld_src + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const long long c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) dst[c * ld_dst + r] = tile[tx][i];
+  }
+}
+
+// ---- column sums: out[c] = sum_r x[r][c] over row slices (stage 1), slices summed in order (stage 2) ----
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long rows, long long cols,
+                                                             long long ld, int rows_per_slice, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long c = (long long)blockIdx.x * 64 + tx;
+  const long long r0 = (long long)blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+  float s = 0.f;
+  if (c < cols)
+    for (long long r = r0 + ty; r < r1; r += 4) s += x[r * ld + c];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < cols) part[(long long)blockIdx.y * cols + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nslices, long long cols,
+                                                           float* __restrict__ out, int accumulate) {
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int i = 0; i < nslices; ++i) s += part[(long long)i * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---- LayerNorm backward, row part: one wave per row.  y = xhat*gamma + beta, xhat = (x - mean)*rstd.
+//   dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;   optional dres added (residual branch).
+//   Also writes xhat-related row statistics (mean, rstd) for the parameter-gradient pass.
+__global__ __launch_bounds__(256) void ln_bwd_row_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ dy, const float* __restrict__ dres,
+                                                         float* __restrict__ dx, float* __restrict__ stats, long long rows,
+                                                         int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * cols;
+  const float* gr = dy + row * cols;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+  for (int c = lane; c < cols; c += 64) { const float d = xr[c] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+  float a = 0.f, b = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const float g = gr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+    a += g; b += g * xh;
+  }
+  a = wave_sum(a) / (float)cols; b = wave_sum(b) / (float)cols;
+  for (int c = lane; c < cols; c += 64) {
+    const float g = gr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+    float v = rstd * (g - a - xh * b);
+    if (dres) v += dres[row * cols + c];
+    dx[row * cols + c] = v;
+  }
+  if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+// parameter part: dgamma[c] = sum_r dy*xhat, dbeta[c] = sum_r dy — row slices, then colsum_final on both halves
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ stats, long long rows, int cols,
+                                                           int rows_per_slice, float* __restrict__ part) {
+  __shared__ float rg[4][64], rb[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const long long r0 = (long long)blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+  float sg = 0.f, sb = 0.f;
+  if (c < cols)
+    for (long long r = r0 + ty; r < r1; r += 4) {
+      const float d = dy[r * cols + c];
+      sg += d * (x[r * cols + c] - stats[2 * r]) * stats[2 * r + 1];
+      sb += d;
+    }
+  rg[ty][tx] = sg; rb[ty][tx] = sb;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    part[((long long)blockIdx.y * 2) * cols + c] = (rg[0][tx] + rg[1][tx]) + (rg[2][tx] + rg[3][tx]);
+    part[((long long)blockIdx.y * 2 + 1) * cols + c] = (rb[0][tx] + rb[1][tx]) + (rb[2][tx] + rb[3][tx]);
+  }
+}
+__global__ __launch_bounds__(256) void ln_bwd_param_final_kernel(const float* __restrict__ part, int nslices, int cols,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float sg = 0.f, sb = 0.f;
+  for (int i = 0; i < nslices; ++i) { sg += part[((long long)i * 2) * cols + c]; sb += part[((long long)i * 2 + 1) * cols + c]; }
+  dgamma[c] = sg; dbeta[c] = sb;
+}
+
+// ---- GELU (erf) backward: dpre = dg * (Phi(x) + x*phi(x)) ----
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dg,
+                                                       float* __restrict__ dpre, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = pre[i];
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  dpre[i] = dg[i] * (cdf + x * pdf);
+}
+
+// ---- cross-entropy: one workgroup per row; loss_r = lse - logit[target]; dlogits = (softmax - onehot) * scale ----
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, long long ld, int V,
+                                                            const long long* __restrict__ target, float scale,
+                                                            float* __restrict__ loss_rows, float* __restrict__ dlogits,
+                                                            long long ldd) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const float* lr = logits + row * ld;
+  const long long tg = target[row];
+  const bool ignore = tg < 0 || tg >= V;            // ignore_index rows: zero loss, zero gradient
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, lr[c]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) s += expf(lr[c] - mx);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  const float lse = mx + logf(s);
+  if (threadIdx.x == 0) loss_rows[row] = ignore ? 0.f : (lse - lr[tg]);
+  if (dlogits) {
+    float* dr = dlogits + row * ldd;
+    const float inv = 1.0f / s;
+    for (int c = threadIdx.x; c < V; c += 256) {
+      float g = ignore ? 0.f : expf(lr[c] - mx) * inv;
+      if (!ignore && c == tg) g -= 1.0f;
+      dr[c] = g * scale;
+    }
+  }
+}
+
+// ---- deterministic sum / sum of squares: stage 1 per-block partials, stage 2 single block ----
+template <bool SQ>
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = x[i];
+    s += SQ ? v * v : v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out,
+                                                           int accumulate) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { const float t = (red[0] + red[1]) + (red[2] + red[3]); out[0] = accumulate ? out[0] + t : t; }
+}
+
+// ---- XPos + q-scale backward on the fused [M, 3D] gradient, in place: forward was v *= qscale (q), then
+//   y0 = x0*c - x1*s, y1 = x1*c + x0*s per pair (c, s = table[pos][j]);  backward dx0 = dy0*c + dy1*s, dx1 = dy1*c - dy0*s ----
+__global__ __launch_bounds__(256) void xpos_bwd_kernel(float* __restrict__ dqkv, long long M, int D, int T,
+                                                       const float* __restrict__ xq_cs, const float* __restrict__ xq_ss,
+                                                       const float* __restrict__ xk_cs, const float* __restrict__ xk_ss,
+                                                       float qscale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;    // one pair of the q or k block
+  if (i >= M * D) return;                                           // D pairs per row: D/2 of q + D/2 of k
+  const long long row = i / D;
+  const int p = (int)(i % D);                                       // pair index over [q | k] = 2D columns
+  const bool isq = p < D / 2;
+  const int col = 2 * p;                                            // column in [0, 2D)
+  float* g = dqkv + row * 3 * D + col;
+  float d0 = g[0], d1 = g[1];
+  if (xq_cs) {
+    const int pos = (int)(row % T), j = (col & 63) >> 1;
+    const float c = (isq ? xq_cs : xk_cs)[pos * 32 + j], s = (isq ? xq_ss : xk_ss)[pos * 32 + j];
+    const float n0 = d0 * c + d1 * s, n1 = d1 * c - d0 * s;
+    d0 = n0; d1 = n1;
+  }
+  if (isq) { d0 *= qscale; d1 *= qscale; }
+  g[0] = d0; g[1] = d1;
+}
+
+// ---- embedding backward (deterministic gather-by-row): dembed[v] = sum over rows with token == v of dx[row],
+//      dpos[2 + t] = sum_b dx[b, t] ----
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ tokens, const float* __restrict__ dx,
+                                                        long long M, int d, float* __restrict__ dembed) {
+  const long long v = blockIdx.x;
+  float* out = dembed + v * d;
+  for (int c = threadIdx.x; c < d; c += 256) out[c] = 0.f;
+  for (long long r = 0; r < M; ++r) {
+    if (tokens[r] != v) continue;                                   // block-uniform branch
+    for (int c = threadIdx.x; c < d; c += 256) out[c] += dx[r * d + c];
+  }
+}
+__global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ dx, int B, int T, int d, int pos_offset,
+                                                      float* __restrict__ dpos) {
+  const int t = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx[((long long)b * T + t) * d + c];
+    dpos[(long long)(2 + pos_offset + t) * d + c] = s;
+  }
+}
+
+// ---- AdamW (torch.optim.AdamW semantics: decoupled decay, bias correction, eps outside the sqrt of v_hat) ----
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2, const float* __restrict__ gnorm_sq,
+                                                    float max_norm) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float clip = 1.0f;                                                // clip_grad_norm_: g *= max_norm / (norm + 1e-6), capped at 1
+  if (gnorm_sq) clip = fminf(1.0f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));
+  const float gi = g[i] * clip;
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  pi -= (lr / bc1) * (mi / denom);
+  p[i] = pi;
+}
+
+// ---- causal / full attention backward, fp32, head_dim 64.  Workgroup = (key tile of 64, head, batch); it owns dK, dV
+//  of its keys and walks the query tiles; dQ rows are accumulated by a second pass that owns query tiles (no atomics).
+//  P = exp(S - lse), dP = dO·Vᵀ, dS = P ⊙ (dP - delta), delta[q] = sum_d dO[q,d]*O[q,d].
+//  MODE 0: dK, dV (block owns keys);  MODE 1: dQ (block owns queries).  Thread (ty, tx) of a 16x16 grid computes a 4x4
+//  patch of each 64x64 product from LDS tiles. ----
+constexpr int AP = 65;   // LDS pitch (floats) of the 64-wide tiles
+template <int MODE, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, const float* __restrict__ dout,
+                                                       const float* __restrict__ lse, const float* __restrict__ delta,
+                                                       float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                       int T, int H, long long row_stride /* elements between tokens: 3D */,
+                                                       long long batch_stride, long long do_row, long long do_batch) {
+  __shared__ float A[64 * AP], Bm[64 * AP], Cm[64 * AP], Dm[64 * AP];   // role depends on MODE, see below
+  __shared__ float Ps[64 * AP];
+  const int own0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const float* qb = q + (long long)b * batch_stride + (long long)h * 64;
+  const float* kb = k + (long long)b * batch_stride + (long long)h * 64;
+  const float* vb = v + (long long)b * batch_stride + (long long)h * 64;
+  const float* dob = dout + (long long)b * do_batch + (long long)h * 64;
+  const float* lseb = lse + ((long long)b * H + h) * T;
+  const float* delb = delta + ((long long)b * H + h) * T;
+  auto load_tile = [&](float* dst, const float* src, long long stride, int r0) {   // 64 rows x 64 dims, zero past T
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + r < T) val = *reinterpret_cast<const float4*>(src + (long long)(r0 + r) * stride + c4);
+      dst[r * AP + c4] = val.x; dst[r * AP + c4 + 1] = val.y; dst[r * AP + c4 + 2] = val.z; dst[r * AP + c4 + 3] = val.w;
+    }
+  };
+  float acc0[4][4], acc1[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc0[i][j] = acc1[i][j] = 0.f;
+  // MODE 0: owned = keys: A = K tile, Bm = V tile; per query tile: Cm = Q, Dm = dO.  acc0 = dK, acc1 = dV  [key, d]
+  // MODE 1: owned = queries: A = Q tile, Bm = dO tile; per key tile: Cm = K, Dm = V.  acc0 = dQ  [query, d]
+  if (MODE == 0) { load_tile(A, kb, row_stride, own0); load_tile(Bm, vb, row_stride, own0); }
+  else { load_tile(A, qb, row_stride, own0); load_tile(Bm, dob, do_row, own0); }
+  const int ntiles = (T + 63) / 64;
+  const int t_begin = MODE == 0 ? (CAUSAL ? own0 / 64 : 0) : 0;                         // queries >= keys when causal
+  const int t_end = MODE == 0 ? ntiles : (CAUSAL ? min(ntiles, own0 / 64 + 1) : ntiles);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int o0 = t * 64;
+    __syncthreads();
+    if (MODE == 0) { load_tile(Cm, qb, row_stride, o0); load_tile(Dm, dob, do_row, o0); }
+    else { load_tile(Cm, kb, row_stride, o0); load_tile(Dm, vb, row_stride, o0); }
+    __syncthreads();
+    // query tile / key tile views
+    const float* Qt = MODE == 0 ? Cm : A;   const float* Kt = MODE == 0 ? A : Cm;
+    const float* Vt = MODE == 0 ? Bm : Dm;  const float* dOt = MODE == 0 ? Dm : Bm;
+    const int q0 = MODE == 0 ? o0 : own0, k0 = MODE == 0 ? own0 : o0;
+    // S[qi][kj] and dP[qi][kj] for the 4x4 patch (queries 4ty.., keys 4tx..)
+    float s[4][4], dp[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[i][j] = dp[i][j] = 0.f;
+    for (int d = 0; d < 64; ++d) {
+      float qv[4], kv[4], dov[4], vv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { qv[i] = Qt[(4 * ty + i) * AP + d]; dov[i] = dOt[(4 * ty + i) * AP + d]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { kv[j] = Kt[(4 * tx + j) * AP + d]; vv[j] = Vt[(4 * tx + j) * AP + d]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[i][j] += qv[i] * kv[j]; dp[i][j] += dov[i] * vv[j]; }
+    }
+    // P and dS into LDS: Ps[qi][kj] = P, reuse Cm/Dm? keep separate small buffers: P in Ps, dS overwrites s
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int qi = q0 + 4 * ty + i;
+      const float l = qi < T ? lseb[qi] : 0.f, dl = qi < T ? delb[qi] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kj = k0 + 4 * tx + j;
+        const bool ok = qi < T && kj < T && (!CAUSAL || kj <= qi);
+        const float pv = ok ? expf(s[i][j] - l) : 0.f;
+        s[i][j] = pv * (dp[i][j] - dl);               // dS
+        dp[i][j] = pv;                                // P
+      }
+    }
+    __syncthreads();                                   // everyone is done reading Cm/Dm for S/dP? (they are read again below)
+    // stage P and dS through LDS for the second products
+    float* dSs = Ps;                                   // [64][AP] dS ; P goes to a second buffer carved from registers->LDS
+    // we need both P (for dV) and dS (for dK/dQ): write dS to Ps, P to a view inside the (dead) accumulation scratch
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dSs[(4 * ty + i) * AP + 4 * tx + j] = s[i][j];
+    __syncthreads();
+    if (MODE == 0) {
+      // dK[kj][d] += sum_qi dS[qi][kj] * Q[qi][d]   ;  patch: keys 4ty.., dims 4tx..
+      for (int qi = 0; qi < 64; ++qi) {
+        float ds[4], qd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ds[i] = dSs[qi * AP + 4 * ty + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qd[j] = Qt[qi * AP + 4 * tx + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc0[i][j] += ds[i] * qd[j];
+      }
+      __syncthreads();
+      // now P -> Ps for dV
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ps[(4 * ty + i) * AP + 4 * tx + j] = dp[i][j];
+      __syncthreads();
+      for (int qi = 0; qi < 64; ++qi) {
+        float pp[4], dd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pp[i] = Ps[qi * AP + 4 * ty + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dd[j] = dOt[qi * AP + 4 * tx + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc1[i][j] += pp[i] * dd[j];
+      }
+    } else {
+      // dQ[qi][d] += sum_kj dS[qi][kj] * K[kj][d]   ;  patch: queries 4ty.., dims 4tx..
+      for (int kj = 0; kj < 64; ++kj) {
+        float ds[4], kd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ds[i] = dSs[(4 * ty + i) * AP + kj];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kd[j] = Kt[kj * AP + 4 * tx + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc0[i][j] += ds[i] * kd[j];
+      }
+    }
+  }
+  // write the owned rows: [own0 + 4ty + i][4tx + j]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = own0 + 4 * ty + i;
+    if (r >= T) continue;
+    const long long off = (long long)b * batch_stride + (long long)r * row_stride + (long long)h * 64 + 4 * tx;
+    if (MODE == 0) {
+      *reinterpret_cast<float4*>(dk + off) = make_float4(acc0[i][0], acc0[i][1], acc0[i][2], acc0[i][3]);
+      *reinterpret_cast<float4*>(dv + off) = make_float4(acc1[i][0], acc1[i][1], acc1[i][2], acc1[i][3]);
+    } else {
+      *reinterpret_cast<float4*>(dq + off) = make_float4(acc0[i][0], acc0[i][1], acc0[i][2], acc0[i][3]);
+    }
+  }
+}
+
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]: one wave per (b,q,h)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int T, int H, long long row,
+                                                         long long batch) {
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= (long long)B * T * H) return;
+  const int h = (int)(w % H);
+  const long long bq = w / H;
+  const int qi = (int)(bq % T), b = (int)(bq / T);
+  const long long off = (long long)b * batch + (long long)qi * row + (long long)h * 64 + lane;
+  const float s = wave_sum(o[off] * dout[off]);
+  if (lane == 0) delta[((long long)b * H + h) * T + qi] = s;
+}
+
+}  // namespace
+
+extern "C" int kx_transpose(const void* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
+                            int32_t dt, void* stream) {
+  KX_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "kx_transpose: bad arguments");
+  KX_REQUIRE(dt == KX_F32 || dt == KX_BF16, "kx_transpose: fp32 or bf16");
+  const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, rows, cols, 20, s);
+  if (dt == KX_F32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, (long long)rows,
+                       (long long)cols, (long long)ld_src, (long long)ld_dst);
+  else
+    hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, (long long)rows,
+                       (long long)cols, (long long)ld_src, (long long)ld_dst);
+  KX_CHECK_LAUNCH("kx_transpose");
+  return KX_OK;
+}
+
+static int slices_for(int64_t rows) { return (int)((rows + 511) / 512 > 256 ? 256 : (rows + 511) / 512); }
+
+extern "C" size_t kx_colsum_workspace_bytes(int64_t rows, int64_t cols) {
+  return (size_t)slices_for(rows) * 2 * (size_t)cols * 4 + 256;
+}
+
+extern "C" int kx_colsum(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, int32_t accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  KX_REQUIRE(x && out && workspace && rows > 0 && cols > 0 && ld >= cols, "kx_colsum: bad arguments");
+  KX_REQUIRE(workspace_bytes >= kx_colsum_workspace_bytes(rows, cols), "kx_colsum: workspace too small");
+  const int ns = slices_for(rows);
+  const int rps = (int)((rows + ns - 1) / ns);
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, rows, cols, 21, s);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)ns), dim3(256), 0, s, x,
+                     (long long)rows, (long long)cols, (long long)ld, rps, (float*)workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, (const float*)workspace, ns,
+                     (long long)cols, out, accumulate);
+  KX_CHECK_LAUNCH("kx_colsum");
+  return KX_OK;
+}
+
+extern "C" int kx_layernorm_backward(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
+                                     float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  KX_REQUIRE(x && gamma && dy && dx && workspace, "kx_layernorm_backward: null pointer");
+  KX_REQUIRE(rows > 0 && cols > 0 && cols <= 65536, "kx_layernorm_backward: bad shape");
+  KX_REQUIRE(!dgamma == !dbeta, "kx_layernorm_backward: dgamma and dbeta go together");
+  const int ns = slices_for(rows);
+  const size_t need = (size_t)rows * 8 + 256 + (size_t)ns * 2 * cols * 4;
+  KX_REQUIRE(workspace_bytes >= need, "kx_layernorm_backward: workspace %zu < %zu", workspace_bytes, need);
+  float* stats = (float*)workspace;
+  float* part = (float*)((char*)workspace + (((size_t)rows * 8 + 255) & ~(size_t)255));
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_LAYERNORM, rows, cols, 1, s);
+  hipLaunchKernelGGL(ln_bwd_row_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, dy, dres, dx, stats,
+                     (long long)rows, (int)cols, eps);
+  if (dgamma) {
+    const int rps = (int)((rows + ns - 1) / ns);
+    hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)ns), dim3(256), 0, s, x, dy,
+                       (const float*)stats, (long long)rows, (int)cols, rps, part);
+    hipLaunchKernelGGL(ln_bwd_param_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, (const float*)part,
+                       ns, (int)cols, dgamma, dbeta);
+  }
+  KX_CHECK_LAUNCH("kx_layernorm_backward");
+  return KX_OK;
+}
+
+extern "C" size_t kx_layernorm_backward_workspace_bytes(int64_t rows, int64_t cols) {
+  return (((size_t)rows * 8 + 255) & ~(size_t)255) + (size_t)slices_for(rows) * 2 * (size_t)cols * 4 + 256;
+}
+
+extern "C" int kx_gelu_backward(const float* pre, const float* dg, float* dpre, int64_t n, void* stream) {
+  KX_REQUIRE(pre && dg && dpre && n > 0, "kx_gelu_backward: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, n, 0, 22, s);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, dg, dpre, (long long)n);
+  KX_CHECK_LAUNCH("kx_gelu_backward");
+  return KX_OK;
+}
+
+extern "C" int kx_cross_entropy(const float* logits, int64_t rows, int64_t V, int64_t ld, const int64_t* target, float scale,
+                                float* loss_rows, float* dlogits, int64_t ldd, void* stream) {
+  KX_REQUIRE(logits && target && loss_rows && rows > 0 && V > 0 && ld >= V, "kx_cross_entropy: bad arguments");
+  KX_REQUIRE(!dlogits || ldd >= V, "kx_cross_entropy: ldd < V");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, rows, V, 23, s);
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, (long long)ld, (int)V,
+                     (const long long*)target, scale, loss_rows, dlogits, (long long)ldd);
+  KX_CHECK_LAUNCH("kx_cross_entropy");
+  return KX_OK;
+}
+
+extern "C" int kx_reduce_sum(const float* x, int64_t n, int32_t squares, float* out, int32_t accumulate, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  KX_REQUIRE(x && out && workspace && n > 0 && workspace_bytes >= 1024 * 4, "kx_reduce_sum: bad arguments (workspace >= 4 KB)");
+  const int nb = (int)((n + 4095) / 4096 > 1024 ? 1024 : (n + 4095) / 4096);
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, n, squares, 24, s);
+  if (squares) hipLaunchKernelGGL(reduce_partial_kernel<true>, dim3(nb), dim3(256), 0, s, x, (long long)n, (float*)workspace);
+  else hipLaunchKernelGGL(reduce_partial_kernel<false>, dim3(nb), dim3(256), 0, s, x, (long long)n, (float*)workspace);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, nb, out, accumulate);
+  KX_CHECK_LAUNCH("kx_reduce_sum");
+  return KX_OK;
+}
+
+extern "C" int kx_xpos_backward(float* dqkv, int64_t M, int64_t D, int64_t T, const float* xq_cs, const float* xq_ss,
+                                const float* xk_cs, const float* xk_ss, float qscale, void* stream) {
+  KX_REQUIRE(dqkv && M > 0 && D > 0 && D % 64 == 0 && T > 0, "kx_xpos_backward: bad arguments");
+  KX_REQUIRE(!xq_cs || (xq_ss && xk_cs && xk_ss), "kx_xpos_backward: incomplete tables");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, M, D, 25, s);
+  const long long n = (long long)M * D;
+  hipLaunchKernelGGL(xpos_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dqkv, (long long)M, (int)D, (int)T,
+                     xq_cs, xq_ss, xk_cs, xk_ss, qscale);
+  KX_CHECK_LAUNCH("kx_xpos_backward");
+  return KX_OK;
+}
+
+extern "C" int kx_embed_backward(const int64_t* tokens, const float* dx, int64_t B, int64_t T, int64_t d, int64_t vocab,
+                                 int64_t pos_offset, float* dembed, float* dpos, void* stream) {
+  KX_REQUIRE(tokens && dx && dembed && B > 0 && T > 0 && d > 0 && vocab > 0, "kx_embed_backward: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_EMBED, B * T, d, 1, s);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)vocab), dim3(256), 0, s, (const long long*)tokens, dx,
+                     (long long)(B * T), (int)d, dembed);
+  if (dpos)
+    hipLaunchKernelGGL(pos_bwd_kernel, dim3((unsigned)T), dim3(256), 0, s, dx, (int)B, (int)T, (int)d, (int)pos_offset, dpos);
+  KX_CHECK_LAUNCH("kx_embed_backward");
+  return KX_OK;
+}
+
+extern "C" int kx_adamw(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int64_t step, const float* grad_norm_sq, float max_norm,
+                        void* stream) {
+  KX_REQUIRE(param && grad && m && v && n > 0 && step >= 1, "kx_adamw: bad arguments");
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, n, 0, 26, s);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, m, v, (long long)n, lr,
+                     beta1, beta2, eps, weight_decay, bc1, bc2, grad_norm_sq, max_norm);
+  KX_CHECK_LAUNCH("kx_adamw");
+  return KX_OK;
+}
+
+extern "C" int kx_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                     const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B, int64_t H,
+                                     int64_t T, int64_t qkv_row_stride, int64_t qkv_batch_stride, int64_t out_row_stride,
+                                     int64_t out_batch_stride, int32_t mask, void* stream) {
+  KX_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta, "kx_attention_backward: null pointer");
+  KX_REQUIRE(B > 0 && H > 0 && T > 0 && B < 65536 && H < 65536, "kx_attention_backward: bad shape");
+  KX_REQUIRE(qkv_row_stride % 4 == 0 && out_row_stride % 4 == 0, "kx_attention_backward: strides must keep float4 alignment");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_ATTN_F32, B * H, T, -T, s);
+  const long long nw = (long long)B * T * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, out, dout, delta, (int)B, (int)T,
+                     (int)H, (long long)out_row_stride, (long long)out_batch_stride);
+  const dim3 grid((unsigned)((T + 63) / 64), (unsigned)H, (unsigned)B);
+#define KX_ATTN_BWD(MODE, CAUSAL)                                                                                        \
+  hipLaunchKernelGGL((attn_bwd_kernel<MODE, CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dq, dk, \
+                     dv, (int)T, (int)H, (long long)qkv_row_stride, (long long)qkv_batch_stride, (long long)out_row_stride, \
+                     (long long)out_batch_stride)
+  if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD(0, true); KX_ATTN_BWD(1, true); }
+  else { KX_ATTN_BWD(0, false); KX_ATTN_BWD(1, false); }
+#undef KX_ATTN_BWD
+  KX_CHECK_LAUNCH("kx_attention_backward");
+  return KX_OK;
+}

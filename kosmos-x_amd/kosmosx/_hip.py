@@ -40,7 +40,8 @@ class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("q_batch_stride", i64), ("q_row_stride", i64),
                 ("k", vp), ("v", vp), ("kv_batch_stride", i64), ("kv_row_stride", i64),
                 ("out", vp), ("out_batch_stride", i64), ("out_row_stride", i64), ("odt", i32),
-                ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64), ("mask", i32), ("prec", i32), ("stats_out", vp)]
+                ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64), ("mask", i32), ("prec", i32), ("stats_out", vp),
+                ("lse_out", vp)]
 
 
 class VitLayer(C.Structure):
@@ -119,6 +120,18 @@ SYMBOLS = {
     "kx_clip_preprocess": (C.c_int, [vp, i64, i32, i32, i64, i64, C.POINTER(ResamplePlan), vp, vp, vp, vp,
                                      C.c_size_t, vp]),
     "kx_token_splice": (C.c_int, [vp, i64, i64, i64, i64, i64, i64, vp, vp, vp]),
+    "kx_transpose": (C.c_int, [vp, vp, i64, i64, i64, i64, i32, vp]),
+    "kx_colsum_workspace_bytes": (C.c_size_t, [i64, i64]),
+    "kx_colsum": (C.c_int, [vp, i64, i64, i64, vp, i32, vp, C.c_size_t, vp]),
+    "kx_layernorm_backward_workspace_bytes": (C.c_size_t, [i64, i64]),
+    "kx_layernorm_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, vp, C.c_size_t, vp]),
+    "kx_gelu_backward": (C.c_int, [vp, vp, vp, i64, vp]),
+    "kx_cross_entropy": (C.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, vp]),
+    "kx_reduce_sum": (C.c_int, [vp, i64, i32, vp, i32, vp, C.c_size_t, vp]),
+    "kx_xpos_backward": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, f32, vp]),
+    "kx_embed_backward": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, vp, vp, vp]),
+    "kx_adamw": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, f32, vp]),
+    "kx_attention_backward": (C.c_int, [vp] * 10 + [i64] * 7 + [i32, vp]),
 }
 
 

@@ -1,0 +1,119 @@
+"""Thin wrappers over the backward / optimizer entry points of libkosmosx_hip.so (training step).
+fp32 CUDA tensors in, fp32 CUDA tensors out; no CPU fallback (the library call fails loudly on anything else)."""
+from __future__ import annotations
+
+import torch
+
+from . import _hip as H
+from .ops import _need_cuda, _stream
+
+
+def _ws(nbytes: int, dev) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 4096), dtype=torch.uint8, device=dev)
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    """[R,C] -> [C,R] contiguous (fp32 or bf16)."""
+    _need_cuda(x)
+    R, Cc = x.shape
+    out = torch.empty((Cc, R), dtype=x.dtype, device=x.device)
+    dt = H.KX_F32 if x.dtype == torch.float32 else H.KX_BF16
+    H.check(H.load().kx_transpose(H.ptr(x), H.ptr(out), R, Cc, x.stride(0), R, dt, _stream()), "kx_transpose")
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+    _need_cuda(x, out)
+    R, Cc = x.shape
+    if out is None:
+        out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    lib = H.load()
+    n = lib.kx_colsum_workspace_bytes(R, Cc)
+    ws = _ws(n, x.device)
+    H.check(lib.kx_colsum(H.ptr(x), R, Cc, x.stride(0), H.ptr(out), int(accumulate), H.ptr(ws), ws.numel(), _stream()),
+            "kx_colsum")
+    return out
+
+
+def layernorm_backward(x, gamma, dy, eps=1e-5, dres=None, want_param_grads=True):
+    """-> (dx, dgamma, dbeta); dres (optional) is added to dx (gradient arriving through the residual branch)."""
+    _need_cuda(x, gamma, dy, dres)
+    R, Cc = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(Cc, dtype=torch.float32, device=x.device) if want_param_grads else None
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device) if want_param_grads else None
+    lib = H.load()
+    ws = _ws(lib.kx_layernorm_backward_workspace_bytes(R, Cc), x.device)
+    H.check(lib.kx_layernorm_backward(H.ptr(x), H.ptr(gamma), H.ptr(dy), H.ptr(dres), H.ptr(dx), H.ptr(dg), H.ptr(db), R, Cc,
+                                      float(eps), H.ptr(ws), ws.numel(), _stream()), "kx_layernorm_backward")
+    return dx, dg, db
+
+
+def gelu_backward(pre, dg):
+    _need_cuda(pre, dg)
+    out = torch.empty_like(pre)
+    H.check(H.load().kx_gelu_backward(H.ptr(pre), H.ptr(dg), H.ptr(out), pre.numel(), _stream()), "kx_gelu_backward")
+    return out
+
+
+def cross_entropy(logits, target, scale, want_grad=True):
+    """logits [M,V] fp32, target [M] int64 -> (loss_rows [M], dlogits [M,V] or None)."""
+    _need_cuda(logits, target)
+    M, V = logits.shape
+    loss = torch.empty(M, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    H.check(H.load().kx_cross_entropy(H.ptr(logits), M, V, logits.stride(0), H.ptr(target), float(scale), H.ptr(loss),
+                                      H.ptr(dl), V, _stream()), "kx_cross_entropy")
+    return loss, dl
+
+
+def reduce_sum(x, squares=False, out=None, accumulate=False):
+    _need_cuda(x, out)
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = _ws(4096, x.device)
+    H.check(H.load().kx_reduce_sum(H.ptr(x), x.numel(), int(squares), H.ptr(out), int(accumulate), H.ptr(ws), ws.numel(),
+                                   _stream()), "kx_reduce_sum")
+    return out
+
+
+def xpos_backward_(dqkv, D, T, tables, qscale):
+    """In place on the fused [M,3D] gradient: undo XPos on the q and k blocks, apply the q scale."""
+    _need_cuda(dqkv)
+    M = dqkv.shape[0]
+    t = [H.ptr(x) for x in tables] if tables is not None else [0, 0, 0, 0]
+    H.check(H.load().kx_xpos_backward(H.ptr(dqkv), M, D, T, *t, float(qscale), _stream()), "kx_xpos_backward")
+    return dqkv
+
+
+def embed_backward(tokens, dx, vocab, max_pos, pos_offset=0):
+    """tokens [B,T] int64, dx [B,T,d] -> (dembed [vocab,d], dpos [max_pos,d])."""
+    _need_cuda(tokens, dx)
+    B, T, d = dx.shape
+    de = torch.empty((vocab, d), dtype=torch.float32, device=dx.device)
+    dp = torch.zeros((max_pos, d), dtype=torch.float32, device=dx.device)
+    H.check(H.load().kx_embed_backward(H.ptr(tokens), H.ptr(dx), B, T, d, vocab, pos_offset, H.ptr(de), H.ptr(dp), _stream()),
+            "kx_embed_backward")
+    return de, dp
+
+
+def adamw_(param, grad, m, v, step, lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, grad_norm_sq=None, max_norm=1.0):
+    _need_cuda(param, grad, m, v, grad_norm_sq)
+    H.check(H.load().kx_adamw(H.ptr(param), H.ptr(grad), H.ptr(m), H.ptr(v), param.numel(), float(lr), float(betas[0]),
+                              float(betas[1]), float(eps), float(weight_decay), int(step), H.ptr(grad_norm_sq),
+                              float(max_norm), _stream()), "kx_adamw")
+
+
+def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True):
+    """qkv [B*T, 3D] fp32 (q pre-scaled and XPos-rotated), out/dout [B,T,D], lse [B,H,T] -> dqkv [B*T, 3D]."""
+    _need_cuda(qkv, out, dout, lse)
+    D = Hh * 64
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, Hh, T), dtype=torch.float32, device=qkv.device)
+    es = 4
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es
+    dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * es, dqkv.data_ptr() + 2 * D * es
+    H.check(H.load().kx_attention_backward(q, k, v, H.ptr(out), H.ptr(dout), H.ptr(lse), dq, dk, dv, H.ptr(delta), B, Hh, T,
+                                           3 * D, T * 3 * D, D, T * D, H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL,
+                                           _stream()), "kx_attention_backward")
+    return dqkv

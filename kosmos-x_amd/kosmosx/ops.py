@@ -92,7 +92,7 @@ def row_stats_finalize(partials, seg_size, eps=1e-5):
     return out
 
 
-def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=False):
+def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=False, lse_out=None):
     """q [B,Tq,H,64], k/v [B,Tk,H,64] (any row/batch strides, last two dims contiguous) -> [B,Tq,H*64]
     (out_x3, fp32 inputs only: KX_BF16X3 rows [hi | hi | lo], [B,Tq,3*H*64] bf16)."""
     _need_cuda(q, k, v)
@@ -111,6 +111,7 @@ def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=Fals
     a.B, a.H, a.Tq, a.Tk = B, Hh, Tq, Tk
     a.mask, a.prec = (H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL), prec
     a.stats_out = H.ptr(stats_out)
+    a.lse_out = H.ptr(lse_out)
     H.check(H.load().kx_attention(C.byref(a), _stream()), "kx_attention")
     return out
 

@@ -1,0 +1,132 @@
+"""Backward / optimizer kernels against torch autograd on the CPU, fp32, through the C ABI."""
+import math
+
+import pytest
+import torch
+
+from kosmosx import grad_ops as G
+from kosmosx import ops
+from helpers import rel_err
+from oracle import kosmos_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("shape,dt", [((70, 130), torch.float32), ((257, 64), torch.bfloat16), ((1, 5), torch.float32)])
+def test_transpose(shape, dt):
+    x = torch.randn(*shape, generator=_g(1)).to(dt)
+    assert torch.equal(G.transpose(x.to(DEV)).cpu(), x.t().contiguous())
+
+
+@pytest.mark.parametrize("shape", [(1, 7), (700, 130), (5000, 64)])
+def test_colsum(shape):
+    x = torch.randn(*shape, generator=_g(2))
+    out = G.colsum(x.to(DEV))
+    assert rel_err(out, x.double().sum(0).float()) < 1e-5
+    out2 = G.colsum(x.to(DEV), out=out, accumulate=True)
+    assert rel_err(out2, 2 * x.double().sum(0).float()) < 1e-5
+    assert torch.equal(G.colsum(x.to(DEV)), G.colsum(x.to(DEV)))           # deterministic
+
+
+@pytest.mark.parametrize("rows,cols", [(3, 64), (114, 2048), (1000, 256)])
+def test_layernorm_backward(rows, cols):
+    g = _g(3)
+    x = (torch.randn(rows, cols, generator=g) * 2 + 0.5).requires_grad_()
+    gam, bet = torch.randn(cols, generator=g).requires_grad_(), torch.randn(cols, generator=g).requires_grad_()
+    dy, dres = torch.randn(rows, cols, generator=g), torch.randn(rows, cols, generator=g)
+    y = torch.nn.functional.layer_norm(x, (cols,), gam, bet, 1e-5)
+    (y * dy).sum().backward()
+    dx, dg, db = G.layernorm_backward(x.detach().to(DEV), gam.detach().to(DEV), dy.to(DEV), dres=dres.to(DEV))
+    assert rel_err(dx, x.grad + dres) < 2e-5
+    assert rel_err(dg, gam.grad) < 2e-5 and rel_err(db, bet.grad) < 2e-5
+
+
+def test_gelu_backward_and_cross_entropy_and_sum():
+    g = _g(4)
+    pre = (torch.randn(50, 300, generator=g) * 2).requires_grad_()
+    dg = torch.randn(50, 300, generator=g)
+    (torch.nn.functional.gelu(pre) * dg).sum().backward()
+    assert rel_err(G.gelu_backward(pre.detach().to(DEV), dg.to(DEV)), pre.grad) < 1e-5
+    logits = (torch.randn(37, 1002, generator=g) * 3).requires_grad_()
+    tgt = torch.randint(0, 1002, (37,), generator=g)
+    tgt[5] = -100                                                   # ignore_index
+    loss = torch.nn.functional.cross_entropy(logits, tgt, ignore_index=-100, reduction="sum")
+    (loss / 36).backward()
+    lr, dl = G.cross_entropy(logits.detach().to(DEV), tgt.to(DEV), 1.0 / 36)
+    assert abs(float(G.reduce_sum(lr)) - float(loss)) < 1e-3 * abs(float(loss))
+    assert rel_err(dl, logits.grad) < 1e-5 and float(lr[5]) == 0.0
+    x = torch.randn(100003, generator=g)
+    assert abs(float(G.reduce_sum(x.to(DEV), squares=True)) - float((x.double() ** 2).sum())) < 1e-2
+
+
+def test_xpos_backward():
+    g = _g(5)
+    B, T, Hh = 2, 9, 2
+    D = Hh * 64
+    raw = torch.randn(B * T, 3 * D, generator=g).requires_grad_()
+    qc, qs = O.xpos_tables(T, 64, 512, 0, False)
+    kc, ks = O.xpos_tables(T, 64, 512, 0, True)
+    q = (raw[:, :D] * 0.125).view(B, T, Hh, 64).transpose(1, 2).reshape(B * Hh, T, 64)
+    k = raw[:, D:2 * D].view(B, T, Hh, 64).transpose(1, 2).reshape(B * Hh, T, 64)
+    q2 = O.apply_xpos(q, qc, qs).view(B, Hh, T, 64).transpose(1, 2).reshape(B * T, D)
+    k2 = O.apply_xpos(k, kc, ks).view(B, Hh, T, 64).transpose(1, 2).reshape(B * T, D)
+    outp = torch.cat([q2, k2, raw[:, 2 * D:]], 1)
+    dy = torch.randn(B * T, 3 * D, generator=g)
+    (outp * dy).sum().backward()
+    tabs = [t.contiguous().to(DEV) for t in (qc, qs, kc, ks)]
+    got = G.xpos_backward_(dy.clone().to(DEV), D, T, tabs, 0.125)
+    assert rel_err(got, raw.grad) < 1e-5
+
+
+def test_embed_backward_and_adamw():
+    g = _g(6)
+    B, T, d, V, P = 3, 7, 64, 50, 32
+    tok = torch.randint(0, V, (B, T), generator=g)
+    emb = torch.randn(V, d, generator=g).requires_grad_()
+    pos = torch.randn(P, d, generator=g).requires_grad_()
+    x = emb[tok] + pos[2:2 + T][None]
+    dx = torch.randn(B, T, d, generator=g)
+    (x * dx).sum().backward()
+    de, dp = G.embed_backward(tok.to(DEV), dx.to(DEV), V, P)
+    assert rel_err(de, emb.grad) < 1e-5 and rel_err(dp, pos.grad) < 1e-5
+    # AdamW against torch.optim.AdamW over 3 steps, with clip_grad_norm_(1.0)
+    p0 = torch.randn(1000, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    p = p0.clone().to(DEV); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g) * 3
+        ref.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        gd = gr.to(DEV)
+        G.adamw_(p, gd, m, v, step, 1e-2, (0.9, 0.95), 1e-8, 0.1, grad_norm_sq=G.reduce_sum(gd, squares=True), max_norm=1.0)
+        assert rel_err(p, ref.detach()) < 1e-5, step
+
+
+@pytest.mark.parametrize("B,Hh,T,causal", [(2, 2, 9, True), (1, 3, 114, True), (2, 1, 130, False), (1, 2, 200, True)])
+def test_attention_backward(B, Hh, T, causal):
+    g = _g(7 + T)
+    D = Hh * 64
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 0.5).requires_grad_()
+    q, k, v = (qkv[:, i * D:(i + 1) * D].reshape(B, T, Hh, 64).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.triu(torch.full((T, T), float("-inf")), 1)
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, D)
+    do = torch.randn(B, T, D, generator=g)
+    (o * do).sum().backward()
+    qd = qkv.detach().to(DEV)
+    q3, k3, v3 = (qd[:, i * D:(i + 1) * D].unflatten(0, (B, T)).unflatten(2, (Hh, 64)) for i in range(3))
+    lse = torch.empty(B, Hh, T, device=DEV)
+    og = ops.attention(q3, k3, v3, causal, lse_out=lse)
+    assert rel_err(og, o.detach()) < 2e-5
+    ref_lse = torch.logsumexp(s.detach(), -1)
+    assert rel_err(lse, ref_lse) < 1e-5
+    dqkv = G.attention_backward(qd, og, do.to(DEV), lse, B, T, Hh, causal)
+    assert rel_err(dqkv, qkv.grad) < 3e-5
