@@ -350,7 +350,8 @@ size_t kx_layernorm_backward_workspace_bytes(int64_t rows, int64_t cols);
 int kx_layernorm_backward(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                           float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps, void* workspace,
                           size_t workspace_bytes, void* stream);
-/* exact (erf) GELU: dpre = dg * (Phi(pre) + pre*phi(pre)) */
+/* exact (erf) GELU forward on a kept pre-activation, and its backward: dpre = dg * (Phi(pre) + pre*phi(pre)) */
+int kx_gelu_forward(const float* pre, float* out, int64_t n, void* stream);
 int kx_gelu_backward(const float* pre, const float* dg, float* dpre, int64_t n, void* stream);
 /* F.cross_entropy rows: loss_rows[r] = logsumexp(logits[r]) - logits[r][target[r]] (0 for targets outside [0,V):
  * ignore_index); dlogits (optional) = (softmax - onehot) * scale. */

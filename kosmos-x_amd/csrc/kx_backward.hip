@@ -112,6 +112,12 @@ __global__ __launch_bounds__(256) void ln_bwd_param_final_kernel(const float* __
   dgamma[c] = sg; dbeta[c] = sb;
 }
 
+// ---- GELU (erf) forward on a saved pre-activation (the training forward keeps both) ----
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = gelu_erf(pre[i]);
+}
+
 // ---- GELU (erf) backward: dpre = dg * (Phi(x) + x*phi(x)) ----
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dg,
                                                        float* __restrict__ dpre, long long n) {
@@ -487,6 +493,15 @@ extern "C" int kx_layernorm_backward(const float* x, const float* gamma, const f
 
 extern "C" size_t kx_layernorm_backward_workspace_bytes(int64_t rows, int64_t cols) {
   return (((size_t)rows * 8 + 255) & ~(size_t)255) + (size_t)slices_for(rows) * 2 * (size_t)cols * 4 + 256;
+}
+
+extern "C" int kx_gelu_forward(const float* pre, float* out, int64_t n, void* stream) {
+  KX_REQUIRE(pre && out && n > 0, "kx_gelu_forward: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, n, 0, 27, s);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, out, (long long)n);
+  KX_CHECK_LAUNCH("kx_gelu_forward");
+  return KX_OK;
 }
 
 extern "C" int kx_gelu_backward(const float* pre, const float* dg, float* dpre, int64_t n, void* stream) {

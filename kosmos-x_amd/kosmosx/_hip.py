@@ -125,6 +125,7 @@ SYMBOLS = {
     "kx_colsum": (C.c_int, [vp, i64, i64, i64, vp, i32, vp, C.c_size_t, vp]),
     "kx_layernorm_backward_workspace_bytes": (C.c_size_t, [i64, i64]),
     "kx_layernorm_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, vp, C.c_size_t, vp]),
+    "kx_gelu_forward": (C.c_int, [vp, vp, i64, vp]),
     "kx_gelu_backward": (C.c_int, [vp, vp, vp, i64, vp]),
     "kx_cross_entropy": (C.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, vp]),
     "kx_reduce_sum": (C.c_int, [vp, i64, i32, vp, i32, vp, C.c_size_t, vp]),

@@ -12,13 +12,22 @@ def _ws(nbytes: int, dev) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 4096), dtype=torch.uint8, device=dev)
 
 
-def transpose(x: torch.Tensor) -> torch.Tensor:
-    """[R,C] -> [C,R] contiguous (fp32 or bf16)."""
+def transpose(x: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
+    """[R,C] -> [C,Rp] (fp32 or bf16), Rp = R rounded up to a multiple of pad_to, the padding columns zero —
+    the K dimension of a GEMM operand has to be a multiple of 32 (fp32) / 64 (bf16)."""
     _need_cuda(x)
     R, Cc = x.shape
-    out = torch.empty((Cc, R), dtype=x.dtype, device=x.device)
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = (torch.zeros if Rp != R else torch.empty)((Cc, Rp), dtype=x.dtype, device=x.device)
     dt = H.KX_F32 if x.dtype == torch.float32 else H.KX_BF16
-    H.check(H.load().kx_transpose(H.ptr(x), H.ptr(out), R, Cc, x.stride(0), R, dt, _stream()), "kx_transpose")
+    H.check(H.load().kx_transpose(H.ptr(x), H.ptr(out), R, Cc, x.stride(0), Rp, dt, _stream()), "kx_transpose")
+    return out
+
+
+def gelu(pre: torch.Tensor) -> torch.Tensor:
+    _need_cuda(pre)
+    out = torch.empty_like(pre)
+    H.check(H.load().kx_gelu_forward(H.ptr(pre), H.ptr(out), pre.numel(), _stream()), "kx_gelu_forward")
     return out
 
 

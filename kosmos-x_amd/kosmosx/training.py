@@ -1,0 +1,184 @@
+"""Training step of the text decoder on the device (/root/reference/train.py:642-656):
+
+    loss = CE(model(input_ids)[:, :-1], input_ids[:, 1:]);  backward;  clip_grad_norm_(1.0);  AdamW step
+
+First slice: `KosmosLanguage` (the decoder-only path), one GPU, fp32 arithmetic end to end (exact-f32 MFMA GEMMs and
+attention, fp32 activations, gradients and optimizer state) so that every gradient can be held against autograd
+(`tests/test_training_gpu.py`).  Every tensor operation is a kernel of libkosmosx_hip.so reached through the C ABI:
+the forward reuses the inference kernels op by op (keeping what the backward needs), the backward's matrix products
+are the same GEMM kernel on transposed operands, the rest is csrc/kx_backward.hip.  Optimizer semantics follow
+train.py:257-410 as intended there: AdamW, betas (0.9, 0.95), weight decay 0.1 on Linear weights and none on
+LayerNorm / embedding / bias parameters, lr 1e-4, gradient-norm clip 1.0.  (As written, the reference's name matching
+leaves everything but the Linear weights out of the optimizer; that quirk is not reproduced.)
+No CPU fallback; Python only sequences launches.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import grad_ops as G
+from . import ops
+from .model import KosmosLanguage, _a
+
+
+class LanguageModelTrainer:
+    def __init__(self, model: KosmosLanguage, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8,
+                 weight_decay: float = 0.1, max_grad_norm: float = 1.0):
+        if not next(model.parameters()).is_cuda:
+            raise RuntimeError("LanguageModelTrainer needs the model on a HIP device: there is no CPU fallback")
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.weight_decay, self.max_grad_norm = weight_decay, max_grad_norm
+        self.step_no = 0
+        self.state = {}          # id(param) -> (m, v)
+        self.grads = {}          # name -> gradient tensor of the last step (kept for inspection / tests)
+
+    # ------------------------------------------------------------------ parameters
+    def _layer_params(self, L):
+        sa, ffn = L.self_attn, _a(L.ffn)
+        return dict(sa_ln=_a(L.self_attn_layer_norm), q=_a(sa.q_proj), k=_a(sa.k_proj), v=_a(sa.v_proj),
+                    inner_ln=_a(sa.inner_attn_ln) if sa.inner_attn_ln is not None else None, o=_a(sa.out_proj),
+                    fl_ln=_a(L.final_layer_norm), fc1=ffn.fc1, fc2=ffn.fc2,
+                    ffn_ln=ffn.ffn_layernorm if getattr(ffn, "ffn_layernorm", None) is not None else None)
+
+    # ------------------------------------------------------------------ one step
+    def step(self, tokens: torch.Tensor, apply_update: bool = True) -> torch.Tensor:
+        """tokens [B,T] int64 on the device.  Returns the mean next-token cross-entropy (a device scalar)."""
+        m, dec = self.model, self.model.decoder
+        a = dec.args
+        B, T = tokens.shape
+        D, F, Hh, V = a.decoder_embed_dim, a.decoder_ffn_embed_dim, a.decoder_attention_heads, a.vocab_size
+        M, eps = B * T, 1e-5
+        dev = tokens.device
+        tokens = tokens.long().contiguous()
+        grads = self.grads = {}
+
+        def lin(x, w, b=None, **kw):                      # x [M,K] fp32 · w[N,K]ᵀ (+ b) — exact-f32 MFMA
+            return ops.gemm(x, w.detach(), None if b is None else b.detach(), **kw)
+
+        # ---------------- forward, keeping what the backward needs ----------------
+        x = ops.embed_splice(tokens, m.embed.weight.detach(), m.embed_positions.weight.detach()).reshape(M, D)
+        xp = dec.layers[0].self_attn.xpos
+        tabs = None
+        if xp is not None:
+            tabs = [t.to(dev) for t in (*xp.tables(T, 0, False), *xp.tables(T, 0, True))]
+        saved = []
+        for L in dec.layers:
+            P = self._layer_params(L)
+            s = {"x_in": x}
+            h1 = ops.layernorm(x, P["sa_ln"].weight.detach(), P["sa_ln"].bias.detach(), eps)
+            wqkv = torch.cat([P["q"].weight, P["k"].weight, P["v"].weight], 0).detach()
+            bqkv = torch.cat([P["q"].bias, P["k"].bias, P["v"].bias], 0).detach()
+            qkv = ops.gemm(h1, wqkv, bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0)
+            q3, k3, v3 = (qkv[:, i * D:(i + 1) * D].unflatten(0, (B, T)).unflatten(2, (Hh, 64)) for i in range(3))
+            lse = torch.empty((B, Hh, T), dtype=torch.float32, device=dev)
+            att = ops.attention(q3, k3, v3, True, lse_out=lse).reshape(M, D)
+            a_n = att if P["inner_ln"] is None else ops.layernorm(att, P["inner_ln"].weight.detach(),
+                                                                   P["inner_ln"].bias.detach(), eps)
+            x = lin(a_n, P["o"].weight, P["o"].bias, residual=x)
+            h2 = ops.layernorm(x, P["fl_ln"].weight.detach(), P["fl_ln"].bias.detach(), eps)
+            pre = lin(h2, P["fc1"].weight, P["fc1"].bias)
+            g = G.gelu(pre)
+            g_n = g if P["ffn_ln"] is None else ops.layernorm(g, P["ffn_ln"].weight.detach(), P["ffn_ln"].bias.detach(), eps)
+            s.update(h1=h1, wqkv=wqkv, qkv=qkv, lse=lse, att=att, a_n=a_n, x_mid=x, h2=h2, pre=pre, g=g, g_n=g_n)
+            x = lin(g_n, P["fc2"].weight, P["fc2"].bias, residual=x)
+            saved.append(s)
+        hf = ops.layernorm(x, dec.layer_norm.weight.detach(), dec.layer_norm.bias.detach(), eps)
+        Vp = (V + 31) // 32 * 32                           # dlogits is a GEMM operand over V in the backward pass
+        logits = torch.zeros((M, Vp), dtype=torch.float32, device=dev)
+        ops.gemm(hf, m.output_projection.weight.detach(), out=logits[:, :V])
+
+        # ---------------- loss: next-token cross-entropy over the B*(T-1) predicting positions ----------------
+        target = torch.full((B, T), -100, dtype=torch.int64, device=dev)
+        target[:, :-1] = tokens[:, 1:]
+        count = B * (T - 1)
+        dlogits = torch.zeros((M, Vp), dtype=torch.float32, device=dev)
+        loss_rows, _ = G.cross_entropy(logits[:, :V], target.reshape(M), 1.0 / count, want_grad=False)
+        self._ce_grad(logits, target.reshape(M), 1.0 / count, dlogits, V)
+        loss = G.reduce_sum(loss_rows) / count
+
+        # ---------------- backward ----------------
+        def dgrad(dy, w):                                  # dX = dY · W          (W [N,K] -> operand Wᵀ [K, Np])
+            return ops.gemm(dy, G.transpose(w.detach(), 32))
+
+        def wgrad(dy, xin):                                # dW = dYᵀ · X         (both transposed, M padded to 32)
+            return ops.gemm(G.transpose(dy, 32), G.transpose(xin, 32))
+
+        grads["output_projection.weight"] = wgrad(dlogits, hf)[:V]
+        dh = ops.gemm(dlogits, G.transpose(m.output_projection.weight.detach(), 32))
+        dx, grads["decoder.layer_norm.weight"], grads["decoder.layer_norm.bias"] = G.layernorm_backward(
+            x, dec.layer_norm.weight.detach(), dh, eps)
+        for li in range(len(dec.layers) - 1, -1, -1):
+            L, s = dec.layers[li], saved[li]
+            P, pfx = self._layer_params(L), f"decoder.layers.{li}."
+            mw = ".A" if a.multiway else ""
+            # x_out = x_mid + fc2(ffn_ln(gelu(fc1(fl_ln(x_mid)))))
+            grads[pfx + f"ffn{mw}.fc2.weight"] = wgrad(dx, s["g_n"])
+            grads[pfx + f"ffn{mw}.fc2.bias"] = G.colsum(dx)
+            dgn = dgrad(dx, P["fc2"].weight)
+            if P["ffn_ln"] is not None:
+                dg, grads[pfx + f"ffn{mw}.ffn_layernorm.weight"], grads[pfx + f"ffn{mw}.ffn_layernorm.bias"] = \
+                    G.layernorm_backward(s["g"], P["ffn_ln"].weight.detach(), dgn, eps)
+            else:
+                dg = dgn
+            dpre = G.gelu_backward(s["pre"], dg)
+            grads[pfx + f"ffn{mw}.fc1.weight"] = wgrad(dpre, s["h2"])
+            grads[pfx + f"ffn{mw}.fc1.bias"] = G.colsum(dpre)
+            dh2 = dgrad(dpre, P["fc1"].weight)
+            dx, grads[pfx + f"final_layer_norm{mw}.weight"], grads[pfx + f"final_layer_norm{mw}.bias"] = \
+                G.layernorm_backward(s["x_mid"], P["fl_ln"].weight.detach(), dh2, eps, dres=dx)
+            # x_mid = x_in + out_proj(inner_ln(attention(xpos(q), xpos(k), v)))
+            grads[pfx + f"self_attn.out_proj{mw}.weight"] = wgrad(dx, s["a_n"])
+            grads[pfx + f"self_attn.out_proj{mw}.bias"] = G.colsum(dx)
+            dan = dgrad(dx, P["o"].weight)
+            if P["inner_ln"] is not None:
+                datt, grads[pfx + f"self_attn.inner_attn_ln{mw}.weight"], grads[pfx + f"self_attn.inner_attn_ln{mw}.bias"] = \
+                    G.layernorm_backward(s["att"], P["inner_ln"].weight.detach(), dan, eps)
+            else:
+                datt = dan
+            dqkv = G.attention_backward(s["qkv"], s["att"].reshape(B, T, D), datt.reshape(B, T, D), s["lse"], B, T, Hh, True)
+            G.xpos_backward_(dqkv, D, T, tabs, 0.125)
+            dwqkv, dbqkv = wgrad(dqkv, s["h1"]), G.colsum(dqkv)
+            for i, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                grads[pfx + f"self_attn.{nm}{mw}.weight"] = dwqkv[i * D:(i + 1) * D]
+                grads[pfx + f"self_attn.{nm}{mw}.bias"] = dbqkv[i * D:(i + 1) * D]
+            dh1 = dgrad(dqkv, s["wqkv"])
+            dx, grads[pfx + f"self_attn_layer_norm{mw}.weight"], grads[pfx + f"self_attn_layer_norm{mw}.bias"] = \
+                G.layernorm_backward(s["x_in"], P["sa_ln"].weight.detach(), dh1, eps, dres=dx)
+        de, dp = G.embed_backward(tokens, dx.reshape(B, T, D), V, m.embed_positions.weight.shape[0])
+        de[m.embed.padding_idx].zero_() if m.embed.padding_idx is not None else None   # nn.Embedding(padding_idx) has no gradient there
+        grads["embed.weight"], grads["embed_positions.weight"] = de, dp
+
+        if apply_update:
+            self._update(grads)
+        return loss
+
+    def _ce_grad(self, logits, target, scale, dlogits, V):
+        from . import _hip as H
+        from .ops import _stream
+        M = logits.shape[0]
+        scratch = torch.empty(M, dtype=torch.float32, device=logits.device)
+        H.check(H.load().kx_cross_entropy(logits.data_ptr(), M, V, logits.stride(0), target.data_ptr(), float(scale),
+                                          scratch.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), _stream()),
+                "kx_cross_entropy")
+
+    # ------------------------------------------------------------------ clip + AdamW
+    def _update(self, grads):
+        params = dict(self.model.named_parameters())
+        self.step_no += 1
+        gsq = None
+        for name, g in grads.items():
+            if name in params:
+                gsq = G.reduce_sum(g.contiguous(), squares=True, out=gsq, accumulate=gsq is not None)
+        self.grad_norm_sq = gsq
+        for name, g in grads.items():
+            p = params.get(name)
+            if p is None:
+                continue
+            st = self.state.get(name)
+            if st is None:
+                st = self.state[name] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+            is_linear_weight = name.endswith(".weight") and p.dim() == 2 and not name.startswith("embed")
+            G.adamw_(p.data, g.contiguous(), st[0], st[1], self.step_no, self.lr, self.betas, self.eps,
+                     self.weight_decay if is_linear_weight else 0.0, grad_norm_sq=gsq, max_norm=self.max_grad_norm)
+        self.model.invalidate_packed() if hasattr(self.model, "invalidate_packed") else None
+        self.model.decoder.invalidate_packed()

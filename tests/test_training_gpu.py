@@ -1,0 +1,80 @@
+"""Training step on the device against autograd + torch.optim.AdamW on the CPU oracle: the loss,
+EVERY parameter gradient, and the parameters after two clipped AdamW steps."""
+import pytest
+import torch
+
+from kosmosx.model import KosmosLanguage
+from kosmosx.training import LanguageModelTrainer
+from oracle import kosmos_oracle as O
+from oracle import train_oracle as TO
+from helpers import oracle_weights, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tiny_lm(seed=1):
+    return KosmosLanguage(vocab_size=1002, dim=256, depth=2, ffn_dim=512, decoder_heads=4, _seed=seed, _perturb=0.1,
+                          _max_positions=128).eval()
+
+
+def _leaf_weights(lm):
+    w = {k: v.clone().requires_grad_() for k, v in oracle_weights(lm).items()}
+    if "decoder.embed_tokens.weight" in w:            # tied alias of embed.weight: one leaf
+        w.pop("decoder.embed_tokens.weight")
+    for k in [k for k in w if k.startswith("decoder.embed_positions") or k.startswith("decoder.output_projection")]:
+        w.pop(k)
+    return w
+
+
+@pytest.mark.parametrize("B,T", [(3, 20), (2, 70)])
+def test_loss_and_every_gradient_match_autograd(B, T):
+    lm = _tiny_lm()
+    tok = torch.randint(2, 1002, (B, T), generator=torch.Generator().manual_seed(B))
+    tok[0, 3] = 1                                             # a padding token in the inputs / targets
+    cfg = O.DecoderCfg(layers=2, dim=256, ffn=512, heads=4, vocab=1002, max_pos=128)
+    w = _leaf_weights(lm)
+    ref_loss = TO.lm_loss(w, tok, cfg)
+    TO.backward(ref_loss, w)
+    tr = LanguageModelTrainer(lm.to(DEV))
+    loss = tr.step(tok.to(DEV), apply_update=False)
+    assert abs(float(loss) - float(ref_loss.detach())) < 2e-5 * abs(float(ref_loss.detach())), (float(loss), float(ref_loss.detach()))
+    names = dict(lm.named_parameters()).keys()
+    checked, errs = 0, {}
+    for name in names:
+        if ".B." in name:
+            continue
+        g_ref = w[name].grad
+        assert name in tr.grads, name
+        e = rel_err(tr.grads[name], g_ref)
+        errs[name] = e
+        checked += 1
+    bad = {k: v for k, v in errs.items() if not v < 2e-4}
+    assert not bad, bad
+    assert checked >= 2 * 18 + 5
+
+
+def test_two_clipped_adamw_steps_match_torch():
+    lm = _tiny_lm(seed=2)
+    cfg = O.DecoderCfg(layers=2, dim=256, ffn=512, heads=4, vocab=1002, max_pos=128)
+    w = _leaf_weights(lm)
+    opt = TO.make_optimizer(w, lr=1e-3)
+    tr = LanguageModelTrainer(lm.to(DEV), lr=1e-3)
+    g = torch.Generator().manual_seed(9)
+    for step in range(2):
+        tok = torch.randint(2, 1002, (2, 24), generator=g)
+        ref_loss = TO.train_step(w, opt, tok, cfg)
+        loss = tr.step(tok.to(DEV))
+        assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss)), step
+    params = dict(lm.named_parameters())
+    # Adam's first steps move every element by ~lr * sign(g): an element whose gradient is rounding noise around zero
+    # can legitimately step the other way, so the bound is RMS-based, with the worst element capped by 2 * lr * steps.
+    for n in w:
+        if n not in params:
+            continue
+        d = params[n].detach().cpu() - w[n].detach()
+        assert float(d.pow(2).mean().sqrt() / w[n].detach().pow(2).mean().sqrt()) < 2e-5, n
+        assert float(d.abs().max()) <= 2.1 * 1e-3 * 2, n
+    # and the updated model still runs the inference path (packed copies were invalidated)
+    out = lm(tok.to(DEV))
+    assert out.shape == (2, 24, 1002) and torch.isfinite(out).all()
