@@ -1,0 +1,70 @@
+"""Training step of the text decoder (BASELINE configs[4] on one GPU): tokens/s of
+forward + backward + clip + AdamW on synthetic token batches, full-size 24L/2048d decoder, fp32 arithmetic
+(the first slice's precision), with the kernel-class breakdown and a bounded CPU sample of the oracle's step."""
+import argparse, json, os, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "kosmos-x_amd"), str(ROOT / "tests")]
+os.environ.setdefault("KOSMOSX_NO_LOGGING_CONFIG", "1")
+import torch
+from kosmosx import _hip
+from kosmosx.model import KosmosLanguage
+from kosmosx.training import LanguageModelTrainer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--seq", type=int, default=512)
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--layers", type=int, default=24)
+ap.add_argument("--cpu-seconds", type=float, default=20.0)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+lm = KosmosLanguage(vocab_size=32002, dim=2048, depth=a.layers, _seed=0).eval().to(dev)
+tr = LanguageModelTrainer(lm)
+g = torch.Generator().manual_seed(0)
+batches = [torch.randint(2, 32002, (a.batch, a.seq), generator=g).to(dev) for _ in range(a.warmup + a.steps + 1)]
+losses = []
+for i in range(a.warmup):
+    losses.append(float(tr.step(batches[i])))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(a.warmup, a.warmup + a.steps):
+    loss = tr.step(batches[i])
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+losses.append(float(loss))
+_hip.prof_enable(True)
+tr.step(batches[-1])
+torch.cuda.synchronize()
+recs = _hip.prof_collect()
+_hip.prof_enable(False)
+agg = {}
+for kind, x, y, z, ms in recs:
+    e = agg.setdefault(kind, [0, 0.0, 0.0]); e[0] += 1; e[1] += ms
+    if "gemm" in str(kind):
+        e[2] += 2.0 * x * y * z
+nparams = sum(p.numel() for p in lm.parameters())
+tokens = a.batch * a.seq
+flops = 6.0 * (nparams - 32002 * 2048 - lm.embed_positions.weight.numel()) * tokens   # matmul parameters x 6 (fwd + 2x bwd)
+res = {"workload": f"KosmosLanguage train step (fwd+bwd+clip+AdamW), {a.layers}L/2048d, B={a.batch} T={a.seq}, fp32",
+       "ms_per_step": round(dt * 1e3, 1), "tokens_per_s": round(tokens / dt, 1), "losses": [round(l, 4) for l in losses],
+       "approx_model_tflops": round(flops / dt / 1e12, 1),
+       "kernels_ms": {k: {"n": v[0], "ms": round(v[1], 1), **({"tflops": round(v[2] / v[1] / 1e9, 1)} if v[2] else {})}
+                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+# bounded CPU sample: the oracle's step (autograd + torch.optim.AdamW) on one short sequence of the same model
+if a.cpu_seconds > 0:
+    from oracle import kosmos_oracle as O
+    from oracle import train_oracle as TO
+    from helpers import oracle_weights
+    cfg = O.DecoderCfg(layers=a.layers, vocab=32002)
+    w = {k: v.clone().requires_grad_() for k, v in oracle_weights(lm).items()
+         if not (k.startswith("decoder.embed_") or k.startswith("decoder.output_projection"))}
+    opt = TO.make_optimizer(w)
+    ctok = batches[0][:1, :128].cpu()
+    n, t_cpu = 0, 0.0
+    while t_cpu < a.cpu_seconds and n < 8:
+        t1 = time.perf_counter(); TO.train_step(w, opt, ctok, cfg); t_cpu += time.perf_counter() - t1; n += 1
+    res["cpu_baseline"] = {"value": round(n * 128 / t_cpu, 1), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"{n} x train step on 1x128 tokens, fp32 torch autograd + AdamW on the oracle, {t_cpu:.1f} s"}
+print(json.dumps(res))
