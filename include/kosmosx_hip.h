@@ -340,6 +340,12 @@ int kx_token_splice(const int64_t* texts, int64_t B, int64_t L, int64_t im_idx, 
 /* dst[c][r] = src[r][c]; dt = KX_F32 or KX_BF16 */
 int kx_transpose(const void* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, int32_t dt,
                  void* stream);
+/* fp32 matrix [rows, cols] -> bf16 GEMM operand: O = transpose ? src^T : src, its K (column) dimension zero-padded to kp
+ * (a multiple of 8; use 64 for kx_gemm), format fmt: 1 = bf16 rows [kp]; 2 / 3 = bf16x3 activation rows [hi|hi|lo] /
+ * weight rows [hi|lo|hi], each 3*kp wide (kx_precision doc).  Mixed-precision training: fp32 master weights,
+ * activations and gradients become operands right before each product. */
+int kx_to_operand(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t kp, int32_t transpose,
+                  int32_t fmt, void* stream);
 /* out[c] (+)= sum_r x[r][c] (bias gradients) */
 size_t kx_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int kx_colsum(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, int32_t accumulate, void* workspace,

@@ -26,6 +26,45 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
   }
 }
 
+// ---- fp32 matrix -> GEMM operand: optional transpose, K padded with zeros to `kp`, format bf16 or one of the two
+//      bf16x3 row layouts (activation [hi|hi|lo], weight [hi|lo|hi]; split_bf16x2 in kx_common.h) ----
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void to_operand_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                         long long rows, long long cols, long long ld_src, long long kp,
+                                                         int fmt) {
+  // output matrix O = TRANSPOSE ? srcT : src, shape [orows, ocols], ocols padded to kp
+  __shared__ float tile[64][65];
+  const long long orows = TRANSPOSE ? cols : rows, ocols = TRANSPOSE ? rows : cols;
+  const long long or0 = (long long)blockIdx.y * 64, oc0 = (long long)blockIdx.x * 64;   // tile of O (oc0 < kp)
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    float v = 0.f;
+    if (TRANSPOSE) {                         // O[or0 + tx'][oc0 + i'] = src[oc0 + i][or0 + tx]: read rows of src
+      const long long r = oc0 + i, c = or0 + tx;
+      if (r < rows && c < cols) v = src[r * ld_src + c];
+      tile[i][tx] = v;                       // tile[k-index][o-row]
+    } else {
+      const long long r = or0 + i, c = oc0 + tx;
+      if (r < rows && c < cols) v = src[r * ld_src + c];
+      tile[i][tx] = v;                       // tile[o-row][k-index]
+    }
+  }
+  __syncthreads();
+  const long long pitch = (fmt == 1 ? 1 : 3) * kp;
+  for (int i = ty; i < 64; i += 4) {
+    const long long orow = or0 + i, oc = oc0 + tx;
+    if (orow >= orows || oc >= kp) continue;
+    const float v = (oc < ocols) ? (TRANSPOSE ? tile[tx][i] : tile[i][tx]) : 0.f;
+    const bf16_t hi = f32_to_bf16(v);
+    bf16_t* o = dst + orow * pitch + oc;
+    if (fmt == 1) { o[0] = hi; continue; }
+    const bf16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
+    o[0] = hi;
+    o[kp] = fmt == 2 ? hi : lo;              // activation [hi|hi|lo], weight [hi|lo|hi]
+    o[2 * kp] = fmt == 2 ? lo : hi;
+  }
+}
+
 // ---- column sums: out[c] = sum_r x[r][c] over row slices (stage 1), slices summed in order (stage 2) ----
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long rows, long long cols,
                                                              long long ld, int rows_per_slice, float* __restrict__ part) {
@@ -440,6 +479,26 @@ extern "C" int kx_transpose(const void* src, void* dst, int64_t rows, int64_t co
     hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, (long long)rows,
                        (long long)cols, (long long)ld_src, (long long)ld_dst);
   KX_CHECK_LAUNCH("kx_transpose");
+  return KX_OK;
+}
+
+extern "C" int kx_to_operand(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t kp,
+                             int32_t transpose, int32_t fmt, void* stream) {
+  KX_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols, "kx_to_operand: bad arguments");
+  KX_REQUIRE(fmt >= 1 && fmt <= 3, "kx_to_operand: fmt 1 = bf16, 2 = bf16x3 activation rows, 3 = bf16x3 weight rows");
+  const int64_t orows = transpose ? cols : rows, ocols = transpose ? rows : cols;
+  KX_REQUIRE(kp >= ocols && kp % 8 == 0, "kx_to_operand: kp=%lld must cover the %lld K values and be a multiple of 8",
+             (long long)kp, (long long)ocols);
+  const dim3 grid((unsigned)((kp + 63) / 64), (unsigned)((orows + 63) / 64));
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, rows, cols, 28, s);
+  if (transpose)
+    hipLaunchKernelGGL(to_operand_kernel<true>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (long long)rows, (long long)cols,
+                       (long long)ld_src, (long long)kp, fmt);
+  else
+    hipLaunchKernelGGL(to_operand_kernel<false>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (long long)rows, (long long)cols,
+                       (long long)ld_src, (long long)kp, fmt);
+  KX_CHECK_LAUNCH("kx_to_operand");
   return KX_OK;
 }
 

@@ -24,6 +24,22 @@ def transpose(x: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
     return out
 
 
+FMT = {"bf16": 1, "bf16x3_act": 2, "bf16x3_w": 3}
+
+
+def to_operand(x: torch.Tensor, fmt: str, transpose_: bool = False) -> torch.Tensor:
+    """fp32 [R,C] -> bf16 GEMM operand of (x^T if transpose_ else x): K padded to a multiple of 64 with zeros, rows
+    [K] (bf16) or [3K] (bf16x3: activation rows hi|hi|lo, weight rows hi|lo|hi)."""
+    _need_cuda(x)
+    R, Cc = x.shape
+    orows, ocols = (Cc, R) if transpose_ else (R, Cc)
+    kp = (ocols + 63) // 64 * 64
+    out = torch.empty((orows, kp if fmt == "bf16" else 3 * kp), dtype=torch.bfloat16, device=x.device)
+    H.check(H.load().kx_to_operand(H.ptr(x), H.ptr(out), R, Cc, x.stride(0), kp, int(transpose_), FMT[fmt], _stream()),
+            "kx_to_operand")
+    return out
+
+
 def gelu(pre: torch.Tensor) -> torch.Tensor:
     _need_cuda(pre)
     out = torch.empty_like(pre)

@@ -2,9 +2,11 @@
 
     loss = CE(model(input_ids)[:, :-1], input_ids[:, 1:]);  backward;  clip_grad_norm_(1.0);  AdamW step
 
-First slice: `KosmosLanguage` (the decoder-only path), one GPU, fp32 arithmetic end to end (exact-f32 MFMA GEMMs and
-attention, fp32 activations, gradients and optimizer state) so that every gradient can be held against autograd
-(`tests/test_training_gpu.py`).  Every tensor operation is a kernel of libkosmosx_hip.so reached through the C ABI:
+First slice: `KosmosLanguage` (the decoder-only path), one GPU.  Master weights, activations, gradients, attention and
+optimizer state are fp32; `precision` picks the arithmetic of the matrix products: "fp32" (exact-f32 MFMA — every
+gradient can be held against autograd at 1e-4), "bf16x3" (bf16 MFMA on split hi/lo operands: fp32-class gradients at
+3x the bf16 work) or "bf16" (plain mixed precision).  In the bf16 modes every fp32 matrix becomes an operand right
+before its product (`kx_to_operand`: cast or split, optional transpose, K padded to 64).  Every tensor operation is a kernel of libkosmosx_hip.so reached through the C ABI:
 the forward reuses the inference kernels op by op (keeping what the backward needs), the backward's matrix products
 are the same GEMM kernel on transposed operands, the rest is csrc/kx_backward.hip.  Optimizer semantics follow
 train.py:257-410 as intended there: AdamW, betas (0.9, 0.95), weight decay 0.1 on Linear weights and none on
@@ -23,7 +25,10 @@ from .model import KosmosLanguage, _a
 
 class LanguageModelTrainer:
     def __init__(self, model: KosmosLanguage, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8,
-                 weight_decay: float = 0.1, max_grad_norm: float = 1.0):
+                 weight_decay: float = 0.1, max_grad_norm: float = 1.0, precision: str = "fp32"):
+        if precision not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError("precision must be fp32, bf16 or bf16x3")
+        self.precision = precision
         if not next(model.parameters()).is_cuda:
             raise RuntimeError("LanguageModelTrainer needs the model on a HIP device: there is no CPU fallback")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
@@ -52,8 +57,17 @@ class LanguageModelTrainer:
         tokens = tokens.long().contiguous()
         grads = self.grads = {}
 
-        def lin(x, w, b=None, **kw):                      # x [M,K] fp32 · w[N,K]ᵀ (+ b) — exact-f32 MFMA
-            return ops.gemm(x, w.detach(), None if b is None else b.detach(), **kw)
+        # operand makers of the chosen arithmetic: A = activation rows, W = weight rows, *T = the transposed matrix
+        if self.precision == "fp32":
+            opA = opW = lambda t: t
+            opAT = opWT = lambda t: G.transpose(t, 32)
+        else:
+            fa, fw = ("bf16", "bf16") if self.precision == "bf16" else ("bf16x3_act", "bf16x3_w")
+            opA, opW = (lambda t: G.to_operand(t, fa)), (lambda t: G.to_operand(t, fw))
+            opAT, opWT = (lambda t: G.to_operand(t, fa, True)), (lambda t: G.to_operand(t, fw, True))
+
+        def lin(x, w, b=None, **kw):                      # x [M,K] · w[N,K]ᵀ (+ b)
+            return ops.gemm(opA(x), opW(w.detach()), None if b is None else b.detach(), **kw)
 
         # ---------------- forward, keeping what the backward needs ----------------
         x = ops.embed_splice(tokens, m.embed.weight.detach(), m.embed_positions.weight.detach()).reshape(M, D)
@@ -68,7 +82,7 @@ class LanguageModelTrainer:
             h1 = ops.layernorm(x, P["sa_ln"].weight.detach(), P["sa_ln"].bias.detach(), eps)
             wqkv = torch.cat([P["q"].weight, P["k"].weight, P["v"].weight], 0).detach()
             bqkv = torch.cat([P["q"].bias, P["k"].bias, P["v"].bias], 0).detach()
-            qkv = ops.gemm(h1, wqkv, bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0)
+            qkv = ops.gemm(opA(h1), opW(wqkv), bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0)
             q3, k3, v3 = (qkv[:, i * D:(i + 1) * D].unflatten(0, (B, T)).unflatten(2, (Hh, 64)) for i in range(3))
             lse = torch.empty((B, Hh, T), dtype=torch.float32, device=dev)
             att = ops.attention(q3, k3, v3, True, lse_out=lse).reshape(M, D)
@@ -85,7 +99,7 @@ class LanguageModelTrainer:
         hf = ops.layernorm(x, dec.layer_norm.weight.detach(), dec.layer_norm.bias.detach(), eps)
         Vp = (V + 31) // 32 * 32                           # dlogits is a GEMM operand over V in the backward pass
         logits = torch.zeros((M, Vp), dtype=torch.float32, device=dev)
-        ops.gemm(hf, m.output_projection.weight.detach(), out=logits[:, :V])
+        ops.gemm(opA(hf), opW(m.output_projection.weight.detach()), out=logits[:, :V])
 
         # ---------------- loss: next-token cross-entropy over the B*(T-1) predicting positions ----------------
         target = torch.full((B, T), -100, dtype=torch.int64, device=dev)
@@ -97,14 +111,15 @@ class LanguageModelTrainer:
         loss = G.reduce_sum(loss_rows) / count
 
         # ---------------- backward ----------------
-        def dgrad(dy, w):                                  # dX = dY · W          (W [N,K] -> operand Wᵀ [K, Np])
-            return ops.gemm(dy, G.transpose(w.detach(), 32))
+        def dgrad(dy, w):                                  # dX = dY · W          (operands dY and Wᵀ [K, N])
+            return ops.gemm(opA(dy), opWT(w.detach()))
 
-        def wgrad(dy, xin):                                # dW = dYᵀ · X         (both transposed, M padded to 32)
-            return ops.gemm(G.transpose(dy, 32), G.transpose(xin, 32))
+        def wgrad(dy, xin):                                # dW = dYᵀ · X         (operands dYᵀ [N, M] and Xᵀ [K, M])
+            return ops.gemm(opAT(dy), opWT(xin))
 
-        grads["output_projection.weight"] = wgrad(dlogits, hf)[:V]
-        dh = ops.gemm(dlogits, G.transpose(m.output_projection.weight.detach(), 32))
+        dl = dlogits if self.precision == "fp32" else dlogits[:, :V]      # fp32 keeps its own zero padding of V to 32
+        grads["output_projection.weight"] = wgrad(dl, hf)[:V]
+        dh = dgrad(dl, m.output_projection.weight)
         dx, grads["decoder.layer_norm.weight"], grads["decoder.layer_norm.bias"] = G.layernorm_backward(
             x, dec.layer_norm.weight.detach(), dh, eps)
         for li in range(len(dec.layers) - 1, -1, -1):

@@ -78,3 +78,27 @@ def test_two_clipped_adamw_steps_match_torch():
     # and the updated model still runs the inference path (packed copies were invalidated)
     out = lm(tok.to(DEV))
     assert out.shape == (2, 24, 1002) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("prec,rms_tol,max_tol", [("bf16x3", 2e-4, 2e-3), ("bf16", 3e-2, 3e-1)])
+def test_mixed_precision_gradients(prec, rms_tol, max_tol):
+    """bf16 MFMA arithmetic on fp32 master weights: bf16x3 (split operands) keeps fp32-class gradients, plain bf16 the
+    usual mixed-precision error.  Every parameter gradient vs autograd (fp32) on the CPU oracle."""
+    lm = _tiny_lm(seed=3)
+    tok = torch.randint(2, 1002, (2, 40), generator=torch.Generator().manual_seed(5))
+    cfg = O.DecoderCfg(layers=2, dim=256, ffn=512, heads=4, vocab=1002, max_pos=128)
+    w = _leaf_weights(lm)
+    ref_loss = TO.lm_loss(w, tok, cfg)
+    TO.backward(ref_loss, w)
+    tr = LanguageModelTrainer(lm.to(DEV), precision=prec)
+    loss = tr.step(tok.to(DEV), apply_update=False)
+    assert abs(float(loss) - float(ref_loss.detach())) < (1e-4 if prec == "bf16x3" else 5e-3) * abs(float(ref_loss.detach()))
+    worst_rms, worst_max = 0.0, 0.0
+    for name in dict(lm.named_parameters()):
+        if ".B." in name:
+            continue
+        g, r = tr.grads[name].float().cpu(), w[name].grad
+        rms = float((g - r).pow(2).mean().sqrt() / (r.pow(2).mean().sqrt() + 1e-30))
+        worst_rms, worst_max = max(worst_rms, rms), max(worst_max, rel_err(g, r))
+    print(f"{prec}: worst gradient error rms {worst_rms:.2e}, max/rms {worst_max:.2e}")
+    assert worst_rms < rms_tol and worst_max < max_tol

@@ -18,10 +18,11 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--layers", type=int, default=24)
 ap.add_argument("--cpu-seconds", type=float, default=20.0)
+ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"], help="arithmetic of the matrix products")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 lm = KosmosLanguage(vocab_size=32002, dim=2048, depth=a.layers, _seed=0).eval().to(dev)
-tr = LanguageModelTrainer(lm)
+tr = LanguageModelTrainer(lm, precision=a.precision)
 g = torch.Generator().manual_seed(0)
 batches = [torch.randint(2, 32002, (a.batch, a.seq), generator=g).to(dev) for _ in range(a.warmup + a.steps + 1)]
 losses = []
@@ -39,15 +40,25 @@ tr.step(batches[-1])
 torch.cuda.synchronize()
 recs = _hip.prof_collect()
 _hip.prof_enable(False)
+MISC = {20: "transpose", 21: "colsum", 22: "gelu_bwd", 23: "cross_entropy", 24: "reduce_sum", 25: "xpos_bwd", 26: "adamw",
+        27: "gelu_fwd", 28: "to_operand", 3: "stats_finalize", 0: "rows_bcast"}
 agg = {}
 for kind, x, y, z, ms in recs:
+    if kind == "misc":
+        kind = "misc:" + MISC.get(int(z), str(z))
+    elif kind == "attn_f32":
+        kind = "attn_f32_bwd" if z < 0 else "attn_f32_fwd"
+    elif kind == "layernorm":
+        kind = "layernorm_bwd" if z == 1 else "layernorm_fwd"
+    elif kind == "embed":
+        kind = "embed_bwd" if z == 1 else "embed_fwd"
     e = agg.setdefault(kind, [0, 0.0, 0.0]); e[0] += 1; e[1] += ms
     if "gemm" in str(kind):
         e[2] += 2.0 * x * y * z
 nparams = sum(p.numel() for p in lm.parameters())
 tokens = a.batch * a.seq
 flops = 6.0 * (nparams - 32002 * 2048 - lm.embed_positions.weight.numel()) * tokens   # matmul parameters x 6 (fwd + 2x bwd)
-res = {"workload": f"KosmosLanguage train step (fwd+bwd+clip+AdamW), {a.layers}L/2048d, B={a.batch} T={a.seq}, fp32",
+res = {"workload": f"KosmosLanguage train step (fwd+bwd+clip+AdamW), {a.layers}L/2048d, B={a.batch} T={a.seq}, {a.precision} products on fp32 master weights",
        "ms_per_step": round(dt * 1e3, 1), "tokens_per_s": round(tokens / dt, 1), "losses": [round(l, 4) for l in losses],
        "approx_model_tflops": round(flops / dt / 1e12, 1),
        "kernels_ms": {k: {"n": v[0], "ms": round(v[1], 1), **({"tflops": round(v[2] / v[1] / 1e9, 1)} if v[2] else {})}
