@@ -2,8 +2,8 @@
 // loss, backward, clip_grad_norm_(1.0), AdamW step — on the text decoder).  First slice: fp32 activations and
 // gradients; the matrix products of the backward pass are the forward GEMM kernel on transposed operands
 // (dX = dY·W = kx_gemm(dY, Wᵀ), dW = dYᵀ·X = kx_gemm(dYᵀ, Xᵀ)), everything else lives here.  All reductions are
-// deterministic (fixed summation order, no atomics).  Row kernels are HBM-bound; the attention backward is a
-// plain LDS-tiled fp32 kernel (correctness first — the matrix-core version is next).
+// deterministic (fixed summation order, no atomics).  Row kernels are HBM-bound; the attention backward runs on the
+// exact-f32 matrix instruction (a plain LDS-tiled VALU version is kept as tuning key 2 = 1).
 #include "kx_common.h"
 
 namespace {
@@ -120,6 +120,78 @@ __global__ __launch_bounds__(256) void ln_bwd_row_kernel(const float* __restrict
   }
   if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
+// Same, one WORKGROUP per row with the row of x and dy resident in registers (cols <= 8192, cols % 4 == 0): one read of
+// each instead of four (the wave-per-row version above re-walks both rows for every statistic: 170 us per launch on
+// a 4096 x 2048 problem).
+__device__ __forceinline__ float block_sum4(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void ln_bwd_row_block_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ dy, const float* __restrict__ dres,
+                                                               float* __restrict__ dx, float* __restrict__ stats, int cols,
+                                                               float eps) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const int nv = cols >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * cols);
+  const float4* gr = reinterpret_cast<const float4*>(dy + row * cols);
+  float4 xv[8], gv[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nv) {
+      xv[i] = xr[c];
+      const float4 d = gr[c], gm = reinterpret_cast<const float4*>(gamma)[c];
+      gv[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+      s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    }
+  }
+  const float mean = block_sum4(s, red) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nv) {
+      const float a = xv[i].x - mean, b = xv[i].y - mean, cc = xv[i].z - mean, d = xv[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = rsqrtf(block_sum4(q, red) / (float)cols + eps);
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nv) {
+      xv[i].x = (xv[i].x - mean) * rstd; xv[i].y = (xv[i].y - mean) * rstd;     // xhat from here on
+      xv[i].z = (xv[i].z - mean) * rstd; xv[i].w = (xv[i].w - mean) * rstd;
+      a += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
+      b += (gv[i].x * xv[i].x + gv[i].y * xv[i].y) + (gv[i].z * xv[i].z + gv[i].w * xv[i].w);
+    }
+  }
+  a = block_sum4(a, red) / (float)cols;
+  b = block_sum4(b, red) / (float)cols;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nv) {
+      float4 v;
+      v.x = rstd * (gv[i].x - a - xv[i].x * b); v.y = rstd * (gv[i].y - a - xv[i].y * b);
+      v.z = rstd * (gv[i].z - a - xv[i].z * b); v.w = rstd * (gv[i].w - a - xv[i].w * b);
+      if (dres) {
+        const float4 r = reinterpret_cast<const float4*>(dres + row * cols)[c];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      reinterpret_cast<float4*>(dx + row * cols)[c] = v;
+    }
+  }
+  if (threadIdx.x == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
 // parameter part: dgamma[c] = sum_r dy*xhat, dbeta[c] = sum_r dy — row slices, then colsum_final on both halves
 __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ stats, long long rows, int cols,
@@ -257,13 +329,40 @@ __global__ __launch_bounds__(256) void xpos_bwd_kernel(float* __restrict__ dqkv,
 //      dpos[2 + t] = sum_b dx[b, t] ----
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ tokens, const float* __restrict__ dx,
                                                         long long M, int d, float* __restrict__ dembed) {
+  // One workgroup per vocabulary row v.  The token list is scanned 256 positions at a time; the (rare) positions whose
+  // token is v are collected into LDS in increasing order and their dx rows summed in that order (deterministic).
+  __shared__ int hits[256];
+  __shared__ int nhit;
   const long long v = blockIdx.x;
-  float* out = dembed + v * d;
-  for (int c = threadIdx.x; c < d; c += 256) out[c] = 0.f;
-  for (long long r = 0; r < M; ++r) {
-    if (tokens[r] != v) continue;                                   // block-uniform branch
-    for (int c = threadIdx.x; c < d; c += 256) out[c] += dx[r * d + c];
+  float acc[8];                                         // thread owns columns threadIdx.x + 256*j (d <= 2048)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (long long r0 = 0; r0 < M; r0 += 256) {
+    const long long r = r0 + threadIdx.x;
+    const bool hit = r < M && tokens[r] == v;
+    if (threadIdx.x == 0) nhit = 0;
+    __syncthreads();
+    if (__syncthreads_or(hit)) {
+      // ordered compaction: a thread's slot = number of hits in lower threads (wave ballot + per-wave offsets)
+      const unsigned long long bal = __ballot(hit);
+      __shared__ int wcount[4];
+      if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = __popcll(bal);
+      __syncthreads();
+      int base = 0;
+      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wcount[w];
+      if (hit) hits[base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int)(r - r0);
+      if (threadIdx.x == 0) nhit = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+      __syncthreads();
+      for (int h = 0; h < nhit; ++h) {
+        const float* src = dx + (r0 + hits[h]) * d;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = threadIdx.x + 256 * j; if (c < d) acc[j] += src[c]; }
+      }
+      __syncthreads();
+    }
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const int c = threadIdx.x + 256 * j; if (c < d) dembed[v * d + c] = acc[j]; }
 }
 __global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ dx, int B, int T, int d, int pos_offset,
                                                       float* __restrict__ dpos) {
@@ -448,6 +547,193 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- the same two passes on the exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32), default ----
+// dK/dV pass: workgroup owns 64 keys, wave w its 16-key block whose K and V rows stay in registers as B operands; the
+// query tiles stream through LDS (Q, dO, lse, delta).  S = Q·Kᵀ is formed with QUERIES in the accumulator rows
+// (lane (g,i): key i, queries 4g..4g+3), so P and dS are directly the B operands of dVᵀ += dOᵀ·P and dKᵀ += Qᵀ·dS
+// (k-slice g of step r <-> query 4g+r on both operands).  dQ pass: the mirror image — wave owns 16 queries (Q, dO rows in
+// registers), K and V tiles in LDS, Sᵀ with KEYS in the accumulator rows, dQᵀ += Kᵀ·dSᵀ.
+constexpr int BP = 68;   // LDS pitch (floats): 16-byte aligned rows, bank-skewed
+__device__ __forceinline__ void lds_frag16(const float* p, float (&f)[16]) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float4 v = q[j]; f[4 * j] = v.x; f[4 * j + 1] = v.y; f[4 * j + 2] = v.z; f[4 * j + 3] = v.w; }
+}
+__device__ __forceinline__ void load_tile64(float* dst, const float* src, long long stride, int r0, int T, int tid) {
+  for (int i = tid; i < 64 * 16; i += 256) {
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < T) val = *reinterpret_cast<const float4*>(src + (long long)(r0 + r) * stride + c4);
+    *reinterpret_cast<float4*>(dst + r * BP + c4) = val;
+  }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ dout,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                float* __restrict__ dk, float* __restrict__ dv, int T, int H,
+                                                                long long row_stride, long long batch_stride,
+                                                                long long do_row, long long do_batch) {
+  __shared__ __attribute__((aligned(16))) float Qs[64 * BP], dOs[64 * BP];
+  __shared__ float Ls[64], Ds[64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int key0 = blockIdx.x * 64, kw0 = key0 + wave * 16, ki = kw0 + i;
+  const float* qb = q + (long long)b * batch_stride + (long long)h * 64;
+  const float* kb = k + (long long)b * batch_stride + (long long)h * 64;
+  const float* vb = v + (long long)b * batch_stride + (long long)h * 64;
+  const float* dob = dout + (long long)b * do_batch + (long long)h * 64;
+  const float* lseb = lse + ((long long)b * H + h) * T;
+  const float* delb = delta + ((long long)b * H + h) * T;
+  float kf[16], vf[16];
+  {
+    const long long ro = (long long)min(ki, T - 1) * row_stride + 16 * g;
+    const float4* kr = reinterpret_cast<const float4*>(kb + ro);
+    const float4* vr = reinterpret_cast<const float4*>(vb + ro);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = kr[j], c = vr[j];
+      kf[4 * j] = a.x; kf[4 * j + 1] = a.y; kf[4 * j + 2] = a.z; kf[4 * j + 3] = a.w;
+      vf[4 * j] = c.x; vf[4 * j + 1] = c.y; vf[4 * j + 2] = c.z; vf[4 * j + 3] = c.w;
+    }
+  }
+  f32x4_t dkt[4], dvt[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { dkt[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvt[d] = dkt[d]; }
+  const int ntiles = (T + 63) >> 6;
+  for (int t = CAUSAL ? key0 >> 6 : 0; t < ntiles; ++t) {
+    const int q0 = t * 64;
+    __syncthreads();
+    load_tile64(Qs, qb, row_stride, q0, T, tid);
+    load_tile64(dOs, dob, do_row, q0, T, tid);
+    if (tid < 64) { const int qq = q0 + tid; Ls[tid] = qq < T ? lseb[qq] : 0.f; Ds[tid] = qq < T ? delb[qq] : 0.f; }
+    __syncthreads();
+    if (kw0 >= T) continue;                                        // wave-uniform; barriers stay aligned
+#pragma unroll 1
+    for (int qbk = 0; qbk < 4; ++qbk) {
+      if (q0 + 16 * qbk >= T) break;
+      if (CAUSAL && q0 + 16 * qbk + 15 < kw0) continue;            // every query of the block precedes every key
+      float qa[16], da[16];
+      lds_frag16(&Qs[(16 * qbk + i) * BP + 16 * g], qa);
+      lds_frag16(&dOs[(16 * qbk + i) * BP + 16 * g], da);
+      f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, pa = sa;
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s2], kf[s2], sa, 0, 0, 0);     // S[q, key]
+        pa = __builtin_amdgcn_mfma_f32_16x16x4f32(da[s2], vf[s2], pa, 0, 0, 0);     // dP[q, key]
+      }
+      float pr[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * qbk + 4 * g + r, qi = q0 + ql;
+        const bool ok = qi < T && ki < T && (!CAUSAL || ki <= qi);
+        pr[r] = ok ? expf(sa[r] - Ls[ql]) : 0.f;
+        ds[r] = pr[r] * (pa[r] - Ds[ql]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* dor = &dOs[(16 * qbk + 4 * g + r) * BP + i];
+        const float* qr = &Qs[(16 * qbk + 4 * g + r) * BP + i];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          dvt[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(dor[d * 16], pr[r], dvt[d], 0, 0, 0);   // dVt[d, key]
+          dkt[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[d * 16], ds[r], dkt[d], 0, 0, 0);    // dKt[d, key]
+        }
+      }
+    }
+  }
+  if (ki < T) {
+    const long long off = (long long)b * batch_stride + (long long)ki * row_stride + (long long)h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      *reinterpret_cast<float4*>(dk + off + d * 16) = make_float4(dkt[d][0], dkt[d][1], dkt[d][2], dkt[d][3]);
+      *reinterpret_cast<float4*>(dv + off + d * 16) = make_float4(dvt[d][0], dvt[d][1], dvt[d][2], dvt[d][3]);
+    }
+  }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const float* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               float* __restrict__ dq, int T, int H, long long row_stride,
+                                                               long long batch_stride, long long do_row, long long do_batch) {
+  __shared__ __attribute__((aligned(16))) float Ks[64 * BP], Vs[64 * BP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 64, qw0 = q0 + wave * 16, qi = qw0 + i;
+  const float* qb = q + (long long)b * batch_stride + (long long)h * 64;
+  const float* kb = k + (long long)b * batch_stride + (long long)h * 64;
+  const float* vb = v + (long long)b * batch_stride + (long long)h * 64;
+  const float* dob = dout + (long long)b * do_batch + (long long)h * 64;
+  float qf[16], dof[16];
+  {
+    const int qc = min(qi, T - 1);
+    const float4* qr = reinterpret_cast<const float4*>(qb + (long long)qc * row_stride + 16 * g);
+    const float4* dr = reinterpret_cast<const float4*>(dob + (long long)qc * do_row + 16 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = qr[j], c = dr[j];
+      qf[4 * j] = a.x; qf[4 * j + 1] = a.y; qf[4 * j + 2] = a.z; qf[4 * j + 3] = a.w;
+      dof[4 * j] = c.x; dof[4 * j + 1] = c.y; dof[4 * j + 2] = c.z; dof[4 * j + 3] = c.w;
+    }
+  }
+  const float lse_i = qi < T ? lse[((long long)b * H + h) * T + qi] : 0.f;
+  const float del_i = qi < T ? delta[((long long)b * H + h) * T + qi] : 0.f;
+  f32x4_t dqt[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) dqt[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (T + 63) >> 6;
+  const int t_end = CAUSAL ? min(ntiles, (q0 >> 6) + 1) : ntiles;
+  for (int t = 0; t < t_end; ++t) {
+    const int k0 = t * 64;
+    __syncthreads();
+    load_tile64(Ks, kb, row_stride, k0, T, tid);
+    load_tile64(Vs, vb, row_stride, k0, T, tid);
+    __syncthreads();
+    if (qw0 >= T) continue;
+#pragma unroll 1
+    for (int kbk = 0; kbk < 4; ++kbk) {
+      if (k0 + 16 * kbk >= T) break;
+      if (CAUSAL && k0 + 16 * kbk > qw0 + 15) break;              // every key of the block follows every query
+      float ka[16], va[16];
+      lds_frag16(&Ks[(16 * kbk + i) * BP + 16 * g], ka);
+      lds_frag16(&Vs[(16 * kbk + i) * BP + 16 * g], va);
+      f32x4_t st = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dpt = st;
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        st = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s2], qf[s2], st, 0, 0, 0);      // St[key, q]
+        dpt = __builtin_amdgcn_mfma_f32_16x16x4f32(va[s2], dof[s2], dpt, 0, 0, 0);   // dPt[key, q]
+      }
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = k0 + 16 * kbk + 4 * g + r;
+        const bool ok = qi < T && kj < T && (!CAUSAL || kj <= qi);
+        const float pv = ok ? expf(st[r] - lse_i) : 0.f;
+        ds[r] = pv * (dpt[r] - del_i);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* kr = &Ks[(16 * kbk + 4 * g + r) * BP + i];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dqt[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[d * 16], ds[r], dqt[d], 0, 0, 0);   // dQt[d, q]
+      }
+    }
+  }
+  if (qi < T) {
+    const long long off = (long long)b * batch_stride + (long long)qi * row_stride + (long long)h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      *reinterpret_cast<float4*>(dq + off + d * 16) = make_float4(dqt[d][0], dqt[d][1], dqt[d][2], dqt[d][3]);
+  }
+}
+
 // delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]: one wave per (b,q,h)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ dout,
                                                          float* __restrict__ delta, int B, int T, int H, long long row,
@@ -537,8 +823,13 @@ extern "C" int kx_layernorm_backward(const float* x, const float* gamma, const f
   float* part = (float*)((char*)workspace + (((size_t)rows * 8 + 255) & ~(size_t)255));
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(KX_K_LAYERNORM, rows, cols, 1, s);
-  hipLaunchKernelGGL(ln_bwd_row_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, dy, dres, dx, stats,
-                     (long long)rows, (int)cols, eps);
+  const bool aligned = ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)dx) & 15) == 0);
+  if (cols % 4 == 0 && cols <= 8192 && aligned)
+    hipLaunchKernelGGL(ln_bwd_row_block_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, gamma, dy, dres, dx, stats, (int)cols,
+                       eps);
+  else
+    hipLaunchKernelGGL(ln_bwd_row_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, dy, dres, dx, stats,
+                       (long long)rows, (int)cols, eps);
   if (dgamma) {
     const int rps = (int)((rows + ns - 1) / ns);
     hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)ns), dim3(256), 0, s, x, dy,
@@ -612,7 +903,7 @@ extern "C" int kx_xpos_backward(float* dqkv, int64_t M, int64_t D, int64_t T, co
 
 extern "C" int kx_embed_backward(const int64_t* tokens, const float* dx, int64_t B, int64_t T, int64_t d, int64_t vocab,
                                  int64_t pos_offset, float* dembed, float* dpos, void* stream) {
-  KX_REQUIRE(tokens && dx && dembed && B > 0 && T > 0 && d > 0 && vocab > 0, "kx_embed_backward: bad arguments");
+  KX_REQUIRE(tokens && dx && dembed && B > 0 && T > 0 && d > 0 && d <= 2048 && vocab > 0, "kx_embed_backward: bad arguments (d <= 2048)");
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(KX_K_EMBED, B * T, d, 1, s);
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)vocab), dim3(256), 0, s, (const long long*)tokens, dx,
@@ -649,6 +940,19 @@ extern "C" int kx_attention_backward(const float* q, const float* k, const float
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, out, dout, delta, (int)B, (int)T,
                      (int)H, (long long)out_row_stride, (long long)out_batch_stride);
   const dim3 grid((unsigned)((T + 63) / 64), (unsigned)H, (unsigned)B);
+  if (kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1) {                  // matrix-core passes (default)
+#define KX_ATTN_BWD_M(CAUSAL)                                                                                          \
+  hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dk, \
+                     dv, (int)T, (int)H, (long long)qkv_row_stride, (long long)qkv_batch_stride,                       \
+                     (long long)out_row_stride, (long long)out_batch_stride);                                          \
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dq, \
+                     (int)T, (int)H, (long long)qkv_row_stride, (long long)qkv_batch_stride, (long long)out_row_stride, \
+                     (long long)out_batch_stride)
+    if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD_M(true); } else { KX_ATTN_BWD_M(false); }
+#undef KX_ATTN_BWD_M
+    KX_CHECK_LAUNCH("kx_attention_backward");
+    return KX_OK;
+  }
 #define KX_ATTN_BWD(MODE, CAUSAL)                                                                                        \
   hipLaunchKernelGGL((attn_bwd_kernel<MODE, CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dq, dk, \
                      dv, (int)T, (int)H, (long long)qkv_row_stride, (long long)qkv_batch_stride, (long long)out_row_stride, \
