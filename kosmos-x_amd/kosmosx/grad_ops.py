@@ -60,13 +60,13 @@ def colsum(x: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = 
     return out
 
 
-def layernorm_backward(x, gamma, dy, eps=1e-5, dres=None, want_param_grads=True):
+def layernorm_backward(x, gamma, dy, eps=1e-5, dres=None, want_param_grads=True, dgamma_out=None, dbeta_out=None):
     """-> (dx, dgamma, dbeta); dres (optional) is added to dx (gradient arriving through the residual branch)."""
-    _need_cuda(x, gamma, dy, dres)
+    _need_cuda(x, gamma, dy, dres, dgamma_out, dbeta_out)
     R, Cc = x.shape
     dx = torch.empty_like(x)
-    dg = torch.empty(Cc, dtype=torch.float32, device=x.device) if want_param_grads else None
-    db = torch.empty(Cc, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dg = (dgamma_out if dgamma_out is not None else torch.empty(Cc, dtype=torch.float32, device=x.device)) if want_param_grads else None
+    db = (dbeta_out if dbeta_out is not None else torch.empty(Cc, dtype=torch.float32, device=x.device)) if want_param_grads else None
     lib = H.load()
     ws = _ws(lib.kx_layernorm_backward_workspace_bytes(R, Cc), x.device)
     H.check(lib.kx_layernorm_backward(H.ptr(x), H.ptr(gamma), H.ptr(dy), H.ptr(dres), H.ptr(dx), H.ptr(dg), H.ptr(db), R, Cc,
@@ -111,12 +111,12 @@ def xpos_backward_(dqkv, D, T, tables, qscale):
     return dqkv
 
 
-def embed_backward(tokens, dx, vocab, max_pos, pos_offset=0):
-    """tokens [B,T] int64, dx [B,T,d] -> (dembed [vocab,d], dpos [max_pos,d])."""
-    _need_cuda(tokens, dx)
+def embed_backward(tokens, dx, vocab, max_pos, pos_offset=0, out_embed=None, out_pos=None):
+    """tokens [B,T] int64, dx [B,T,d] -> (dembed [vocab,d], dpos [max_pos,d]; rows of dpos outside [2, 2+T) are zero)."""
+    _need_cuda(tokens, dx, out_embed, out_pos)
     B, T, d = dx.shape
-    de = torch.empty((vocab, d), dtype=torch.float32, device=dx.device)
-    dp = torch.zeros((max_pos, d), dtype=torch.float32, device=dx.device)
+    de = out_embed if out_embed is not None else torch.empty((vocab, d), dtype=torch.float32, device=dx.device)
+    dp = out_pos.zero_() if out_pos is not None else torch.zeros((max_pos, d), dtype=torch.float32, device=dx.device)
     H.check(H.load().kx_embed_backward(H.ptr(tokens), H.ptr(dx), B, T, d, vocab, pos_offset, H.ptr(de), H.ptr(dp), _stream()),
             "kx_embed_backward")
     return de, dp

@@ -71,3 +71,63 @@ class LogitsGatherer:
         for ev, _ in self._pending:
             torch.cuda.current_stream().wait_event(ev)
         self._pending.clear()
+
+
+class ZeroShardedOptimizer:
+    """ZeRO-stage-1-style data parallelism for the training step (BASELINE configs[4]: the
+    reference's config/zero3.json shards parameters, gradients and optimizer state; this first step shards the
+    optimizer state and the update, the two thirds of the memory that matter for AdamW): every rank holds the whole
+    flat fp32 parameter and gradient buffers and 1/world of the Adam moments.  One step is
+
+        reduce-scatter(gradients, SUM)   — each rank receives the sum of its slice (the loss scale carries 1/world)
+        all-reduce(|slice|^2)            — the global gradient norm for clip_grad_norm_
+        AdamW on the slice               — decay region / no-decay region of the flat layout
+        all-gather(parameters)           — every rank ends the step with identical parameters
+
+    i.e. exactly two bandwidth collectives of the parameter size per step, both of the ring-friendly kind xGMI
+    wants, and no collective inside forward or backward.  The arithmetic is injected (`adamw`, `sumsq`): HIP kernels
+    in the product (kosmosx/training.py), torch reference ops in the gloo CPU test.
+
+    Layout contract: flat buffers of `padded` = world * shard floats; [0, n_decay) are the weight-decayed
+    parameters, [n_decay, total) the others, [total, padded) zero padding.
+    """
+
+    def __init__(self, total: int, n_decay: int, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.total, self.n_decay = total, n_decay
+        self.shard = (total + self.world - 1) // self.world
+        self.shard = (self.shard + 3) // 4 * 4                    # keep 16-byte aligned slices
+        self.padded = self.shard * self.world
+        self.lo, self.hi = self.rank * self.shard, (self.rank + 1) * self.shard
+
+    def regions(self):
+        """[(start, stop, decayed?)] of this rank's slice, in flat coordinates (padding excluded)."""
+        out = []
+        a, b = self.lo, min(self.hi, self.n_decay)
+        if b > a:
+            out.append((a, b, True))
+        a, b = max(self.lo, self.n_decay), min(self.hi, self.total)
+        if b > a:
+            out.append((a, b, False))
+        return out
+
+    def step(self, flat_p, flat_g, m, v, adamw, sumsq, force: bool = False):
+        """flat_p / flat_g: [padded]; m / v: [shard] (this rank's moments).  adamw(p, g, m, v, decayed, gnorm_sq) updates
+        in place; sumsq(x) -> 1-element tensor.  Returns the global squared gradient norm (1-element tensor)."""
+        distributed = self.world > 1 or (force and dist.is_initialized())
+        if distributed:
+            g_shard = torch.empty(self.shard, dtype=flat_g.dtype, device=flat_g.device)
+            dist.reduce_scatter_tensor(g_shard, flat_g, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            g_shard = flat_g[self.lo:self.hi]
+        gsq = sumsq(g_shard)
+        if distributed:
+            dist.all_reduce(gsq, op=dist.ReduceOp.SUM, group=self.group)
+        for a, b, decayed in self.regions():
+            s = slice(a - self.lo, b - self.lo)
+            adamw(flat_p[a:b], g_shard[s], m[s], v[s], decayed, gsq)
+        if distributed:
+            dist.all_gather_into_tensor(flat_p, flat_p[self.lo:self.hi].clone(), group=self.group)
+        return gsq

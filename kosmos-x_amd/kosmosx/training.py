@@ -25,7 +25,8 @@ from .model import KosmosLanguage, _a
 
 class LanguageModelTrainer:
     def __init__(self, model: KosmosLanguage, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8,
-                 weight_decay: float = 0.1, max_grad_norm: float = 1.0, precision: str = "fp32"):
+                 weight_decay: float = 0.1, max_grad_norm: float = 1.0, precision: str = "fp32", process_group=None,
+                 force_collectives: bool = False):
         if precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError("precision must be fp32, bf16 or bf16x3")
         self.precision = precision
@@ -34,8 +35,54 @@ class LanguageModelTrainer:
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.weight_decay, self.max_grad_norm = weight_decay, max_grad_norm
         self.step_no = 0
-        self.state = {}          # id(param) -> (m, v)
-        self.grads = {}          # name -> gradient tensor of the last step (kept for inspection / tests)
+        self.group = process_group
+        self._force_collectives = force_collectives
+        self._build_flat()
+
+    # ------------------------------------------------------------------ flat fp32 buffers (parameters, gradients, moments)
+    def _build_flat(self):
+        """All parameters live in ONE flat fp32 buffer ([weight-decayed | others | padding]; q, k, v adjacent so the fused
+        qkv gradient is one GEMM output), gradients are written straight into the matching views of a second one: the
+        gradient norm is one reduction, AdamW two launches, and the data-parallel step two collectives over a slice
+        (kosmosx.parallel.ZeroShardedOptimizer)."""
+        from .parallel import ZeroShardedOptimizer
+        m, dec = self.model, self.model.decoder
+        mw = ".A" if dec.args.multiway else ""
+        params = dict(m.named_parameters())
+        decay, nodecay = [], []
+        for li in range(len(dec.layers)):
+            pfx = f"decoder.layers.{li}."
+            decay += [pfx + f"self_attn.{n}{mw}.weight" for n in ("q_proj", "k_proj", "v_proj", "out_proj")]
+            decay += [pfx + f"ffn{mw}.fc1.weight", pfx + f"ffn{mw}.fc2.weight"]
+            nodecay += [pfx + f"self_attn.{n}{mw}.bias" for n in ("q_proj", "k_proj", "v_proj")]
+        for name, p in params.items():
+            if name in decay or name in nodecay:
+                continue
+            (decay if (name.endswith(".weight") and p.dim() == 2 and not name.startswith("embed")) else nodecay).append(name)
+        self.names = decay + nodecay
+        n_decay = sum(params[n].numel() for n in decay)
+        total = sum(params[n].numel() for n in self.names)
+        self.zero = ZeroShardedOptimizer(total, n_decay, self.group)
+        dev = next(m.parameters()).device
+        self.flat_p = torch.zeros(self.zero.padded, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(self.zero.padded, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(self.zero.shard, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.zero.shard, dtype=torch.float32, device=dev)
+        self.offset, off = {}, 0
+        for n in self.names:
+            p = params[n]
+            self.flat_p[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + p.numel()].view(p.shape)
+            self.offset[n] = off
+            off += p.numel()
+        self.grads = {n: self.flat_g[self.offset[n]:self.offset[n] + params[n].numel()].view(params[n].shape) for n in self.names}
+
+    def _gspan(self, first: str, rows: int, cols: int | None = None):
+        """A gradient view that starts at parameter `first` and spans adjacent parameters (fused q|k|v)."""
+        o = self.offset[first]
+        n = rows * (cols or 1)
+        t = self.flat_g[o:o + n]
+        return t.view(rows, cols) if cols else t
 
     # ------------------------------------------------------------------ parameters
     def _layer_params(self, L):
@@ -55,7 +102,8 @@ class LanguageModelTrainer:
         M, eps = B * T, 1e-5
         dev = tokens.device
         tokens = tokens.long().contiguous()
-        grads = self.grads = {}
+        grads = self.grads                                    # views into the flat gradient buffer
+        world = self.zero.world
 
         # operand makers of the chosen arithmetic: A = activation rows, W = weight rows, *T = the transposed matrix
         if self.precision == "fp32":
@@ -107,64 +155,64 @@ class LanguageModelTrainer:
         count = B * (T - 1)
         dlogits = torch.zeros((M, Vp), dtype=torch.float32, device=dev)
         loss_rows, _ = G.cross_entropy(logits[:, :V], target.reshape(M), 1.0 / count, want_grad=False)
-        self._ce_grad(logits, target.reshape(M), 1.0 / count, dlogits, V)
+        # data parallel: every rank's gradient carries 1/world, so the reduce-scatter SUM is the average
+        self._ce_grad(logits, target.reshape(M), 1.0 / (count * world), dlogits, V)
         loss = G.reduce_sum(loss_rows) / count
 
-        # ---------------- backward ----------------
+        # ---------------- backward: every parameter gradient is written into its view of the flat buffer ----------------
         def dgrad(dy, w):                                  # dX = dY · W          (operands dY and Wᵀ [K, N])
             return ops.gemm(opA(dy), opWT(w.detach()))
 
-        def wgrad(dy, xin):                                # dW = dYᵀ · X         (operands dYᵀ [N, M] and Xᵀ [K, M])
-            return ops.gemm(opAT(dy), opWT(xin))
+        def wgrad(dy, xin, out=None):                      # dW = dYᵀ · X         (operands dYᵀ [N, M] and Xᵀ [K, M])
+            return ops.gemm(opAT(dy), opWT(xin), out=out)
 
-        dl = dlogits if self.precision == "fp32" else dlogits[:, :V]      # fp32 keeps its own zero padding of V to 32
-        grads["output_projection.weight"] = wgrad(dl, hf)[:V]
+        def ln_bwd(xin, ln_name, gamma, dy, dres=None):
+            dxo, _, _ = G.layernorm_backward(xin, gamma.detach(), dy, eps, dres=dres, dgamma_out=grads[ln_name + ".weight"],
+                                             dbeta_out=grads[ln_name + ".bias"])
+            return dxo
+
+        if self.precision == "fp32":                       # fp32 keeps its own zero padding of V to a multiple of 32
+            grads["output_projection.weight"].copy_(wgrad(dlogits, hf)[:V])
+            dl = dlogits
+        else:
+            dl = dlogits[:, :V]
+            wgrad(dl, hf, out=grads["output_projection.weight"])
         dh = dgrad(dl, m.output_projection.weight)
-        dx, grads["decoder.layer_norm.weight"], grads["decoder.layer_norm.bias"] = G.layernorm_backward(
-            x, dec.layer_norm.weight.detach(), dh, eps)
+        dx = ln_bwd(x, "decoder.layer_norm", dec.layer_norm.weight, dh)
+        mw = ".A" if a.multiway else ""
         for li in range(len(dec.layers) - 1, -1, -1):
             L, s = dec.layers[li], saved[li]
             P, pfx = self._layer_params(L), f"decoder.layers.{li}."
-            mw = ".A" if a.multiway else ""
             # x_out = x_mid + fc2(ffn_ln(gelu(fc1(fl_ln(x_mid)))))
-            grads[pfx + f"ffn{mw}.fc2.weight"] = wgrad(dx, s["g_n"])
-            grads[pfx + f"ffn{mw}.fc2.bias"] = G.colsum(dx)
+            wgrad(dx, s["g_n"], out=grads[pfx + f"ffn{mw}.fc2.weight"])
+            G.colsum(dx, out=grads[pfx + f"ffn{mw}.fc2.bias"])
             dgn = dgrad(dx, P["fc2"].weight)
-            if P["ffn_ln"] is not None:
-                dg, grads[pfx + f"ffn{mw}.ffn_layernorm.weight"], grads[pfx + f"ffn{mw}.ffn_layernorm.bias"] = \
-                    G.layernorm_backward(s["g"], P["ffn_ln"].weight.detach(), dgn, eps)
-            else:
-                dg = dgn
+            dg = dgn if P["ffn_ln"] is None else ln_bwd(s["g"], pfx + f"ffn{mw}.ffn_layernorm", P["ffn_ln"].weight, dgn)
             dpre = G.gelu_backward(s["pre"], dg)
-            grads[pfx + f"ffn{mw}.fc1.weight"] = wgrad(dpre, s["h2"])
-            grads[pfx + f"ffn{mw}.fc1.bias"] = G.colsum(dpre)
+            wgrad(dpre, s["h2"], out=grads[pfx + f"ffn{mw}.fc1.weight"])
+            G.colsum(dpre, out=grads[pfx + f"ffn{mw}.fc1.bias"])
             dh2 = dgrad(dpre, P["fc1"].weight)
-            dx, grads[pfx + f"final_layer_norm{mw}.weight"], grads[pfx + f"final_layer_norm{mw}.bias"] = \
-                G.layernorm_backward(s["x_mid"], P["fl_ln"].weight.detach(), dh2, eps, dres=dx)
+            dx = ln_bwd(s["x_mid"], pfx + f"final_layer_norm{mw}", P["fl_ln"].weight, dh2, dres=dx)
             # x_mid = x_in + out_proj(inner_ln(attention(xpos(q), xpos(k), v)))
-            grads[pfx + f"self_attn.out_proj{mw}.weight"] = wgrad(dx, s["a_n"])
-            grads[pfx + f"self_attn.out_proj{mw}.bias"] = G.colsum(dx)
+            wgrad(dx, s["a_n"], out=grads[pfx + f"self_attn.out_proj{mw}.weight"])
+            G.colsum(dx, out=grads[pfx + f"self_attn.out_proj{mw}.bias"])
             dan = dgrad(dx, P["o"].weight)
-            if P["inner_ln"] is not None:
-                datt, grads[pfx + f"self_attn.inner_attn_ln{mw}.weight"], grads[pfx + f"self_attn.inner_attn_ln{mw}.bias"] = \
-                    G.layernorm_backward(s["att"], P["inner_ln"].weight.detach(), dan, eps)
-            else:
-                datt = dan
+            datt = dan if P["inner_ln"] is None else ln_bwd(s["att"], pfx + f"self_attn.inner_attn_ln{mw}",
+                                                             P["inner_ln"].weight, dan)
             dqkv = G.attention_backward(s["qkv"], s["att"].reshape(B, T, D), datt.reshape(B, T, D), s["lse"], B, T, Hh, True)
             G.xpos_backward_(dqkv, D, T, tabs, 0.125)
-            dwqkv, dbqkv = wgrad(dqkv, s["h1"]), G.colsum(dqkv)
-            for i, nm in enumerate(("q_proj", "k_proj", "v_proj")):
-                grads[pfx + f"self_attn.{nm}{mw}.weight"] = dwqkv[i * D:(i + 1) * D]
-                grads[pfx + f"self_attn.{nm}{mw}.bias"] = dbqkv[i * D:(i + 1) * D]
+            # q | k | v are adjacent in the flat layout: one GEMM output / one column sum covers the three
+            wgrad(dqkv, s["h1"], out=self._gspan(pfx + f"self_attn.q_proj{mw}.weight", 3 * D, D))
+            G.colsum(dqkv, out=self._gspan(pfx + f"self_attn.q_proj{mw}.bias", 3 * D))
             dh1 = dgrad(dqkv, s["wqkv"])
-            dx, grads[pfx + f"self_attn_layer_norm{mw}.weight"], grads[pfx + f"self_attn_layer_norm{mw}.bias"] = \
-                G.layernorm_backward(s["x_in"], P["sa_ln"].weight.detach(), dh1, eps, dres=dx)
-        de, dp = G.embed_backward(tokens, dx.reshape(B, T, D), V, m.embed_positions.weight.shape[0])
-        de[m.embed.padding_idx].zero_() if m.embed.padding_idx is not None else None   # nn.Embedding(padding_idx) has no gradient there
-        grads["embed.weight"], grads["embed_positions.weight"] = de, dp
+            dx = ln_bwd(s["x_in"], pfx + f"self_attn_layer_norm{mw}", P["sa_ln"].weight, dh1, dres=dx)
+        G.embed_backward(tokens, dx.reshape(B, T, D), V, m.embed_positions.weight.shape[0],
+                         out_embed=grads["embed.weight"], out_pos=grads["embed_positions.weight"])
+        if m.embed.padding_idx is not None:
+            grads["embed.weight"][m.embed.padding_idx].zero_()     # nn.Embedding(padding_idx) has no gradient there
 
         if apply_update:
-            self._update(grads)
+            self._update()
         return loss
 
     def _ce_grad(self, logits, target, scale, dlogits, V):
@@ -176,24 +224,15 @@ class LanguageModelTrainer:
                                           scratch.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), _stream()),
                 "kx_cross_entropy")
 
-    # ------------------------------------------------------------------ clip + AdamW
-    def _update(self, grads):
-        params = dict(self.model.named_parameters())
+    # ------------------------------------------------------------------ clip + AdamW (+ the data-parallel exchange)
+    def _update(self):
         self.step_no += 1
-        gsq = None
-        for name, g in grads.items():
-            if name in params:
-                gsq = G.reduce_sum(g.contiguous(), squares=True, out=gsq, accumulate=gsq is not None)
-        self.grad_norm_sq = gsq
-        for name, g in grads.items():
-            p = params.get(name)
-            if p is None:
-                continue
-            st = self.state.get(name)
-            if st is None:
-                st = self.state[name] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
-            is_linear_weight = name.endswith(".weight") and p.dim() == 2 and not name.startswith("embed")
-            G.adamw_(p.data, g.contiguous(), st[0], st[1], self.step_no, self.lr, self.betas, self.eps,
-                     self.weight_decay if is_linear_weight else 0.0, grad_norm_sq=gsq, max_norm=self.max_grad_norm)
-        self.model.invalidate_packed() if hasattr(self.model, "invalidate_packed") else None
-        self.model.decoder.invalidate_packed()
+        step = self.step_no
+
+        def adamw(p, g, m, v, decayed, gsq):
+            G.adamw_(p, g, m, v, step, self.lr, self.betas, self.eps, self.weight_decay if decayed else 0.0,
+                     grad_norm_sq=gsq, max_norm=self.max_grad_norm)
+
+        self.grad_norm_sq = self.zero.step(self.flat_p, self.flat_g, self.m, self.v, adamw,
+                                           lambda t: G.reduce_sum(t, squares=True), force=self._force_collectives)
+        self.model.decoder.invalidate_packed()              # the inference path's operand copies are stale now

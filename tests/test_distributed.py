@@ -75,3 +75,86 @@ def test_shard_range_partitions_the_batch():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# Training step across ranks: ZeRO-1-style sharded AdamW == the single-process optimizer on the
+# averaged gradient.  The collectives and the slice arithmetic are the product's (kosmosx.parallel); the elementwise
+# arithmetic injected here is torch on the CPU (on the GPU it is kx_adamw / kx_reduce_sum).
+# ---------------------------------------------------------------------------------------------
+def _ref_adamw(lr, betas, eps, wd, max_norm, step):
+    def adamw(p, g, m, v, decayed, gsq):
+        clip = min(1.0, max_norm / (float(gsq.sqrt()) + 1e-6))
+        g = g * clip
+        p.mul_(1 - lr * (wd if decayed else 0.0))
+        m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+        v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+        bc1, bc2 = 1 - betas[0] ** step, 1 - betas[1] ** step
+        p.addcdiv_(m, v.sqrt() / (bc2 ** 0.5) + eps, value=-lr / bc1)
+    return adamw
+
+
+def _zero_worker(rank, world, port, q):
+    for p in (str(ROOT), str(ROOT / "kosmos-x_amd"), str(ROOT / "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KOSMOSX_NO_LOGGING_CONFIG="1")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kosmosx.parallel import ZeroShardedOptimizer
+    total, n_decay = 1003, 700                                         # not divisible by the world size
+    z = ZeroShardedOptimizer(total, n_decay)
+    g0 = torch.Generator().manual_seed(3)
+    flat_p = torch.zeros(z.padded); flat_p[:total] = torch.randn(total, generator=g0)      # replicated start
+    m, v = torch.zeros(z.shard), torch.zeros(z.shard)
+    per_rank = [torch.randn(total, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    for step in (1, 2):
+        flat_g = torch.zeros(z.padded)
+        flat_g[:total] = per_rank[rank] * step / world                 # each rank's gradient already carries 1/world
+        z.step(flat_p, flat_g, m, v, _ref_adamw(1e-2, (0.9, 0.95), 1e-8, 0.1, 1.0, step), lambda x: (x * x).sum().reshape(1))
+    if rank == 0:
+        q.put(flat_p[:total].clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero_sharded_adamw_equals_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single process: torch.optim.AdamW on the averaged gradient with clip_grad_norm_
+    total, n_decay, world = 1003, 700, 2
+    p0 = torch.randn(total, generator=torch.Generator().manual_seed(3))
+    pa, pb = torch.nn.Parameter(p0[:n_decay].clone()), torch.nn.Parameter(p0[n_decay:].clone())
+    opt = torch.optim.AdamW([{"params": [pa], "weight_decay": 0.1}, {"params": [pb], "weight_decay": 0.0}], lr=1e-2,
+                            betas=(0.9, 0.95), eps=1e-8)
+    per_rank = [torch.randn(total, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    for step in (1, 2):
+        gavg = sum(per_rank) * step / world
+        pa.grad, pb.grad = gavg[:n_decay].clone(), gavg[n_decay:].clone()
+        torch.nn.utils.clip_grad_norm_([pa, pb], 1.0)
+        opt.step()
+    ref = torch.cat([pa.detach(), pb.detach()])
+    assert (got - ref).abs().max() < 1e-6
+
+
+def test_zero_shard_regions_cover_the_parameters_once():
+    from kosmosx.parallel import ZeroShardedOptimizer
+    for total, n_decay in ((1003, 700), (16, 16), (10, 0), (4097, 1)):
+        for world in (1, 2, 3, 8):
+            seen = torch.zeros(total, dtype=torch.int32)
+            for rank in range(world):
+                z = ZeroShardedOptimizer.__new__(ZeroShardedOptimizer)
+                z.group, z.world, z.rank, z.total, z.n_decay = None, world, rank, total, n_decay
+                z.shard = ((total + world - 1) // world + 3) // 4 * 4
+                z.padded, z.lo, z.hi = z.shard * world, rank * z.shard, (rank + 1) * z.shard
+                for a, b, dec in z.regions():
+                    seen[a:b] += 1
+                    assert (b <= n_decay) if dec else (a >= n_decay)
+            assert int(seen.min()) == 1 and int(seen.max()) == 1

@@ -102,3 +102,26 @@ def test_mixed_precision_gradients(prec, rms_tol, max_tol):
         worst_rms, worst_max = max(worst_rms, rms), max(worst_max, rel_err(g, r))
     print(f"{prec}: worst gradient error rms {worst_rms:.2e}, max/rms {worst_max:.2e}")
     assert worst_rms < rms_tol and worst_max < max_tol
+
+
+def test_sharded_update_over_rccl_single_rank_matches_local_update():
+    """The data-parallel exchange (reduce-scatter, norm all-reduce, all-gather) driven through RCCL with one rank:
+    same parameters as the local update, bit for bit (sum over one rank is the identity)."""
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    tok = torch.randint(2, 1002, (2, 24), generator=torch.Generator().manual_seed(11)).to(DEV)
+    a, b = _tiny_lm(seed=4).to(DEV), _tiny_lm(seed=4).to(DEV)
+    ta = LanguageModelTrainer(a, lr=1e-3, precision="bf16")
+    la = [float(ta.step(tok)) for _ in range(2)]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        tb = LanguageModelTrainer(b, lr=1e-3, precision="bf16", force_collectives=True)
+        lb = [float(tb.step(tok)) for _ in range(2)]
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert la == lb
+    assert torch.equal(ta.flat_p, tb.flat_p)
