@@ -130,3 +130,10 @@ def test_attention_backward(B, Hh, T, causal):
     assert rel_err(lse, ref_lse) < 1e-5
     dqkv = G.attention_backward(qd, og, do.to(DEV), lse, B, T, Hh, causal)
     assert rel_err(dqkv, qkv.grad) < 3e-5
+    from kosmosx import _hip
+    _hip.load().kx_set_tuning(2, 1)                      # the first version: LDS-tiled VALU passes
+    try:
+        first = G.attention_backward(qd, og, do.to(DEV), lse, B, T, Hh, causal)
+    finally:
+        _hip.load().kx_set_tuning(2, 0)
+    assert rel_err(first, qkv.grad) < 3e-5
