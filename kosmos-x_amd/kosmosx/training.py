@@ -97,7 +97,13 @@ class LanguageModelTrainer:
         """tokens [B,T] int64 on the device.  Returns the mean next-token cross-entropy (a device scalar)."""
         m, dec = self.model, self.model.decoder
         a = dec.args
+        if not isinstance(tokens, torch.Tensor) or tokens.dim() != 2 or not tokens.is_cuda:
+            raise TypeError("tokens must be a [B, T] integer tensor on the HIP device (no CPU fallback)")
         B, T = tokens.shape
+        if T < 2:
+            raise ValueError("next-token training needs at least two positions per sequence")
+        if T + 2 > self.model.embed_positions.weight.shape[0]:
+            raise IndexError(f"index out of range in self: {T} tokens exceed the position table")   # SURVEY H3
         D, F, Hh, V = a.decoder_embed_dim, a.decoder_ffn_embed_dim, a.decoder_attention_heads, a.vocab_size
         M, eps = B * T, 1e-5
         dev = tokens.device
