@@ -277,6 +277,31 @@ def main():
             model.invalidate_packed()
         model.precision = args.precision
 
+    # ---- SURVEY 8f row 1 next to the headline: one training step of the text decoder (never part of `value`) ----
+    training = None
+    if rank == 0 and world == 1 and not force_dist and not args.no_cpu_baseline:
+        try:
+            from kosmosx.model import KosmosLanguage
+            from kosmosx.training import LanguageModelTrainer
+            lm = KosmosLanguage(vocab_size=cfg.vocab, dim=cfg.decoder.decoder_embed_dim, _seed=0).eval().to(dev)
+            tr = LanguageModelTrainer(lm, precision="bf16")
+            tb = [torch.randint(2, cfg.vocab, (8, 512), generator=g).to(dev) for _ in range(4)]
+            tr.step(tb[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(1, 4):
+                tloss = tr.step(tb[i])
+            torch.cuda.synchronize()
+            dt_t = (time.perf_counter() - t1) / 3
+            training = {"workload": "KosmosLanguage 24L/2048d next-token step: forward + backward + clip_grad_norm_(1.0) + "
+                                    "AdamW, 8 x 512 tokens, bf16 products on fp32 master weights (tools/bench_train.py)",
+                        "tokens_per_s": round(8 * 512 / dt_t, 1), "ms_per_step": round(dt_t * 1e3, 2),
+                        "loss": round(float(tloss), 4)}
+            del tr, lm, tb
+            torch.cuda.empty_cache()
+        except Exception as e:                      # the headline line must not depend on the extra leg
+            training = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- cpu_baseline: the oracle (a port — the reference's third-party stack is absent) on the host cores ----
     cpu_baseline = None
     if cpu_weights is not None:
@@ -341,7 +366,7 @@ def main():
             "algorithmic_gflop_per_sample": round(fl["total"] / 1e9, 2),
             "model_tflops": round(fl["total"] * total / elapsed / 1e12, 2),
             "mfma_peak_frac_end_to_end": round(fl["total"] * total / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "other_precision_modes": other_modes,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "other_precision_modes": other_modes, "training_step": training,
             "kernel_breakdown": breakdown,
             "gemm_shapes": gemm_shapes,
             "build_seconds": round(t_build, 1),
