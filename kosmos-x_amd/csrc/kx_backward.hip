@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   p[i] = pi;
 }
 
-// ---- causal / full attention backward, fp32, head_dim 64.  Workgroup = (key tile of 64, head, batch); it owns dK, dV
+// ---- causal / full attention backward, fp32, head_dim 64 — FIRST VERSION (tuning key 2 = 1), on the VALU.  Workgroup = (key tile of 64, head, batch); it owns dK, dV
 //  of its keys and walks the query tiles; dQ rows are accumulated by a second pass that owns query tiles (no atomics).
 //  P = exp(S - lse), dP = dO·Vᵀ, dS = P ⊙ (dP - delta), delta[q] = sum_d dO[q,d]*O[q,d].
 //  MODE 0: dK, dV (block owns keys);  MODE 1: dQ (block owns queries).  Thread (ty, tx) of a 16x16 grid computes a 4x4
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s[i][j] += qv[i] * kv[j]; dp[i][j] += dov[i] * vv[j]; }
     }
-    // P and dS into LDS: Ps[qi][kj] = P, reuse Cm/Dm? keep separate small buffers: P in Ps, dS overwrites s
+    // P and dS of the patch (dS overwrites s, P overwrites dp); they go through LDS (Ps) for the second products
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int qi = q0 + 4 * ty + i;
@@ -477,10 +477,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         dp[i][j] = pv;                                // P
       }
     }
-    __syncthreads();                                   // everyone is done reading Cm/Dm for S/dP? (they are read again below)
-    // stage P and dS through LDS for the second products
-    float* dSs = Ps;                                   // [64][AP] dS ; P goes to a second buffer carved from registers->LDS
-    // we need both P (for dV) and dS (for dK/dQ): write dS to Ps, P to a view inside the (dead) accumulation scratch
+    float* dSs = Ps;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -242,7 +242,6 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
   const int64_t G = w->image / w->patch, P = G * G, S = P + 1, M = B * S, MP = B * P, D = w->dim;
   SplitkScope sk(v.splitk, KX_SPLITK_WS);
   const int ct = cdt(prec);
-  const size_t es = esz(prec);
   KX_TRY(kx_launch_patchify(pixels, v.patches, B, w->image, w->patch, w->kpad, prec, s));
   KX_TRY(gemm(v.patches, w->kpad, w->wpatch, w->kpad, v.patch_out, D, KX_F32, MP, D, nullptr, nullptr, 0, 1.f, 0,
               prec, s));
@@ -289,7 +288,6 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
   SplitkScope sk(p.splitk, KX_SPLITK_WS);
   const int64_t F = D * w->ff_mult;
   const int ct = cdt(prec);
-  const size_t es = esz(prec);
   KX_TRY(kx_launch_rows_bcast(w->latents_p, p.lat, B, n, D, s));
   for (int i = 0; i < w->depth; ++i) {
     const kx_perceiver_layer& L = w->layer[i];
