@@ -28,6 +28,27 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
 
 // ---- fp32 matrix -> GEMM operand: optional transpose, K padded with zeros to `kp`, format bf16 or one of the two
 //      bf16x3 row layouts (activation [hi|hi|lo], weight [hi|lo|hi]; split_bf16x2 in kx_common.h) ----
+// plain (non-transposed) conversion, 4 values per thread: the common case (weights and activations with K % 4 == 0)
+__global__ __launch_bounds__(256) void to_operand_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              long long rows, long long cols, long long ld_src, long long kp,
+                                                              int fmt) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;         // quad index over rows x kp/4
+  const long long kq = kp >> 2;
+  if (q >= rows * kq) return;
+  const long long r = q / kq, c = (q - r * kq) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c + 3 < cols) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+  else if (c < cols) { const float* p = src + r * ld_src + c; v.x = p[0]; if (c + 1 < cols) v.y = p[1]; if (c + 2 < cols) v.z = p[2]; }
+  uint2 h, l;
+  split_bf16x2(v.x, v.y, h.x, l.x); split_bf16x2(v.z, v.w, h.y, l.y);
+  bf16_t* o = dst + r * (fmt == 1 ? 1 : 3) * kp + c;
+  *reinterpret_cast<uint2*>(o) = h;
+  if (fmt != 1) {
+    *reinterpret_cast<uint2*>(o + kp) = fmt == 2 ? h : l;
+    *reinterpret_cast<uint2*>(o + 2 * kp) = fmt == 2 ? l : h;
+  }
+}
+
 template <bool TRANSPOSE>
 __global__ __launch_bounds__(256) void to_operand_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                          long long rows, long long cols, long long ld_src, long long kp,
@@ -68,16 +89,40 @@ __global__ __launch_bounds__(256) void to_operand_kernel(const float* __restrict
 // ---- column sums: out[c] = sum_r x[r][c] over row slices (stage 1), slices summed in order (stage 2) ----
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long rows, long long cols,
                                                              long long ld, int rows_per_slice, float* __restrict__ part) {
-  __shared__ float red[4][64];
+  // workgroup = 256 columns (64 threads x float4) x 4 row lanes over one row slice; rows are read as whole 1 KB segments
+  __shared__ float4 red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long long c = (long long)blockIdx.x * 64 + tx;
+  const long long c = ((long long)blockIdx.x * 64 + tx) * 4;
   const long long r0 = (long long)blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
-  float s = 0.f;
-  if (c < cols)
-    for (long long r = r0 + ty; r < r1; r += 4) s += x[r * ld + c];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool vec = c + 3 < cols && (ld & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+  if (vec) {
+    for (long long r = r0 + ty; r < r1; r += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  } else if (c < cols) {
+    for (long long r = r0 + ty; r < r1; r += 4) {
+      const float* p = x + r * ld + c;
+      s.x += p[0];
+      if (c + 1 < cols) s.y += p[1];
+      if (c + 2 < cols) s.z += p[2];
+      if (c + 3 < cols) s.w += p[3];
+    }
+  }
   red[ty][tx] = s;
   __syncthreads();
-  if (ty == 0 && c < cols) part[(long long)blockIdx.y * cols + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  if (ty == 0 && c < cols) {
+    float* o = part + (long long)blockIdx.y * cols + c;
+    const float t0 = (red[0][tx].x + red[1][tx].x) + (red[2][tx].x + red[3][tx].x);
+    const float t1 = (red[0][tx].y + red[1][tx].y) + (red[2][tx].y + red[3][tx].y);
+    const float t2 = (red[0][tx].z + red[1][tx].z) + (red[2][tx].z + red[3][tx].z);
+    const float t3 = (red[0][tx].w + red[1][tx].w) + (red[2][tx].w + red[3][tx].w);
+    o[0] = t0;
+    if (c + 1 < cols) o[1] = t1;
+    if (c + 2 < cols) o[2] = t2;
+    if (c + 3 < cols) o[3] = t3;
+  }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nslices, long long cols,
                                                            float* __restrict__ out, int accumulate) {
@@ -778,6 +823,9 @@ extern "C" int kx_to_operand(const float* src, void* dst, int64_t rows, int64_t 
   if (transpose)
     hipLaunchKernelGGL(to_operand_kernel<true>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (long long)rows, (long long)cols,
                        (long long)ld_src, (long long)kp, fmt);
+  else if ((ld_src & 3) == 0 && (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 7) == 0)
+    hipLaunchKernelGGL(to_operand_rows_kernel, dim3((unsigned)((rows * (kp >> 2) + 255) / 256)), dim3(256), 0, s, src,
+                       (bf16_t*)dst, (long long)rows, (long long)cols, (long long)ld_src, (long long)kp, fmt);
   else
     hipLaunchKernelGGL(to_operand_kernel<false>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (long long)rows, (long long)cols,
                        (long long)ld_src, (long long)kp, fmt);
@@ -785,7 +833,7 @@ extern "C" int kx_to_operand(const float* src, void* dst, int64_t rows, int64_t 
   return KX_OK;
 }
 
-static int slices_for(int64_t rows) { return (int)((rows + 511) / 512 > 256 ? 256 : (rows + 511) / 512); }
+static int slices_for(int64_t rows) { return (int)((rows + 63) / 64 > 256 ? 256 : (rows + 63) / 64); }
 
 extern "C" size_t kx_colsum_workspace_bytes(int64_t rows, int64_t cols) {
   return (size_t)slices_for(rows) * 2 * (size_t)cols * 4 + 256;
@@ -799,7 +847,7 @@ extern "C" int kx_colsum(const float* x, int64_t rows, int64_t cols, int64_t ld,
   const int rps = (int)((rows + ns - 1) / ns);
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(KX_K_MISC, rows, cols, 21, s);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)ns), dim3(256), 0, s, x,
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)ns), dim3(256), 0, s, x,
                      (long long)rows, (long long)cols, (long long)ld, rps, (float*)workspace);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, (const float*)workspace, ns,
                      (long long)cols, out, accumulate);

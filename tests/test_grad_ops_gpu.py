@@ -137,3 +137,23 @@ def test_attention_backward(B, Hh, T, causal):
     finally:
         _hip.load().kx_set_tuning(2, 0)
     assert rel_err(first, qkv.grad) < 3e-5
+
+
+@pytest.mark.parametrize("shape", [(70, 130), (64, 64), (5, 257), (300, 2048)])
+@pytest.mark.parametrize("transpose", [False, True])
+@pytest.mark.parametrize("fmt", ["bf16", "bf16x3_act", "bf16x3_w"])
+def test_to_operand_formats(shape, transpose, fmt):
+    """fp32 matrix -> GEMM operand: optional transpose, K zero-padded to 64, bf16 or the two bf16x3 row layouts."""
+    x = torch.randn(*shape, generator=_g(sum(shape)))
+    o = x.t().contiguous() if transpose else x
+    kp = (o.shape[1] + 63) // 64 * 64
+    pad = torch.zeros(o.shape[0], kp)
+    pad[:, :o.shape[1]] = o
+    hi = pad.to(torch.bfloat16)
+    lo = (pad - hi.float()).to(torch.bfloat16)
+    ref = {"bf16": hi, "bf16x3_act": torch.cat([hi, hi, lo], 1), "bf16x3_w": torch.cat([hi, lo, hi], 1)}[fmt]
+    got = G.to_operand(x.to(DEV), fmt, transpose)
+    assert torch.equal(got.cpu(), ref)
+    sub = G.to_operand(x.to(DEV)[:, 1:], fmt, transpose)          # a column-sliced (unaligned) source view
+    o2 = x[:, 1:].t().contiguous() if transpose else x[:, 1:]
+    assert torch.equal(sub.cpu()[:, :o2.shape[1]], o2.to(torch.bfloat16))
