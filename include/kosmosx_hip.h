@@ -377,11 +377,13 @@ int kx_embed_backward(const int64_t* tokens, const float* dx, int64_t B, int64_t
 int kx_adamw(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float weight_decay, int64_t step, const float* grad_norm_sq, float max_norm, void* stream);
 /* Attention backward (fp32, head_dim 64): q/k/v/dq/dk/dv are column blocks of fused [B*T, 3D] buffers (row / batch
- * strides in elements), out/dout [B,T,D]; lse [B,H,T] from kx_attention (lse_out); delta [B,H,T] scratch. */
+ * strides in elements), out/dout [B,T,D]; lse [B,H,T] from kx_attention (lse_out); delta [B,H,T] scratch.
+ * prec: KX_PREC_F32 = exact-f32 MFMA; KX_PREC_BF16 = bf16 MFMA products (the fp32 inputs are rounded on the way in,
+ * statistics and accumulators stay fp32) for mixed-precision training. */
 int kx_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* dout,
                           const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B, int64_t H, int64_t T,
                           int64_t qkv_row_stride, int64_t qkv_batch_stride, int64_t out_row_stride,
-                          int64_t out_batch_stride, int32_t mask, void* stream);
+                          int64_t out_batch_stride, int32_t mask, int32_t prec, void* stream);
 
 /* Kernel-variant selection for in-process A/B measurement (tools/gemm_bench.py, tools/ln_bench.py).  Defaults (all 0) are the
  * shipped configuration.  key 0: LayerNorm variant (0 wave-per-row, 1 workgroup-per-row);

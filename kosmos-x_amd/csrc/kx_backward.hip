@@ -776,6 +776,195 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
   }
 }
 
+// ---- the two passes with bf16 products (v_mfma_f32_16x16x32_bf16) for mixed-precision training: q, k, v, dO arrive as
+// fp32 and are rounded to bf16 on the way into LDS / registers; S, dP, P, dS, lse, delta and every accumulator stay
+// fp32.  Same decomposition as the fp32 kernels above.  The second products (dVt += dOt·P, dKt += Qt·dS, dQt += Kt·dSt)
+// contract over the ROWS of an LDS tile, which is what kx_attention's bf16 kernel does for O^T += V^T·P^T: the tile stays
+// row-major (pitch 160 B) and the A fragment comes from ds_read_b64_tr_b16, the accumulator-layout probabilities are
+// the B operand (k-slice (g,v) <-> tile row 32c + 16(v>>2) + 4g + (v&3), the same map on both operands).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+constexpr int XS = 80;   // LDS row pitch in bf16 elements (160 B)
+__device__ __forceinline__ void stage_tile_bf16(bf16_t* dst, const float* src, long long stride, int r0, int T, int tid) {
+  for (int i = tid; i < 64 * 16; i += 256) {
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < T) v = *reinterpret_cast<const float4*>(src + (long long)(r0 + r) * stride + c4);
+    uint2 o; o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+    *reinterpret_cast<uint2*>(dst + r * XS + c4) = o;
+  }
+}
+__device__ __forceinline__ u32x4_t row_frag_global(const float* rowp, int g, int s2) {   // 8 fp32 -> 8 bf16 of k-step s2
+  const float4 a = *reinterpret_cast<const float4*>(rowp + 32 * s2 + 8 * g);
+  const float4 b = *reinterpret_cast<const float4*>(rowp + 32 * s2 + 8 * g + 4);
+  return (u32x4_t){pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
+}
+__device__ __forceinline__ u32x4_t tile_row_frag(const bf16_t* X, int rb, int s2, int g, int i) {
+  return *reinterpret_cast<const u32x4_t*>(X + (rb * 16 + i) * XS + 32 * s2 + 8 * g);
+}
+__device__ __forceinline__ u32x4_t tile_tr_frag(const bf16_t* X, int c, int d, int g, int li) {
+  const bf16_t* vr = X + (32 * c + 4 * g + (li >> 2)) * XS + d * 16 + (li & 3) * 4;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)vr);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vr + 16 * XS));
+  const u32x2_t lo2 = __builtin_bit_cast(u32x2_t, lo), hi2 = __builtin_bit_cast(u32x2_t, hi);
+  return (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]};
+}
+__device__ __forceinline__ f32x4_t mfma_bf16(u32x4_t a, u32x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void pack_blocks(const f32x4_t (&y)[4], u32x4_t (&pf)[2]) {   // 4 row-blocks -> 2 B fragments
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    pf[c][0] = pack_bf16x2(y[2 * c][0], y[2 * c][1]);
+    pf[c][1] = pack_bf16x2(y[2 * c][2], y[2 * c][3]);
+    pf[c][2] = pack_bf16x2(y[2 * c + 1][0], y[2 * c + 1][1]);
+    pf[c][3] = pack_bf16x2(y[2 * c + 1][2], y[2 * c + 1][3]);
+  }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ dout,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                float* __restrict__ dk, float* __restrict__ dv, int T, int H,
+                                                                long long row_stride, long long batch_stride,
+                                                                long long do_row, long long do_batch) {
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * XS], dOs[64 * XS];
+  __shared__ float Ls[64], Ds[64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int key0 = blockIdx.x * 64, kw0 = key0 + wave * 16, ki = kw0 + i;
+  const float* qb = q + (long long)b * batch_stride + (long long)h * 64;
+  const float* kb = k + (long long)b * batch_stride + (long long)h * 64;
+  const float* vb = v + (long long)b * batch_stride + (long long)h * 64;
+  const float* dob = dout + (long long)b * do_batch + (long long)h * 64;
+  const float* lseb = lse + ((long long)b * H + h) * T;
+  const float* delb = delta + ((long long)b * H + h) * T;
+  u32x4_t kfix[2], vfix[2];
+  {
+    const long long ro = (long long)min(ki, T - 1) * row_stride;
+    kfix[0] = row_frag_global(kb + ro, g, 0); kfix[1] = row_frag_global(kb + ro, g, 1);
+    vfix[0] = row_frag_global(vb + ro, g, 0); vfix[1] = row_frag_global(vb + ro, g, 1);
+  }
+  f32x4_t dkt[4], dvt[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { dkt[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvt[d] = dkt[d]; }
+  const int ntiles = (T + 63) >> 6;
+  for (int t = CAUSAL ? key0 >> 6 : 0; t < ntiles; ++t) {
+    const int q0 = t * 64;
+    __syncthreads();
+    stage_tile_bf16(Qs, qb, row_stride, q0, T, tid);
+    stage_tile_bf16(dOs, dob, do_row, q0, T, tid);
+    if (tid < 64) { const int qq = q0 + tid; Ls[tid] = qq < T ? lseb[qq] : 0.f; Ds[tid] = qq < T ? delb[qq] : 0.f; }
+    __syncthreads();
+    if (kw0 >= T) continue;
+    f32x4_t pb[4], sb[4];                              // P and dS of the four 16-query blocks: lane (g,i): key i, queries 4g+r
+#pragma unroll
+    for (int qbk = 0; qbk < 4; ++qbk) {
+      f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, pa = sa;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        sa = mfma_bf16(tile_row_frag(Qs, qbk, s2, g, i), kfix[s2], sa);     // S[q, key]
+        pa = mfma_bf16(tile_row_frag(dOs, qbk, s2, g, i), vfix[s2], pa);    // dP[q, key]
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * qbk + 4 * g + r, qi = q0 + ql;
+        const bool ok = qi < T && ki < T && (!CAUSAL || ki <= qi);
+        const float pv = ok ? expf(sa[r] - Ls[ql]) : 0.f;
+        pb[qbk][r] = pv;
+        sb[qbk][r] = pv * (pa[r] - Ds[ql]);
+      }
+    }
+    u32x4_t pfP[2], pfS[2];
+    pack_blocks(pb, pfP);
+    pack_blocks(sb, pfS);
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        dvt[d] = mfma_bf16(tile_tr_frag(dOs, c, d, g, i), pfP[c], dvt[d]);    // dVt[d, key] += dOt[d, q] P[q, key]
+        dkt[d] = mfma_bf16(tile_tr_frag(Qs, c, d, g, i), pfS[c], dkt[d]);     // dKt[d, key] += Qt[d, q] dS[q, key]
+      }
+  }
+  if (ki < T) {
+    const long long off = (long long)b * batch_stride + (long long)ki * row_stride + (long long)h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      *reinterpret_cast<float4*>(dk + off + d * 16) = make_float4(dkt[d][0], dkt[d][1], dkt[d][2], dkt[d][3]);
+      *reinterpret_cast<float4*>(dv + off + d * 16) = make_float4(dvt[d][0], dvt[d][1], dvt[d][2], dvt[d][3]);
+    }
+  }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const float* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               float* __restrict__ dq, int T, int H, long long row_stride,
+                                                               long long batch_stride, long long do_row, long long do_batch) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * XS], Vs[64 * XS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 64, qw0 = q0 + wave * 16, qi = qw0 + i;
+  const float* qb = q + (long long)b * batch_stride + (long long)h * 64;
+  const float* kb = k + (long long)b * batch_stride + (long long)h * 64;
+  const float* vb = v + (long long)b * batch_stride + (long long)h * 64;
+  const float* dob = dout + (long long)b * do_batch + (long long)h * 64;
+  const int qc = min(qi, T - 1);
+  u32x4_t qfix[2], dofix[2];
+  qfix[0] = row_frag_global(qb + (long long)qc * row_stride, g, 0); qfix[1] = row_frag_global(qb + (long long)qc * row_stride, g, 1);
+  dofix[0] = row_frag_global(dob + (long long)qc * do_row, g, 0); dofix[1] = row_frag_global(dob + (long long)qc * do_row, g, 1);
+  const float lse_i = qi < T ? lse[((long long)b * H + h) * T + qi] : 0.f;
+  const float del_i = qi < T ? delta[((long long)b * H + h) * T + qi] : 0.f;
+  f32x4_t dqt[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) dqt[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (T + 63) >> 6;
+  const int t_end = CAUSAL ? min(ntiles, (q0 >> 6) + 1) : ntiles;
+  for (int t = 0; t < t_end; ++t) {
+    const int k0 = t * 64;
+    __syncthreads();
+    stage_tile_bf16(Ks, kb, row_stride, k0, T, tid);
+    stage_tile_bf16(Vs, vb, row_stride, k0, T, tid);
+    __syncthreads();
+    if (qw0 >= T) continue;
+    f32x4_t sb[4];                                     // dSt of the four 16-key blocks: lane (g,i): query i, keys 4g+r
+#pragma unroll
+    for (int kbk = 0; kbk < 4; ++kbk) {
+      f32x4_t st = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dpt = st;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        st = mfma_bf16(tile_row_frag(Ks, kbk, s2, g, i), qfix[s2], st);       // St[key, q]
+        dpt = mfma_bf16(tile_row_frag(Vs, kbk, s2, g, i), dofix[s2], dpt);    // dPt[key, q]
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = k0 + 16 * kbk + 4 * g + r;
+        const bool ok = qi < T && kj < T && (!CAUSAL || kj <= qi);
+        const float pv = ok ? expf(st[r] - lse_i) : 0.f;
+        sb[kbk][r] = pv * (dpt[r] - del_i);
+      }
+    }
+    u32x4_t pfS[2];
+    pack_blocks(sb, pfS);
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) dqt[d] = mfma_bf16(tile_tr_frag(Ks, c, d, g, i), pfS[c], dqt[d]);   // dQt[d, q] += Kt[d, key] dSt[key, q]
+  }
+  if (qi < T) {
+    const long long off = (long long)b * batch_stride + (long long)qi * row_stride + (long long)h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      *reinterpret_cast<float4*>(dq + off + d * 16) = make_float4(dqt[d][0], dqt[d][1], dqt[d][2], dqt[d][3]);
+  }
+}
+
 // delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]: one wave per (b,q,h)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ dout,
                                                          float* __restrict__ delta, int B, int T, int H, long long row,
@@ -975,16 +1164,32 @@ extern "C" int kx_adamw(float* param, const float* grad, float* m, float* v, int
 extern "C" int kx_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* dout,
                                      const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B, int64_t H,
                                      int64_t T, int64_t qkv_row_stride, int64_t qkv_batch_stride, int64_t out_row_stride,
-                                     int64_t out_batch_stride, int32_t mask, void* stream) {
+                                     int64_t out_batch_stride, int32_t mask, int32_t prec, void* stream) {
   KX_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta, "kx_attention_backward: null pointer");
   KX_REQUIRE(B > 0 && H > 0 && T > 0 && B < 65536 && H < 65536, "kx_attention_backward: bad shape");
-  KX_REQUIRE(qkv_row_stride % 4 == 0 && out_row_stride % 4 == 0, "kx_attention_backward: strides must keep float4 alignment");
+  KX_REQUIRE(qkv_row_stride % 4 == 0 && out_row_stride % 4 == 0 && qkv_batch_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
+                 (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+             "kx_attention_backward: pointers and strides must keep 16-byte alignment");
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(KX_K_ATTN_F32, B * H, T, -T, s);
   const long long nw = (long long)B * T * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, out, dout, delta, (int)B, (int)T,
                      (int)H, (long long)out_row_stride, (long long)out_batch_stride);
   const dim3 grid((unsigned)((T + 63) / 64), (unsigned)H, (unsigned)B);
+  KX_REQUIRE(prec == KX_PREC_F32 || prec == KX_PREC_BF16, "kx_attention_backward: products in fp32 or bf16");
+  if (prec == KX_PREC_BF16) {                                      // bf16 products, fp32 inputs / statistics / accumulators
+#define KX_ATTN_BWD_B(CAUSAL)                                                                                          \
+  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dk, \
+                     dv, (int)T, (int)H, (long long)qkv_row_stride, (long long)qkv_batch_stride,                       \
+                     (long long)out_row_stride, (long long)out_batch_stride);                                          \
+  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dq, \
+                     (int)T, (int)H, (long long)qkv_row_stride, (long long)qkv_batch_stride, (long long)out_row_stride, \
+                     (long long)out_batch_stride)
+    if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD_B(true); } else { KX_ATTN_BWD_B(false); }
+#undef KX_ATTN_BWD_B
+    KX_CHECK_LAUNCH("kx_attention_backward");
+    return KX_OK;
+  }
   if (kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1) {                  // matrix-core passes (default)
 #define KX_ATTN_BWD_M(CAUSAL)                                                                                          \
   hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dk, \

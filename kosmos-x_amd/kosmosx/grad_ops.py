@@ -129,7 +129,7 @@ def adamw_(param, grad, m, v, step, lr, betas=(0.9, 0.95), eps=1e-8, weight_deca
                               float(max_norm), _stream()), "kx_adamw")
 
 
-def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True):
+def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True, bf16_products=False):
     """qkv [B*T, 3D] fp32 (q pre-scaled and XPos-rotated), out/dout [B,T,D], lse [B,H,T] -> dqkv [B*T, 3D]."""
     _need_cuda(qkv, out, dout, lse)
     D = Hh * 64
@@ -140,5 +140,5 @@ def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True):
     dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * es, dqkv.data_ptr() + 2 * D * es
     H.check(H.load().kx_attention_backward(q, k, v, H.ptr(out), H.ptr(dout), H.ptr(lse), dq, dk, dv, H.ptr(delta), B, Hh, T,
                                            3 * D, T * 3 * D, D, T * D, H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL,
-                                           _stream()), "kx_attention_backward")
+                                           H.KX_PREC_BF16 if bf16_products else H.KX_PREC_F32, _stream()), "kx_attention_backward")
     return dqkv

@@ -205,7 +205,8 @@ class LanguageModelTrainer:
             dan = dgrad(dx, P["o"].weight)
             datt = dan if P["inner_ln"] is None else ln_bwd(s["att"], pfx + f"self_attn.inner_attn_ln{mw}",
                                                              P["inner_ln"].weight, dan)
-            dqkv = G.attention_backward(s["qkv"], s["att"].reshape(B, T, D), datt.reshape(B, T, D), s["lse"], B, T, Hh, True)
+            dqkv = G.attention_backward(s["qkv"], s["att"].reshape(B, T, D), datt.reshape(B, T, D), s["lse"], B, T, Hh, True,
+                                        bf16_products=self.precision == "bf16")
             G.xpos_backward_(dqkv, D, T, tabs, 0.125)
             # q | k | v are adjacent in the flat layout: one GEMM output / one column sum covers the three
             wgrad(dqkv, s["h1"], out=self._gspan(pfx + f"self_attn.q_proj{mw}.weight", 3 * D, D))

@@ -137,6 +137,10 @@ def test_attention_backward(B, Hh, T, causal):
     finally:
         _hip.load().kx_set_tuning(2, 0)
     assert rel_err(first, qkv.grad) < 3e-5
+    # bf16 products (mixed-precision training): fp32 statistics, operands rounded on the way in
+    mixed = G.attention_backward(qd, og, do.to(DEV), lse, B, T, Hh, causal, bf16_products=True)
+    rms = float((mixed.cpu() - qkv.grad).pow(2).mean().sqrt() / qkv.grad.pow(2).mean().sqrt())
+    assert rms < 1.5e-2 and rel_err(mixed, qkv.grad) < 0.2, rms
 
 
 @pytest.mark.parametrize("shape", [(70, 130), (64, 64), (5, 257), (300, 2048)])
