@@ -23,6 +23,17 @@ from . import ops
 from .model import KosmosLanguage, _a
 
 
+def cosine_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5) -> float:
+    """The learning-rate factor of transformers.get_cosine_schedule_with_warmup at `step` (what train.py:567-583 builds
+    with 1 % warm-up): linear ramp 0 -> 1 over the warm-up steps, then half a cosine down to 0.  Host arithmetic; feed
+    `base_lr * factor` to `LanguageModelTrainer.lr` before each step."""
+    import math
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
 class LanguageModelTrainer:
     def __init__(self, model: KosmosLanguage, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.1, max_grad_norm: float = 1.0, precision: str = "fp32", process_group=None,
