@@ -77,8 +77,14 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restri
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         int p0, p1, p2;
-        if constexpr (LDS) {                     // plain LDS addressing (a pointer that may be either space is FLAT)
-          p0 = row_lds[loff[r] + o]; p1 = row_lds[loff[r] + o + 1]; p2 = row_lds[loff[r] + o + 2];
+        if constexpr (LDS) {
+          // Two aligned dword reads + v_alignbyte instead of three byte reads: sub-dword LDS reads with scattered
+          // addresses keep the LDS address unit busy ~26 cycles per wave instruction (PMC: SQ_LDS_IDX_ACTIVE /
+          // SQ_INSTS_LDS; 29 % of all wave cycles were SQ_WAIT_INST_LDS) — dword reads run at full rate.
+          const int a = loff[r] + o;
+          const uint32_t* w32 = reinterpret_cast<const uint32_t*>(row_lds) + (a >> 2);
+          const uint32_t px4 = __builtin_amdgcn_alignbyte(w32[1], w32[0], a & 3);
+          p0 = px4 & 255u; p1 = (px4 >> 8) & 255u; p2 = (px4 >> 16) & 255u;
         } else {
           p0 = grow[r][o]; p1 = grow[r][o + 1]; p2 = grow[r][o + 2];
         }
@@ -168,7 +174,7 @@ extern "C" int kx_clip_preprocess(const uint8_t* src, int64_t B, int32_t H, int3
   uint32_t* tmp = reinterpret_cast<uint32_t*>(workspace);
   // crop windows wider than 64 KB of source row (square-ish images beyond ~21k pixels) read their taps straight from
   // global memory (L2-served); tuning key 6 forces that path for tests
-  const int lds_row = (plan->span_px * 3 + 15 + 15) & ~15;      // span + worst-case misalignment, 16-byte pitch
+  const int lds_row = (plan->span_px * 3 + 15 + 8 + 15) & ~15;  // span + worst-case misalignment + the dword over-read, 16-byte pitch
   const bool force_global = kx_tuning_get(KX_TUNE_PREPROCESS_NO_LDS) != 0;
   {
     KxProfScope prof(KX_K_MISC, B, (int64_t)H * W, 10, s);
