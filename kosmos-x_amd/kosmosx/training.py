@@ -37,10 +37,11 @@ def cosine_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_s
 class LanguageModelTrainer:
     def __init__(self, model: KosmosLanguage, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.1, max_grad_norm: float = 1.0, precision: str = "fp32", process_group=None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, checkpoint_activations: bool = False):
         if precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError("precision must be fp32, bf16 or bf16x3")
         self.precision = precision
+        self.checkpoint_activations = checkpoint_activations
         if not next(model.parameters()).is_cuda:
             raise RuntimeError("LanguageModelTrainer needs the model on a HIP device: there is no CPU fallback")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
@@ -140,8 +141,8 @@ class LanguageModelTrainer:
         tabs = None
         if xp is not None:
             tabs = [t.to(dev) for t in (*xp.tables(T, 0, False), *xp.tables(T, 0, True))]
-        saved = []
-        for L in dec.layers:
+        def layer_forward(L, x):
+            """One decoder layer; returns the layer output and everything its backward needs."""
             P = self._layer_params(L)
             s = {"x_in": x}
             h1 = ops.layernorm(x, P["sa_ln"].weight.detach(), P["sa_ln"].bias.detach(), eps)
@@ -159,8 +160,16 @@ class LanguageModelTrainer:
             g = G.gelu(pre)
             g_n = g if P["ffn_ln"] is None else ops.layernorm(g, P["ffn_ln"].weight.detach(), P["ffn_ln"].bias.detach(), eps)
             s.update(h1=h1, wqkv=wqkv, qkv=qkv, lse=lse, att=att, a_n=a_n, x_mid=x, h2=h2, pre=pre, g=g, g_n=g_n)
-            x = lin(g_n, P["fc2"].weight, P["fc2"].bias, residual=x)
-            saved.append(s)
+            return lin(g_n, P["fc2"].weight, P["fc2"].bias, residual=x), s
+
+        # checkpoint_activations: keep only each layer's input (4 bytes x d per token instead of ~21x that) and run the
+        # layer's forward again right before its backward — one third more GEMM work for batches that do not fit otherwise
+        saved = []
+        for L in dec.layers:
+            x_in = x
+            x, s = layer_forward(L, x)
+            saved.append({"x_in": x_in} if self.checkpoint_activations else s)
+            del s
         hf = ops.layernorm(x, dec.layer_norm.weight.detach(), dec.layer_norm.bias.detach(), eps)
         Vp = (V + 31) // 32 * 32                           # dlogits is a GEMM operand over V in the backward pass
         logits = torch.zeros((M, Vp), dtype=torch.float32, device=dev)
@@ -199,6 +208,9 @@ class LanguageModelTrainer:
         mw = ".A" if a.multiway else ""
         for li in range(len(dec.layers) - 1, -1, -1):
             L, s = dec.layers[li], saved[li]
+            if self.checkpoint_activations:
+                _, s = layer_forward(L, s["x_in"])
+                saved[li] = None
             P, pfx = self._layer_params(L), f"decoder.layers.{li}."
             # x_out = x_mid + fc2(ffn_ln(gelu(fc1(fl_ln(x_mid)))))
             wgrad(dx, s["g_n"], out=grads[pfx + f"ffn{mw}.fc2.weight"])

@@ -153,3 +153,13 @@ def test_repeated_steps_overfit_a_fixed_batch(prec):
     assert 6.0 < losses[0] < 8.0                       # ln(1002) = 6.9 at initialisation
     assert losses[-1] < 0.4 * losses[0], (losses[0], losses[-1])
     assert all(torch.isfinite(p).all() for p in lm.parameters())
+
+
+def test_activation_checkpointing_gives_identical_gradients():
+    """Recomputing each layer's forward before its backward is the same arithmetic: bit-identical loss and gradients."""
+    tok = torch.randint(2, 1002, (2, 40), generator=torch.Generator().manual_seed(13)).to(DEV)
+    a, b = _tiny_lm(seed=7).to(DEV), _tiny_lm(seed=7).to(DEV)
+    ta = LanguageModelTrainer(a, precision="bf16")
+    tb = LanguageModelTrainer(b, precision="bf16", checkpoint_activations=True)
+    la, lb = ta.step(tok, apply_update=False), tb.step(tok, apply_update=False)
+    assert float(la) == float(lb) and torch.equal(ta.flat_g, tb.flat_g)

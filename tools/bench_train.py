@@ -22,6 +22,7 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--layers", type=int, default=24)
 ap.add_argument("--cpu-seconds", type=float, default=20.0)
+ap.add_argument("--checkpoint", action="store_true", help="keep only layer inputs, recompute each layer before its backward")
 ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"], help="arithmetic of the matrix products")
 a = ap.parse_args()
 import torch.distributed as dist
@@ -33,7 +34,7 @@ if world > 1 or force:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 lm = KosmosLanguage(vocab_size=32002, dim=2048, depth=a.layers, _seed=0).eval().to(dev)      # same seed: replicated weights
-tr = LanguageModelTrainer(lm, precision=a.precision, force_collectives=force)
+tr = LanguageModelTrainer(lm, precision=a.precision, force_collectives=force, checkpoint_activations=a.checkpoint)
 g = torch.Generator().manual_seed(1000 + rank)                                               # per-rank batch shard
 batches = [torch.randint(2, 32002, (a.batch, a.seq), generator=g).to(dev) for _ in range(a.warmup + a.steps + 1)]
 losses = []
