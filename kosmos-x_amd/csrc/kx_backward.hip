@@ -794,6 +794,23 @@ __device__ __forceinline__ void stage_tile_bf16(bf16_t* dst, const float* src, l
     *reinterpret_cast<uint2*>(dst + r * XS + c4) = o;
   }
 }
+// the same in two halves, so the global loads of tile t+1 fly while tile t is multiplied (4 float4 per thread and tile)
+__device__ __forceinline__ void tile_gload(float4 (&reg)[4], const float* src, long long stride, int r0, int T, int tid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j, r = i >> 4, c4 = (i & 15) * 4;
+    reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < T) reg[j] = *reinterpret_cast<const float4*>(src + (long long)(r0 + r) * stride + c4);
+  }
+}
+__device__ __forceinline__ void tile_lstore(bf16_t* dst, const float4 (&reg)[4], int tid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j, r = i >> 4, c4 = (i & 15) * 4;
+    uint2 o; o.x = pack_bf16x2(reg[j].x, reg[j].y); o.y = pack_bf16x2(reg[j].z, reg[j].w);
+    *reinterpret_cast<uint2*>(dst + r * XS + c4) = o;
+  }
+}
 __device__ __forceinline__ u32x4_t row_frag_global(const float* rowp, int g, int s2) {   // 8 fp32 -> 8 bf16 of k-step s2
   const float4 a = *reinterpret_cast<const float4*>(rowp + 32 * s2 + 8 * g);
   const float4 b = *reinterpret_cast<const float4*>(rowp + 32 * s2 + 8 * g + 4);
@@ -829,8 +846,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const float* __r
                                                                 float* __restrict__ dk, float* __restrict__ dv, int T, int H,
                                                                 long long row_stride, long long batch_stride,
                                                                 long long do_row, long long do_batch) {
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * XS], dOs[64 * XS];
-  __shared__ float Ls[64], Ds[64];
+  __shared__ __attribute__((aligned(16))) bf16_t Qb[2][64 * XS], dOb[2][64 * XS];
+  __shared__ float Lb[2][64], Db[2][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
@@ -852,42 +869,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const float* __r
 #pragma unroll
   for (int d = 0; d < 4; ++d) { dkt[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvt[d] = dkt[d]; }
   const int ntiles = (T + 63) >> 6;
-  for (int t = CAUSAL ? key0 >> 6 : 0; t < ntiles; ++t) {
-    const int q0 = t * 64;
-    __syncthreads();
-    stage_tile_bf16(Qs, qb, row_stride, q0, T, tid);
-    stage_tile_bf16(dOs, dob, do_row, q0, T, tid);
-    if (tid < 64) { const int qq = q0 + tid; Ls[tid] = qq < T ? lseb[qq] : 0.f; Ds[tid] = qq < T ? delb[qq] : 0.f; }
-    __syncthreads();
-    if (kw0 >= T) continue;
-    f32x4_t pb[4], sb[4];                              // P and dS of the four 16-query blocks: lane (g,i): key i, queries 4g+r
-#pragma unroll
-    for (int qbk = 0; qbk < 4; ++qbk) {
-      f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, pa = sa;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        sa = mfma_bf16(tile_row_frag(Qs, qbk, s2, g, i), kfix[s2], sa);     // S[q, key]
-        pa = mfma_bf16(tile_row_frag(dOs, qbk, s2, g, i), vfix[s2], pa);    // dP[q, key]
+  const int t0 = CAUSAL ? key0 >> 6 : 0;
+  float4 qreg[4], doreg[4];
+  float lreg = 0.f, dreg = 0.f;
+  auto gload = [&](int t) {
+    tile_gload(qreg, qb, row_stride, t * 64, T, tid);
+    tile_gload(doreg, dob, do_row, t * 64, T, tid);
+    if (tid < 64) { const int qq = t * 64 + tid; lreg = qq < T ? lseb[qq] : 0.f; dreg = qq < T ? delb[qq] : 0.f; }
+  };
+  auto lstore = [&](int buf) {
+    tile_lstore(Qb[buf], qreg, tid);
+    tile_lstore(dOb[buf], doreg, tid);
+    if (tid < 64) { Lb[buf][tid] = lreg; Db[buf][tid] = dreg; }
+  };
+  gload(t0);
+  lstore(0);
+  __syncthreads();
+  for (int t = t0; t < ntiles; ++t) {
+    const int q0 = t * 64, buf = (t - t0) & 1;
+    const bf16_t* Qs = Qb[buf];
+    const bf16_t* dOs = dOb[buf];
+    const float* Ls = Lb[buf];
+    const float* Ds = Db[buf];
+    if (t + 1 < ntiles) gload(t + 1);                 // in flight during this tile's MFMAs
+    if (kw0 < T) {
+      f32x4_t pb[4], sb[4];                              // P and dS of the four 16-query blocks: lane (g,i): key i, queries 4g+r
+  #pragma unroll
+      for (int qbk = 0; qbk < 4; ++qbk) {
+        f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, pa = sa;
+  #pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          sa = mfma_bf16(tile_row_frag(Qs, qbk, s2, g, i), kfix[s2], sa);     // S[q, key]
+          pa = mfma_bf16(tile_row_frag(dOs, qbk, s2, g, i), vfix[s2], pa);    // dP[q, key]
+        }
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = 16 * qbk + 4 * g + r, qi = q0 + ql;
+          const bool ok = qi < T && ki < T && (!CAUSAL || ki <= qi);
+          const float pv = ok ? expf(sa[r] - Ls[ql]) : 0.f;
+          pb[qbk][r] = pv;
+          sb[qbk][r] = pv * (pa[r] - Ds[ql]);
+        }
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ql = 16 * qbk + 4 * g + r, qi = q0 + ql;
-        const bool ok = qi < T && ki < T && (!CAUSAL || ki <= qi);
-        const float pv = ok ? expf(sa[r] - Ls[ql]) : 0.f;
-        pb[qbk][r] = pv;
-        sb[qbk][r] = pv * (pa[r] - Ds[ql]);
-      }
+      u32x4_t pfP[2], pfS[2];
+      pack_blocks(pb, pfP);
+      pack_blocks(sb, pfS);
+  #pragma unroll
+      for (int d = 0; d < 4; ++d)
+  #pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          dvt[d] = mfma_bf16(tile_tr_frag(dOs, c, d, g, i), pfP[c], dvt[d]);    // dVt[d, key] += dOt[d, q] P[q, key]
+          dkt[d] = mfma_bf16(tile_tr_frag(Qs, c, d, g, i), pfS[c], dkt[d]);     // dKt[d, key] += Qt[d, q] dS[q, key]
+        }
     }
-    u32x4_t pfP[2], pfS[2];
-    pack_blocks(pb, pfP);
-    pack_blocks(sb, pfS);
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        dvt[d] = mfma_bf16(tile_tr_frag(dOs, c, d, g, i), pfP[c], dvt[d]);    // dVt[d, key] += dOt[d, q] P[q, key]
-        dkt[d] = mfma_bf16(tile_tr_frag(Qs, c, d, g, i), pfS[c], dkt[d]);     // dKt[d, key] += Qt[d, q] dS[q, key]
-      }
+    if (t + 1 < ntiles) lstore(buf ^ 1);
+    __syncthreads();
   }
   if (ki < T) {
     const long long off = (long long)b * batch_stride + (long long)ki * row_stride + (long long)h * 64 + 4 * g;
@@ -905,7 +941,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const float* __re
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ dq, int T, int H, long long row_stride,
                                                                long long batch_stride, long long do_row, long long do_batch) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * XS], Vs[64 * XS];
+  __shared__ __attribute__((aligned(16))) bf16_t Kb[2][64 * XS], Vb[2][64 * XS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
@@ -926,36 +962,50 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const float* __re
   for (int d = 0; d < 4; ++d) dqt[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int ntiles = (T + 63) >> 6;
   const int t_end = CAUSAL ? min(ntiles, (q0 >> 6) + 1) : ntiles;
+  float4 kreg[4], vreg[4];
+  auto gload = [&](int t) {
+    tile_gload(kreg, kb, row_stride, t * 64, T, tid);
+    tile_gload(vreg, vb, row_stride, t * 64, T, tid);
+  };
+  auto lstore = [&](int buf) {
+    tile_lstore(Kb[buf], kreg, tid);
+    tile_lstore(Vb[buf], vreg, tid);
+  };
+  gload(0);
+  lstore(0);
+  __syncthreads();
   for (int t = 0; t < t_end; ++t) {
-    const int k0 = t * 64;
-    __syncthreads();
-    stage_tile_bf16(Ks, kb, row_stride, k0, T, tid);
-    stage_tile_bf16(Vs, vb, row_stride, k0, T, tid);
-    __syncthreads();
-    if (qw0 >= T) continue;
-    f32x4_t sb[4];                                     // dSt of the four 16-key blocks: lane (g,i): query i, keys 4g+r
-#pragma unroll
-    for (int kbk = 0; kbk < 4; ++kbk) {
-      f32x4_t st = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dpt = st;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        st = mfma_bf16(tile_row_frag(Ks, kbk, s2, g, i), qfix[s2], st);       // St[key, q]
-        dpt = mfma_bf16(tile_row_frag(Vs, kbk, s2, g, i), dofix[s2], dpt);    // dPt[key, q]
+    const int k0 = t * 64, buf = t & 1;
+    const bf16_t* Ks = Kb[buf];
+    const bf16_t* Vs = Vb[buf];
+    if (t + 1 < t_end) gload(t + 1);                  // in flight during this tile's MFMAs
+    if (qw0 < T) {
+      f32x4_t sb[4];                                     // dSt of the four 16-key blocks: lane (g,i): query i, keys 4g+r
+  #pragma unroll
+      for (int kbk = 0; kbk < 4; ++kbk) {
+        f32x4_t st = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dpt = st;
+  #pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          st = mfma_bf16(tile_row_frag(Ks, kbk, s2, g, i), qfix[s2], st);       // St[key, q]
+          dpt = mfma_bf16(tile_row_frag(Vs, kbk, s2, g, i), dofix[s2], dpt);    // dPt[key, q]
+        }
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kj = k0 + 16 * kbk + 4 * g + r;
+          const bool ok = qi < T && kj < T && (!CAUSAL || kj <= qi);
+          const float pv = ok ? expf(st[r] - lse_i) : 0.f;
+          sb[kbk][r] = pv * (dpt[r] - del_i);
+        }
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kj = k0 + 16 * kbk + 4 * g + r;
-        const bool ok = qi < T && kj < T && (!CAUSAL || kj <= qi);
-        const float pv = ok ? expf(st[r] - lse_i) : 0.f;
-        sb[kbk][r] = pv * (dpt[r] - del_i);
-      }
+      u32x4_t pfS[2];
+      pack_blocks(sb, pfS);
+  #pragma unroll
+      for (int d = 0; d < 4; ++d)
+  #pragma unroll
+        for (int c = 0; c < 2; ++c) dqt[d] = mfma_bf16(tile_tr_frag(Ks, c, d, g, i), pfS[c], dqt[d]);   // dQt[d, q] += Kt[d, key] dSt[key, q]
     }
-    u32x4_t pfS[2];
-    pack_blocks(sb, pfS);
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) dqt[d] = mfma_bf16(tile_tr_frag(Ks, c, d, g, i), pfS[c], dqt[d]);   // dQt[d, q] += Kt[d, key] dSt[key, q]
+    if (t + 1 < t_end) lstore(buf ^ 1);
+    __syncthreads();
   }
   if (qi < T) {
     const long long off = (long long)b * batch_stride + (long long)qi * row_stride + (long long)h * 64 + 4 * g;
