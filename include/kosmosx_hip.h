@@ -128,6 +128,12 @@ typedef struct {
   const float* ln_gamma; const float* ln_beta; float ln_eps;
   const float* stats_partials; int64_t stats_in_nseg; int64_t stats_in_seg; float stats_eps;
   int32_t stats_out_seg;
+  /* Row-owning split-K reduce (skinny problems, N <= 8192, N % 4 == 0): when ln_out is given, the reduce kernel — one
+   * workgroup per output row — also writes LayerNorm(C[m, :]) * ln_out_gamma + ln_out_beta to ln_out [M, N] (dtype
+   * ln_out_dt), i.e. the LayerNorm that would follow this GEMM costs no launch; with stats_partials it also takes the
+   * folded-LN statistics straight from the producer's partials.  Only valid when the call will be split
+   * (kx_gemm fails otherwise; the stage-level entry points check with the same rule before asking). */
+  void* ln_out; int32_t ln_out_dt; const float* ln_out_gamma; const float* ln_out_beta; float ln_out_eps;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 

@@ -111,11 +111,18 @@ inline int qdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : KX_F32; }
 inline int aprec(int prec) { return prec == KX_PREC_BF16 ? KX_PREC_BF16 : KX_PREC_F32; }
 inline int64_t kmul(int prec) { return prec == KX_PREC_BF16X3 ? 3 : 1; }
 
+// what the row-owning split-K reduce can absorb (kx_gemm_args: stats_partials, ln_out)
+struct RowFusion {
+  const float* partials = nullptr; int64_t nseg = 0, seg = 0;            // folded-LN statistics straight from the producer
+  void* ln_out = nullptr; int ln_dt = 0; const float* ln_g = nullptr; const float* ln_b = nullptr;   // the LayerNorm that follows
+  float eps = 0.f;
+};
+
 int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t ldc, int cdtype, int64_t M, int64_t N,
          const float* bias, const float* residual, int act, float qscale, int64_t qcols, int prec, hipStream_t s,
          const float* xq_cs = nullptr, const float* xq_ss = nullptr, const float* xk_cs = nullptr,
          const float* xk_ss = nullptr, int64_t xT = 0, int64_t xdim = 0, const float* row_stats = nullptr,
-         const float* colsum = nullptr, float* stats_out = nullptr) {
+         const float* colsum = nullptr, float* stats_out = nullptr, const RowFusion* rf = nullptr) {
   kx_gemm_args g;
   memset(&g, 0, sizeof(g));
   // bf16x3: the same bf16 kernels over the 3K-wide split operands ([hi|hi|lo] activations x [hi|lo|hi] weights)
@@ -127,7 +134,19 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   g.prec = km == 3 ? KX_PREC_BF16 : prec; g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
   g.row_stats = row_stats; g.colsum = colsum; g.stats_out = stats_out;
   g.splitk_ws = g_splitk_ws; g.splitk_ws_bytes = g_splitk_ws_bytes; g.splitk = 0;
+  if (rf) {
+    g.stats_partials = rf->partials; g.stats_in_nseg = rf->nseg; g.stats_in_seg = rf->seg; g.stats_eps = rf->eps;
+    g.ln_out = rf->ln_out; g.ln_out_dt = rf->ln_dt; g.ln_out_gamma = rf->ln_g; g.ln_out_beta = rf->ln_b; g.ln_out_eps = rf->eps;
+  }
   return kx_gemm(&g, (void*)s);
+}
+
+// Will kx_gemm's automatic choice split this (M, N, K) problem, i.e. is the row-owning reduce (RowFusion) available?
+// Same rule as kx_gemm itself; an explicit tile override (A/B runs) keeps the separate kernels.
+bool row_reduce_available(int64_t M, int64_t N, int64_t K, int prec) {
+  if (kx_tuning_get(KX_TUNE_GEMM_TILE) != 0 || N > 8192 || N % 4 != 0) return false;
+  const int gp = prec == KX_PREC_BF16X3 ? KX_PREC_BF16 : prec;
+  return kx_gemm_auto_splits(M, N, K * kmul(prec), gp, g_splitk_ws_bytes) > 1;
 }
 
 // tile 16 (weight streaming, bf16, M <= 16) with its prologues — see kx_gemm_args in the header
@@ -247,9 +266,13 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
               prec, s));
   KX_TRY(kx_launch_vit_assemble(v.patch_out, w->cls, w->pos, v.xpre, B, (int)S, (int)D, s));
   KX_TRY(ln(v.xpre, nullptr, w->pre_g, w->pre_b, out, KX_F32, M, D, w->eps, s));
+  // At batch 1 (M = 257) the GEMMs are split-K and the layer is a chain of dependent ~12 us launches: the residual
+  // GEMMs' row-owning reduce kernels also write the LayerNorm that follows (layer_norm2 / the next layer's layer_norm1).
+  const bool fuse_o = row_reduce_available(M, D, D, prec), fuse_2 = row_reduce_available(M, D, w->ffn, prec);
+  bool h_ready = false;                                   // v.h already holds layer_norm1(out) of this layer
   for (int i = 0; i < w->layers; ++i) {
     const kx_vit_layer& L = w->layer[i];
-    KX_TRY(ln(out, nullptr, L.ln1_g, L.ln1_b, v.h, ct, M, D, w->eps, s));
+    if (!h_ready) KX_TRY(ln(out, nullptr, L.ln1_g, L.ln1_b, v.h, ct, M, D, w->eps, s));
     KX_TRY(gemm(v.h, D, L.wqkv, D, v.qkv, 3 * D, qdt(prec), M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s));
     kx_attn_args a;
     memset(&a, 0, sizeof(a));
@@ -259,10 +282,17 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
     a.out = v.att; a.out_batch_stride = S * D * kmul(prec); a.out_row_stride = D * kmul(prec); a.odt = ct;
     a.B = B; a.H = w->heads; a.Tq = S; a.Tk = S; a.mask = KX_ATTN_FULL; a.prec = aprec(prec);
     KX_TRY(kx_attention(&a, stream));
-    KX_TRY(gemm(v.att, D, L.wo, D, out, D, KX_F32, M, D, L.bo, out, 0, 1.f, 0, prec, s));
-    KX_TRY(ln(out, nullptr, L.ln2_g, L.ln2_b, v.h, ct, M, D, w->eps, s));
+    RowFusion ro, r2;
+    ro.ln_out = v.h; ro.ln_dt = ct; ro.ln_g = L.ln2_g; ro.ln_b = L.ln2_b; ro.eps = w->eps;
+    KX_TRY(gemm(v.att, D, L.wo, D, out, D, KX_F32, M, D, L.bo, out, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr, 0,
+                0, nullptr, nullptr, nullptr, fuse_o ? &ro : nullptr));
+    if (!fuse_o) KX_TRY(ln(out, nullptr, L.ln2_g, L.ln2_b, v.h, ct, M, D, w->eps, s));
     KX_TRY(gemm(v.h, D, L.w1, D, v.ff, w->ffn, ct, M, w->ffn, L.b1, nullptr, w->act, 1.f, 0, prec, s));
-    KX_TRY(gemm(v.ff, w->ffn, L.w2, w->ffn, out, D, KX_F32, M, D, L.b2, out, 0, 1.f, 0, prec, s));
+    const bool next = fuse_2 && i + 1 < w->layers;
+    if (next) { r2.ln_out = v.h; r2.ln_dt = ct; r2.ln_g = w->layer[i + 1].ln1_g; r2.ln_b = w->layer[i + 1].ln1_b; r2.eps = w->eps; }
+    KX_TRY(gemm(v.ff, w->ffn, L.w2, w->ffn, out, D, KX_F32, M, D, L.b2, out, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
+                nullptr, 0, 0, nullptr, nullptr, nullptr, next ? &r2 : nullptr));
+    h_ready = next;
   }
   return KX_OK;
 }
@@ -347,10 +377,15 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
   SplitkScope sk(d.splitk, KX_SPLITK_WS);
   const int ct = cdt(prec);
   const size_t es = esz(prec);
+  // Batch-1-sized problems (M = T = 114: every GEMM is split-K): the residual GEMMs' row-owning reduce kernels take the
+  // folded-LN statistics straight from the producer's partials and write the LayerNorm that follows (final_layer_norm,
+  // the next layer's self_attn_layer_norm, the decoder's last LayerNorm) — 9 launches per layer instead of 13.
+  const bool fuse_o = row_reduce_available(M, D, D, prec), fuse_2 = row_reduce_available(M, D, F, prec);
+  bool h_ready = false;                                   // d.h already holds the LayerNorm this layer starts with
   for (int i = 0; i < w->layers; ++i) {
     const kx_decoder_layer& L = w->layer[i];
     // x = x + out_proj(inner_attn_ln(attn(xpos(q), xpos(k), v)))   on self_attn_layer_norm(x)
-    KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
+    if (!h_ready) KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
     KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, qdt(prec), M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
                 w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? T : 0, w->xpos ? D : 0));
     if (kcache) {   // incremental decoding: keep this layer's (XPos-rotated) keys and values
@@ -365,33 +400,53 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     a.kv_batch_stride = T * 3 * D; a.kv_row_stride = 3 * D;
     a.B = B; a.H = w->heads; a.Tq = T; a.Tk = T; a.mask = KX_ATTN_CAUSAL; a.prec = aprec(prec);
     a.out = d.att; a.out_batch_stride = T * D * kmul(prec); a.out_row_stride = D * kmul(prec); a.odt = ct;
+    RowFusion ro, r2;
+    ro.ln_out = d.h; ro.ln_dt = ct; ro.ln_g = L.fl_g; ro.ln_b = L.fl_b; ro.eps = w->eps;
     if (w->subln) {
       // inner_attn_ln folded into out_proj: the attention kernel emits per-(row, head) partial statistics, the GEMM
       // multiplies the un-normalised output by γ⊙Wo and applies rstd·(acc − mean·colsum) + (β·Woᵀ + bo) in its epilogue
       a.stats_out = d.partials;
       KX_TRY(kx_attention(&a, stream));
-      KX_TRY(kx_row_stats_finalize(d.partials, M, w->heads, 64, w->eps, d.stats, stream));
-      KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
-                  0, 0, d.stats, L.wo_colsum, nullptr));
+      if (fuse_o) {
+        ro.partials = d.partials; ro.nseg = w->heads; ro.seg = 64;
+        KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
+                    0, 0, nullptr, L.wo_colsum, nullptr, &ro));
+      } else {
+        KX_TRY(kx_row_stats_finalize(d.partials, M, w->heads, 64, w->eps, d.stats, stream));
+        KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
+                    0, 0, d.stats, L.wo_colsum, nullptr));
+      }
     } else {
       KX_TRY(kx_attention(&a, stream));
-      KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s));
+      KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr, 0,
+                  0, nullptr, nullptr, nullptr, fuse_o ? &ro : nullptr));
     }
     // x = x + fc2(ffn_layernorm(gelu(fc1(final_layer_norm(x)))))
-    KX_TRY(ln(x, nullptr, L.fl_g, L.fl_b, d.h, ct, M, D, w->eps, s));
+    if (!fuse_o) KX_TRY(ln(x, nullptr, L.fl_g, L.fl_b, d.h, ct, M, D, w->eps, s));
+    const bool last = i + 1 == w->layers;
+    r2.ln_out = d.h; r2.ln_dt = ct; r2.eps = w->eps;
+    r2.ln_g = last ? w->ln_g : w->layer[i + 1].sa_g; r2.ln_b = last ? w->ln_b : w->layer[i + 1].sa_b;
     if (w->subln) {
       // ffn_layernorm folded into fc2 the same way; fc1's epilogue emits the row statistics of gelu(fc1)
       KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
                   nullptr, 0, 0, nullptr, nullptr, d.partials));
-      KX_TRY(kx_row_stats_finalize(d.partials, M, F / 64, 64, w->eps, d.stats, stream));
-      KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
-                  0, 0, d.stats, L.w2_colsum, nullptr));
+      if (fuse_2) {
+        r2.partials = d.partials; r2.nseg = F / 64; r2.seg = 64;
+        KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
+                    0, 0, nullptr, L.w2_colsum, nullptr, &r2));
+      } else {
+        KX_TRY(kx_row_stats_finalize(d.partials, M, F / 64, 64, w->eps, d.stats, stream));
+        KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
+                    0, 0, d.stats, L.w2_colsum, nullptr));
+      }
     } else {
       KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s));
-      KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s));
+      KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                  nullptr, nullptr, nullptr, fuse_2 ? &r2 : nullptr));
     }
+    h_ready = fuse_2;                                     // d.h = the next layer's (or the final) LayerNorm of x
   }
-  KX_TRY(ln(x, nullptr, w->ln_g, w->ln_b, d.h, ct, M, D, w->eps, s));
+  if (!h_ready) KX_TRY(ln(x, nullptr, w->ln_g, w->ln_b, d.h, ct, M, D, w->eps, s));
   KX_TRY(gemm(d.h, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab, nullptr, nullptr, 0, 1.f, 0, prec, s));
   return KX_OK;
 }

@@ -44,6 +44,8 @@ struct GemmParams {
   // weight-streaming variant (gemv_fused_kernel) only
   const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
   const float* stats_partials; int stats_in_nseg; float stats_in_seg, stats_eps;
+  // row-owning split-K reduce: optional LayerNorm of the finished row as a second output
+  void* ln_out; int ln_out_dt; const float *ln_out_g, *ln_out_b; float ln_out_eps;
 };
 
 // Everything of the fused epilogue except the store: x[0..3] = columns n..n+3 of row m (in range: m < M, n < N).
@@ -549,6 +551,105 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   epilogue4<ACT>(q, m, n, acc);
 }
 
+// Row-owning variant of the reduce kernel: one workgroup per output row (N <= 8192: 8 float4 per thread).  Besides the
+// slice sum + fused epilogue it can (a) derive the consumer-side folded-LN statistics of its row from the producer's
+// partials (no kx_row_stats_finalize launch) and (b) apply the LayerNorm that FOLLOWS this GEMM to the finished row and
+// write it as a second output (no kx_layernorm launch).  At batch 1 the forward is a chain of ~420 dependent launches of
+// ~12 us each; these two fusions remove ~100 of them.
+template <int ACT>
+__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParams p) {
+  __shared__ float red[4];
+  __shared__ float st[2];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  auto bsum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  GemmParams q = p;
+  q.splitk = 1;
+  if (p.stats_partials) {
+    const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
+    float sm = 0.f;
+    for (int j = tid; j < p.stats_in_nseg; j += 256) sm += pr[j].x;
+    const float mean = bsum(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
+    float m2 = 0.f;
+    for (int j = tid; j < p.stats_in_nseg; j += 256) {
+      const float2 v = pr[j];
+      const float d = v.x / p.stats_in_seg - mean;
+      m2 += v.y + p.stats_in_seg * d * d;
+    }
+    const float var = bsum(m2) / (p.stats_in_seg * (float)p.stats_in_nseg);
+    if (tid == 0) { st[0] = mean; st[1] = rsqrtf(var + p.stats_eps); }
+    __syncthreads();
+    q.row_stats = nullptr;                             // the fold is applied below with (mean, rstd) from LDS
+  }
+  float x[8][4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = 4 * (tid + 256 * j);
+    x[j][0] = x[j][1] = x[j][2] = x[j][3] = 0.f;
+    if (n < p.N) {
+      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < p.splitk; ++z)
+        acc += *reinterpret_cast<const f32x4_t*>(p.partial + ((long long)z * p.M + m) * p.N + n);
+      if (p.stats_partials) {                          // rstd * (acc - mean * colsum): first step of the epilogue
+        const float4 c = *reinterpret_cast<const float4*>(p.colsum + n);
+        const float mu = st[0], rs = st[1];
+        acc[0] = rs * (acc[0] - mu * c.x); acc[1] = rs * (acc[1] - mu * c.y);
+        acc[2] = rs * (acc[2] - mu * c.z); acc[3] = rs * (acc[3] - mu * c.w);
+      }
+      epilogue_compute4<ACT>(q, m, n, acc, x[j]);
+      const long long off = (long long)m * p.ldc + n;
+      if (p.c_x3) {
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
+        uint2 hh, ll;
+        split_bf16x2(x[j][0], x[j][1], hh.x, ll.x); split_bf16x2(x[j][2], x[j][3], hh.y, ll.y);
+        *reinterpret_cast<uint2*>(c) = hh; *reinterpret_cast<uint2*>(c + p.N) = hh; *reinterpret_cast<uint2*>(c + 2ll * p.N) = ll;
+      } else if (p.c_bf16) {
+        uint2 o; o.x = pack_bf16x2(x[j][0], x[j][1]); o.y = pack_bf16x2(x[j][2], x[j][3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off) = make_float4(x[j][0], x[j][1], x[j][2], x[j][3]);
+      }
+      s += (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
+    }
+  }
+  if (!p.ln_out) return;
+  const float mean = bsum(s) / (float)p.N;
+  float qv = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (4 * (tid + 256 * j) < p.N) {
+      const float a = x[j][0] - mean, b = x[j][1] - mean, c = x[j][2] - mean, d = x[j][3] - mean;
+      qv += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = rsqrtf(bsum(qv) / (float)p.N + p.ln_out_eps);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = 4 * (tid + 256 * j);
+    if (n >= p.N) continue;
+    const float4 gm = *reinterpret_cast<const float4*>(p.ln_out_g + n), bt = *reinterpret_cast<const float4*>(p.ln_out_b + n);
+    const float o0 = (x[j][0] - mean) * rstd * gm.x + bt.x, o1 = (x[j][1] - mean) * rstd * gm.y + bt.y;
+    const float o2 = (x[j][2] - mean) * rstd * gm.z + bt.z, o3 = (x[j][3] - mean) * rstd * gm.w + bt.w;
+    if (p.ln_out_dt == KX_BF16X3) {
+      bf16_t* c = reinterpret_cast<bf16_t*>(p.ln_out) + (long long)m * 3 * p.N + n;
+      uint2 hh, ll;
+      split_bf16x2(o0, o1, hh.x, ll.x); split_bf16x2(o2, o3, hh.y, ll.y);
+      *reinterpret_cast<uint2*>(c) = hh; *reinterpret_cast<uint2*>(c + p.N) = hh; *reinterpret_cast<uint2*>(c + 2ll * p.N) = ll;
+    } else if (p.ln_out_dt == KX_BF16) {
+      uint2 o; o.x = pack_bf16x2(o0, o1); o.y = pack_bf16x2(o2, o3);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.ln_out) + (long long)m * p.N + n) = o;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.ln_out) + (long long)m * p.N + n) = make_float4(o0, o1, o2, o3);
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Deep-pipelined variant: 256(m) x 128(n) x 64 block tile, 8 waves (4 x 2, 64x64 each), 3-stage LDS ring
 // (3 x 48 KB = 144 of the CU's 160 KB), ONE raw s_barrier per K-tile and a COUNTED s_waitcnt vmcnt(6):
@@ -970,6 +1071,18 @@ int launch_p5(GemmParams& p, hipStream_t s) {
 }
 
 int launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
+  if (p.ln_out || (p.stats_partials && p.splitk > 1 && !p.ln_g)) {          // row-owning reduce with its fusions
+    const dim3 rg((unsigned)p.M), rb(256);
+    switch (p.act) {
+      case KX_ACT_NONE: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_NONE>, rg, rb, 0, s, p); break;
+      case KX_ACT_GELU: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_GELU>, rg, rb, 0, s, p); break;
+      case KX_ACT_GELU_FAST: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_GELU_FAST>, rg, rb, 0, s, p); break;
+      case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_QUICK_GELU>, rg, rb, 0, s, p); break;
+      default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+    }
+    KX_CHECK_LAUNCH("kx_gemm(split-K row reduce)");
+    return KX_OK;
+  }
   const long long work = (long long)p.M * ((p.N + 3) / 4);
   const dim3 rgrid((unsigned)((work + 255) / 256)), block(256);
   switch (p.act) {
@@ -1169,6 +1282,28 @@ int launch(GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+// K slices for a 64x64-tile launch: ~512 workgroups streaming the weights, at most 16 slices, at least two K-tiles per
+// slice, partials [slices, M, N] fp32 within the scratch.  `forced` > 0 overrides the count (tests).
+static long long splitk_slices(int64_t M, int64_t N, int64_t K, int bk, size_t ws_bytes, int forced) {
+  const long long tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  const long long nk_all = K / bk;
+  long long sp = forced > 0 ? forced : (tiles >= 384 ? 1 : (512 + tiles - 1) / tiles);
+  if (sp > 16) sp = 16;
+  if (sp > nk_all / 2) sp = nk_all / 2;
+  while (sp > 1 && (size_t)sp * M * N * 4 > ws_bytes) --sp;
+  if (sp > 1) {
+    const long long kchunk = (nk_all + sp - 1) / sp;
+    sp = (nk_all + kchunk - 1) / kchunk;          // no empty slices
+  }
+  return sp < 1 ? 1 : sp;
+}
+
+int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_bytes) {
+  auto cdiv = [](long long x, long long y) { return (x + y - 1) / y; };
+  if (!ws_bytes || cdiv(M, 128) * cdiv(N, 128) >= 192) return 1;       // the automatic tile choice is not 64x64
+  return (int)splitk_slices(M, N, K, prec == KX_PREC_BF16 ? 64 : 32, ws_bytes, 0);
+}
+
 extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   KX_REQUIRE(a != nullptr, "kx_gemm: null args");
   KX_REQUIRE(a->A && a->W && a->C, "kx_gemm: null operand pointer");
@@ -1216,6 +1351,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   p.stagger_ticks = 0;
   p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
   p.stats_partials = nullptr; p.stats_in_nseg = 0; p.stats_in_seg = p.stats_eps = 0.f;
+  p.ln_out = nullptr; p.ln_out_dt = 0; p.ln_out_g = p.ln_out_b = nullptr; p.ln_out_eps = 0.f;
   {
     // The prefetching store loop pays where the epilogue has per-row global operands to wait for (residual, folded-LN
     // statistics, XPos tables); bias-only bf16 epilogues measured ~5 % faster on the plain rolled loop.
@@ -1267,7 +1403,6 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     }
   }
   if (tile == 64 && a->stats_out && !(a->splitk_ws && a->splitk != 1)) tile = 128;   // 64x64 waves own 32 columns only
-  const bool gemv_extras = a->ln_gamma || a->stats_partials || (a->stats_out_seg != 0 && a->stats_out_seg != 64);
   if (tile == 16) {
     KX_REQUIRE(a->prec == KX_PREC_BF16 && a->M <= 16, "kx_gemm: tile 16 (weight streaming) is bf16, M <= 16 only");
     KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * 2 + 16) <= 128 * 1024 && a->K % 4 == 0),
@@ -1282,24 +1417,37 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     p.stats_in_seg = (float)a->stats_in_seg; p.stats_eps = a->stats_eps;
     if (a->stats_out) p.stats_nseg = (int)(a->N / 16);
   } else {
-    KX_REQUIRE(!gemv_extras, "kx_gemm: ln_gamma / stats_partials / stats_out_seg = 16 belong to tile 16 (weight streaming)");
+    KX_REQUIRE(!(a->ln_gamma || (a->stats_out_seg != 0 && a->stats_out_seg != 64)),
+               "kx_gemm: ln_gamma / stats_out_seg = 16 belong to tile 16 (weight streaming)");
+    if (a->stats_partials) {                            // consumed by the row-owning split-K reduce (checked below)
+      KX_REQUIRE(a->colsum && !a->row_stats && a->stats_in_nseg > 0 && a->stats_in_seg > 0,
+                 "kx_gemm: stats_partials needs colsum, nseg, seg size and excludes row_stats");
+      p.stats_partials = a->stats_partials; p.stats_in_nseg = (int)a->stats_in_nseg;
+      p.stats_in_seg = (float)a->stats_in_seg; p.stats_eps = a->stats_eps;
+    }
   }
   if (tile == 64 && a->splitk_ws) {
     // Skinny problems (batch-1 shapes: M = 114 / 257 / 64) are weight-streaming bound and a 64x64 grid of N/64 x 2
     // workgroups leaves most CUs idle while each one walks all of K serially.  Slice K so that ~512 workgroups
     // stream the weights concurrently; partials are small ([splits][M][N] fp32, L2/MALL resident).
-    const long long tiles = ((a->M + 63) / 64) * ((a->N + 63) / 64);
-    const long long nk_all = a->K / bk;
-    long long sp = a->splitk > 0 ? a->splitk : (tiles >= 384 ? 1 : (512 + tiles - 1) / tiles);
-    if (sp > 16) sp = 16;
-    if (sp > nk_all / 2) sp = nk_all / 2;
-    while (sp > 1 && (size_t)sp * a->M * a->N * 4 > a->splitk_ws_bytes) --sp;
+    const long long sp = splitk_slices(a->M, a->N, a->K, bk, a->splitk_ws_bytes, a->splitk);
     if (sp > 1) {
-      const long long kchunk = (nk_all + sp - 1) / sp;
-      sp = (nk_all + kchunk - 1) / kchunk;          // no empty slices
       p.splitk = (int)sp;
       p.partial = (float*)a->splitk_ws;
     }
+  }
+  // row-owning reduce (LayerNorm of the output row as a second output; folded-LN statistics from partials)
+  p.ln_out = a->ln_out; p.ln_out_dt = a->ln_out_dt; p.ln_out_g = a->ln_out_gamma; p.ln_out_b = a->ln_out_beta;
+  p.ln_out_eps = a->ln_out_eps;
+  if (a->ln_out || (a->stats_partials && tile != 16)) {
+    KX_REQUIRE(p.splitk > 1 && a->N <= 8192 && a->N % 4 == 0 && p.vec_ok,
+               "kx_gemm: ln_out / stats_partials need the split-K row reduce (skinny problem with scratch, N <= 8192, "
+               "N %% 4 == 0, aligned C): M=%lld N=%lld K=%lld splits=%d", (long long)a->M, (long long)a->N, (long long)a->K,
+               p.splitk);
+    KX_REQUIRE(!a->ln_out || (a->ln_out_gamma && a->ln_out_beta && (((uintptr_t)a->ln_out | (uintptr_t)a->ln_out_gamma |
+                                                                   (uintptr_t)a->ln_out_beta) & 15) == 0),
+               "kx_gemm: ln_out needs 16-byte aligned gamma / beta / output");
+    KX_REQUIRE(!a->stats_out, "kx_gemm: the row reduce does not produce statistics");
   }
   const int kind = a->prec != KX_PREC_BF16 ? (tile == 64 ? KX_K_GEMM_F32_64 : KX_K_GEMM_F32_128)
                    : (tile == 64 || tile == 16) ? KX_K_GEMM_BF16_64

@@ -33,7 +33,8 @@ class GemmArgs(C.Structure):
                 ("splitk_ws", vp), ("splitk_ws_bytes", C.c_size_t), ("splitk", i32),
                 ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
                 ("stats_partials", vp), ("stats_in_nseg", i64), ("stats_in_seg", i64), ("stats_eps", f32),
-                ("stats_out_seg", i32)]
+                ("stats_out_seg", i32),
+                ("ln_out", vp), ("ln_out_dt", i32), ("ln_out_gamma", vp), ("ln_out_beta", vp), ("ln_out_eps", f32)]
 
 
 class AttnArgs(C.Structure):

@@ -47,10 +47,13 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, o
 
 def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
          xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None, splitk_ws=None,
-         splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0, out_x3=False):
+         splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0, out_x3=False,
+         ln_out=None):
     """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32].
     tile=16 (weight streaming, bf16, M <= 16) extras: ln = (gamma, beta, eps) with `a` the raw fp32 rows;
-    stats_partials [M,nseg,2] instead of row_stats; stats_out_seg=16."""
+    stats_partials [M,nseg,2] instead of row_stats; stats_out_seg=16.
+    ln_out = (gamma, beta, eps, dtype) with split-K scratch on a skinny problem: also returns LayerNorm(out) (the
+    row-owning reduce kernel); the call then returns (out, ln)."""
     _need_cuda(a, w, bias, residual, out)
     M, K = a.shape
     N = w.shape[0]
@@ -78,8 +81,13 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
         g.stats_partials, g.stats_in_nseg = H.ptr(stats_partials), stats_partials.shape[1]
         g.stats_in_seg, g.stats_eps = stats_in_seg, float(stats_eps)
     g.stats_out_seg = stats_out_seg
+    lnt = None
+    if ln_out is not None:
+        lnt = torch.empty((M, N), dtype=ln_out[3], device=a.device)
+        g.ln_out, g.ln_out_dt = H.ptr(lnt), _cdt(ln_out[3])
+        g.ln_out_gamma, g.ln_out_beta, g.ln_out_eps = H.ptr(ln_out[0]), H.ptr(ln_out[1]), float(ln_out[2])
     H.check(H.load().kx_gemm(C.byref(g), _stream()), "kx_gemm")
-    return out
+    return out if lnt is None else (out, lnt)
 
 
 def row_stats_finalize(partials, seg_size, eps=1e-5):

@@ -510,3 +510,34 @@ def test_bf16x3_gemm_is_two_orders_closer_to_fp32_than_bf16():
     e_plain, e_x3 = rel_err(plain, ref), rel_err(x3, ref)
     print(f"GEMM K={K}: bf16 {e_plain:.2e}, bf16x3 {e_x3:.2e}")
     assert e_x3 < 5e-5 and e_x3 * 100 < e_plain
+
+
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(114, 2048, 2048), (257, 1024, 4096), (5, 264, 512)])
+def test_gemm_row_reduce_fuses_layernorm_and_statistics(prec, M, N, K):
+    """Skinny split-K problems: the row-owning reduce kernel also writes LayerNorm(C) (the LayerNorm that follows the
+    GEMM) and takes the folded-LN statistics from the producer's partials — same results as the separate kernels."""
+    g = _g(M + N + K)
+    a = torch.randn(M, K, generator=g).to(prec).to(DEV)
+    w = (torch.randn(N, K, generator=g) / 40).to(prec).to(DEV)
+    bias, res = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    gam, bet = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    plain = res.clone()
+    ops.gemm(a, w, bias, plain, out=plain, tile=64, splitk_ws=ws)
+    ln_sep = ops.layernorm(plain, gam, bet, out_dtype=torch.bfloat16)
+    fused = res.clone()
+    _, ln_f = ops.gemm(a, w, bias, fused, out=fused, tile=64, splitk_ws=ws, ln_out=(gam, bet, 1e-5, torch.bfloat16))
+    assert torch.equal(fused, plain)
+    assert ((ln_f.float() - ln_sep.float()).abs() <= ln_sep.float().abs() * 2 ** -7 + 1e-5).all()     # <= 1 bf16 ulp: summation order
+    _, ln32 = ops.gemm(a, w, bias, res.clone(), tile=64, splitk_ws=ws, ln_out=(gam, bet, 1e-5, torch.float32))
+    assert rel_err(ln32, ops.layernorm(plain, gam, bet).cpu()) < 1e-5
+    # folded-LN consumer: statistics from partials inside the reduce == finalize kernel + row_stats
+    part = torch.rand(M, K // 64, 2, generator=g).to(DEV)
+    part[:, :, 0] = part[:, :, 0] * 64 - 32
+    cs = torch.randn(N, generator=g).to(DEV)
+    via_stats = ops.gemm(a, w, bias, res.clone(), tile=64, splitk_ws=ws, row_stats=ops.row_stats_finalize(part, 64), colsum=cs)
+    via_part = ops.gemm(a, w, bias, res.clone(), tile=64, splitk_ws=ws, stats_partials=part, stats_in_seg=64, colsum=cs)
+    assert rel_err(via_part, via_stats.cpu()) < 1e-5
+    with pytest.raises(RuntimeError, match="row reduce"):
+        ops.gemm(a, w, bias, res.clone(), tile=128, ln_out=(gam, bet, 1e-5, torch.bfloat16))
