@@ -541,3 +541,34 @@ def test_gemm_row_reduce_fuses_layernorm_and_statistics(prec, M, N, K):
     assert rel_err(via_part, via_stats.cpu()) < 1e-5
     with pytest.raises(RuntimeError, match="row reduce"):
         ops.gemm(a, w, bias, res.clone(), tile=128, ln_out=(gam, bet, 1e-5, torch.bfloat16))
+
+
+def test_gemm_randomised_shapes_and_epilogues():
+    """40 seeded random problems through the automatic variant choice (every tile kernel, split-K with and without
+    scratch, ragged M / N, all epilogue combinations): products of bf16-representable inputs are exact in fp32, so the
+    bound is tight whatever kernel runs."""
+    rng = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))           # noqa: E731
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    for case in range(40):
+        prec = torch.bfloat16 if ri(0, 3) else torch.float32
+        M = [ri(1, 70), ri(100, 700), ri(1000, 4200)][ri(0, 2)]
+        N = 8 * ri(1, 160) if ri(0, 1) else 64 * ri(1, 40)
+        K = 64 * ri(1, 24)
+        act = ["none", "gelu", "quick_gelu"][ri(0, 2)]
+        a = torch.randn(M, K, generator=rng).to(prec)
+        w = (torch.randn(N, K, generator=rng) / 24).to(prec)
+        bias = torch.randn(N, generator=rng) if ri(0, 1) else None
+        res = torch.randn(M, N, generator=rng) if ri(0, 1) else None
+        qcols = 64 * ri(0, N // 64) if ri(0, 2) == 0 else 0
+        out_bf16 = res is None and ri(0, 1) == 1
+        ref = _gemm_ref(a.float(), w.float(), bias, res, act, 0.125, qcols)
+        kw = dict(splitk_ws=ws) if ri(0, 1) else {}
+        out = ops.gemm(a.to(DEV), w.to(DEV), None if bias is None else bias.to(DEV), None if res is None else res.to(DEV),
+                       act, qscale=0.125, qcols=qcols, out_dtype=torch.bfloat16 if out_bf16 else torch.float32, **kw)
+        tag = (case, str(prec), M, N, K, act, bias is not None, res is not None, qcols, out_bf16, bool(kw))
+        if out_bf16:
+            assert ((out.float().cpu() - ref).abs() <= ref.abs() * 2 ** -8 + 2e-5).all(), tag
+        else:
+            # fast erf in bf16 mode (1.5e-7 abs) and fp32 summation order: a few 1e-6 of the output scale
+            assert rel_err(out, ref) < 3e-5, tag
