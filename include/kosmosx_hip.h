@@ -153,8 +153,8 @@ typedef struct {
   int32_t prec;
   float* stats_out;                           /* optional [B*Tq, H, 2]: per row and head (sum, M2 about the head's mean)
                                                  of the 64 output values, for the folded inner_attn_ln */
-  float* lse_out;                             /* optional [B,H,Tq] fp32: log-sum-exp of each query's scores (fp32 matrix-core
-                                                 kernel only): what kx_attention_backward needs to rebuild P */
+  float* lse_out;                             /* optional [B,H,Tq] fp32: log-sum-exp of each query's scores: what
+                                                 kx_attention_backward needs to rebuild P */
 } kx_attn_args;
 int kx_attention(const kx_attn_args* args, void* stream);
 
@@ -382,11 +382,12 @@ int kx_embed_backward(const int64_t* tokens, const float* dx, int64_t B, int64_t
  * clip_grad_norm_'s factor min(1, max_norm / (norm + 1e-6)) to the gradient on the fly. */
 int kx_adamw(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float weight_decay, int64_t step, const float* grad_norm_sq, float max_norm, void* stream);
-/* Attention backward (fp32, head_dim 64): q/k/v/dq/dk/dv are column blocks of fused [B*T, 3D] buffers (row / batch
- * strides in elements), out/dout [B,T,D]; lse [B,H,T] from kx_attention (lse_out); delta [B,H,T] scratch.
- * prec: KX_PREC_F32 = exact-f32 MFMA; KX_PREC_BF16 = bf16 MFMA products (the fp32 inputs are rounded on the way in,
+/* Attention backward (head_dim 64): q/k/v/dq/dk/dv are column blocks of fused [B*T, 3D] buffers (row / batch strides in
+ * elements, the same for the inputs and the fp32 gradients), out/dout [B,T,D] fp32; lse [B,H,T] from kx_attention
+ * (lse_out); delta [B,H,T] scratch.  qkv_dt: dtype of q/k/v (KX_F32, or KX_BF16 with bf16 products).
+ * prec: KX_PREC_F32 = exact-f32 MFMA; KX_PREC_BF16 = bf16 MFMA products (fp32 inputs are rounded on the way in,
  * statistics and accumulators stay fp32) for mixed-precision training. */
-int kx_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* dout,
+int kx_attention_backward(const void* q, const void* k, const void* v, int32_t qkv_dt, const float* out, const float* dout,
                           const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B, int64_t H, int64_t T,
                           int64_t qkv_row_stride, int64_t qkv_batch_stride, int64_t out_row_stride,
                           int64_t out_batch_stride, int32_t mask, int32_t prec, void* stream);

@@ -342,6 +342,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     const int qi = qw0 + qb * 16 + li;
+    if (p.lse_out && g == 0 && qi < p.Tq)            // log-sum-exp of the query's scores, for the backward pass
+      p.lse_out[((long long)b * p.H + h) * p.Tq + qi] = m_run[qb] + logf(l);
     if (p.stats_out) {   // (sum, M2 about the mean) of this query's 64 outputs for head h: 16 local values x 4 lanes
       float sm = 0.f;
 #pragma unroll
@@ -613,8 +615,8 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
   p.stats_out = a->stats_out;
   p.lse_out = a->lse_out;
-  KX_REQUIRE(!a->lse_out || (a->prec == KX_PREC_F32 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1),
-             "kx_attention: lse_out is produced by the fp32 matrix-core kernel only");
+  KX_REQUIRE(!a->lse_out || kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1,
+             "kx_attention: lse_out is not produced by the first-version (A/B) kernels");
   KX_REQUIRE(!a->stats_out || !(a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1),
              "kx_attention: stats_out is not implemented by the v1 A/B kernel");
   hipStream_t s = (hipStream_t)stream;

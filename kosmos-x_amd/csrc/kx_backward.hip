@@ -811,6 +811,27 @@ __device__ __forceinline__ void tile_lstore(bf16_t* dst, const float4 (&reg)[4],
     *reinterpret_cast<uint2*>(dst + r * XS + c4) = o;
   }
 }
+__device__ __forceinline__ u32x4_t row_frag_global(const bf16_t* rowp, int g, int s2) {  // bf16 source: one 16-byte load
+  return *reinterpret_cast<const u32x4_t*>(rowp + 32 * s2 + 8 * g);
+}
+// bf16 source tiles: two float4-sized registers carry 8 elements each (half as many loads)
+__device__ __forceinline__ void tile_gload(float4 (&reg)[4], const bf16_t* src, long long stride, int r0, int T, int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + 256 * j, r = i >> 3, c8 = (i & 7) * 8;
+    reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < T) reg[j] = *reinterpret_cast<const float4*>(src + (long long)(r0 + r) * stride + c8);
+  }
+}
+__device__ __forceinline__ void tile_lstore_b(bf16_t* dst, const float4 (&reg)[4], int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + 256 * j, r = i >> 3, c8 = (i & 7) * 8;
+    *reinterpret_cast<float4*>(dst + r * XS + c8) = reg[j];
+  }
+}
+__device__ __forceinline__ void tile_lstore_any(bf16_t* dst, const float4 (&reg)[4], int tid, const float*) { tile_lstore(dst, reg, tid); }
+__device__ __forceinline__ void tile_lstore_any(bf16_t* dst, const float4 (&reg)[4], int tid, const bf16_t*) { tile_lstore_b(dst, reg, tid); }
 __device__ __forceinline__ u32x4_t row_frag_global(const float* rowp, int g, int s2) {   // 8 fp32 -> 8 bf16 of k-step s2
   const float4 a = *reinterpret_cast<const float4*>(rowp + 32 * s2 + 8 * g);
   const float4 b = *reinterpret_cast<const float4*>(rowp + 32 * s2 + 8 * g + 4);
@@ -839,9 +860,9 @@ __device__ __forceinline__ void pack_blocks(const f32x4_t (&y)[4], u32x4_t (&pf)
   }
 }
 
-template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                const float* __restrict__ v, const float* __restrict__ dout,
+template <bool CAUSAL, typename QT>   // QT: element type of q, k, v (fp32 rounded on the way in, or bf16 as stored)
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __restrict__ q, const QT* __restrict__ k,
+                                                                const QT* __restrict__ v, const float* __restrict__ dout,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 float* __restrict__ dk, float* __restrict__ dv, int T, int H,
                                                                 long long row_stride, long long batch_stride,
@@ -853,9 +874,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const float* __r
   const int g = lane >> 4, i = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   const int key0 = blockIdx.x * 64, kw0 = key0 + wave * 16, ki = kw0 + i;
-  const float* qb = q + (long long)b * batch_stride + (long long)h * 64;
-  const float* kb = k + (long long)b * batch_stride + (long long)h * 64;
-  const float* vb = v + (long long)b * batch_stride + (long long)h * 64;
+  const QT* qb = q + (long long)b * batch_stride + (long long)h * 64;
+  const QT* kb = k + (long long)b * batch_stride + (long long)h * 64;
+  const QT* vb = v + (long long)b * batch_stride + (long long)h * 64;
   const float* dob = dout + (long long)b * do_batch + (long long)h * 64;
   const float* lseb = lse + ((long long)b * H + h) * T;
   const float* delb = delta + ((long long)b * H + h) * T;
@@ -878,7 +899,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const float* __r
     if (tid < 64) { const int qq = t * 64 + tid; lreg = qq < T ? lseb[qq] : 0.f; dreg = qq < T ? delb[qq] : 0.f; }
   };
   auto lstore = [&](int buf) {
-    tile_lstore(Qb[buf], qreg, tid);
+    tile_lstore_any(Qb[buf], qreg, tid, qb);
     tile_lstore(dOb[buf], doreg, tid);
     if (tid < 64) { Lb[buf][tid] = lreg; Db[buf][tid] = dreg; }
   };
@@ -935,9 +956,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const float* __r
   }
 }
 
-template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                               const float* __restrict__ v, const float* __restrict__ dout,
+template <bool CAUSAL, typename QT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const QT* __restrict__ q, const QT* __restrict__ k,
+                                                               const QT* __restrict__ v, const float* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ dq, int T, int H, long long row_stride,
                                                                long long batch_stride, long long do_row, long long do_batch) {
@@ -947,9 +968,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const float* __re
   const int g = lane >> 4, i = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 64, qw0 = q0 + wave * 16, qi = qw0 + i;
-  const float* qb = q + (long long)b * batch_stride + (long long)h * 64;
-  const float* kb = k + (long long)b * batch_stride + (long long)h * 64;
-  const float* vb = v + (long long)b * batch_stride + (long long)h * 64;
+  const QT* qb = q + (long long)b * batch_stride + (long long)h * 64;
+  const QT* kb = k + (long long)b * batch_stride + (long long)h * 64;
+  const QT* vb = v + (long long)b * batch_stride + (long long)h * 64;
   const float* dob = dout + (long long)b * do_batch + (long long)h * 64;
   const int qc = min(qi, T - 1);
   u32x4_t qfix[2], dofix[2];
@@ -968,8 +989,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const float* __re
     tile_gload(vreg, vb, row_stride, t * 64, T, tid);
   };
   auto lstore = [&](int buf) {
-    tile_lstore(Kb[buf], kreg, tid);
-    tile_lstore(Vb[buf], vreg, tid);
+    tile_lstore_any(Kb[buf], kreg, tid, kb);
+    tile_lstore_any(Vb[buf], vreg, tid, vb);
   };
   gload(0);
   lstore(0);
@@ -1211,11 +1232,14 @@ extern "C" int kx_adamw(float* param, const float* grad, float* m, float* v, int
   return KX_OK;
 }
 
-extern "C" int kx_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* dout,
-                                     const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B, int64_t H,
+extern "C" int kx_attention_backward(const void* qv_, const void* kv_, const void* vv_, int32_t qkv_dt, const float* out,
+                                     const float* dout, const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B, int64_t H,
                                      int64_t T, int64_t qkv_row_stride, int64_t qkv_batch_stride, int64_t out_row_stride,
                                      int64_t out_batch_stride, int32_t mask, int32_t prec, void* stream) {
+  const float* q = (const float*)qv_; const float* k = (const float*)kv_; const float* v = (const float*)vv_;
   KX_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta, "kx_attention_backward: null pointer");
+  KX_REQUIRE(qkv_dt == KX_F32 || (qkv_dt == KX_BF16 && prec == KX_PREC_BF16),
+             "kx_attention_backward: q/k/v are fp32, or bf16 with bf16 products");
   KX_REQUIRE(B > 0 && H > 0 && T > 0 && B < 65536 && H < 65536, "kx_attention_backward: bad shape");
   KX_REQUIRE(qkv_row_stride % 4 == 0 && out_row_stride % 4 == 0 && qkv_batch_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
                  (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
@@ -1228,14 +1252,15 @@ extern "C" int kx_attention_backward(const float* q, const float* k, const float
   const dim3 grid((unsigned)((T + 63) / 64), (unsigned)H, (unsigned)B);
   KX_REQUIRE(prec == KX_PREC_F32 || prec == KX_PREC_BF16, "kx_attention_backward: products in fp32 or bf16");
   if (prec == KX_PREC_BF16) {                                      // bf16 products, fp32 inputs / statistics / accumulators
-#define KX_ATTN_BWD_B(CAUSAL)                                                                                          \
-  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dk, \
-                     dv, (int)T, (int)H, (long long)qkv_row_stride, (long long)qkv_batch_stride,                       \
-                     (long long)out_row_stride, (long long)out_batch_stride);                                          \
-  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dq, \
-                     (int)T, (int)H, (long long)qkv_row_stride, (long long)qkv_batch_stride, (long long)out_row_stride, \
-                     (long long)out_batch_stride)
-    if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD_B(true); } else { KX_ATTN_BWD_B(false); }
+#define KX_ATTN_BWD_B(CAUSAL, QT)                                                                                      \
+  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<CAUSAL, QT>), grid, dim3(256), 0, s, (const QT*)qv_, (const QT*)kv_,     \
+                     (const QT*)vv_, dout, lse, (const float*)delta, dk, dv, (int)T, (int)H, (long long)qkv_row_stride, \
+                     (long long)qkv_batch_stride, (long long)out_row_stride, (long long)out_batch_stride);              \
+  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<CAUSAL, QT>), grid, dim3(256), 0, s, (const QT*)qv_, (const QT*)kv_,      \
+                     (const QT*)vv_, dout, lse, (const float*)delta, dq, (int)T, (int)H, (long long)qkv_row_stride,     \
+                     (long long)qkv_batch_stride, (long long)out_row_stride, (long long)out_batch_stride)
+    if (qkv_dt == KX_BF16) { if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD_B(true, bf16_t); } else { KX_ATTN_BWD_B(false, bf16_t); } }
+    else if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD_B(true, float); } else { KX_ATTN_BWD_B(false, float); }
 #undef KX_ATTN_BWD_B
     KX_CHECK_LAUNCH("kx_attention_backward");
     return KX_OK;

@@ -130,15 +130,20 @@ def adamw_(param, grad, m, v, step, lr, betas=(0.9, 0.95), eps=1e-8, weight_deca
 
 
 def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True, bf16_products=False):
-    """qkv [B*T, 3D] fp32 (q pre-scaled and XPos-rotated), out/dout [B,T,D], lse [B,H,T] -> dqkv [B*T, 3D]."""
+    """qkv [B*T, 3D] (q pre-scaled and XPos-rotated; fp32, or bf16 with bf16_products), out/dout [B,T,D] fp32, lse [B,H,T]
+    -> dqkv [B*T, 3D] fp32."""
     _need_cuda(qkv, out, dout, lse)
     D = Hh * 64
-    dqkv = torch.empty_like(qkv)
+    if qkv.dtype == torch.bfloat16 and not bf16_products:
+        raise TypeError("bf16 q/k/v need bf16_products=True")
+    dqkv = torch.empty(qkv.shape, dtype=torch.float32, device=qkv.device)
     delta = torch.empty((B, Hh, T), dtype=torch.float32, device=qkv.device)
-    es = 4
+    es = qkv.element_size()
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es
-    dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * es, dqkv.data_ptr() + 2 * D * es
-    H.check(H.load().kx_attention_backward(q, k, v, H.ptr(out), H.ptr(dout), H.ptr(lse), dq, dk, dv, H.ptr(delta), B, Hh, T,
-                                           3 * D, T * 3 * D, D, T * D, H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL,
-                                           H.KX_PREC_BF16 if bf16_products else H.KX_PREC_F32, _stream()), "kx_attention_backward")
+    dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * 4, dqkv.data_ptr() + 2 * D * 4
+    H.check(H.load().kx_attention_backward(q, k, v, H.KX_BF16 if qkv.dtype == torch.bfloat16 else H.KX_F32, H.ptr(out),
+                                           H.ptr(dout), H.ptr(lse), dq, dk, dv, H.ptr(delta), B, Hh, T, 3 * D, T * 3 * D, D,
+                                           T * D, H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL,
+                                           H.KX_PREC_BF16 if bf16_products else H.KX_PREC_F32, _stream()),
+            "kx_attention_backward")
     return dqkv

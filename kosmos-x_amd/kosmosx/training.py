@@ -148,10 +148,12 @@ class LanguageModelTrainer:
             h1 = ops.layernorm(x, P["sa_ln"].weight.detach(), P["sa_ln"].bias.detach(), eps)
             wqkv = torch.cat([P["q"].weight, P["k"].weight, P["v"].weight], 0).detach()
             bqkv = torch.cat([P["q"].bias, P["k"].bias, P["v"].bias], 0).detach()
-            qkv = ops.gemm(opA(h1), opW(wqkv), bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0)
+            # bf16 mode: q, k, v live in bf16 (flash kernel with bf16 products forward and backward, fp32 statistics)
+            qkv = ops.gemm(opA(h1), opW(wqkv), bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0,
+                           out_dtype=torch.bfloat16 if self.precision == "bf16" else torch.float32)
             q3, k3, v3 = (qkv[:, i * D:(i + 1) * D].unflatten(0, (B, T)).unflatten(2, (Hh, 64)) for i in range(3))
             lse = torch.empty((B, Hh, T), dtype=torch.float32, device=dev)
-            att = ops.attention(q3, k3, v3, True, lse_out=lse).reshape(M, D)
+            att = ops.attention(q3, k3, v3, True, out_dtype=torch.float32, lse_out=lse).reshape(M, D)
             a_n = att if P["inner_ln"] is None else ops.layernorm(att, P["inner_ln"].weight.detach(),
                                                                    P["inner_ln"].bias.detach(), eps)
             x = lin(a_n, P["o"].weight, P["o"].bias, residual=x)

@@ -141,6 +141,15 @@ def test_attention_backward(B, Hh, T, causal):
     mixed = G.attention_backward(qd, og, do.to(DEV), lse, B, T, Hh, causal, bf16_products=True)
     rms = float((mixed.cpu() - qkv.grad).pow(2).mean().sqrt() / qkv.grad.pow(2).mean().sqrt())
     assert rms < 1.5e-2 and rel_err(mixed, qkv.grad) < 0.2, rms
+    # ... and with q/k/v stored in bf16: the bf16 flash forward supplies out and the log-sum-exp
+    qb = qd.to(torch.bfloat16)
+    qb3, kb3, vb3 = (qb[:, i * D:(i + 1) * D].unflatten(0, (B, T)).unflatten(2, (Hh, 64)) for i in range(3))
+    lse16 = torch.empty(B, Hh, T, device=DEV)
+    o16 = ops.attention(qb3, kb3, vb3, causal, out_dtype=torch.float32, lse_out=lse16)
+    assert rel_err(lse16, ref_lse) < 2e-2 and rel_err(o16, o.detach()) < 3e-2
+    stored = G.attention_backward(qb, o16, do.to(DEV), lse16, B, T, Hh, causal, bf16_products=True)
+    rms = float((stored.cpu() - qkv.grad).pow(2).mean().sqrt() / qkv.grad.pow(2).mean().sqrt())
+    assert rms < 2e-2, rms
 
 
 @pytest.mark.parametrize("shape", [(70, 130), (64, 64), (5, 257), (300, 2048)])
