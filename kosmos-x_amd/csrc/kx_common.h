@@ -56,15 +56,14 @@ struct KxProfScope {
 
 // ---- device helpers ----
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
-// round-to-nearest-even, NaN preserved (matches torch .to(torch.bfloat16))
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even (matches torch .to(torch.bfloat16)); gfx950 converts in hardware: v_cvt_pk_bf16_f32, one
+// instruction per PAIR of values where the integer sequence (and, compare, bit-extract, add, select, shift) took
+// eight per value — the bf16 store epilogues and the softmax's P packing were paying that on the VALU.
+typedef float kx_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 kx_bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((kx_f32x2_t){lo, hi}, kx_bf16x2_t));
 }
 // bf16x3 operand format (KX_BF16X3): a value v travels as hi = bf16(v) and lo = bf16(v - hi) (16 mantissa bits together);
 // an operand row of K values is stored as [hi(K) | hi(K) | lo(K)] and the matching weight row as [hi | lo | hi], so
