@@ -167,6 +167,21 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
 //   * causal: tiles above the diagonal are never loaded; a wave skips the MFMA/softmax work of a tile that lies
 //     entirely above its own queries, and waves without a live query only help with the loads.
 // ---------------------------------------------------------------------------------------------------------
+// Raw v_max3_f32: fmaxf() makes the compiler canonicalise each input first (IEEE-mode sNaN quieting, one extra
+// v_max per value: 28 instructions for a 16-value row maximum instead of 8).  Scores are MFMA outputs or -inf.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max(seed, x over the four lanes {i, i+16, i+32, i+48}) on the VALU (gfx950 v_permlane16/32_swap) — no LDS round
+// trips (ds_bpermute) inside the softmax's dependent chain.
+__device__ __forceinline__ float quad_max(float x, float seed) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = max3_raw(__uint_as_float(r[0]), __uint_as_float(r[1]), seed);
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return max3_raw(__uint_as_float(q[0]), __uint_as_float(q[1]), m);
+}
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 constexpr int VSTR = 80;   // V tile row pitch in elements (160 B)
@@ -201,10 +216,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
     qf[qb][1] = *reinterpret_cast<const u32x4_t*>(qr + 32);
   }
   f32x4_t ot[2][4];
-  float m_run[2], l_run[2];
+  float m_run[2];
+  f32x4_t lt[2];      // row sums of P by MFMA against a ones fragment: every register of lane (g,i) holds l(query i)
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+    m_run[qb] = -INFINITY; lt[qb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < 4; ++d) ot[qb][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
@@ -214,17 +230,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
 
   // cooperative tile loads: thread owns chunks c = tid, tid+256 -> (row c>>3, 16-B part c&7)
   u32x4_t kreg[2], vreg[2];
-  auto gload = [&](int t) {
+  auto gload = [&](int t) {   // rows past Tk are clamped to the last key: finite data, masked to P = 0 by the softmax
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = tid + 256 * j, row = c >> 3, part = c & 7;
-      const int key = t * 64 + row;
-      kreg[j] = (u32x4_t){0u, 0u, 0u, 0u};
-      vreg[j] = kreg[j];
-      if (key < p.Tk) {
-        kreg[j] = *reinterpret_cast<const u32x4_t*>(kp + (long long)key * p.krs + part * 8);
-        vreg[j] = *reinterpret_cast<const u32x4_t*>(vp + (long long)key * p.krs + part * 8);
-      }
+      const long long off = (long long)min(t * 64 + row, p.Tk - 1) * p.krs + part * 8;
+      kreg[j] = *reinterpret_cast<const u32x4_t*>(kp + off);
+      vreg[j] = *reinterpret_cast<const u32x4_t*>(vp + off);
     }
   };
   auto lstore = [&](int buf) {
@@ -265,12 +277,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
       // ---- online softmax per query block (query = lane&15; its keys sit in 4 lanes x 16 registers) ----
       // Masking is needed only on the tile that holds the sequence end or crosses this wave's diagonal (wave-uniform).
       const bool need_mask = (kv0 + 63 >= p.Tk) || (CAUSAL && kv0 + 63 > qw0);
+      // Tile 0 holds key 0, which no mask removes (causal: key 0 <= every query), so the running maximum is finite
+      // from the first tile on and exp2(-inf - finite) = 0 covers the start: no -inf guard in the chain.
       u32x4_t pf[2][2];
+      float mneg[2], alpha[2];
+      constexpr float LOG2E = 1.44269504088896340736f;
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        const int qi = qw0 + qb * 16 + li;
-        float mloc = -INFINITY;
         if (need_mask) {
+          const int qi = qw0 + qb * 16 + li;
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -278,35 +293,36 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
               const int key = kv0 + kb * 16 + 4 * g + r;
               const bool ok = key < p.Tk && (!CAUSAL || key <= qi);
               st[qb][kb][r] = ok ? st[qb][kb][r] : -INFINITY;
-              mloc = fmaxf(mloc, st[qb][kb][r]);
             }
-        } else {
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb)
-            mloc = fmaxf(fmaxf(mloc, fmaxf(st[qb][kb][0], st[qb][kb][1])), fmaxf(st[qb][kb][2], st[qb][kb][3]));
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run[qb], mloc);
-        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        // 16 in-lane values: four independent v_max3 chains, then the 4-lane exchange (the two query blocks interleave)
+        const float a0 = max3_raw(st[qb][0][0], st[qb][0][1], st[qb][0][2]);
+        const float a1 = max3_raw(st[qb][1][0], st[qb][1][1], st[qb][1][2]);
+        const float a2 = max3_raw(st[qb][2][0], st[qb][2][1], st[qb][2][2]);
+        const float a3 = max3_raw(st[qb][3][0], st[qb][3][1], st[qb][3][2]);
+        const float b0 = max3_raw(a0, st[qb][0][3], st[qb][1][3]);
+        const float b1 = max3_raw(a1, st[qb][2][3], st[qb][3][3]);
+        const float c0 = max3_raw(b0, a2, a3);
+        const float m_new = quad_max(max3_raw(c0, b1, m_run[qb]), m_run[qb]);
         // exp(s - m) as one FMA + v_exp_f32 (2^x): exp2(s*log2e - m*log2e)
-        constexpr float LOG2E = 1.44269504088896340736f;
-        const float mneg = -m_safe * LOG2E;
-        const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qb], LOG2E, mneg));
-        float psum = 0.f;
+        mneg[qb] = -m_new * LOG2E;
+        alpha[qb] = __builtin_amdgcn_exp2f(fmaf(m_run[qb], LOG2E, mneg[qb]));
+        m_run[qb] = m_new;
+      }
+      if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {   // the running max moved for some query: rescale O and l
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) ot[qb][d] *= alpha[qb];
+          lt[qb] *= alpha[qb];
+        }
+      }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            st[qb][kb][r] = __builtin_amdgcn_exp2f(fmaf(st[qb][kb][r], LOG2E, mneg));
-            psum += st[qb][kb][r];
-          }
-        l_run[qb] = l_run[qb] * alpha + psum;
-        m_run[qb] = m_new;
-        if (!__all(alpha == 1.0f)) {      // the running max moved for some query of the wave: rescale O
-#pragma unroll
-          for (int d = 0; d < 4; ++d) ot[qb][d] *= alpha;
-        }
+          for (int r = 0; r < 4; ++r) st[qb][kb][r] = __builtin_amdgcn_exp2f(fmaf(st[qb][kb][r], LOG2E, mneg[qb]));
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           pf[qb][c][0] = pack_bf16x2(st[qb][2 * c][0], st[qb][2 * c][1]);
@@ -314,6 +330,16 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
           pf[qb][c][2] = pack_bf16x2(st[qb][2 * c + 1][0], st[qb][2 * c + 1][1]);
           pf[qb][c][3] = pack_bf16x2(st[qb][2 * c + 1][2], st[qb][2 * c + 1][3]);
         }
+      }
+      // ---- l += 1^T P^T on the matrix pipe (4 MFMAs replace 32 VALU adds per lane; the kernel is VALU-bound) ----
+      {
+        const u32x4_t ones = (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            lt[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones),
+                                                             __builtin_bit_cast(bf16x8_t, pf[qb][c]), lt[qb], 0, 0, 0);
       }
       // ---- O^T += V^T P^T : V fragment by transpose-read, k index (g,v) <-> key 32c + 16(v>>2) + 4g + (v&3) ----
 #pragma unroll
@@ -337,9 +363,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
   }
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    float l = l_run[qb];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    const float l = lt[qb][0];           // sum over all keys of the bf16 P the PV product used
     const float inv = 1.0f / l;
     const int qi = qw0 + qb * 16 + li;
     if (p.lse_out && g == 0 && qi < p.Tq)            // log-sum-exp of the query's scores, for the backward pass
