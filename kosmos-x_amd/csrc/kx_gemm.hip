@@ -40,6 +40,7 @@ struct GemmParams {
   // wall-clock ticks) late, so the CUs' epilogues (HBM bursts) stop coinciding — see launch_p5
   int stagger_ticks;
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
+  int persistent;       // 256-column kernel: > 0 = launch this many workgroups, each walking its tiles itself
   int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
   // weight-streaming variant (gemv_fused_kernel) only
   const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
@@ -889,6 +890,22 @@ int launch_p3(GemmParams& p, hipStream_t s) {
 // MFMA): 1.34 vs 1.37 PFLOP/s.  Sustained, this kernel holds the board at its 1400 W cap at ~2.04 GHz
 // (profiles/r01_h_power_*.log): the limit left is power, not LDS or issue slots.)
 // -------------------------------------------------------------------------------------------------
+// Timeline instrumentation of the 256x256 kernel (built only with -DKX_TIMELINE into a side library for
+// tools/gemm_timeline.py; the shipped library compiles these to nothing).
+#ifdef KX_TIMELINE
+__device__ unsigned long long kx_tl[8];
+#define KX_TL_STAMP(i) unsigned long long kx_t##i = __builtin_readcyclecounter()
+#define KX_TL_COMMIT()                                                                  \
+  if (threadIdx.x == 0) {                                                               \
+    atomicAdd(&kx_tl[0], kx_t1 - kx_t0); atomicAdd(&kx_tl[1], kx_t2 - kx_t1);           \
+    atomicAdd(&kx_tl[2], kx_t3 - kx_t2); atomicAdd(&kx_tl[3], kx_t4 - kx_t3);           \
+    atomicAdd(&kx_tl[4], kx_t5 - kx_t4); atomicAdd(&kx_tl[5], 1ull);                    \
+  }
+#else
+#define KX_TL_STAMP(i)
+#define KX_TL_COMMIT()
+#endif
+
 template <typename T, int ACT, int BM>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   constexpr int BN = 256, ROWB = 128;
@@ -899,7 +916,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = blockIdx.x;
+  // persistent launch (grid = one workgroup per CU, p.persistent): the workgroup walks tiles bid, bid + grid, ... itself
+  // instead of being retired and re-dispatched per tile — same tile->CU order, no dispatch/retire gap between tiles
+  for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+  KX_TL_STAMP(0);
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   constexpr int GROUP = 4;
@@ -972,6 +992,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  KX_TL_STAMP(1);
   const bool lag = wave >= 4;
   const bool work = !p.skip_idle_waves || m0 + wm * (BM / 2) < p.M;   // see gemm_kernel_p3
   if (lag) __builtin_amdgcn_s_barrier();
@@ -1027,11 +1048,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
   }
   if (!lag) __builtin_amdgcn_s_barrier();
+  KX_TL_STAMP(2);
 
   // ---- epilogue staged through LDS in two 64-row halves (8 waves x 64x64 fp32 = 128 KB) ----
   constexpr int WN = 64, CH = WN / 4;
   const bool pre = p.stats_out != nullptr;
   if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
+  KX_TL_STAMP(3);
   GemmParams q = p;
   q.bias = nullptr; q.stats_out = nullptr;
   constexpr int HR = BM / 4;                 // rows per epilogue half per wave
@@ -1051,14 +1074,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     else store_loop<ACT, WN>(p, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
   };
   park_and_store(std::integral_constant<int, 0>{});
+  KX_TL_STAMP(4);
   park_and_store(std::integral_constant<int, 1>{});
+  KX_TL_STAMP(5);
+  KX_TL_COMMIT();
+  if (bid + (int)gridDim.x < nwg) __syncthreads();   // the parked rows have been read back before the next tile's fill
+  }  // tiles of this workgroup
 }
 
 template <typename T, int BM>
 int launch_p5(GemmParams& p, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + 255) / 256;
-  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+  const int nwg = p.tiles_m * p.tiles_n;
+  const dim3 grid(p.persistent > 0 ? (nwg < p.persistent ? nwg : p.persistent) : nwg), block(512);
   switch (p.act) {
     case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM>), grid, block, 0, s, p); break;
     case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU, BM>), grid, block, 0, s, p); break;
@@ -1068,6 +1097,18 @@ int launch_p5(GemmParams& p, hipStream_t s) {
   }
   KX_CHECK_LAUNCH("kx_gemm(p5)");
   return KX_OK;
+}
+
+// CUs of the current device (one process drives one GPU; cached after the first call)
+int kx_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  return cus;
 }
 
 int launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
@@ -1357,6 +1398,10 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     // statistics, XPos tables); bias-only bf16 epilogues measured ~5 % faster on the plain rolled loop.
     const int mode = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE);   // 0 auto, 1 never, 2 always (A/B)
     p.skip_idle_waves = kx_tuning_get(KX_TUNE_GEMM_IDLE_SKIP) != 1;   // A/B: 1 = off
+    {   // one persistent workgroup per CU unless told otherwise (key 7: -1 = one workgroup per tile, n > 0 = n workgroups)
+      const int pv = kx_tuning_get(KX_TUNE_GEMM_PERSISTENT);
+      p.persistent = pv < 0 ? 0 : pv > 0 ? pv : kx_cu_count();
+    }
     p.fast_epilogue = mode == 2 || (mode == 0 && (a->residual || a->row_stats || a->xpos_dim > 0));
   }
   hipStream_t s = (hipStream_t)stream;
@@ -1475,3 +1520,11 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   kx_set_error("kx_gemm: unknown tile variant %d", tile);
   return KX_ERR_UNSUPPORTED;
 }
+
+#ifdef KX_TIMELINE
+extern "C" int kx_timeline_read(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(kx_tl), 64) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(kx_tl), z, 64) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
