@@ -352,6 +352,11 @@ int kx_transpose(const void* src, void* dst, int64_t rows, int64_t cols, int64_t
  * activations and gradients become operands right before each product. */
 int kx_to_operand(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t kp, int32_t transpose,
                   int32_t fmt, void* stream);
+/* One pass over an fp32 matrix producing the bf16 operand rows dst [rows, kp] and/or the transposed operand rows
+ * dst_t [cols, kpt] (kp >= cols, kpt >= rows, multiples of 8, padding zero; either output may be NULL).  A gradient
+ * matrix is consumed both ways (data gradient / weight gradient), a weight forward and backward. */
+int kx_to_operand_pair(const float* src, void* dst, void* dst_t, int64_t rows, int64_t cols, int64_t ld_src, int64_t kp,
+                       int64_t kpt, void* stream);
 /* out[c] (+)= sum_r x[r][c] (bias gradients) */
 size_t kx_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int kx_colsum(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, int32_t accumulate, void* workspace,

@@ -49,6 +49,56 @@ __global__ __launch_bounds__(256) void to_operand_rows_kernel(const float* __res
   }
 }
 
+// bf16 operand AND its transpose from one pass over an fp32 matrix (training: a gradient matrix is needed as dY rows
+// for the data gradient and as dY^T rows for the weight gradient; a weight as W rows forward and W^T rows backward).
+// 64 x 64 tile through LDS; both outputs leave as 16-byte stores (8 bf16 per lane).  dst [rows, kp] / dst_t [cols, kpt],
+// padding columns zero; either may be null.
+__global__ __launch_bounds__(256) void to_operand_pair_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              bf16_t* __restrict__ dst_t, long long rows, long long cols,
+                                                              long long ld_src, long long kp, long long kpt) {
+  __shared__ float tile[64][65];
+  const long long r0 = (long long)blockIdx.y * 64, c0 = (long long)blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  {
+    const int tx = tid & 15, ty = tid >> 4;                 // 16 lanes x float4 per row, 16 rows per pass
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long r = r0 + ty + 16 * i, c = c0 + 4 * tx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows) {
+        if (c + 3 < cols) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+        else { const float* q = src + r * ld_src + c; if (c < cols) v.x = q[0]; if (c + 1 < cols) v.y = q[1]; if (c + 2 < cols) v.z = q[2]; }
+      }
+      float* t = &tile[ty + 16 * i][4 * tx];
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+  }
+  __syncthreads();
+  const int ox = tid & 7, oy = tid >> 3;                     // 8 lanes x 8 values per output row, 32 rows per pass
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rr = oy + 32 * i;
+    if (dst) {                                               // straight: row r0+rr, columns c0 + 8*ox .. +7
+      const long long r = r0 + rr, c = c0 + 8 * ox;
+      if (r < rows && c < kp) {
+        const float* t = &tile[rr][8 * ox];
+        uint4 o;
+        o.x = pack_bf16x2(t[0], t[1]); o.y = pack_bf16x2(t[2], t[3]); o.z = pack_bf16x2(t[4], t[5]); o.w = pack_bf16x2(t[6], t[7]);
+        *reinterpret_cast<uint4*>(dst + r * kp + c) = o;
+      }
+    }
+    if (dst_t) {                                             // transposed: row c0+rr, columns r0 + 8*ox .. +7
+      const long long r = c0 + rr, c = r0 + 8 * ox;
+      if (r < cols && c < kpt) {
+        uint4 o;
+        o.x = pack_bf16x2(tile[8 * ox][rr], tile[8 * ox + 1][rr]); o.y = pack_bf16x2(tile[8 * ox + 2][rr], tile[8 * ox + 3][rr]);
+        o.z = pack_bf16x2(tile[8 * ox + 4][rr], tile[8 * ox + 5][rr]); o.w = pack_bf16x2(tile[8 * ox + 6][rr], tile[8 * ox + 7][rr]);
+        *reinterpret_cast<uint4*>(dst_t + r * kpt + c) = o;
+      }
+    }
+  }
+}
+
 template <bool TRANSPOSE>
 __global__ __launch_bounds__(256) void to_operand_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                          long long rows, long long cols, long long ld_src, long long kp,
@@ -1090,6 +1140,27 @@ extern "C" int kx_to_operand(const float* src, void* dst, int64_t rows, int64_t 
     hipLaunchKernelGGL(to_operand_kernel<false>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (long long)rows, (long long)cols,
                        (long long)ld_src, (long long)kp, fmt);
   KX_CHECK_LAUNCH("kx_to_operand");
+  return KX_OK;
+}
+
+extern "C" int kx_to_operand_pair(const float* src, void* dst, void* dst_t, int64_t rows, int64_t cols, int64_t ld_src,
+                                  int64_t kp, int64_t kpt, void* stream) {
+  KX_REQUIRE(src && (dst || dst_t) && rows > 0 && cols > 0 && ld_src >= cols, "kx_to_operand_pair: bad arguments");
+  KX_REQUIRE(!dst || (kp >= cols && kp % 8 == 0 && (((uintptr_t)dst) & 15) == 0),
+             "kx_to_operand_pair: kp=%lld must cover %lld columns, be a multiple of 8, dst 16-byte aligned", (long long)kp,
+             (long long)cols);
+  KX_REQUIRE(!dst_t || (kpt >= rows && kpt % 8 == 0 && (((uintptr_t)dst_t) & 15) == 0),
+             "kx_to_operand_pair: kpt=%lld must cover %lld rows, be a multiple of 8, dst_t 16-byte aligned", (long long)kpt,
+             (long long)rows);
+  KX_REQUIRE((ld_src & 3) == 0 && (((uintptr_t)src) & 15) == 0, "kx_to_operand_pair: src rows must be 16-byte aligned");
+  // the grid covers the padded extents so the zero padding is written too
+  const int64_t ec = dst && kp > cols ? kp : cols, er = dst_t && kpt > rows ? kpt : rows;
+  const dim3 grid((unsigned)((ec + 63) / 64), (unsigned)((er + 63) / 64));
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, rows, cols, 28, s);
+  hipLaunchKernelGGL(to_operand_pair_kernel, grid, dim3(256), 0, s, src, (bf16_t*)dst, (bf16_t*)dst_t, (long long)rows,
+                     (long long)cols, (long long)ld_src, (long long)kp, (long long)kpt);
+  KX_CHECK_LAUNCH("kx_to_operand_pair");
   return KX_OK;
 }
 

@@ -40,6 +40,19 @@ def to_operand(x: torch.Tensor, fmt: str, transpose_: bool = False) -> torch.Ten
     return out
 
 
+def to_operand_pair(x: torch.Tensor, straight: bool = True, transposed: bool = True):
+    """fp32 [R,C] -> (bf16 operand rows [R, Cp], bf16 rows of x^T [C, Rp]) in one pass (Cp / Rp = C / R rounded up to 64,
+    padding zero); an output that is not asked for is None."""
+    _need_cuda(x)
+    R, Cc = x.shape
+    kp, kpt = (Cc + 63) // 64 * 64, (R + 63) // 64 * 64
+    a = torch.empty((R, kp), dtype=torch.bfloat16, device=x.device) if straight else None
+    t = torch.empty((Cc, kpt), dtype=torch.bfloat16, device=x.device) if transposed else None
+    H.check(H.load().kx_to_operand_pair(H.ptr(x), H.ptr(a), H.ptr(t), R, Cc, x.stride(0), kp, kpt, _stream()),
+            "kx_to_operand_pair")
+    return a, t
+
+
 def gelu(pre: torch.Tensor) -> torch.Tensor:
     _need_cuda(pre)
     out = torch.empty_like(pre)

@@ -129,11 +129,24 @@ class LanguageModelTrainer:
             opAT = opWT = lambda t: G.transpose(t, 32)
         else:
             fa, fw = ("bf16", "bf16") if self.precision == "bf16" else ("bf16x3_act", "bf16x3_w")
-            opA, opW = (lambda t: G.to_operand(t, fa)), (lambda t: G.to_operand(t, fw))
-            opAT, opWT = (lambda t: G.to_operand(t, fa, True)), (lambda t: G.to_operand(t, fw, True))
+            # a tensor that already is bf16 (bf16 mode: the LayerNorm outputs, produced as operands) passes through /
+            # is only transposed — the same values a cast of the fp32 tensor would give, without the fp32 round trip
+            opA = lambda t: t if t.dtype == torch.bfloat16 else G.to_operand(t, fa)
+            opW = lambda t: G.to_operand(t, fw)
+            opAT = lambda t: G.to_operand(t, fa, True)
+            opWT = lambda t: G.transpose(t, 64) if t.dtype == torch.bfloat16 else G.to_operand(t, fw, True)
+        ln_dt = torch.bfloat16 if self.precision == "bf16" else torch.float32   # LayerNorm outputs are GEMM operands only
+        # a matrix that is consumed both as rows and as rows of its transpose (a gradient: data / weight gradient; a weight:
+        # forward / backward) becomes both operands in one pass over it in bf16 mode
+        if self.precision == "bf16":
+            pairA = pairW = lambda t: G.to_operand_pair(t)
+        else:
+            pairA = lambda t: (opA(t), opAT(t))
+            pairW = lambda t: (opW(t), opWT(t))
 
-        def lin(x, w, b=None, **kw):                      # x [M,K] · w[N,K]ᵀ (+ b)
-            return ops.gemm(opA(x), opW(w.detach()), None if b is None else b.detach(), **kw)
+        def lin(x, w, b=None, **kw):                      # x [M,K] · w[N,K]ᵀ (+ b); returns (y, wᵀ operand for the backward)
+            wa, wt = pairW(w.detach())
+            return ops.gemm(opA(x), wa, None if b is None else b.detach(), **kw), wt
 
         # ---------------- forward, keeping what the backward needs ----------------
         x = ops.embed_splice(tokens, m.embed.weight.detach(), m.embed_positions.weight.detach()).reshape(M, D)
@@ -145,24 +158,29 @@ class LanguageModelTrainer:
             """One decoder layer; returns the layer output and everything its backward needs."""
             P = self._layer_params(L)
             s = {"x_in": x}
-            h1 = ops.layernorm(x, P["sa_ln"].weight.detach(), P["sa_ln"].bias.detach(), eps)
+            h1 = ops.layernorm(x, P["sa_ln"].weight.detach(), P["sa_ln"].bias.detach(), eps, out_dtype=ln_dt)
             wqkv = torch.cat([P["q"].weight, P["k"].weight, P["v"].weight], 0).detach()
             bqkv = torch.cat([P["q"].bias, P["k"].bias, P["v"].bias], 0).detach()
             # bf16 mode: q, k, v live in bf16 (flash kernel with bf16 products forward and backward, fp32 statistics)
-            qkv = ops.gemm(opA(h1), opW(wqkv), bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0,
+            wqkv_a, wqkv_t = pairW(wqkv)
+            qkv = ops.gemm(opA(h1), wqkv_a, bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0,
                            out_dtype=torch.bfloat16 if self.precision == "bf16" else torch.float32)
+            del wqkv_a
             q3, k3, v3 = (qkv[:, i * D:(i + 1) * D].unflatten(0, (B, T)).unflatten(2, (Hh, 64)) for i in range(3))
             lse = torch.empty((B, Hh, T), dtype=torch.float32, device=dev)
             att = ops.attention(q3, k3, v3, True, out_dtype=torch.float32, lse_out=lse).reshape(M, D)
             a_n = att if P["inner_ln"] is None else ops.layernorm(att, P["inner_ln"].weight.detach(),
-                                                                   P["inner_ln"].bias.detach(), eps)
-            x = lin(a_n, P["o"].weight, P["o"].bias, residual=x)
-            h2 = ops.layernorm(x, P["fl_ln"].weight.detach(), P["fl_ln"].bias.detach(), eps)
-            pre = lin(h2, P["fc1"].weight, P["fc1"].bias)
+                                                                   P["inner_ln"].bias.detach(), eps, out_dtype=ln_dt)
+            x, wo_t = lin(a_n, P["o"].weight, P["o"].bias, residual=x)
+            h2 = ops.layernorm(x, P["fl_ln"].weight.detach(), P["fl_ln"].bias.detach(), eps, out_dtype=ln_dt)
+            pre, w1_t = lin(h2, P["fc1"].weight, P["fc1"].bias)
             g = G.gelu(pre)
-            g_n = g if P["ffn_ln"] is None else ops.layernorm(g, P["ffn_ln"].weight.detach(), P["ffn_ln"].bias.detach(), eps)
-            s.update(h1=h1, wqkv=wqkv, qkv=qkv, lse=lse, att=att, a_n=a_n, x_mid=x, h2=h2, pre=pre, g=g, g_n=g_n)
-            return lin(g_n, P["fc2"].weight, P["fc2"].bias, residual=x), s
+            g_n = g if P["ffn_ln"] is None else ops.layernorm(g, P["ffn_ln"].weight.detach(), P["ffn_ln"].bias.detach(), eps,
+                                                              out_dtype=ln_dt)
+            y, w2_t = lin(g_n, P["fc2"].weight, P["fc2"].bias, residual=x)
+            s.update(h1=h1, wqkv_t=wqkv_t, wo_t=wo_t, w1_t=w1_t, w2_t=w2_t, qkv=qkv, lse=lse, att=att, a_n=a_n, x_mid=x,
+                     h2=h2, pre=pre, g=g, g_n=g_n)
+            return y, s
 
         # checkpoint_activations: keep only each layer's input (4 bytes x d per token instead of ~21x that) and run the
         # layer's forward again right before its backward — one third more GEMM work for batches that do not fit otherwise
@@ -172,10 +190,12 @@ class LanguageModelTrainer:
             x, s = layer_forward(L, x)
             saved.append({"x_in": x_in} if self.checkpoint_activations else s)
             del s
-        hf = ops.layernorm(x, dec.layer_norm.weight.detach(), dec.layer_norm.bias.detach(), eps)
+        hf = ops.layernorm(x, dec.layer_norm.weight.detach(), dec.layer_norm.bias.detach(), eps, out_dtype=ln_dt)
         Vp = (V + 31) // 32 * 32                           # dlogits is a GEMM operand over V in the backward pass
         logits = torch.zeros((M, Vp), dtype=torch.float32, device=dev)
-        ops.gemm(opA(hf), opW(m.output_projection.weight.detach()), out=logits[:, :V])
+        wout_a, wout_t = pairW(m.output_projection.weight.detach())
+        ops.gemm(opA(hf), wout_a, out=logits[:, :V])
+        del wout_a
 
         # ---------------- loss: next-token cross-entropy over the B*(T-1) predicting positions ----------------
         target = torch.full((B, T), -100, dtype=torch.int64, device=dev)
@@ -188,11 +208,11 @@ class LanguageModelTrainer:
         loss = G.reduce_sum(loss_rows) / count
 
         # ---------------- backward: every parameter gradient is written into its view of the flat buffer ----------------
-        def dgrad(dy, w):                                  # dX = dY · W          (operands dY and Wᵀ [K, N])
-            return ops.gemm(opA(dy), opWT(w.detach()))
+        def dgrad(dy_a, w_t):                              # dX = dY · W          (operands dY and Wᵀ [K, N])
+            return ops.gemm(dy_a, w_t)
 
-        def wgrad(dy, xin, out=None):                      # dW = dYᵀ · X         (operands dYᵀ [N, M] and Xᵀ [K, M])
-            return ops.gemm(opAT(dy), opWT(xin), out=out)
+        def wgrad(dy_t, xin, out=None):                    # dW = dYᵀ · X         (operands dYᵀ [N, M] and Xᵀ [K, M])
+            return ops.gemm(dy_t, opWT(xin), out=out)
 
         def ln_bwd(xin, ln_name, gamma, dy, dres=None):
             dxo, _, _ = G.layernorm_backward(xin, gamma.detach(), dy, eps, dres=dres, dgamma_out=grads[ln_name + ".weight"],
@@ -200,44 +220,54 @@ class LanguageModelTrainer:
             return dxo
 
         if self.precision == "fp32":                       # fp32 keeps its own zero padding of V to a multiple of 32
-            grads["output_projection.weight"].copy_(wgrad(dlogits, hf)[:V])
-            dl = dlogits
+            dl_a, dl_t = pairA(dlogits)
+            grads["output_projection.weight"].copy_(wgrad(dl_t, hf)[:V])
         else:
-            dl = dlogits[:, :V]
-            wgrad(dl, hf, out=grads["output_projection.weight"])
-        dh = dgrad(dl, m.output_projection.weight)
+            dl_a, dl_t = pairA(dlogits[:, :V])
+            wgrad(dl_t, hf, out=grads["output_projection.weight"])
+        dh = dgrad(dl_a, wout_t)
+        del dl_a, dl_t, wout_t
         dx = ln_bwd(x, "decoder.layer_norm", dec.layer_norm.weight, dh)
         mw = ".A" if a.multiway else ""
         for li in range(len(dec.layers) - 1, -1, -1):
             L, s = dec.layers[li], saved[li]
             if self.checkpoint_activations:
                 _, s = layer_forward(L, s["x_in"])
-                saved[li] = None
+            saved[li] = None
             P, pfx = self._layer_params(L), f"decoder.layers.{li}."
             # x_out = x_mid + fc2(ffn_ln(gelu(fc1(fl_ln(x_mid)))))
-            wgrad(dx, s["g_n"], out=grads[pfx + f"ffn{mw}.fc2.weight"])
+            dx_a, dx_t = pairA(dx)
+            wgrad(dx_t, s["g_n"], out=grads[pfx + f"ffn{mw}.fc2.weight"])
             G.colsum(dx, out=grads[pfx + f"ffn{mw}.fc2.bias"])
-            dgn = dgrad(dx, P["fc2"].weight)
+            dgn = dgrad(dx_a, s["w2_t"])
+            del dx_a, dx_t
             dg = dgn if P["ffn_ln"] is None else ln_bwd(s["g"], pfx + f"ffn{mw}.ffn_layernorm", P["ffn_ln"].weight, dgn)
             dpre = G.gelu_backward(s["pre"], dg)
-            wgrad(dpre, s["h2"], out=grads[pfx + f"ffn{mw}.fc1.weight"])
+            dp_a, dp_t = pairA(dpre)
+            wgrad(dp_t, s["h2"], out=grads[pfx + f"ffn{mw}.fc1.weight"])
             G.colsum(dpre, out=grads[pfx + f"ffn{mw}.fc1.bias"])
-            dh2 = dgrad(dpre, P["fc1"].weight)
+            dh2 = dgrad(dp_a, s["w1_t"])
+            del dp_a, dp_t
             dx = ln_bwd(s["x_mid"], pfx + f"final_layer_norm{mw}", P["fl_ln"].weight, dh2, dres=dx)
             # x_mid = x_in + out_proj(inner_ln(attention(xpos(q), xpos(k), v)))
-            wgrad(dx, s["a_n"], out=grads[pfx + f"self_attn.out_proj{mw}.weight"])
+            dx_a, dx_t = pairA(dx)
+            wgrad(dx_t, s["a_n"], out=grads[pfx + f"self_attn.out_proj{mw}.weight"])
             G.colsum(dx, out=grads[pfx + f"self_attn.out_proj{mw}.bias"])
-            dan = dgrad(dx, P["o"].weight)
+            dan = dgrad(dx_a, s["wo_t"])
+            del dx_a, dx_t
             datt = dan if P["inner_ln"] is None else ln_bwd(s["att"], pfx + f"self_attn.inner_attn_ln{mw}",
                                                              P["inner_ln"].weight, dan)
             dqkv = G.attention_backward(s["qkv"], s["att"].reshape(B, T, D), datt.reshape(B, T, D), s["lse"], B, T, Hh, True,
                                         bf16_products=self.precision == "bf16")
             G.xpos_backward_(dqkv, D, T, tabs, 0.125)
             # q | k | v are adjacent in the flat layout: one GEMM output / one column sum covers the three
-            wgrad(dqkv, s["h1"], out=self._gspan(pfx + f"self_attn.q_proj{mw}.weight", 3 * D, D))
+            dq_a, dq_t = pairA(dqkv)
+            wgrad(dq_t, s["h1"], out=self._gspan(pfx + f"self_attn.q_proj{mw}.weight", 3 * D, D))
             G.colsum(dqkv, out=self._gspan(pfx + f"self_attn.q_proj{mw}.bias", 3 * D))
-            dh1 = dgrad(dqkv, s["wqkv"])
-            dx = ln_bwd(s["x_in"], pfx + f"self_attn_layer_norm{mw}", P["sa_ln"].weight, dh1, dres=dx)
+            dh1 = dgrad(dq_a, s["wqkv_t"])
+            x_in = s["x_in"]
+            del dq_a, dq_t, s
+            dx = ln_bwd(x_in, pfx + f"self_attn_layer_norm{mw}", P["sa_ln"].weight, dh1, dres=dx)
         G.embed_backward(tokens, dx.reshape(B, T, D), V, m.embed_positions.weight.shape[0],
                          out_embed=grads["embed.weight"], out_pos=grads["embed_positions.weight"])
         if m.embed.padding_idx is not None:

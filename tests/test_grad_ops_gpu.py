@@ -152,6 +152,21 @@ def test_attention_backward(B, Hh, T, causal):
     assert rms < 2e-2, rms
 
 
+@pytest.mark.parametrize("shape", [(70, 132), (64, 64), (5, 260), (300, 2048), (129, 8)])
+def test_to_operand_pair_matches_the_two_single_conversions(shape):
+    """One pass over an fp32 matrix -> bf16 operand rows and the rows of its transpose, both zero-padded to 64."""
+    x = torch.randn(*shape, generator=_g(7 + sum(shape))).to(DEV)
+    a, t = G.to_operand_pair(x)
+    assert torch.equal(a, G.to_operand(x, "bf16", False)) and torch.equal(t, G.to_operand(x, "bf16", True))
+    a2, none = G.to_operand_pair(x, transposed=False)
+    none2, t2 = G.to_operand_pair(x, straight=False)
+    assert none is None and none2 is None and torch.equal(a2, a) and torch.equal(t2, t)
+    big = torch.randn(shape[0], shape[1] + 12, generator=_g(3)).to(DEV)           # a row-strided source view
+    v = big[:, :shape[1]]
+    a3, t3 = G.to_operand_pair(v)
+    assert torch.equal(a3, G.to_operand(v, "bf16", False)) and torch.equal(t3, G.to_operand(v, "bf16", True))
+
+
 @pytest.mark.parametrize("shape", [(70, 130), (64, 64), (5, 257), (300, 2048)])
 @pytest.mark.parametrize("transpose", [False, True])
 @pytest.mark.parametrize("fmt", ["bf16", "bf16x3_act", "bf16x3_w"])
