@@ -353,10 +353,12 @@ int kx_transpose(const void* src, void* dst, int64_t rows, int64_t cols, int64_t
 int kx_to_operand(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t kp, int32_t transpose,
                   int32_t fmt, void* stream);
 /* One pass over an fp32 matrix producing the bf16 operand rows dst [rows, kp] and/or the transposed operand rows
- * dst_t [cols, kpt] (kp >= cols, kpt >= rows, multiples of 8, padding zero; either output may be NULL).  A gradient
- * matrix is consumed both ways (data gradient / weight gradient), a weight forward and backward. */
+ * dst_t [cols, kpt] (kp >= cols, kpt >= rows, multiples of 8, padding zero; either output may be NULL) and, when
+ * `colsum` is not NULL, colsum[c] = sum_r src[r][c] (a bias gradient; deterministic: one partial row per 64-row slice in
+ * `workspace`, summed in slice order).  A gradient matrix is consumed all three ways, a weight forward and backward. */
+size_t kx_to_operand_pair_workspace_bytes(int64_t rows, int64_t cols);
 int kx_to_operand_pair(const float* src, void* dst, void* dst_t, int64_t rows, int64_t cols, int64_t ld_src, int64_t kp,
-                       int64_t kpt, void* stream);
+                       int64_t kpt, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
 /* out[c] (+)= sum_r x[r][c] (bias gradients) */
 size_t kx_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int kx_colsum(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, int32_t accumulate, void* workspace,

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void to_operand_rows_kernel(const float* __res
 // padding columns zero; either may be null.
 __global__ __launch_bounds__(256) void to_operand_pair_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                               bf16_t* __restrict__ dst_t, long long rows, long long cols,
-                                                              long long ld_src, long long kp, long long kpt) {
+                                                              long long ld_src, long long kp, long long kpt,
+                                                              float* __restrict__ colsum_part) {
   __shared__ float tile[64][65];
   const long long r0 = (long long)blockIdx.y * 64, c0 = (long long)blockIdx.x * 64;
   const int tid = threadIdx.x;
@@ -74,6 +75,12 @@ __global__ __launch_bounds__(256) void to_operand_pair_kernel(const float* __res
     }
   }
   __syncthreads();
+  if (colsum_part && tid < 64 && c0 + tid < cols) {          // bias gradient: this 64-row slice's column sums (fp32 source)
+    float sum = 0.f;
+#pragma unroll 16
+    for (int r = 0; r < 64; ++r) sum += tile[r][tid];
+    colsum_part[(long long)blockIdx.y * cols + c0 + tid] = sum;
+  }
   const int ox = tid & 7, oy = tid >> 3;                     // 8 lanes x 8 values per output row, 32 rows per pass
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __rest
                                                                 long long row_stride, long long batch_stride,
                                                                 long long do_row, long long do_batch) {
   __shared__ __attribute__((aligned(16))) bf16_t Qb[2][64 * XS], dOb[2][64 * XS];
-  __shared__ float Lb[2][64], Db[2][64];
+  __shared__ __attribute__((aligned(16))) float Lb[2][64], Db[2][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
@@ -951,7 +958,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __rest
   auto lstore = [&](int buf) {
     tile_lstore_any(Qb[buf], qreg, tid, qb);
     tile_lstore(dOb[buf], doreg, tid);
-    if (tid < 64) { Lb[buf][tid] = lreg; Db[buf][tid] = dreg; }
+    if (tid < 64) { Lb[buf][tid] = lreg * 1.44269504088896340736f; Db[buf][tid] = dreg; }
   };
   gload(t0);
   lstore(0);
@@ -973,13 +980,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __rest
           sa = mfma_bf16(tile_row_frag(Qs, qbk, s2, g, i), kfix[s2], sa);     // S[q, key]
           pa = mfma_bf16(tile_row_frag(dOs, qbk, s2, g, i), vfix[s2], pa);    // dP[q, key]
         }
+        // exp(s - lse) as one FMA + v_exp_f32 (the stored statistic is lse*log2e), computed unconditionally and
+        // selected (the accurate expf is ~9 instructions and made the mask a branch); the four rows' statistics come
+        // in one 16-byte LDS read each
+        const float4 L4 = *reinterpret_cast<const float4*>(Ls + 16 * qbk + 4 * g);
+        const float4 D4 = *reinterpret_cast<const float4*>(Ds + 16 * qbk + 4 * g);
+        const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
   #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ql = 16 * qbk + 4 * g + r, qi = q0 + ql;
+          const int qi = q0 + 16 * qbk + 4 * g + r;
           const bool ok = qi < T && ki < T && (!CAUSAL || ki <= qi);
-          const float pv = ok ? expf(sa[r] - Ls[ql]) : 0.f;
+          const float e = __builtin_amdgcn_exp2f(fmaf(sa[r], 1.44269504088896340736f, -Lr[r]));
+          const float pv = ok ? e : 0.f;
           pb[qbk][r] = pv;
-          sb[qbk][r] = pv * (pa[r] - Ds[ql]);
+          sb[qbk][r] = pv * (pa[r] - Dr[r]);
         }
       }
       u32x4_t pfP[2], pfS[2];
@@ -1026,7 +1040,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const QT* __restr
   u32x4_t qfix[2], dofix[2];
   qfix[0] = row_frag_global(qb + (long long)qc * row_stride, g, 0); qfix[1] = row_frag_global(qb + (long long)qc * row_stride, g, 1);
   dofix[0] = row_frag_global(dob + (long long)qc * do_row, g, 0); dofix[1] = row_frag_global(dob + (long long)qc * do_row, g, 1);
-  const float lse_i = qi < T ? lse[((long long)b * H + h) * T + qi] : 0.f;
+  const float lse2_i = (qi < T ? lse[((long long)b * H + h) * T + qi] : 0.f) * 1.44269504088896340736f;   // lse*log2e
   const float del_i = qi < T ? delta[((long long)b * H + h) * T + qi] : 0.f;
   f32x4_t dqt[4];
 #pragma unroll
@@ -1064,8 +1078,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const QT* __restr
         for (int r = 0; r < 4; ++r) {
           const int kj = k0 + 16 * kbk + 4 * g + r;
           const bool ok = qi < T && kj < T && (!CAUSAL || kj <= qi);
-          const float pv = ok ? expf(st[r] - lse_i) : 0.f;
-          sb[kbk][r] = pv * (dpt[r] - del_i);
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[r], 1.44269504088896340736f, -lse2_i));
+          sb[kbk][r] = (ok ? e : 0.f) * (dpt[r] - del_i);
         }
       }
       u32x4_t pfS[2];
@@ -1143,8 +1157,15 @@ extern "C" int kx_to_operand(const float* src, void* dst, int64_t rows, int64_t 
   return KX_OK;
 }
 
+static inline int64_t pair_grid_rows(int64_t rows, int64_t kpt, bool has_t) { return ((has_t && kpt > rows ? kpt : rows) + 63) / 64; }
+
+extern "C" size_t kx_to_operand_pair_workspace_bytes(int64_t rows, int64_t cols) {
+  return (size_t)(((rows + 63) / 64 * 64 + 64) / 64) * (size_t)cols * sizeof(float);      // one partial row per 64-row slice
+}
+
 extern "C" int kx_to_operand_pair(const float* src, void* dst, void* dst_t, int64_t rows, int64_t cols, int64_t ld_src,
-                                  int64_t kp, int64_t kpt, void* stream) {
+                                  int64_t kp, int64_t kpt, float* colsum, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
   KX_REQUIRE(src && (dst || dst_t) && rows > 0 && cols > 0 && ld_src >= cols, "kx_to_operand_pair: bad arguments");
   KX_REQUIRE(!dst || (kp >= cols && kp % 8 == 0 && (((uintptr_t)dst) & 15) == 0),
              "kx_to_operand_pair: kp=%lld must cover %lld columns, be a multiple of 8, dst 16-byte aligned", (long long)kp,
@@ -1154,12 +1175,19 @@ extern "C" int kx_to_operand_pair(const float* src, void* dst, void* dst_t, int6
              (long long)rows);
   KX_REQUIRE((ld_src & 3) == 0 && (((uintptr_t)src) & 15) == 0, "kx_to_operand_pair: src rows must be 16-byte aligned");
   // the grid covers the padded extents so the zero padding is written too
-  const int64_t ec = dst && kp > cols ? kp : cols, er = dst_t && kpt > rows ? kpt : rows;
-  const dim3 grid((unsigned)((ec + 63) / 64), (unsigned)((er + 63) / 64));
+  const int64_t ec = dst && kp > cols ? kp : cols;
+  const int64_t gy = pair_grid_rows(rows, kpt, dst_t != nullptr);
+  KX_REQUIRE(gy <= 65535, "kx_to_operand_pair: %lld rows exceed the grid", (long long)rows);
+  KX_REQUIRE(!colsum || (workspace && workspace_bytes >= (size_t)gy * (size_t)cols * sizeof(float)),
+             "kx_to_operand_pair: the column sums need %zu bytes of workspace", (size_t)gy * (size_t)cols * sizeof(float));
+  const dim3 grid((unsigned)((ec + 63) / 64), (unsigned)gy);
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(KX_K_MISC, rows, cols, 28, s);
   hipLaunchKernelGGL(to_operand_pair_kernel, grid, dim3(256), 0, s, src, (bf16_t*)dst, (bf16_t*)dst_t, (long long)rows,
-                     (long long)cols, (long long)ld_src, (long long)kp, (long long)kpt);
+                     (long long)cols, (long long)ld_src, (long long)kp, (long long)kpt, colsum ? (float*)workspace : nullptr);
+  if (colsum)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
+                       (int)gy, (long long)cols, colsum, 0);
   KX_CHECK_LAUNCH("kx_to_operand_pair");
   return KX_OK;
 }

@@ -40,16 +40,21 @@ def to_operand(x: torch.Tensor, fmt: str, transpose_: bool = False) -> torch.Ten
     return out
 
 
-def to_operand_pair(x: torch.Tensor, straight: bool = True, transposed: bool = True):
+def to_operand_pair(x: torch.Tensor, straight: bool = True, transposed: bool = True, colsum_out: torch.Tensor | None = None):
     """fp32 [R,C] -> (bf16 operand rows [R, Cp], bf16 rows of x^T [C, Rp]) in one pass (Cp / Rp = C / R rounded up to 64,
-    padding zero); an output that is not asked for is None."""
-    _need_cuda(x)
+    padding zero); an output that is not asked for is None.  colsum_out [C] fp32: also the column sums (a bias gradient)."""
+    _need_cuda(x, colsum_out)
     R, Cc = x.shape
     kp, kpt = (Cc + 63) // 64 * 64, (R + 63) // 64 * 64
     a = torch.empty((R, kp), dtype=torch.bfloat16, device=x.device) if straight else None
     t = torch.empty((Cc, kpt), dtype=torch.bfloat16, device=x.device) if transposed else None
-    H.check(H.load().kx_to_operand_pair(H.ptr(x), H.ptr(a), H.ptr(t), R, Cc, x.stride(0), kp, kpt, _stream()),
-            "kx_to_operand_pair")
+    lib = H.load()
+    ws, n = None, 0
+    if colsum_out is not None:
+        n = lib.kx_to_operand_pair_workspace_bytes(R, Cc)
+        ws = _ws(n, x.device)
+    H.check(lib.kx_to_operand_pair(H.ptr(x), H.ptr(a), H.ptr(t), R, Cc, x.stride(0), kp, kpt, H.ptr(colsum_out), H.ptr(ws),
+                                   ws.numel() if ws is not None else 0, _stream()), "kx_to_operand_pair")
     return a, t
 
 

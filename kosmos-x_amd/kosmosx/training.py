@@ -138,11 +138,17 @@ class LanguageModelTrainer:
         ln_dt = torch.bfloat16 if self.precision == "bf16" else torch.float32   # LayerNorm outputs are GEMM operands only
         # a matrix that is consumed both as rows and as rows of its transpose (a gradient: data / weight gradient; a weight:
         # forward / backward) becomes both operands in one pass over it in bf16 mode
+        # (the same pass also sums a gradient's columns — the bias gradient — while the tile is in LDS)
         if self.precision == "bf16":
-            pairA = pairW = lambda t: G.to_operand_pair(t)
+            pairW = lambda t: G.to_operand_pair(t)
+            pairA = lambda t, bias_out=None: G.to_operand_pair(t, colsum_out=bias_out)
         else:
-            pairA = lambda t: (opA(t), opAT(t))
             pairW = lambda t: (opW(t), opWT(t))
+
+            def pairA(t, bias_out=None):
+                if bias_out is not None:
+                    G.colsum(t, out=bias_out)
+                return opA(t), opAT(t)
 
         def lin(x, w, b=None, **kw):                      # x [M,K] · w[N,K]ᵀ (+ b); returns (y, wᵀ operand for the backward)
             wa, wt = pairW(w.detach())
@@ -236,23 +242,20 @@ class LanguageModelTrainer:
             saved[li] = None
             P, pfx = self._layer_params(L), f"decoder.layers.{li}."
             # x_out = x_mid + fc2(ffn_ln(gelu(fc1(fl_ln(x_mid)))))
-            dx_a, dx_t = pairA(dx)
+            dx_a, dx_t = pairA(dx, grads[pfx + f"ffn{mw}.fc2.bias"])
             wgrad(dx_t, s["g_n"], out=grads[pfx + f"ffn{mw}.fc2.weight"])
-            G.colsum(dx, out=grads[pfx + f"ffn{mw}.fc2.bias"])
             dgn = dgrad(dx_a, s["w2_t"])
             del dx_a, dx_t
             dg = dgn if P["ffn_ln"] is None else ln_bwd(s["g"], pfx + f"ffn{mw}.ffn_layernorm", P["ffn_ln"].weight, dgn)
             dpre = G.gelu_backward(s["pre"], dg)
-            dp_a, dp_t = pairA(dpre)
+            dp_a, dp_t = pairA(dpre, grads[pfx + f"ffn{mw}.fc1.bias"])
             wgrad(dp_t, s["h2"], out=grads[pfx + f"ffn{mw}.fc1.weight"])
-            G.colsum(dpre, out=grads[pfx + f"ffn{mw}.fc1.bias"])
             dh2 = dgrad(dp_a, s["w1_t"])
             del dp_a, dp_t
             dx = ln_bwd(s["x_mid"], pfx + f"final_layer_norm{mw}", P["fl_ln"].weight, dh2, dres=dx)
             # x_mid = x_in + out_proj(inner_ln(attention(xpos(q), xpos(k), v)))
-            dx_a, dx_t = pairA(dx)
+            dx_a, dx_t = pairA(dx, grads[pfx + f"self_attn.out_proj{mw}.bias"])
             wgrad(dx_t, s["a_n"], out=grads[pfx + f"self_attn.out_proj{mw}.weight"])
-            G.colsum(dx, out=grads[pfx + f"self_attn.out_proj{mw}.bias"])
             dan = dgrad(dx_a, s["wo_t"])
             del dx_a, dx_t
             datt = dan if P["inner_ln"] is None else ln_bwd(s["att"], pfx + f"self_attn.inner_attn_ln{mw}",
@@ -261,9 +264,8 @@ class LanguageModelTrainer:
                                         bf16_products=self.precision == "bf16")
             G.xpos_backward_(dqkv, D, T, tabs, 0.125)
             # q | k | v are adjacent in the flat layout: one GEMM output / one column sum covers the three
-            dq_a, dq_t = pairA(dqkv)
+            dq_a, dq_t = pairA(dqkv, self._gspan(pfx + f"self_attn.q_proj{mw}.bias", 3 * D))
             wgrad(dq_t, s["h1"], out=self._gspan(pfx + f"self_attn.q_proj{mw}.weight", 3 * D, D))
-            G.colsum(dqkv, out=self._gspan(pfx + f"self_attn.q_proj{mw}.bias", 3 * D))
             dh1 = dgrad(dq_a, s["wqkv_t"])
             x_in = s["x_in"]
             del dq_a, dq_t, s

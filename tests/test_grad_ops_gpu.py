@@ -158,6 +158,10 @@ def test_to_operand_pair_matches_the_two_single_conversions(shape):
     x = torch.randn(*shape, generator=_g(7 + sum(shape))).to(DEV)
     a, t = G.to_operand_pair(x)
     assert torch.equal(a, G.to_operand(x, "bf16", False)) and torch.equal(t, G.to_operand(x, "bf16", True))
+    cs = torch.empty(shape[1], dtype=torch.float32, device=DEV)
+    a1, t1 = G.to_operand_pair(x, colsum_out=cs)                                  # + the column sums (bias gradient)
+    assert torch.equal(a1, a) and torch.equal(t1, t)
+    torch.testing.assert_close(cs.cpu(), x.cpu().double().sum(0).float(), rtol=2e-6, atol=2e-5)
     a2, none = G.to_operand_pair(x, transposed=False)
     none2, t2 = G.to_operand_pair(x, straight=False)
     assert none is None and none2 is None and torch.equal(a2, a) and torch.equal(t2, t)
