@@ -40,7 +40,8 @@ struct GemmParams {
   // wall-clock ticks) late, so the CUs' epilogues (HBM bursts) stop coinciding — see launch_p5
   int stagger_ticks;
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
-  int persistent;       // 256-column kernel: > 0 = launch this many workgroups, each walking its tiles itself
+  int lean_epilogue;    // 256-column kernel: accumulator-level epilogue + pure data movement (see lean_store_*)
+  int persistent;       // 256x256 kernel: > 0 = launch this many workgroups, each walking its tiles itself
   int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
   // weight-streaming variant (gemv_fused_kernel) only
   const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
@@ -382,7 +383,69 @@ template <> struct Mma<float> {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <typename T, int BM, int BN, int ACT>
+// ---- lean bf16 epilogue of the tile kernels (tile fully inside N, 16-byte aligned rows) -------------------------
+// The generic store loops re-derive addresses, bounds and option flags for every 8 values (~100 instructions per pass,
+// two LDS halves, four barriers): 27k cycles per 256x256 tile for a plain bf16 store against a 100k-cycle K loop, while
+// a bare store kernel retires the same 128 wave-wide stores in 4.3k (tools/probes/store_probe.hip).  This path does
+// the arithmetic ONCE at accumulator level (lane (g,li) of fragment (a,b): row b*16+li, columns a*16+4g..+3), parks the
+// whole tile as bf16 (BM x 512 B, 16-byte chunks XOR-swizzled by row&7), and after ONE barrier every wave instruction
+// stores two full 512-byte rows: 6.5k cycles.  Outputs with a residual / folded-LN consume (fp32) and the q-scale + XPos
+// epilogue keep the generic loops: an accumulator-level fp32 path measured the same 71k cycles (it waits on the
+// residual loads either way) and the XPos variant still spilled.
+template <int ACT, int FM, int FN>
+__device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc)[FN][FM], int ncol0, int g) {
+  // Straight-line on purpose: a run-time branch whose two sides both rewrite the 128 accumulator registers made the
+  // compiler keep two copies of them (spills) — which is also why the variants are separate kernel instantiations.
+  // q-scale: a wave's 64 columns lie on one side of the boundary (qcols % 64 == 0, checked by kx_gemm) -> one scalar
+  const float qsc = ncol0 < p.qcols ? p.qscale : 1.0f;
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + ncol0 + a * 16 + 4 * g);
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      f32x4_t v = acc[a][b];
+      v[0] = (v[0] + bias.x) * qsc; v[1] = (v[1] + bias.y) * qsc; v[2] = (v[2] + bias.z) * qsc; v[3] = (v[3] + bias.w) * qsc;
+      if constexpr (ACT != KX_ACT_NONE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = apply_act<ACT>(v[q]);
+      }
+      acc[a][b] = v;
+    }
+  }
+}
+
+template <int BM, int BN, int NW, int FM, int FN>   // tile BM x BN, NW waves, wave sub-tile at (row_w0, col_w0)
+__device__ __forceinline__ void lean_store_bf16(const GemmParams& p, const f32x4_t (&acc)[FN][FM], char* smem, int m0,
+                                                int n0, int row_w0, int col_w0, int wave, int lane, int g, int li) {
+  constexpr int RB = BN * 2, CPR = BN / 8;        // bytes and 16-byte chunks per tile row
+  constexpr int RPI = 64 / CPR, RPP = NW * RPI;   // rows per wave instruction / per pass of the workgroup
+  static_assert(BM % RPP == 0 && CPR >= 8 && 64 % CPR == 0, "tile rows must split into whole store passes");
+  __syncthreads();                               // the K loop's last fragment reads are done
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int rt = row_w0 + b * 16 + li;
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const int chunk = ((col_w0 >> 3) + a * 2 + (g >> 1)) ^ (rt & 7);
+      uint2 v;
+      v.x = pack_bf16x2(acc[a][b][0], acc[a][b][1]);
+      v.y = pack_bf16x2(acc[a][b][2], acc[a][b][3]);
+      *reinterpret_cast<uint2*>(smem + rt * RB + chunk * 16 + (g & 1) * 8) = v;
+    }
+  }
+  __syncthreads();
+  const int cl = lane % CPR, rl = lane / CPR;
+  bf16_t* cbase = reinterpret_cast<bf16_t*>(p.C) + n0 + cl * 8;
+#pragma unroll
+  for (int ps = 0; ps < BM / RPP; ++ps) {
+    const int rt = ps * RPP + wave * RPI + rl;
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + rt * RB + ((cl ^ (rt & 7)) << 4));
+    if (m0 + rt < p.M) *reinterpret_cast<uint4*>(cbase + (long long)(m0 + rt) * p.ldc) = v;
+  }
+}
+
+template <typename T, int BM, int BN, int ACT, int EPI = 0>   // EPI 1: lean bf16 epilogue (see above)
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int ROWB = 128;                 // bytes per staged tile row = one BK slice
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
@@ -494,6 +557,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   // walks it back row-major: 16 lanes emit one full 256-B row segment per instruction and the epilogue body
   // exists once, inside a rolled loop.
   constexpr int WM = BM / 2, WN = BN / 2;
+  if constexpr (EPI == 1) {           // bias + activation on the accumulators, the tile parked once as bf16, full-row stores
+    lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g);
+    lean_store_bf16<BM, BN, 4, FM, FN>(p, acc, smem, m0, n0, wm * WM, wn * WN, wave, lane, g, li);
+    return;
+  }
   constexpr int CH = WN / 4;          // 16-byte chunks per sub-tile row (16 or 8)
   constexpr int RPI = 64 / CH;        // rows covered by one wave-wide access
   const bool pre = p.stats_out != nullptr && p.splitk == 1;   // folded sub-LN producer: see prepass_bias_act_stats
@@ -906,7 +974,10 @@ __device__ unsigned long long kx_tl[8];
 #define KX_TL_COMMIT()
 #endif
 
-template <typename T, int ACT, int BM>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
+// EPI: 0 generic store loops, 1 lean bf16 tile store, 4 the same with produced row statistics — separate kernels (one
+// epilogue each:
+// with all three behind run-time branches the register allocator spilled accumulators inside the K loop)
+template <typename T, int ACT, int BM, int EPI>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   constexpr int BN = 256, ROWB = 128;
   static_assert(BM % 64 == 0, "BM must split into 2 wave rows of whole 16-row fragments and 8 staging waves");
@@ -930,9 +1001,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const int tm = first_m + (wg % per_group) % gsz;
   const int tn = (wg % per_group) / gsz;
   if (p.stagger_ticks > 0 && bid < 256) {
-    const int ph = (bid >> 3) & 3;
+    const int ph = p.stagger_ticks >= 100000 ? (bid & 7) : ((bid >> 3) & 3);   // >= 100000: per-XCD phases, ticks - 100000
     if (ph) {
-      const unsigned long long t0 = wall_clock64(), d = (unsigned long long)ph * p.stagger_ticks;
+      const unsigned long long t0 = wall_clock64(), d = (unsigned long long)ph * (p.stagger_ticks % 100000);
       while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(32);
     }
   }
@@ -1053,6 +1124,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   // ---- epilogue staged through LDS in two 64-row halves (8 waves x 64x64 fp32 = 128 KB) ----
   constexpr int WN = 64, CH = WN / 4;
   const bool pre = p.stats_out != nullptr;
+  if constexpr (EPI == 1 || EPI == 4) {            // bias / activation (/ statistics) on the accumulators, bf16 tile store
+    if constexpr (EPI == 4) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
+    else lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g);
+    KX_TL_STAMP(3);
+    lean_store_bf16<BM, 256, 8, FM, FN>(p, acc, smem, m0, n0, wm * (BM / 2), wn * WN, wave, lane, g, li);
+    KX_TL_STAMP(4);
+    KX_TL_STAMP(5);
+    KX_TL_COMMIT();
+  } else {
   if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
   KX_TL_STAMP(3);
   GemmParams q = p;
@@ -1078,25 +1158,35 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   park_and_store(std::integral_constant<int, 1>{});
   KX_TL_STAMP(5);
   KX_TL_COMMIT();
+  }  // generic epilogue
   if (bid + (int)gridDim.x < nwg) __syncthreads();   // the parked rows have been read back before the next tile's fill
   }  // tiles of this workgroup
+}
+
+template <typename T, int BM, int EPI>
+int launch_p5e(GemmParams& p, hipStream_t s) {
+  const int nwg = p.tiles_m * p.tiles_n;
+  const dim3 grid(p.persistent > 0 ? (nwg < p.persistent ? nwg : p.persistent) : nwg), block(512);
+  // the lean variants are instantiated for the activations the forward uses them with; anything else takes EPI 0
+  if (p.act == KX_ACT_NONE && EPI != 4) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, EPI>), grid, block, 0, s, p);
+  else if (p.act == KX_ACT_GELU_FAST && (EPI == 0 || EPI == 1 || EPI == 4))
+    hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, (EPI == 1 || EPI == 4) ? EPI : 0>), grid, block, 0, s, p);
+  else if (p.act == KX_ACT_QUICK_GELU && (EPI == 0 || EPI == 1))
+    hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_QUICK_GELU, BM, EPI == 1 ? 1 : 0>), grid, block, 0, s, p);
+  else if (EPI != 0) return launch_p5e<T, BM, 0>(p, s);
+  else if (p.act == KX_ACT_NONE) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, 0>), grid, block, 0, s, p);
+  else if (p.act == KX_ACT_GELU) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU, BM, 0>), grid, block, 0, s, p);
+  else { kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG; }
+  KX_CHECK_LAUNCH("kx_gemm(p5)");
+  return KX_OK;
 }
 
 template <typename T, int BM>
 int launch_p5(GemmParams& p, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + 255) / 256;
-  const int nwg = p.tiles_m * p.tiles_n;
-  const dim3 grid(p.persistent > 0 ? (nwg < p.persistent ? nwg : p.persistent) : nwg), block(512);
-  switch (p.act) {
-    case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM>), grid, block, 0, s, p); break;
-    case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU, BM>), grid, block, 0, s, p); break;
-    case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM>), grid, block, 0, s, p); break;
-    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_QUICK_GELU, BM>), grid, block, 0, s, p); break;
-    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
-  }
-  KX_CHECK_LAUNCH("kx_gemm(p5)");
-  return KX_OK;
+  if (p.lean_epilogue && p.N % 256 == 0) return p.stats_out ? launch_p5e<T, BM, 4>(p, s) : launch_p5e<T, BM, 1>(p, s);
+  return launch_p5e<T, BM, 0>(p, s);
 }
 
 // CUs of the current device (one process drives one GPU; cached after the first call)
@@ -1309,6 +1399,13 @@ int launch(GemmParams& p, hipStream_t s) {
     KX_CHECK_LAUNCH("kx_gemm(split-K)");
     return launch_splitk_reduce(p, s);
   }
+  if constexpr (BM == 160 && sizeof(T) == 2) {     // the ViT's bf16-output GEMMs (qkv, fc1): lean epilogue
+    if (p.lean_epilogue && !p.stats_out && p.N % BN == 0) {
+      if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
+      if (p.act == KX_ACT_QUICK_GELU) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
+      if (p.act == KX_ACT_GELU_FAST) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU_FAST, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
+    }
+  }
   // the activation is a compile-time property of the kernel: a runtime switch costs ~4 scalar branches per value
   switch (p.act) {
     case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p); break;
@@ -1402,6 +1499,10 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       const int pv = kx_tuning_get(KX_TUNE_GEMM_PERSISTENT);
       p.persistent = pv < 0 ? 0 : pv > 0 ? pv : kx_cu_count();
     }
+    // the lean epilogue covers bf16 outputs (not bf16x3) without residual / folded-LN consume / XPos on
+    // 16-byte-aligned rows; launch_p5 also asks for N % 256 == 0.  Everything else keeps the generic loops.
+    p.lean_epilogue = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1 && p.c_bf16 && !p.c_x3 && p.vec8_ok && !a->residual &&
+                      !a->row_stats && !a->xpos_dim && a->qcols % 64 == 0 && !(a->stats_out && a->qcols);
     p.fast_epilogue = mode == 2 || (mode == 0 && (a->residual || a->row_stats || a->xpos_dim > 0));
   }
   hipStream_t s = (hipStream_t)stream;
