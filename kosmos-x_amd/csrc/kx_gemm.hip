@@ -187,12 +187,16 @@ __device__ __forceinline__ void epilogue8_bf16(const GemmParams& p, int m, int n
 // replaces issued those loads inside each pass and waited for them pass by pass: ~1 us of latency x 32 passes made
 // the in-place fp32 residual epilogue of a 256x256 tile cost as much as its whole K = 2048 main loop
 // (measured: 47 us of a 94 us tile).  Same operation order as epilogue_compute4, so results are bit-identical.
-template <int ACT, int WN, int CPL>
+template <int ACT, int WN, int CPL, int CHUNK_F32 = 64>
 __device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float* cw, int rows, int lane, int mbase,
                                                 int nwave) {
   constexpr int CH = WN / 4;
   constexpr int LPR = WN / CPL, RPI = 64 / LPR, NV = CPL / 4;
-  constexpr int U = 32 / RPI;                         // passes per chunk of 32 rows (8 for fp32, 4 for bf16 outputs)
+  // rows whose epilogue operands (residual, statistics, XPos entries) are requested together.  fp32 outputs: 64 — one
+  // exposed load latency per 64-row half instead of two where the registers allow (the 256-column kernel still holds
+  // half of its accumulators while the first half is stored: it spilled at 64 and passes 32);
+  constexpr int CHUNK = CPL == 4 ? CHUNK_F32 : 32;
+  constexpr int U = CHUNK / RPI;                      // passes per chunk (16 for fp32, 4 for bf16 outputs)
   const int cl = lane % LPR, rl = lane / LPR;
   const int n = nwave + cl * CPL;
   const bool has_rs = p.row_stats != nullptr, has_res = p.residual != nullptr;
@@ -210,7 +214,7 @@ __device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float
     cs[v] = (nv < p.xpos_dim ? p.xq_cs : p.xk_cs) + j;
     ss[v] = (nv < p.xpos_dim ? p.xq_ss : p.xk_ss) + j;
   }
-  for (int r0 = 0; r0 < rows; r0 += 32) {
+  for (int r0 = 0; r0 < rows; r0 += CHUNK) {
     float4 res[U][NV];
     float2 rs[U], xc[U][NV], xs[U][NV];
 #pragma unroll
@@ -284,12 +288,12 @@ __device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float
 
 // The store loop every tile kernel runs over its LDS-parked fp32 sub-tile (`rows` x WN, 16-B chunks XOR-swizzled by
 // row): row-major walk, fused epilogue, coalesced row segments.
-template <int ACT, int WN>
+template <int ACT, int WN, int CHUNK_F32 = 64>
 __device__ __forceinline__ void store_loop(const GemmParams& p, const float* cw, int rows, int lane, int mbase,
                                            int nwave) {
   constexpr int CH = WN / 4;
   if (p.vec_ok && nwave + WN <= p.N && !p.stats_out && p.fast_epilogue) {
-    if (!p.c_bf16) { store_loop_fast<ACT, WN, 4>(p, cw, rows, lane, mbase, nwave); return; }
+    if (!p.c_bf16) { store_loop_fast<ACT, WN, 4, CHUNK_F32>(p, cw, rows, lane, mbase, nwave); return; }
     if (p.vec8_ok) { store_loop_fast<ACT, WN, 8>(p, cw, rows, lane, mbase, nwave); return; }
   }
   if (p.c_bf16 && p.vec8_ok) {
@@ -1150,8 +1154,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
         *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][half * (FM / 2) + b];
       }
     __syncthreads();
-    if (pre) store_loop<KX_ACT_NONE, WN>(q, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
-    else store_loop<ACT, WN>(p, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
+    if (pre) store_loop<KX_ACT_NONE, WN, 32>(q, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
+    else store_loop<ACT, WN, 32>(p, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
   };
   park_and_store(std::integral_constant<int, 0>{});
   KX_TL_STAMP(4);
