@@ -59,5 +59,29 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
+def build_timeline(verbose: bool = True) -> Path:
+    """Side library with the 256-column GEMM kernel's timeline stamps compiled in (-DKX_TIMELINE), for
+    tools/gemm_timeline.py.  Never loaded by the product (KOSMOSX_HIP_LIB points the tool at it)."""
+    out = BUILD_DIR / "tl"
+    out.mkdir(parents=True, exist_ok=True)
+    srcs = sorted(CSRC.glob("*.hip"))
+
+    def cc(src: Path) -> Path:
+        obj = out / (src.stem + ".o")
+        cmd = [HIPCC, *FLAGS, "-DKX_TIMELINE", "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(cc, srcs))
+    lib = out / "libkosmosx_hip_tl.so"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(lib)], check=True)
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--timeline" in sys.argv:
+        print(build_timeline())

@@ -1,5 +1,5 @@
 """Where a 256x256 GEMM tile's time goes (GPU box only).  Needs the side library built with -DKX_TIMELINE
-(kosmos-x_amd/build/tl/libkosmosx_hip_tl.so) and KOSMOSX_HIP_LIB pointing at it.  Thread 0 of every
+(`python kosmos-x_amd/build.py --timeline` -> kosmos-x_amd/build/tl/libkosmosx_hip_tl.so) and KOSMOSX_HIP_LIB pointing at it.  Thread 0 of every
 workgroup stamps the shader clock at six points of each tile; the sums are read back per launch."""
 import ctypes as C, json, os, sys
 from pathlib import Path
