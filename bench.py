@@ -65,9 +65,9 @@ _PMC_KEYS = {"gemm_bf16_160x128": "gemm_kernel<bf16,160,128", "gemm_bf16_128x128
 def pmc_traffic(kernel, args):
     """roofline.traffic: HBM-side bytes per launch of the dominant kernel.  PMC counters need rocprofv3 around the
     process, so they are not collected here: the value comes from the committed PMC pass of this same command
-    (tools/pmc_round.sh -> tools/pmc_summary.py -> profiles/r01_j_pmc.json; FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950
+    (tools/pmc_round.sh -> tools/pmc_summary.py -> profiles/r01_v_pmc.json; FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950
     correction) and is only reported for the default workload it was measured on; otherwise null."""
-    f = Path(__file__).resolve().parent / "profiles" / "r01_j_pmc.json"
+    f = Path(__file__).resolve().parent / "profiles" / "r01_v_pmc.json"
     key = _PMC_KEYS.get(kernel)
     if not (f.exists() and key and args.batch == 32 and args.text_len == 50 and args.precision == "bf16"):
         return {"traffic": None}
@@ -76,7 +76,7 @@ def pmc_traffic(kernel, args):
     if not n:
         return {"traffic": None}
     t = sum(v["launches"] * (v["fetch_bytes_x2"] + v["write_bytes"]) for v in rows) / n
-    return {"traffic": round(t), "traffic_unit": "bytes/launch", "traffic_source": "profiles/r01_j_pmc_summary.md"}
+    return {"traffic": round(t), "traffic_unit": "bytes/launch", "traffic_source": "profiles/r01_v_pmc_summary.md"}
 
 
 def kernel_report(records, steps):
