@@ -405,7 +405,8 @@ int kx_attention_backward(const void* q, const void* k, const void* v, int32_t q
  * key 2: attention variant (0 = bf16 v2: 32 queries/wave, transpose-read V, prefetched tiles / fp32 on the matrix
  *        cores; 1 = the first versions: bf16 v1 / fp32 wave-per-query VALU kernel);
  * key 3: 256x256 GEMM start stagger per phase group in 10 ns ticks (0 = none; measured useless, kept for A/B);
- * key 4: GEMM store loop (0 auto, 1 rolled per-pass loads, 2 prefetching);
+ * key 4: GEMM epilogue (0 auto: lean bf16 tile store where it applies, prefetching store loop for residual / statistics /
+ *        XPos operands; 1 rolled per-pass loop everywhere, no lean epilogue; 2 prefetching loop everywhere);
  * key 5: phased GEMM kernels skip the MFMAs of waves whose rows are all beyond M (0 on, 1 off);
  * key 6: kx_clip_preprocess reads its taps from global memory instead of the LDS-staged row (0 auto, 1 force);
  * key 7: the 256-column GEMM kernel is launched persistently, each workgroup walking its own tiles (0 = one workgroup
