@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KX_ABI_VERSION 1
+#define KX_ABI_VERSION 2
 
 typedef enum {
   KX_OK = 0,
@@ -47,9 +47,21 @@ typedef enum {
  * travels as hi = bf16(v), lo = bf16(v - hi); an activation row is stored as [hi(K) | hi(K) | lo(K)] (dtype
  * KX_BF16X3, 3K bf16 per row) and the matching weight row as [hi | lo | hi], so an ordinary bf16 GEMM over 3K
  * accumulates a_hi*w_hi + a_hi*w_lo + a_lo*w_hi in fp32 — 16 mantissa bits per operand at 3x the bf16 MFMA work.
- * Attention and the residual stream stay fp32.  ~1e-4 parity with the fp32 reference (bf16: ~4e-2, fp32: ~1e-5). */
-typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2 } kx_precision;
-typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2 } kx_dtype;
+ * Attention and the residual stream stay fp32.  ~1e-4 parity with the fp32 reference (bf16: ~4e-2, fp32: ~1e-5).
+ *
+ * KX_PREC_F16C ("fp16, compensated"): the cheapest arithmetic that holds the north star's 1e-3 on the logits (measured
+ * 1.4e-4; tools/precision_study.py).  One fp16 product carries the values; the two first-order rounding corrections
+ * a_hi*dw + da*w_hi — each 2^-12 of the result, so 4 bits of them suffice — run on the block-scaled fp8 (e4m3) MFMA at
+ * twice the fp16 rate: 2x the bf16 MFMA time instead of bf16x3's 3x.  Operand rows (dtype KX_F16C), K values = 4K bytes:
+ *   activation row  [ h = fp16(a) (2K B) | e = fp8(a) (K B)                 | r = fp8((a - h) * 2^11) (K B) ]
+ *   weight row      [ h = fp16(w) (2K B) | r = fp8((w - h) * 2^(s+11)) (K B) | e = fp8(w * 2^s) (K B)        ]
+ * with one exponent s per weight ROW (|w| * 2^s <= 128), handed to the scaled MFMA as the E8M0 byte 127 - s; the
+ * activation-side scale is the constant 2^-11.  A packed weight matrix is N such rows followed by the N scale bytes
+ * (kx_gemm_args.w_scale).  fp8 conversions saturate at +-448; values must fit fp16 (|a| < 65504).  K % 128 == 0.
+ * Attention takes fp32 q/k/v and multiplies fp16 (hi, lo) pairs: three products per score / output, P split the same
+ * way.  The residual stream, statistics and accumulators stay fp32. */
+typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3 } kx_precision;
+typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3 } kx_dtype;
 typedef enum { KX_ACT_NONE = 0, KX_ACT_GELU = 1, KX_ACT_QUICK_GELU = 2 } kx_act;
 typedef enum { KX_ATTN_FULL = 0, KX_ATTN_CAUSAL = 1 } kx_attn_mask;
 
@@ -134,6 +146,9 @@ typedef struct {
    * folded-LN statistics straight from the producer's partials.  Only valid when the call will be split
    * (kx_gemm fails otherwise; the stage-level entry points check with the same rule before asking). */
   void* ln_out; int32_t ln_out_dt; const float* ln_out_gamma; const float* ln_out_beta; float ln_out_eps;
+  /* KX_PREC_F16C only: [N] E8M0 scale bytes of the weight rows (see kx_precision).  A, W are KX_F16C rows: lda/ldw (and
+   * ldc for a KX_F16C output) count 2-byte units (>= 2K, >= 2N), K is the number of values per row (K % 128 == 0). */
+  const uint8_t* w_scale;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 

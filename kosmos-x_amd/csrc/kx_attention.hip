@@ -19,7 +19,7 @@ namespace {
 struct AttnParams {
   const char* q; long long qbs, qrs;          // element strides
   const char* k; const char* v; long long kbs, krs;
-  void* out; long long obs, ors; int o_bf16, o_x3;
+  void* out; long long obs, ors; int o_bf16, o_x3, o_f16c;
   int B, H, Tq, Tk;
   float* stats_out;   // [B*Tq, H, 2] partial LayerNorm statistics of the output rows (folded inner_attn_ln), or null
   float* lse_out;     // [B, H, Tq] log-sum-exp of the scores (fp32 matrix-core kernel; for the backward pass), or null
@@ -403,6 +403,252 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
   }  // pass
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// KX_PREC_F16C attention: the v2 structure on SPLIT fp16 operands.  q, k, v arrive in fp32 (the qkv GEMM's fp32 output);
+// every operand value x travels as hi = fp16(x), lo = fp16(x - hi) (22 mantissa bits) and each product is three MFMAs
+// (hi*hi + hi*lo + lo*hi; the dropped lo*lo term is 2^-24): S^T = K Q^T and O^T = V^T P^T with P = exp(S - m) split the
+// same way.  Plain fp16 operands miss the 1e-3 logit bound on their own (1.7e-3, tools/precision_study.py); the exact-f32
+// matrix instruction the bf16x3 mode uses here runs at 1/16 of the fp16 rate.
+// The split happens once per tile when the K / V rows are written to LDS (hi and lo planes), for Q when it is loaded,
+// for P in registers.  All four operands are scaled by 2^8 before the split so that the lo parts of O(0.1) values stay
+// normal fp16 numbers: S' = 2^16 S (folded into the exp2 constant), O' and l' carry 2^16 / 2^8 (folded into 1/l).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_f16x8(const float (&x)[8], u32x4_t& hi, u32x4_t& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const kx_f16x2_t h = __builtin_convertvector((kx_f32x2_t){x[2 * j], x[2 * j + 1]}, kx_f16x2_t);
+    hi[j] = __builtin_bit_cast(unsigned, h);
+    lo[j] = pack_f16x2(x[2 * j] - (float)h[0], x[2 * j + 1] - (float)h[1]);
+  }
+}
+__device__ __forceinline__ f32x4_t mma_f16(u32x4_t a, u32x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned short Kh[2][64 * 64], Kl[2][64 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned short Vh[2][64 * VSTR], Vl[2][64 * VSTR];
+  constexpr float SC = 256.0f;                               // operand pre-scale (see above)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int nx = (p.Tq + 127) >> 7;
+  const int qb_second = nx - 1 - (int)blockIdx.x;            // causal: query-block pairs (x, nx-1-x), see v2
+  const int npass = (CAUSAL && qb_second > (int)blockIdx.x) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qblk0 = (pass == 0 ? (int)blockIdx.x : qb_second) * 128;
+  const int qw0 = qblk0 + wave * 32;
+  const bool wave_live = qw0 < p.Tq;
+  const float* qp = reinterpret_cast<const float*>(p.q) + (long long)b * p.qbs + (long long)h * 64;
+  const float* kp = reinterpret_cast<const float*>(p.k) + (long long)b * p.kbs + (long long)h * 64;
+  const float* vp = reinterpret_cast<const float*>(p.v) + (long long)b * p.kbs + (long long)h * 64;
+
+  u32x4_t qh[2][2], ql[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float* qr = qp + (long long)min(qw0 + qb * 16 + li, p.Tq - 1) * p.qrs + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float4 a = *reinterpret_cast<const float4*>(qr + 32 * ks), c = *reinterpret_cast<const float4*>(qr + 32 * ks + 4);
+      const float x[8] = {a.x * SC, a.y * SC, a.z * SC, a.w * SC, c.x * SC, c.y * SC, c.z * SC, c.w * SC};
+      split_f16x8(x, qh[qb][ks], ql[qb][ks]);
+    }
+  }
+  f32x4_t ot[2][4];
+  float m_run[2], l_run[2];     // m in units of the scaled scores S' = 2^16 S
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ot[qb][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  int ntiles = (p.Tk + 63) >> 6;
+  if (CAUSAL) ntiles = min(ntiles, (min(qblk0 + 127, p.Tq - 1) >> 6) + 1);
+
+  // cooperative tile loads: thread owns (row c>>3, 8-value part c&7) for c = tid, tid + 256: two float4 each of K and V
+  float4 kreg[2][2], vreg[2][2];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + 256 * j, row = c >> 3, part = c & 7;
+      const long long off = (long long)min(t * 64 + row, p.Tk - 1) * p.krs + part * 8;
+      kreg[j][0] = *reinterpret_cast<const float4*>(kp + off); kreg[j][1] = *reinterpret_cast<const float4*>(kp + off + 4);
+      vreg[j][0] = *reinterpret_cast<const float4*>(vp + off); vreg[j][1] = *reinterpret_cast<const float4*>(vp + off + 4);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + 256 * j, row = c >> 3, part = c & 7;
+      u32x4_t hi, lo;
+      const float kx[8] = {kreg[j][0].x * SC, kreg[j][0].y * SC, kreg[j][0].z * SC, kreg[j][0].w * SC,
+                           kreg[j][1].x * SC, kreg[j][1].y * SC, kreg[j][1].z * SC, kreg[j][1].w * SC};
+      split_f16x8(kx, hi, lo);
+      *reinterpret_cast<u32x4_t*>(&Kh[buf][row * 64 + ((part ^ (row & 7)) << 3)]) = hi;
+      *reinterpret_cast<u32x4_t*>(&Kl[buf][row * 64 + ((part ^ (row & 7)) << 3)]) = lo;
+      const float vx[8] = {vreg[j][0].x * SC, vreg[j][0].y * SC, vreg[j][0].z * SC, vreg[j][0].w * SC,
+                           vreg[j][1].x * SC, vreg[j][1].y * SC, vreg[j][1].z * SC, vreg[j][1].w * SC};
+      split_f16x8(vx, hi, lo);
+      *reinterpret_cast<u32x4_t*>(&Vh[buf][row * VSTR + part * 8]) = hi;
+      *reinterpret_cast<u32x4_t*>(&Vl[buf][row * VSTR + part * 8]) = lo;
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1, kv0 = t * 64;
+    if (t + 1 < ntiles) gload(t + 1);
+    const bool work = wave_live && (!CAUSAL || kv0 <= min(qw0 + 31, p.Tq - 1));
+    if (work) {
+      // ---- S'^T = K' Q'^T, three products per (key block, k-step, query block) ----
+      f32x4_t st[2][4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        st[0][kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        st[1][kb] = st[0][kb];
+        const int krow = kb * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int ko = krow * 64 + (((ks * 4 + g) ^ (krow & 7)) << 3);
+          const u32x4_t kh = *reinterpret_cast<const u32x4_t*>(&Kh[buf][ko]);
+          const u32x4_t kl = *reinterpret_cast<const u32x4_t*>(&Kl[buf][ko]);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) {
+            st[qb][kb] = mma_f16(kl, qh[qb][ks], st[qb][kb]);
+            st[qb][kb] = mma_f16(kh, ql[qb][ks], st[qb][kb]);
+            st[qb][kb] = mma_f16(kh, qh[qb][ks], st[qb][kb]);
+          }
+        }
+      }
+      const bool need_mask = (kv0 + 63 >= p.Tk) || (CAUSAL && kv0 + 63 > qw0);
+      u32x4_t ph[2][2], pl[2][2];
+      float mneg[2], alpha[2];
+      constexpr float L2S = 1.44269504088896340736f / (SC * SC);     // exp(S) = exp2(S' * log2e / 2^16)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        if (need_mask) {
+          const int qi = qw0 + qb * 16 + li;
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kv0 + kb * 16 + 4 * g + r;
+              const bool ok = key < p.Tk && (!CAUSAL || key <= qi);
+              st[qb][kb][r] = ok ? st[qb][kb][r] : -INFINITY;
+            }
+        }
+        const float a0 = max3_raw(st[qb][0][0], st[qb][0][1], st[qb][0][2]);
+        const float a1 = max3_raw(st[qb][1][0], st[qb][1][1], st[qb][1][2]);
+        const float a2 = max3_raw(st[qb][2][0], st[qb][2][1], st[qb][2][2]);
+        const float a3 = max3_raw(st[qb][3][0], st[qb][3][1], st[qb][3][2]);
+        const float b0 = max3_raw(a0, st[qb][0][3], st[qb][1][3]);
+        const float b1 = max3_raw(a1, st[qb][2][3], st[qb][3][3]);
+        const float c0 = max3_raw(b0, a2, a3);
+        const float m_new = quad_max(max3_raw(c0, b1, m_run[qb]), m_run[qb]);
+        // P' = 2^8 exp(S - m): the 2^8 rides in the exponent (+8)
+        mneg[qb] = fmaf(-m_new, L2S, 8.0f);
+        alpha[qb] = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * L2S);
+        m_run[qb] = m_new;
+      }
+      if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) ot[qb][d] *= alpha[qb];
+          l_run[qb] *= alpha[qb];
+        }
+      }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st[qb][kb][r] = __builtin_amdgcn_exp2f(fmaf(st[qb][kb][r], L2S, mneg[qb]));
+            ps += st[qb][kb][r];
+          }
+        l_run[qb] += ps;                           // this lane's 16 keys; the four lanes of a query meet at the end
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float x[8] = {st[qb][2 * c][0], st[qb][2 * c][1], st[qb][2 * c][2], st[qb][2 * c][3],
+                              st[qb][2 * c + 1][0], st[qb][2 * c + 1][1], st[qb][2 * c + 1][2], st[qb][2 * c + 1][3]};
+          split_f16x8(x, ph[qb][c], pl[qb][c]);
+        }
+      }
+      // ---- O'^T += V'^T P'^T : V fragments by transpose-read from the hi and lo planes (k map as in v2) ----
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int vo = (32 * c + 4 * g + (li >> 2)) * VSTR + d * 16 + (li & 3) * 4;
+          const u32x2_t h0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vh[buf][vo]));
+          const u32x2_t h1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vh[buf][vo + 16 * VSTR]));
+          const u32x2_t l0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vl[buf][vo]));
+          const u32x2_t l1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vl[buf][vo + 16 * VSTR]));
+          const u32x4_t vh = (u32x4_t){h0[0], h0[1], h1[0], h1[1]}, vl = (u32x4_t){l0[0], l0[1], l1[0], l1[1]};
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) {
+            ot[qb][d] = mma_f16(vl, ph[qb][c], ot[qb][d]);
+            ot[qb][d] = mma_f16(vh, pl[qb][c], ot[qb][d]);
+            ot[qb][d] = mma_f16(vh, ph[qb][c], ot[qb][d]);
+          }
+        }
+    }
+    if (t + 1 < ntiles) lstore(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l = l_run[qb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / (l * SC);               // O' = 2^16 sum(p v), l' = 2^8 sum(p)
+    const int qi = qw0 + qb * 16 + li;
+    if (p.lse_out && g == 0 && qi < p.Tq)
+      p.lse_out[((long long)b * p.H + h) * p.Tq + qi] = m_run[qb] * (1.0f / (SC * SC)) + logf(l * (1.0f / SC));
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { ot[qb][d][0] *= inv; ot[qb][d][1] *= inv; ot[qb][d][2] *= inv; ot[qb][d][3] *= inv; }
+    if (p.stats_out) {
+      float sm = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) sm += (ot[qb][d][0] + ot[qb][d][1]) + (ot[qb][d][2] + ot[qb][d][3]);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const float mu = sm * (1.0f / 64.0f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float dv = ot[qb][d][r] - mu; m2 += dv * dv; }
+      m2 += __shfl_xor(m2, 16, 64);
+      m2 += __shfl_xor(m2, 32, 64);
+      if (g == 0 && qi < p.Tq)
+        *reinterpret_cast<float2*>(p.stats_out + 2 * (((long long)b * p.Tq + qi) * p.H + h)) = make_float2(sm, m2);
+    }
+    if (qi < p.Tq) {
+      const long long col0 = (long long)h * 64 + 4 * g;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const float o4[4] = {ot[qb][d][0], ot[qb][d][1], ot[qb][d][2], ot[qb][d][3]};
+        if (p.o_f16c) {                           // KX_F16C row of D = H*64 values: strides count 2-byte units
+          f16c_store4(reinterpret_cast<char*>(p.out) + ((long long)b * p.obs + (long long)qi * p.ors) * 2, col0 + d * 16,
+                      (long long)p.H * 64, o4);
+        } else {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long long)b * p.obs + (long long)qi * p.ors + col0 +
+                                     d * 16) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        }
+      }
+    }
+  }
+  }  // pass
+}
+
 // fp32 parity path, first version (tuning key 2 = 1): one wave per query on the VALU, exact expf, scores in LDS.
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
@@ -620,8 +866,8 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   KX_REQUIRE(a->B > 0 && a->H > 0 && a->Tq > 0 && a->Tk > 0, "kx_attention: empty problem");
   KX_REQUIRE(a->H < 65536 && a->B < 65536, "kx_attention: B/H exceed the grid limits");
   KX_REQUIRE(a->mask != KX_ATTN_CAUSAL || a->Tq == a->Tk, "kx_attention: the causal mask needs Tq == Tk");
-  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32, "kx_attention: bad precision");
-  const int es = a->prec == KX_PREC_BF16 ? 2 : 4;
+  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32 || a->prec == KX_PREC_F16C, "kx_attention: bad precision");
+  const int es = a->prec == KX_PREC_BF16 ? 2 : 4;                 // KX_PREC_F16C takes fp32 q, k, v
   KX_REQUIRE((a->q_row_stride * es) % 16 == 0 && (a->kv_row_stride * es) % 16 == 0 &&
                  (a->q_batch_stride * es) % 16 == 0 && (a->kv_batch_stride * es) % 16 == 0,
              "kx_attention: strides must keep 16-byte alignment");
@@ -633,6 +879,10 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.k = (const char*)a->k; p.v = (const char*)a->v; p.kbs = a->kv_batch_stride; p.krs = a->kv_row_stride;
   p.out = a->out; p.obs = a->out_batch_stride; p.ors = a->out_row_stride; p.o_bf16 = a->odt == KX_BF16;
   p.o_x3 = a->odt == KX_BF16X3;
+  p.o_f16c = a->odt == KX_F16C;
+  KX_REQUIRE(!p.o_f16c || (a->prec == KX_PREC_F16C && a->out_row_stride >= 2 * a->H * 64),
+             "kx_attention: a KX_F16C output is produced by the KX_PREC_F16C kernel (row stride >= 2*H*64 2-byte units)");
+  KX_REQUIRE(a->prec != KX_PREC_F16C || a->odt == KX_F16C || a->odt == KX_F32, "kx_attention: KX_PREC_F16C writes KX_F16C or fp32");
   KX_REQUIRE(!p.o_x3 || (a->prec == KX_PREC_F32 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1 &&
                          a->out_row_stride >= 3 * a->H * 64),
              "kx_attention: a KX_BF16X3 output is produced by the fp32 matrix-core kernel only (row stride >= 3*H*64)");
@@ -644,8 +894,14 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   KX_REQUIRE(!a->stats_out || !(a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1),
              "kx_attention: stats_out is not implemented by the v1 A/B kernel");
   hipStream_t s = (hipStream_t)stream;
-  KxProfScope prof(a->prec == KX_PREC_BF16 ? KX_K_ATTN_BF16 : KX_K_ATTN_F32, a->B * a->H, a->Tq, a->Tk, s);
-  if (a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1) {   // v1, kept for A/B
+  KxProfScope prof(a->prec == KX_PREC_F32 ? KX_K_ATTN_F32 : KX_K_ATTN_BF16, a->B * a->H, a->Tq, a->Tk, s);
+  if (a->prec == KX_PREC_F16C) {
+    const unsigned nx = (unsigned)((a->Tq + 127) / 128);
+    if (a->mask == KX_ATTN_CAUSAL)
+      hipLaunchKernelGGL(attn_f16s_kernel<true>, dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL(attn_f16s_kernel<false>, dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+  } else if (a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1) {   // v1, kept for A/B
     dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, p);

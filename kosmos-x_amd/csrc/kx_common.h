@@ -12,6 +12,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+struct f16c_t { unsigned short bits; };   // tag type: KX_F16C operand rows (2-byte units; see kx_precision)
 
 // ---- host-side error plumbing (thread-local message, no exceptions across the ABI) ----
 void kx_set_error(const char* fmt, ...);
@@ -72,6 +75,43 @@ __device__ __forceinline__ void split_bf16x2(float a, float b, unsigned& hi, uns
   const bf16_t ah = f32_to_bf16(a), bh = f32_to_bf16(b);
   hi = (unsigned)ah | ((unsigned)bh << 16);
   lo = pack_bf16x2(a - bf16_to_f32(ah), b - bf16_to_f32(bh));
+}
+// ---- f16c operand format (KX_F16C, see kx_precision in the header): h = fp16(v), e = fp8(v), r = fp8((v - h) * 2^11) ----
+typedef _Float16 kx_f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((kx_f32x2_t){lo, hi}, kx_f16x2_t));
+}
+// v_cvt_pk_fp8_f32 rounds to nearest even but turns |x| > 448 into NaN (probed: tools/probes/f8_probe.hip) -> clamp first
+__device__ __forceinline__ float clamp_fp8(float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); }
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+  int v = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_fp8(a), clamp_fp8(b), 0, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_fp8(c), clamp_fp8(d), v, true);
+  return (unsigned)v;
+}
+// 4 values -> h (2 dwords of fp16), e, r (one dword of fp8 each)
+__device__ __forceinline__ void f16c_pack4(float a, float b, float c, float d, uint2& h, unsigned& e, unsigned& r) {
+  const kx_f16x2_t h0 = __builtin_convertvector((kx_f32x2_t){a, b}, kx_f16x2_t);
+  const kx_f16x2_t h1 = __builtin_convertvector((kx_f32x2_t){c, d}, kx_f16x2_t);
+  h.x = __builtin_bit_cast(unsigned, h0); h.y = __builtin_bit_cast(unsigned, h1);
+  e = pack_fp8x4(a, b, c, d);
+  r = pack_fp8x4((a - (float)h0[0]) * 2048.0f, (b - (float)h0[1]) * 2048.0f, (c - (float)h1[0]) * 2048.0f,
+                 (d - (float)h1[1]) * 2048.0f);
+}
+// Store 4 / 8 consecutive values of a KX_F16C row: `row` = row base (bytes), n = first column, N = values per row.
+__device__ __forceinline__ void f16c_store4(char* row, long long n, long long N, const float (&x)[4]) {
+  uint2 h; unsigned e, r;
+  f16c_pack4(x[0], x[1], x[2], x[3], h, e, r);
+  *reinterpret_cast<uint2*>(row + 2 * n) = h;
+  *reinterpret_cast<unsigned*>(row + 2 * N + n) = e;
+  *reinterpret_cast<unsigned*>(row + 3 * N + n) = r;
+}
+__device__ __forceinline__ void f16c_store8(char* row, long long n, long long N, const float (&x)[4], const float (&y)[4]) {
+  uint2 h0, h1; uint2 e, r;
+  f16c_pack4(x[0], x[1], x[2], x[3], h0, e.x, r.x);
+  f16c_pack4(y[0], y[1], y[2], y[3], h1, e.y, r.y);
+  *reinterpret_cast<uint4*>(row + 2 * n) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint2*>(row + 2 * N + n) = e;
+  *reinterpret_cast<uint2*>(row + 3 * N + n) = r;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }

@@ -102,14 +102,19 @@ struct Carver {
     return p;
   }
 };
-// GEMM-operand activations: bf16 (2 B), fp32 (4 B) or bf16x3 (3 x 2 B per value: [hi | hi | lo] rows, kx_precision doc)
+// GEMM-operand activations: bf16 (2 B), fp32 (4 B), bf16x3 (3 x 2 B per value: [hi | hi | lo] rows) or f16c (4 B per
+// value: [fp16 | fp8 | fp8 residual] rows) — kx_precision doc
 inline size_t esz(int prec) { return prec == KX_PREC_BF16 ? 2 : prec == KX_PREC_BF16X3 ? 6 : 4; }
-inline int cdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : prec == KX_PREC_BF16X3 ? KX_BF16X3 : KX_F32; }
-// q/k/v (attention inputs) and the attention arithmetic: bf16x3 keeps them in fp32 on the exact-f32 matrix instruction
+inline int cdt(int prec) {
+  return prec == KX_PREC_BF16 ? KX_BF16 : prec == KX_PREC_BF16X3 ? KX_BF16X3 : prec == KX_PREC_F16C ? KX_F16C : KX_F32;
+}
+// q/k/v (attention inputs) and the attention arithmetic: bf16x3 keeps them in fp32 on the exact-f32 matrix instruction,
+// f16c keeps them in fp32 and multiplies split fp16 (hi, lo) pairs (attn_f16s_kernel)
 inline size_t qes(int prec) { return prec == KX_PREC_BF16 ? 2 : 4; }
 inline int qdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : KX_F32; }
-inline int aprec(int prec) { return prec == KX_PREC_BF16 ? KX_PREC_BF16 : KX_PREC_F32; }
-inline int64_t kmul(int prec) { return prec == KX_PREC_BF16X3 ? 3 : 1; }
+inline int aprec(int prec) { return prec == KX_PREC_BF16 ? KX_PREC_BF16 : prec == KX_PREC_F16C ? KX_PREC_F16C : KX_PREC_F32; }
+// operand row length in 2-byte units per value (the unit lda / ldc / attention output strides count for these formats)
+inline int64_t kmul(int prec) { return prec == KX_PREC_BF16X3 ? 3 : prec == KX_PREC_F16C ? 2 : 1; }
 
 // what the row-owning split-K reduce can absorb (kx_gemm_args: stats_partials, ln_out)
 struct RowFusion {
@@ -126,12 +131,16 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   kx_gemm_args g;
   memset(&g, 0, sizeof(g));
   // bf16x3: the same bf16 kernels over the 3K-wide split operands ([hi|hi|lo] activations x [hi|lo|hi] weights)
+  // f16c: fp16 + fp8 correction segments, 4K bytes per row; a packed weight matrix is N rows followed by N scale bytes
   const int64_t km = kmul(prec);
-  g.A = A; g.lda = lda * km; g.W = W; g.ldw = K * km; g.C = C; g.ldc = cdtype == KX_BF16X3 ? 3 * ldc : ldc; g.cdt = cdtype;
-  g.bias = bias; g.residual = residual; g.ldr = ldc; g.M = M; g.N = N; g.K = K * km;
+  const bool f16c = prec == KX_PREC_F16C;
+  g.A = A; g.lda = lda * km; g.W = W; g.ldw = K * km; g.C = C;
+  g.ldc = cdtype == KX_BF16X3 ? 3 * ldc : cdtype == KX_F16C ? 2 * ldc : ldc; g.cdt = cdtype;
+  g.bias = bias; g.residual = residual; g.ldr = ldc; g.M = M; g.N = N; g.K = f16c ? K : K * km;
+  if (f16c) g.w_scale = (const uint8_t*)W + (size_t)N * (size_t)K * 4;
   g.act = act; g.qscale = qscale; g.qcols = qcols;
   g.xq_cs = xq_cs; g.xq_ss = xq_ss; g.xk_cs = xk_cs; g.xk_ss = xk_ss; g.xpos_T = xT; g.xpos_dim = xdim;
-  g.prec = km == 3 ? KX_PREC_BF16 : prec; g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
+  g.prec = km == 3 ? KX_PREC_BF16 : prec;   // bf16x3 runs the bf16 kernels over 3K g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
   g.row_stats = row_stats; g.colsum = colsum; g.stats_out = stats_out;
   g.splitk_ws = g_splitk_ws; g.splitk_ws_bytes = g_splitk_ws_bytes; g.splitk = 0;
   if (rf) {
@@ -145,6 +154,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
 // Same rule as kx_gemm itself; an explicit tile override (A/B runs) keeps the separate kernels.
 bool row_reduce_available(int64_t M, int64_t N, int64_t K, int prec) {
   if (kx_tuning_get(KX_TUNE_GEMM_TILE) != 0 || N > 8192 || N % 4 != 0) return false;
+  if (prec == KX_PREC_F16C) return kx_gemm_auto_splits(M, N, K, prec, g_splitk_ws_bytes) > 1;
   const int gp = prec == KX_PREC_BF16X3 ? KX_PREC_BF16 : prec;
   return kx_gemm_auto_splits(M, N, K * kmul(prec), gp, g_splitk_ws_bytes) > 1;
 }
@@ -251,6 +261,7 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
   KX_REQUIRE(w->dim == w->heads * 64, "kx_vit_forward: head_dim must be 64 (dim=%d heads=%d)", w->dim, w->heads);
   KX_REQUIRE(w->image % w->patch == 0 && w->kpad >= 3 * w->patch * w->patch && w->kpad % 64 == 0,
              "kx_vit_forward: bad patch geometry");
+  KX_REQUIRE(prec != KX_PREC_F16C || w->kpad % 128 == 0, "kx_vit_forward: KX_PREC_F16C needs kpad %% 128 == 0");
   KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_vit_forward: workspace must be 256-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const VitBufs v = vit_plan(w, B, prec, (char*)workspace);
@@ -359,7 +370,8 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
                                 void* vcache, int64_t Tmax) {
   KX_REQUIRE(w && x && logits && workspace, "kx_decoder_forward: null pointer");
   KX_REQUIRE(!kcache == !vcache, "kx_decoder_prefill: kcache and vcache must be given together");
-  KX_REQUIRE(!kcache || prec != KX_PREC_BF16X3, "kx_decoder_prefill: incremental decoding is offered in bf16 and fp32");
+  KX_REQUIRE(!kcache || (prec != KX_PREC_BF16X3 && prec != KX_PREC_F16C),
+             "kx_decoder_prefill: incremental decoding is offered in bf16 and fp32");
   KX_REQUIRE(!kcache || T <= Tmax, "kx_decoder_prefill: %lld tokens do not fit a %lld-row cache", (long long)T,
              (long long)Tmax);
   KX_REQUIRE(B > 0 && T > 0, "kx_decoder_forward: empty input");
@@ -472,7 +484,8 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
                                       void* vcache, int64_t Tmax, void* logits, int32_t ldt, void* workspace,
                                       size_t workspace_bytes, int32_t prec, void* stream) {
   KX_REQUIRE(w && x && logits && workspace && kcache && vcache, "kx_decoder_decode_step: null pointer");
-  KX_REQUIRE(prec != KX_PREC_BF16X3, "kx_decoder_decode_step: incremental decoding is offered in bf16 and fp32");
+  KX_REQUIRE(prec != KX_PREC_BF16X3 && prec != KX_PREC_F16C,
+             "kx_decoder_decode_step: incremental decoding is offered in bf16 and fp32");
   KX_REQUIRE(B > 0 && t >= 0 && t < Tmax, "kx_decoder_decode_step: position %lld outside the cache of %lld rows",
              (long long)t, (long long)Tmax);
   KX_REQUIRE(w->dim == w->heads * 64, "kx_decoder_decode_step: head_dim must be 64");

@@ -13,1416 +13,8 @@
 //    MFMA path and the exact-f32 MFMA path (fp32 parity mode).
 //  * blockIdx → tile map is XCD-aware (bijective remap so each XCD's L2 sees a contiguous run of
 //    tiles) and grouped 8 tile-rows deep so neighbouring blocks share operand panels.
-#include "kx_common.h"
-#include <type_traits>
+#include "kx_gemm_impl.h"
 
-namespace {
-
-struct GemmParams {
-  const char* A; const char* W;
-  long long lda_b, ldw_b;  // row pitch in BYTES
-  void* C; long long ldc; int c_bf16;
-  int c_x3;   // KX_BF16X3 output: [hi(N) | hi(N) | lo(N)] per row (c_bf16 is set too)
-  const float* bias; const float* residual; long long ldr;
-  int M, N, K;
-  int act; float qscale; int qcols;
-  const float *xq_cs, *xq_ss, *xk_cs, *xk_ss; int xpos_T, xpos_dim;
-  int tiles_m, tiles_n;
-  int vec_ok;  // ldc % 4 == 0 (&& ldr % 4 == 0): 16-byte epilogue accesses are aligned
-  int vec8_ok; // additionally ldc % 8 == 0: 8 bf16 outputs per lane can go out as one 16-byte store
-  // folded sub-LayerNorm (see kx_gemm_args): consume per-row (mean, rstd) + column sums, produce partial statistics
-  const float* row_stats; const float* colsum;
-  float* stats_out; int stats_nseg;
-  // split-K (skinny problems): blockIdx.y = K slice; raw fp32 partials go to `partial` [splitk][M][N], the fused
-  // epilogue runs in splitk_reduce_kernel, which sums the slices in a fixed order (deterministic)
-  int splitk; float* partial;
-  // 256x256 kernel: first-round workgroups of phase group g = (blockIdx >> 3) & 3 start g * stagger_ticks (10 ns
-  // wall-clock ticks) late, so the CUs' epilogues (HBM bursts) stop coinciding — see launch_p5
-  int stagger_ticks;
-  int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
-  int lean_epilogue;    // 256-column kernel: accumulator-level epilogue + pure data movement (see lean_store_*)
-  int persistent;       // 256x256 kernel: > 0 = launch this many workgroups, each walking its tiles itself
-  int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
-  // weight-streaming variant (gemv_fused_kernel) only
-  const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
-  const float* stats_partials; int stats_in_nseg; float stats_in_seg, stats_eps;
-  // row-owning split-K reduce: optional LayerNorm of the finished row as a second output
-  void* ln_out; int ln_out_dt; const float *ln_out_g, *ln_out_b; float ln_out_eps;
-};
-
-// Everything of the fused epilogue except the store: x[0..3] = columns n..n+3 of row m (in range: m < M, n < N).
-template <int ACT>
-__device__ __forceinline__ void epilogue_compute4(const GemmParams& p, int m, int n, f32x4_t acc, float (&x)[4]) {
-  x[0] = acc[0]; x[1] = acc[1]; x[2] = acc[2]; x[3] = acc[3];
-  const bool full = (n + 3 < p.N);
-  if (p.row_stats) {
-    // y = LN(a)·Wᵀ with the LayerNorm folded out of the operand:  rstd·(a·W'ᵀ − mean·Σ_k W'[n,k]),  W' = γ ⊙ W;
-    // the β·Wᵀ term arrives through `bias`.
-    const float2 ms = *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)m);
-    if (full) {
-      const float4 c = *reinterpret_cast<const float4*>(p.colsum + n);
-      x[0] = ms.y * (x[0] - ms.x * c.x); x[1] = ms.y * (x[1] - ms.x * c.y);
-      x[2] = ms.y * (x[2] - ms.x * c.z); x[3] = ms.y * (x[3] - ms.x * c.w);
-    } else {
-      for (int j = 0; j < 4; ++j) if (n + j < p.N) x[j] = ms.y * (x[j] - ms.x * p.colsum[n + j]);
-    }
-  }
-  if (p.bias) {
-    if (full) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-      x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
-    } else {
-      for (int j = 0; j < 4; ++j) if (n + j < p.N) x[j] += p.bias[n + j];
-    }
-  }
-  if (n < p.qcols) { x[0] *= p.qscale; x[1] *= p.qscale; x[2] *= p.qscale; x[3] *= p.qscale; }
-  if (p.xpos_dim && n < 2 * p.xpos_dim) {
-    // torchscale apply_rotary_pos_emb: y = x*dup(cos*scale) + rotate_every_two(x)*dup(sin*scale)
-    const bool isq = n < p.xpos_dim;
-    const float* cs = isq ? p.xq_cs : p.xk_cs;
-    const float* ss = isq ? p.xq_ss : p.xk_ss;
-    const int pos = m % p.xpos_T;
-    const int j = (n & 63) >> 1;
-    const float2 c = *reinterpret_cast<const float2*>(cs + pos * 32 + j);
-    const float2 s = *reinterpret_cast<const float2*>(ss + pos * 32 + j);
-    const float y0 = x[0] * c.x + (-x[1]) * s.x;
-    const float y1 = x[1] * c.x + x[0] * s.x;
-    const float y2 = x[2] * c.y + (-x[3]) * s.y;
-    const float y3 = x[3] * c.y + x[2] * s.y;
-    x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;
-  }
-  if constexpr (ACT != KX_ACT_NONE) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = apply_act<ACT>(x[j]);
-  }
-  if (p.stats_out) {
-    // (split-K reduce kernel only; the tile kernels take statistics at accumulator level, prepass_bias_act_stats)
-    // partial LayerNorm statistics of this row over the 64 columns held by the aligned 16-lane group (N % 64 == 0
-    // is enforced, rows are uniform per group): (sum, sum of squares about the segment mean) — combined exactly
-    // by kx_row_stats_finalize with Chan's formula, so no E[x²]−mean² cancellation.
-    float sm = (x[0] + x[1]) + (x[2] + x[3]);
-    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
-    const float mu = sm * (1.0f / 64.0f);
-    const float d0 = x[0] - mu, d1 = x[1] - mu, d2 = x[2] - mu, d3 = x[3] - mu;
-    float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64); m2 += __shfl_xor(m2, 8, 64);
-    if ((n & 63) == 0)
-      *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (n >> 6))) = make_float2(sm, m2);
-  }
-  if (p.residual) {
-    const long long roff = (long long)m * p.ldr + n;
-    if (full && p.vec_ok) {
-      const float4 r = *reinterpret_cast<const float4*>(p.residual + roff);
-      x[0] += r.x; x[1] += r.y; x[2] += r.z; x[3] += r.w;
-    } else {
-      for (int j = 0; j < 4; ++j) if (n + j < p.N) x[j] += p.residual[roff + j];
-    }
-  }
-}
-
-template <int ACT>
-__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32x4_t acc) {
-  if (m >= p.M || n >= p.N) return;
-  float x[4];
-  epilogue_compute4<ACT>(p, m, n, acc, x);
-  const bool full = (n + 3 < p.N);
-  const long long off = (long long)m * p.ldc + n;
-  if (p.c_x3) {                                   // N % 8 == 0 and aligned rows are enforced on the host
-    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
-    uint2 h, l;
-    split_bf16x2(x[0], x[1], h.x, l.x); split_bf16x2(x[2], x[3], h.y, l.y);
-    *reinterpret_cast<uint2*>(c) = h;
-    *reinterpret_cast<uint2*>(c + p.N) = h;
-    *reinterpret_cast<uint2*>(c + 2 * (long long)p.N) = l;
-  } else if (p.c_bf16) {
-    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
-    if (full && p.vec_ok) {
-      uint2 o; o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]);
-      *reinterpret_cast<uint2*>(c) = o;
-    } else {
-      for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = f32_to_bf16(x[j]);
-    }
-  } else {
-    float* c = reinterpret_cast<float*>(p.C) + off;
-    if (full && p.vec_ok) {
-      *reinterpret_cast<float4*>(c) = make_float4(x[0], x[1], x[2], x[3]);
-    } else {
-      for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = x[j];
-    }
-  }
-}
-
-// bf16 outputs: 8 columns per lane -> one 16-byte store.  With 4 columns per lane the 8-byte stores are issue-bound
-// (a bf16 store loop measured slower than the fp32 one that moves twice the bytes).  Needs vec_ok, N % 8 == 0 rows.
-template <int ACT>
-__device__ __forceinline__ void epilogue8_bf16(const GemmParams& p, int m, int n, f32x4_t lo, f32x4_t hi) {
-  if (m >= p.M || n >= p.N) return;
-  if (n + 7 < p.N) {
-    float x[4], y[4];
-    epilogue_compute4<ACT>(p, m, n, lo, x);
-    epilogue_compute4<ACT>(p, m, n + 4, hi, y);
-    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n;
-    if (p.c_x3) {
-      uint4 h, l;
-      split_bf16x2(x[0], x[1], h.x, l.x); split_bf16x2(x[2], x[3], h.y, l.y);
-      split_bf16x2(y[0], y[1], h.z, l.z); split_bf16x2(y[2], y[3], h.w, l.w);
-      *reinterpret_cast<uint4*>(c) = h;
-      *reinterpret_cast<uint4*>(c + p.N) = h;
-      *reinterpret_cast<uint4*>(c + 2 * (long long)p.N) = l;
-    } else {
-      uint4 o;
-      o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]);
-      o.z = pack_bf16x2(y[0], y[1]); o.w = pack_bf16x2(y[2], y[3]);
-      *reinterpret_cast<uint4*>(c) = o;
-    }
-  } else {
-    epilogue4<ACT>(p, m, n, lo);
-    epilogue4<ACT>(p, m, n + 4, hi);
-  }
-}
-
-// Fast path of the store loop (whole 16-byte column groups inside N, aligned rows): the epilogue's global READS —
-// residual, folded-LN row statistics, XPos table entries — are issued for U passes up front, and everything that
-// depends only on the column (bias, column sums, q-scale / XPos selectors) is loaded once.  The rolled loop it
-// replaces issued those loads inside each pass and waited for them pass by pass: ~1 us of latency x 32 passes made
-// the in-place fp32 residual epilogue of a 256x256 tile cost as much as its whole K = 2048 main loop
-// (measured: 47 us of a 94 us tile).  Same operation order as epilogue_compute4, so results are bit-identical.
-template <int ACT, int WN, int CPL, int CHUNK_F32 = 64>
-__device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float* cw, int rows, int lane, int mbase,
-                                                int nwave) {
-  constexpr int CH = WN / 4;
-  constexpr int LPR = WN / CPL, RPI = 64 / LPR, NV = CPL / 4;
-  // rows whose epilogue operands (residual, statistics, XPos entries) are requested together.  fp32 outputs: 64 — one
-  // exposed load latency per 64-row half instead of two where the registers allow (the 256-column kernel still holds
-  // half of its accumulators while the first half is stored: it spilled at 64 and passes 32);
-  constexpr int CHUNK = CPL == 4 ? CHUNK_F32 : 32;
-  constexpr int U = CHUNK / RPI;                      // passes per chunk (16 for fp32, 4 for bf16 outputs)
-  const int cl = lane % LPR, rl = lane / LPR;
-  const int n = nwave + cl * CPL;
-  const bool has_rs = p.row_stats != nullptr, has_res = p.residual != nullptr;
-  float4 bias[NV], csum[NV];
-  bool qs[NV], xp[NV];
-  const float *cs[NV], *ss[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int nv = n + 4 * v;
-    bias[v] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nv) : make_float4(0.f, 0.f, 0.f, 0.f);
-    csum[v] = has_rs ? *reinterpret_cast<const float4*>(p.colsum + nv) : make_float4(0.f, 0.f, 0.f, 0.f);
-    qs[v] = nv < p.qcols;
-    xp[v] = p.xpos_dim && nv < 2 * p.xpos_dim;
-    const int j = (nv & 63) >> 1;
-    cs[v] = (nv < p.xpos_dim ? p.xq_cs : p.xk_cs) + j;
-    ss[v] = (nv < p.xpos_dim ? p.xq_ss : p.xk_ss) + j;
-  }
-  for (int r0 = 0; r0 < rows; r0 += CHUNK) {
-    float4 res[U][NV];
-    float2 rs[U], xc[U][NV], xs[U][NV];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int m = min(mbase + r0 + u * RPI + rl, p.M - 1);       // clamped for the loads; the store is predicated
-      if (has_rs) rs[u] = *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)m);
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        if (has_res) res[u][v] = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n + 4 * v);
-        if (xp[v]) {
-          const int pos = m % p.xpos_T;
-          xc[u][v] = *reinterpret_cast<const float2*>(cs[v] + pos * 32);
-          xs[u][v] = *reinterpret_cast<const float2*>(ss[v] + pos * 32);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ml = r0 + u * RPI + rl, m = (r0 + u * RPI < rows) ? mbase + ml : p.M;   // past `rows`: no store
-      float x[NV][4];
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const f32x4_t a =
-            *reinterpret_cast<const f32x4_t*>(cw + ml * WN + (((NV * cl + v) ^ (ml & (CH - 1))) << 2));
-        float* y = x[v];
-        y[0] = a[0]; y[1] = a[1]; y[2] = a[2]; y[3] = a[3];
-        if (has_rs) {
-          y[0] = rs[u].y * (y[0] - rs[u].x * csum[v].x); y[1] = rs[u].y * (y[1] - rs[u].x * csum[v].y);
-          y[2] = rs[u].y * (y[2] - rs[u].x * csum[v].z); y[3] = rs[u].y * (y[3] - rs[u].x * csum[v].w);
-        }
-        if (p.bias) { y[0] += bias[v].x; y[1] += bias[v].y; y[2] += bias[v].z; y[3] += bias[v].w; }
-        if (qs[v]) { y[0] *= p.qscale; y[1] *= p.qscale; y[2] *= p.qscale; y[3] *= p.qscale; }
-        if (xp[v]) {
-          const float2 c = xc[u][v], sn = xs[u][v];
-          const float y0 = y[0] * c.x + (-y[1]) * sn.x;
-          const float y1 = y[1] * c.x + y[0] * sn.x;
-          const float y2 = y[2] * c.y + (-y[3]) * sn.y;
-          const float y3 = y[3] * c.y + y[2] * sn.y;
-          y[0] = y0; y[1] = y1; y[2] = y2; y[3] = y3;
-        }
-        if constexpr (ACT != KX_ACT_NONE) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) y[j] = apply_act<ACT>(y[j]);
-        }
-        if (has_res) { y[0] += res[u][v].x; y[1] += res[u][v].y; y[2] += res[u][v].z; y[3] += res[u][v].w; }
-      }
-      if (m < p.M) {
-        if constexpr (CPL == 8) {
-          bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n;
-          if (p.c_x3) {
-            uint4 h, l;
-            split_bf16x2(x[0][0], x[0][1], h.x, l.x); split_bf16x2(x[0][2], x[0][3], h.y, l.y);
-            split_bf16x2(x[1][0], x[1][1], h.z, l.z); split_bf16x2(x[1][2], x[1][3], h.w, l.w);
-            *reinterpret_cast<uint4*>(c) = h;
-            *reinterpret_cast<uint4*>(c + p.N) = h;
-            *reinterpret_cast<uint4*>(c + 2 * (long long)p.N) = l;
-          } else {
-            uint4 o;
-            o.x = pack_bf16x2(x[0][0], x[0][1]); o.y = pack_bf16x2(x[0][2], x[0][3]);
-            o.z = pack_bf16x2(x[1][0], x[1][1]); o.w = pack_bf16x2(x[1][2], x[1][3]);
-            *reinterpret_cast<uint4*>(c) = o;
-          }
-        } else {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long long)m * p.ldc + n) =
-              make_float4(x[0][0], x[0][1], x[0][2], x[0][3]);
-        }
-      }
-    }
-  }
-}
-
-// The store loop every tile kernel runs over its LDS-parked fp32 sub-tile (`rows` x WN, 16-B chunks XOR-swizzled by
-// row): row-major walk, fused epilogue, coalesced row segments.
-template <int ACT, int WN, int CHUNK_F32 = 64>
-__device__ __forceinline__ void store_loop(const GemmParams& p, const float* cw, int rows, int lane, int mbase,
-                                           int nwave) {
-  constexpr int CH = WN / 4;
-  if (p.vec_ok && nwave + WN <= p.N && !p.stats_out && p.fast_epilogue) {
-    if (!p.c_bf16) { store_loop_fast<ACT, WN, 4, CHUNK_F32>(p, cw, rows, lane, mbase, nwave); return; }
-    if (p.vec8_ok) { store_loop_fast<ACT, WN, 8>(p, cw, rows, lane, mbase, nwave); return; }
-  }
-  if (p.c_bf16 && p.vec8_ok) {
-    constexpr int L8 = WN / 8, RPI8 = 64 / L8;          // lanes per row, rows per wave-wide pass
-    const int cl = lane % L8, rl = lane / L8;
-#pragma unroll 2
-    for (int r = 0; r < rows; r += RPI8) {
-      const int ml = r + rl;
-      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + (((2 * cl) ^ (ml & (CH - 1))) << 2));
-      const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + (((2 * cl + 1) ^ (ml & (CH - 1))) << 2));
-      epilogue8_bf16<ACT>(p, mbase + ml, nwave + cl * 8, lo, hi);
-    }
-  } else {
-    constexpr int RPI = 64 / CH;
-    const int cl = lane % CH, rl = lane / CH;
-#pragma unroll 2
-    for (int r = 0; r < rows; r += RPI) {
-      const int ml = r + rl;
-      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
-      epilogue4<ACT>(p, mbase + ml, nwave + cl * 4, v);
-    }
-  }
-}
-
-// Producer side of the folded sub-LayerNorm, at ACCUMULATOR level (before the LDS staging): bias + activation are
-// applied in place and the row statistics of the wave's 64 columns are reduced where they are cheapest — a lane of
-// the 16x16 accumulator layout already holds 16 of a row's 64 values (4 fragments x 4 columns), the other 48 sit
-// in the lanes +16/+32/+48.  2 shuffles per value instead of 6 per float4 in the store loop (measured: −12 us of a
-// 149 us fc1 launch).  The store loop then runs without bias/activation.
-template <int ACT, int FM, int FN>
-__device__ __forceinline__ void prepass_bias_act_stats(const GemmParams& p, f32x4_t (&acc)[FN][FM], int mrow0,
-                                                       int ncol0, int g, int li) {
-  static_assert(FN % 4 == 0, "a wave must own whole 64-column statistics segments");
-#pragma unroll
-  for (int sg = 0; sg < FN / 4; ++sg) {
-    const int nseg0 = ncol0 + sg * 64;
-    if (nseg0 >= p.N) return;                     // whole segment outside (N % 64 == 0)
-    float4 bias[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-      bias[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nseg0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      float sm = 0.f;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        f32x4_t v = acc[sg * 4 + a][b];
-        v[0] = apply_act<ACT>(v[0] + bias[a].x); v[1] = apply_act<ACT>(v[1] + bias[a].y);
-        v[2] = apply_act<ACT>(v[2] + bias[a].z); v[3] = apply_act<ACT>(v[3] + bias[a].w);
-        acc[sg * 4 + a][b] = v;
-        sm += (v[0] + v[1]) + (v[2] + v[3]);
-      }
-      sm += __shfl_xor(sm, 16, 64);
-      sm += __shfl_xor(sm, 32, 64);
-      const float mu = sm * (1.0f / 64.0f);
-      float m2 = 0.f;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const f32x4_t v = acc[sg * 4 + a][b];
-        const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
-        m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      }
-      m2 += __shfl_xor(m2, 16, 64);
-      m2 += __shfl_xor(m2, 32, 64);
-      const int m = mrow0 + b * 16 + li;
-      if (g == 0 && m < p.M)
-        *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (nseg0 >> 6))) = make_float2(sm, m2);
-    }
-  }
-}
-
-// one k-step (4 chunks of 16 B across the 4 lane groups) of MFMA work for a 16x16 fragment pair
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static __device__ __forceinline__ f32x4_t step(u32x4_t w, u32x4_t a, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, a),
-                                                   c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  // lane group g holds k = 4g..4g+3 of a 16-wide k-step; element s feeds MFMA s (same k map on both
-  // operands, so the sum over k is complete and exact f32).
-  static __device__ __forceinline__ f32x4_t step(u32x4_t w, u32x4_t a, f32x4_t c) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[s]), __uint_as_float(a[s]), c, 0, 0, 0);
-    return c;
-  }
-};
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void gbl_void_t;
-
-// ---- lean bf16 epilogue of the tile kernels (tile fully inside N, 16-byte aligned rows) -------------------------
-// The generic store loops re-derive addresses, bounds and option flags for every 8 values (~100 instructions per pass,
-// two LDS halves, four barriers): 27k cycles per 256x256 tile for a plain bf16 store against a 100k-cycle K loop, while
-// a bare store kernel retires the same 128 wave-wide stores in 4.3k (tools/probes/store_probe.hip).  This path does
-// the arithmetic ONCE at accumulator level (lane (g,li) of fragment (a,b): row b*16+li, columns a*16+4g..+3), parks the
-// whole tile as bf16 (BM x 512 B, 16-byte chunks XOR-swizzled by row&7), and after ONE barrier every wave instruction
-// stores two full 512-byte rows: 6.5k cycles.  Outputs with a residual / folded-LN consume (fp32) and the q-scale + XPos
-// epilogue keep the generic loops: an accumulator-level fp32 path measured the same 71k cycles (it waits on the
-// residual loads either way) and the XPos variant still spilled.
-template <int ACT, int FM, int FN>
-__device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc)[FN][FM], int ncol0, int g) {
-  // Straight-line on purpose: a run-time branch whose two sides both rewrite the 128 accumulator registers made the
-  // compiler keep two copies of them (spills) — which is also why the variants are separate kernel instantiations.
-  // q-scale: a wave's 64 columns lie on one side of the boundary (qcols % 64 == 0, checked by kx_gemm) -> one scalar
-  const float qsc = ncol0 < p.qcols ? p.qscale : 1.0f;
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + ncol0 + a * 16 + 4 * g);
-#pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      f32x4_t v = acc[a][b];
-      v[0] = (v[0] + bias.x) * qsc; v[1] = (v[1] + bias.y) * qsc; v[2] = (v[2] + bias.z) * qsc; v[3] = (v[3] + bias.w) * qsc;
-      if constexpr (ACT != KX_ACT_NONE) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = apply_act<ACT>(v[q]);
-      }
-      acc[a][b] = v;
-    }
-  }
-}
-
-template <int BM, int BN, int NW, int FM, int FN>   // tile BM x BN, NW waves, wave sub-tile at (row_w0, col_w0)
-__device__ __forceinline__ void lean_store_bf16(const GemmParams& p, const f32x4_t (&acc)[FN][FM], char* smem, int m0,
-                                                int n0, int row_w0, int col_w0, int wave, int lane, int g, int li) {
-  constexpr int RB = BN * 2, CPR = BN / 8;        // bytes and 16-byte chunks per tile row
-  constexpr int RPI = 64 / CPR, RPP = NW * RPI;   // rows per wave instruction / per pass of the workgroup
-  static_assert(BM % RPP == 0 && CPR >= 8 && 64 % CPR == 0, "tile rows must split into whole store passes");
-  __syncthreads();                               // the K loop's last fragment reads are done
-#pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    const int rt = row_w0 + b * 16 + li;
-#pragma unroll
-    for (int a = 0; a < FN; ++a) {
-      const int chunk = ((col_w0 >> 3) + a * 2 + (g >> 1)) ^ (rt & 7);
-      uint2 v;
-      v.x = pack_bf16x2(acc[a][b][0], acc[a][b][1]);
-      v.y = pack_bf16x2(acc[a][b][2], acc[a][b][3]);
-      *reinterpret_cast<uint2*>(smem + rt * RB + chunk * 16 + (g & 1) * 8) = v;
-    }
-  }
-  __syncthreads();
-  const int cl = lane % CPR, rl = lane / CPR;
-  bf16_t* cbase = reinterpret_cast<bf16_t*>(p.C) + n0 + cl * 8;
-#pragma unroll
-  for (int ps = 0; ps < BM / RPP; ++ps) {
-    const int rt = ps * RPP + wave * RPI + rl;
-    const uint4 v = *reinterpret_cast<const uint4*>(smem + rt * RB + ((cl ^ (rt & 7)) << 4));
-    if (m0 + rt < p.M) *reinterpret_cast<uint4*>(cbase + (long long)(m0 + rt) * p.ldc) = v;
-  }
-}
-
-template <typename T, int BM, int BN, int ACT, int EPI = 0>   // EPI 1: lean bf16 epilogue (see above)
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
-  constexpr int ROWB = 128;                 // bytes per staged tile row = one BK slice
-  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
-  constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave (2x2 waves)
-  constexpr int IA = BM / 32, IW = BN / 32;  // glds instructions per wave per stage (8 rows each)
-  constexpr int EPI_BYTES = BM * BN * 4;     // the epilogue parks the whole fp32 tile in LDS
-  constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
-  static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU must fit the 160 KB LDS");
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
-
-  // ---- XCD-aware, grouped tile mapping ----
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GROUP = 8;
-  const int per_group = GROUP * p.tiles_n;
-  const int grp = wg / per_group;
-  const int first_m = grp * GROUP;
-  const int gsz = min(p.tiles_m - first_m, GROUP);
-  const int tm = first_m + (wg % per_group) % gsz;
-  const int tn = (wg % per_group) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
-  const int g = lane >> 4, li = lane & 15;
-
-  // ---- staging source pointers: lane covers row (lane>>3), 16-B chunk (lane&7) of 8 rows ----
-  const int srow = lane >> 3, schunk = lane & 7;
-  const char* srcA[IA];
-  const char* srcW[IW];
-#pragma unroll
-  for (int j = 0; j < IA; ++j) {
-    const int row = wave * (BM / 4) + j * 8 + srow;            // tile row
-    const int gm = min(m0 + row, p.M - 1);                      // clamp: out-of-range rows duplicate the last
-    srcA[j] = p.A + (long long)gm * p.lda_b + ((schunk ^ (row & 7)) << 4);
-  }
-#pragma unroll
-  for (int j = 0; j < IW; ++j) {
-    const int row = wave * (BN / 4) + j * 8 + srow;
-    const int gn = min(n0 + row, p.N - 1);
-    srcW[j] = p.W + (long long)gn * p.ldw_b + ((schunk ^ (row & 7)) << 4);
-  }
-
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * STAGE;
-    const long long koff = (long long)kt * ROWB;
-#pragma unroll
-    for (int j = 0; j < IA; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff),
-                                       (lds_void_t*)(base + (wave * (BM / 4) + j * 8) * ROWB), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < IW; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcW[j] + koff),
-                                       (lds_void_t*)(base + A_BYTES + (wave * (BN / 4) + j * 8) * ROWB), 16, 0, 0);
-  };
-
-  f32x4_t acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets (bytes) inside a stage, k-step 0; k-step 1 flips chunk bit 2 (cg ^= 4)
-  int offA[FM], offW[FN];
-#pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    const int row = wm * (BM / 2) + b * 16 + li;
-    offA[b] = row * ROWB + ((g ^ (row & 7)) << 4);
-  }
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    const int row = wn * (BN / 2) + a * 16 + li;
-    offW[a] = A_BYTES + row * ROWB + ((g ^ (row & 7)) << 4);
-  }
-
-  const int nk_all = p.K / (ROWB / (int)sizeof(T));
-  const int kchunk = (nk_all + p.splitk - 1) / p.splitk;
-  const int kt0 = (int)blockIdx.y * kchunk;
-  const int nk = min(nk_all, kt0 + kchunk);   // this block multiplies K-tiles [kt0, nk)
-  if (kt0 < nk) stage(kt0 & 1, kt0);
-  for (int kt = kt0; kt < nk; ++kt) {
-    // stage kt has landed (this wave's DMA) and every wave is done reading the other buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* base = smem + (kt & 1) * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      u32x4_t fa[FM], fw[FN];
-#pragma unroll
-      for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ (ks << 6)));
-#pragma unroll
-      for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ (ks << 6)));
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
-    }
-  }
-
-  // ---- epilogue, staged through LDS ----
-  // The accumulator layout (lane = 1 row x 4 columns per fragment) would store 64-byte row segments and
-  // unroll the fused epilogue 16x (a >60 KB instruction stream executed cold once per tile).  Instead each
-  // wave parks its (BM/2)x(BN/2) fp32 sub-tile in its own slice of the (now idle) staging LDS — 16-B chunks
-  // XOR-swizzled by row so both the fragment-shaped writes and the row-shaped reads are conflict-free — and
-  // walks it back row-major: 16 lanes emit one full 256-B row segment per instruction and the epilogue body
-  // exists once, inside a rolled loop.
-  constexpr int WM = BM / 2, WN = BN / 2;
-  if constexpr (EPI == 1) {           // bias + activation on the accumulators, the tile parked once as bf16, full-row stores
-    lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g);
-    lean_store_bf16<BM, BN, 4, FM, FN>(p, acc, smem, m0, n0, wm * WM, wn * WN, wave, lane, g, li);
-    return;
-  }
-  constexpr int CH = WN / 4;          // 16-byte chunks per sub-tile row (16 or 8)
-  constexpr int RPI = 64 / CH;        // rows covered by one wave-wide access
-  const bool pre = p.stats_out != nullptr && p.splitk == 1;   // folded sub-LN producer: see prepass_bias_act_stats
-  if constexpr (FN == 4) {
-    if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, g, li);
-  }
-  GemmParams q = p;                   // what is left for the store loop after the pre-pass
-  q.bias = nullptr; q.stats_out = nullptr;
-  __syncthreads();                    // every wave is done reading the last stage
-  float* cw = reinterpret_cast<float*>(smem) + wave * (WM * WN);
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      const int ml = b * 16 + li, c = a * 4 + g;
-      *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][b];
-    }
-  __syncthreads();
-  if (p.splitk > 1) {                 // split-K: raw fp32 partials, the reduce kernel owns the epilogue
-    const int cl = lane % CH, rl = lane / CH;
-    const int mbase = m0 + wm * WM, nbase = n0 + wn * WN + cl * 4;
-    for (int r = 0; r < WM; r += RPI) {
-      const int ml = r + rl, m = mbase + ml;
-      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
-      if (m < p.M && nbase < p.N) {
-        float* dst = p.partial + ((long long)blockIdx.y * p.M + m) * p.N + nbase;
-        if (nbase + 3 < p.N && (p.N & 3) == 0) *reinterpret_cast<f32x4_t*>(dst) = v;
-        else for (int j = 0; j < 4; ++j) if (nbase + j < p.N) dst[j] = v[j];
-      }
-    }
-  } else if (pre) {
-    store_loop<KX_ACT_NONE, WN>(q, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);
-  } else {
-    store_loop<ACT, WN>(p, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);
-  }
-}
-
-// Sums the K-slice partials of a split-K launch in slice order and runs the fused epilogue.  Thread = one row x 4
-// columns; consecutive threads walk a row, so the 16-lane groups of the LayerNorm-statistics epilogue hold 64
-// consecutive columns of one row (N % 64 == 0 in that mode).
-template <int ACT>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
-  const int n4 = (p.N + 3) >> 2;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)p.M * n4) return;
-  const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
-  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const bool vec = (n + 3 < p.N) && (p.N & 3) == 0;
-  for (int z = 0; z < p.splitk; ++z) {
-    const float* src = p.partial + ((long long)z * p.M + m) * p.N + n;
-    if (vec) acc += *reinterpret_cast<const f32x4_t*>(src);
-    else for (int j = 0; j < 4; ++j) if (n + j < p.N) acc[j] += src[j];
-  }
-  GemmParams q = p;
-  q.splitk = 1;
-  epilogue4<ACT>(q, m, n, acc);
-}
-
-// Row-owning variant of the reduce kernel: one workgroup per output row (N <= 8192: 8 float4 per thread).  Besides the
-// slice sum + fused epilogue it can (a) derive the consumer-side folded-LN statistics of its row from the producer's
-// partials (no kx_row_stats_finalize launch) and (b) apply the LayerNorm that FOLLOWS this GEMM to the finished row and
-// write it as a second output (no kx_layernorm launch).  At batch 1 the forward is a chain of ~420 dependent launches of
-// ~12 us each; these two fusions remove ~100 of them.
-template <int ACT>
-__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParams p) {
-  __shared__ float red[4];
-  __shared__ float st[2];
-  const int m = blockIdx.x, tid = threadIdx.x;
-  auto bsum = [&](float v) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-  };
-  GemmParams q = p;
-  q.splitk = 1;
-  if (p.stats_partials) {
-    const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
-    float sm = 0.f;
-    for (int j = tid; j < p.stats_in_nseg; j += 256) sm += pr[j].x;
-    const float mean = bsum(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
-    float m2 = 0.f;
-    for (int j = tid; j < p.stats_in_nseg; j += 256) {
-      const float2 v = pr[j];
-      const float d = v.x / p.stats_in_seg - mean;
-      m2 += v.y + p.stats_in_seg * d * d;
-    }
-    const float var = bsum(m2) / (p.stats_in_seg * (float)p.stats_in_nseg);
-    if (tid == 0) { st[0] = mean; st[1] = rsqrtf(var + p.stats_eps); }
-    __syncthreads();
-    q.row_stats = nullptr;                             // the fold is applied below with (mean, rstd) from LDS
-  }
-  float x[8][4];
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = 4 * (tid + 256 * j);
-    x[j][0] = x[j][1] = x[j][2] = x[j][3] = 0.f;
-    if (n < p.N) {
-      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      for (int z = 0; z < p.splitk; ++z)
-        acc += *reinterpret_cast<const f32x4_t*>(p.partial + ((long long)z * p.M + m) * p.N + n);
-      if (p.stats_partials) {                          // rstd * (acc - mean * colsum): first step of the epilogue
-        const float4 c = *reinterpret_cast<const float4*>(p.colsum + n);
-        const float mu = st[0], rs = st[1];
-        acc[0] = rs * (acc[0] - mu * c.x); acc[1] = rs * (acc[1] - mu * c.y);
-        acc[2] = rs * (acc[2] - mu * c.z); acc[3] = rs * (acc[3] - mu * c.w);
-      }
-      epilogue_compute4<ACT>(q, m, n, acc, x[j]);
-      const long long off = (long long)m * p.ldc + n;
-      if (p.c_x3) {
-        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
-        uint2 hh, ll;
-        split_bf16x2(x[j][0], x[j][1], hh.x, ll.x); split_bf16x2(x[j][2], x[j][3], hh.y, ll.y);
-        *reinterpret_cast<uint2*>(c) = hh; *reinterpret_cast<uint2*>(c + p.N) = hh; *reinterpret_cast<uint2*>(c + 2ll * p.N) = ll;
-      } else if (p.c_bf16) {
-        uint2 o; o.x = pack_bf16x2(x[j][0], x[j][1]); o.y = pack_bf16x2(x[j][2], x[j][3]);
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
-      } else {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off) = make_float4(x[j][0], x[j][1], x[j][2], x[j][3]);
-      }
-      s += (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
-    }
-  }
-  if (!p.ln_out) return;
-  const float mean = bsum(s) / (float)p.N;
-  float qv = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (4 * (tid + 256 * j) < p.N) {
-      const float a = x[j][0] - mean, b = x[j][1] - mean, c = x[j][2] - mean, d = x[j][3] - mean;
-      qv += (a * a + b * b) + (c * c + d * d);
-    }
-  }
-  const float rstd = rsqrtf(bsum(qv) / (float)p.N + p.ln_out_eps);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = 4 * (tid + 256 * j);
-    if (n >= p.N) continue;
-    const float4 gm = *reinterpret_cast<const float4*>(p.ln_out_g + n), bt = *reinterpret_cast<const float4*>(p.ln_out_b + n);
-    const float o0 = (x[j][0] - mean) * rstd * gm.x + bt.x, o1 = (x[j][1] - mean) * rstd * gm.y + bt.y;
-    const float o2 = (x[j][2] - mean) * rstd * gm.z + bt.z, o3 = (x[j][3] - mean) * rstd * gm.w + bt.w;
-    if (p.ln_out_dt == KX_BF16X3) {
-      bf16_t* c = reinterpret_cast<bf16_t*>(p.ln_out) + (long long)m * 3 * p.N + n;
-      uint2 hh, ll;
-      split_bf16x2(o0, o1, hh.x, ll.x); split_bf16x2(o2, o3, hh.y, ll.y);
-      *reinterpret_cast<uint2*>(c) = hh; *reinterpret_cast<uint2*>(c + p.N) = hh; *reinterpret_cast<uint2*>(c + 2ll * p.N) = ll;
-    } else if (p.ln_out_dt == KX_BF16) {
-      uint2 o; o.x = pack_bf16x2(o0, o1); o.y = pack_bf16x2(o2, o3);
-      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.ln_out) + (long long)m * p.N + n) = o;
-    } else {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.ln_out) + (long long)m * p.N + n) = make_float4(o0, o1, o2, o3);
-    }
-  }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Deep-pipelined variant: 256(m) x 128(n) x 64 block tile, 8 waves (4 x 2, 64x64 each), 3-stage LDS ring
-// (3 x 48 KB = 144 of the CU's 160 KB), ONE raw s_barrier per K-tile and a COUNTED s_waitcnt vmcnt(6):
-// the six LDS-DMA instructions a wave issues for tile t+2 stay in flight across the barrier while tile t is
-// multiplied, so HBM/L2 latency is hidden behind a full tile of MFMA work instead of being drained at every
-// barrier (guide T3+T4).  The larger tile also halves the L2->LDS bytes per flop relative to 128x128
-// (85 vs 64 flop/B): the 128x128 kernel saturates the ~34 TB/s aggregate L2 near 1.0-1.1 PFLOP/s.
-// One workgroup per CU (2 waves per SIMD).
-// -------------------------------------------------------------------------------------------------
-template <typename T, int ACT, bool PHASED>
-__global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
-  constexpr int BM = 256, BN = 128, ROWB = 128;
-  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;   // 48 KB
-  constexpr int NST = 3;
-  constexpr int FM = 4, FN = 4;              // 64x64 per wave
-  constexpr int IA = 4, IW = 2;              // glds instructions per wave per stage (8 rows each)
-  constexpr int NLD = IA + IW;               // = the vmcnt distance of one tile
-  static_assert(NLD == 6, "the inline-asm vmcnt immediates below assume 6 loads per tile");
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
-
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GROUP = 4;
-  const int per_group = GROUP * p.tiles_n;
-  const int grp = wg / per_group;
-  const int first_m = grp * GROUP;
-  const int gsz = min(p.tiles_m - first_m, GROUP);
-  const int tm = first_m + (wg % per_group) % gsz;
-  const int tn = (wg % per_group) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
-  const int g = lane >> 4, li = lane & 15;
-
-  const int srow = lane >> 3, schunk = lane & 7;
-  const char* srcA[IA];
-  const char* srcW[IW];
-#pragma unroll
-  for (int j = 0; j < IA; ++j) {
-    const int row = wave * 32 + j * 8 + srow;
-    const int gm = min(m0 + row, p.M - 1);
-    srcA[j] = p.A + (long long)gm * p.lda_b + ((schunk ^ (row & 7)) << 4);
-  }
-#pragma unroll
-  for (int j = 0; j < IW; ++j) {
-    const int row = wave * 16 + j * 8 + srow;
-    const int gn = min(n0 + row, p.N - 1);
-    srcW[j] = p.W + (long long)gn * p.ldw_b + ((schunk ^ (row & 7)) << 4);
-  }
-  auto stage = [&](int slot, int kt) {
-    char* base = smem + slot * STAGE;
-    const long long koff = (long long)kt * ROWB;
-#pragma unroll
-    for (int j = 0; j < IA; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff), (lds_void_t*)(base + (wave * 32 + j * 8) * ROWB),
-                                       16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < IW; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcW[j] + koff),
-                                       (lds_void_t*)(base + A_BYTES + (wave * 16 + j * 8) * ROWB), 16, 0, 0);
-  };
-
-  f32x4_t acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  int offA[FM], offW[FN];
-#pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    const int row = wm * 64 + b * 16 + li;
-    offA[b] = row * ROWB + ((g ^ (row & 7)) << 4);
-  }
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    const int row = wn * 64 + a * 16 + li;
-    offW[a] = A_BYTES + row * ROWB + ((g ^ (row & 7)) << 4);
-  }
-
-  const int nk = p.K / (ROWB / (int)sizeof(T));
-  stage(0, 0);
-  if (nk > 1) {
-    stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile 0 landed, tile 1 may still fly
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  int slot = 0;
-  if constexpr (!PHASED) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = kt + 2 < nk;
-      if (more) stage(slot == 0 ? 2 : slot - 1, kt + 2);   // (kt+2)%3: the slot tile kt-1 just vacated
-      const char* base = smem + slot * STAGE;
-  #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        u32x4_t fa[FM], fw[FN];
-  #pragma unroll
-        for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ (ks << 6)));
-  #pragma unroll
-        for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ (ks << 6)));
-  #pragma unroll
-        for (int a = 0; a < FN; ++a)
-  #pragma unroll
-          for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
-      }
-      // tile kt+1 must be resident (all waves' pieces) before anyone reads it; tile kt+2 keeps flying
-      if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      slot = slot == 2 ? 0 : slot + 1;
-    }
-
-  } else {
-    // Phased schedule (the guide's 8-phase idea, 4 phases per K-tile): each K-tile is split into
-    //   R0: [issue tile t+2's DMA] + ds_read the ks=0 fragments | M0: 16 MFMA | R1: ds_read ks=1 (+ the counted
-    //   vmcnt for tile t+1) | M1: 16 MFMA,   every phase closed by a raw s_barrier.
-    // Waves 4-7 (the second wave on each SIMD) run ONE PHASE BEHIND waves 0-3 (one extra barrier up front, one
-    // extra for waves 0-3 at the end), so on every SIMD one wave is in an MFMA phase while its partner is in a
-    // read phase: the matrix pipe never waits for LDS or for the barrier, and s_setprio has a role split to
-    // arbitrate.  Hazards: a slot is refilled (R0 of tile t+2... its previous tenant t-1) only after every wave's
-    // R1(t-1) reads retired before a barrier both groups have passed; tile t+1 is read only after every wave's
-    // vmcnt(6) in R1(t), which for the lagging group precedes the barrier the leading group passes into R0(t+1).
-    const bool lag = wave >= 4;
-    // a wave whose 64 rows all lie beyond M (M = 3648 = 14.25 x 256: three of the last tile's four wave rows) only
-    // stages and keeps the barrier cadence — under the board's power cap wasted MFMAs cost clock, not just slots
-    const bool work = !p.skip_idle_waves || m0 + wm * 64 < p.M;
-    if (lag) __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = kt + 2 < nk;
-      const char* base = smem + slot * STAGE;
-      u32x4_t fa[FM], fw[FN];
-      // ---- R0 ----
-      if (more) stage(slot == 0 ? 2 : slot - 1, kt + 2);
-      if (work) {
-#pragma unroll
-      for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + offA[b]);
-#pragma unroll
-      for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + offW[a]);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- M0 ----
-      if (work) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
-      __builtin_amdgcn_s_setprio(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- R1 ----
-      if (work) {
-#pragma unroll
-      for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ 64));
-#pragma unroll
-      for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ 64));
-      }
-      if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- M1 ----
-      if (work) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
-      __builtin_amdgcn_s_setprio(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      slot = slot == 2 ? 0 : slot + 1;
-    }
-    if (!lag) __builtin_amdgcn_s_barrier();
-  }
-
-  // ---- epilogue staged through LDS (see gemm_kernel) ----
-  constexpr int WM = 64, WN = 64, CH = WN / 4;
-  const bool pre = p.stats_out != nullptr;
-  if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, g, li);
-  GemmParams q = p;
-  q.bias = nullptr; q.stats_out = nullptr;
-  float* cw = reinterpret_cast<float*>(smem) + wave * (WM * WN);
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      const int ml = b * 16 + li, c = a * 4 + g;
-      *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][b];
-    }
-  __syncthreads();
-  if (pre) store_loop<KX_ACT_NONE, WN>(q, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);
-  else store_loop<ACT, WN>(p, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);
-}
-
-template <typename T, bool PHASED>
-int launch_p3(GemmParams& p, hipStream_t s) {
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 127) / 128;
-  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
-  switch (p.act) {
-    case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel_p3<T, KX_ACT_NONE, PHASED>), grid, block, 0, s, p); break;
-    case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel_p3<T, KX_ACT_GELU, PHASED>), grid, block, 0, s, p); break;
-    case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel_p3<T, KX_ACT_GELU_FAST, PHASED>), grid, block, 0, s, p); break;
-    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel_p3<T, KX_ACT_QUICK_GELU, PHASED>), grid, block, 0, s, p); break;
-    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
-  }
-  KX_CHECK_LAUNCH("kx_gemm(p3)");
-  return KX_OK;
-}
-
-// -------------------------------------------------------------------------------------------------
-// 256 x 256 x 64 phased variant for the large problems (C3: M = 65,472): 8 waves (2 x 4), each owning a
-// 128(m) x 64(n) sub-tile = 8 x 4 fragments.  Why: at 64x64 per wave every MFMA needs 0.5 ds_read_b128 (1 KB) plus
-// its share of the LDS-DMA fill (256 B) = 768 B of LDS traffic per MFMA, i.e. 192 of the CU's 256 B/clk at full
-// MFMA rate — the 128x128 and 256x128 kernels are LDS-bandwidth bound near 1.0-1.1 PFLOP/s.  A 128x64 wave tile
-// needs 12 reads per 32 MFMAs (0.375 KB) and the 256x256 block halves the fill per flop (128 B): 512 B/MFMA.
-// Two LDS stages of 64 KB (128 of 160 KB), one workgroup per CU; the fill of tile t+1 is issued when tile t's
-// first phase starts and waited for (vmcnt(0)) in its third phase, so it has two MFMA phases to land.
-// Same 4-phase / lagging-half schedule as gemm_kernel_p3<PHASED>.
-// (A v_mfma_f32_32x32x16_bf16 version of this kernel — same LDS traffic, half the MFMA instructions — measured
-// 1.16 vs 1.36 PFLOP/s at 8192^3 and was dropped.  So was a 4-wave version with 128x128 per wave, accumulators
-// pinned to all 256 AGPRs and a hand-interleaved read/DMA/MFMA stream (384 instead of 512 B of LDS traffic per
-// MFMA): 1.34 vs 1.37 PFLOP/s.  Sustained, this kernel holds the board at its 1400 W cap at ~2.04 GHz
-// (profiles/r01_h_power_*.log): the limit left is power, not LDS or issue slots.)
-// -------------------------------------------------------------------------------------------------
-// Timeline instrumentation of the 256x256 kernel (built only with -DKX_TIMELINE into a side library for
-// tools/gemm_timeline.py; the shipped library compiles these to nothing).
-#ifdef KX_TIMELINE
-__device__ unsigned long long kx_tl[8];
-#define KX_TL_STAMP(i) unsigned long long kx_t##i = __builtin_readcyclecounter()
-#define KX_TL_COMMIT()                                                                  \
-  if (threadIdx.x == 0) {                                                               \
-    atomicAdd(&kx_tl[0], kx_t1 - kx_t0); atomicAdd(&kx_tl[1], kx_t2 - kx_t1);           \
-    atomicAdd(&kx_tl[2], kx_t3 - kx_t2); atomicAdd(&kx_tl[3], kx_t4 - kx_t3);           \
-    atomicAdd(&kx_tl[4], kx_t5 - kx_t4); atomicAdd(&kx_tl[5], 1ull);                    \
-  }
-#else
-#define KX_TL_STAMP(i)
-#define KX_TL_COMMIT()
-#endif
-
-// EPI: 0 generic store loops, 1 lean bf16 tile store, 4 the same with produced row statistics — separate kernels (one
-// epilogue each:
-// with all three behind run-time branches the register allocator spilled accumulators inside the K loop)
-template <typename T, int ACT, int BM, int EPI>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
-__global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
-  constexpr int BN = 256, ROWB = 128;
-  static_assert(BM % 64 == 0, "BM must split into 2 wave rows of whole 16-row fragments and 8 staging waves");
-  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;   // 64 KB
-  constexpr int FM = BM / 32, FN = 4;        // (BM/2)(m) x 64(n) per wave
-  constexpr int IA = BM / 64, IW = 4;        // glds instructions per wave per stage (8 rows each)
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-  const int nwg = p.tiles_m * p.tiles_n;
-  // persistent launch (grid = one workgroup per CU, p.persistent): the workgroup walks tiles bid, bid + grid, ... itself
-  // instead of being retired and re-dispatched per tile — same tile->CU order, no dispatch/retire gap between tiles
-  for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
-  KX_TL_STAMP(0);
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GROUP = 4;
-  const int per_group = GROUP * p.tiles_n;
-  const int grp = wg / per_group;
-  const int first_m = grp * GROUP;
-  const int gsz = min(p.tiles_m - first_m, GROUP);
-  const int tm = first_m + (wg % per_group) % gsz;
-  const int tn = (wg % per_group) / gsz;
-  if (p.stagger_ticks > 0 && bid < 256) {
-    const int ph = p.stagger_ticks >= 100000 ? (bid & 7) : ((bid >> 3) & 3);   // >= 100000: per-XCD phases, ticks - 100000
-    if (ph) {
-      const unsigned long long t0 = wall_clock64(), d = (unsigned long long)ph * (p.stagger_ticks % 100000);
-      while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(32);
-    }
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
-  const int g = lane >> 4, li = lane & 15;
-
-  const int srow = lane >> 3, schunk = lane & 7;
-  const char* srcA[IA];
-  const char* srcW[IW];
-#pragma unroll
-  for (int j = 0; j < IA; ++j) {
-    const int row = wave * (BM / 8) + j * 8 + srow;
-    const int gm = min(m0 + row, p.M - 1);
-    srcA[j] = p.A + (long long)gm * p.lda_b + ((schunk ^ (row & 7)) << 4);
-  }
-#pragma unroll
-  for (int j = 0; j < IW; ++j) {
-    const int row = wave * 32 + j * 8 + srow;
-    const int gn = min(n0 + row, p.N - 1);
-    srcW[j] = p.W + (long long)gn * p.ldw_b + ((schunk ^ (row & 7)) << 4);
-  }
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * STAGE;
-    const long long koff = (long long)kt * ROWB;
-#pragma unroll
-    for (int j = 0; j < IA; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff),
-                                       (lds_void_t*)(base + (wave * (BM / 8) + j * 8) * ROWB), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < IW; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcW[j] + koff),
-                                       (lds_void_t*)(base + A_BYTES + (wave * 32 + j * 8) * ROWB), 16, 0, 0);
-  };
-
-  f32x4_t acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  int offA[FM], offW[FN];
-#pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    const int row = wm * (BM / 2) + b * 16 + li;
-    offA[b] = row * ROWB + ((g ^ (row & 7)) << 4);
-  }
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    const int row = wn * 64 + a * 16 + li;
-    offW[a] = A_BYTES + row * ROWB + ((g ^ (row & 7)) << 4);
-  }
-
-  const int nk = p.K / (ROWB / (int)sizeof(T));
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  KX_TL_STAMP(1);
-  const bool lag = wave >= 4;
-  const bool work = !p.skip_idle_waves || m0 + wm * (BM / 2) < p.M;   // see gemm_kernel_p3
-  if (lag) __builtin_amdgcn_s_barrier();
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* base = smem + (kt & 1) * STAGE;
-    u32x4_t fa[FM], fw[FN];
-    // ---- R0 ----
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    if (work) {
-#pragma unroll
-    for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + offW[a]);
-#pragma unroll
-    for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + offA[b]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- M0 ----
-    if (work) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-      for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
-    __builtin_amdgcn_s_setprio(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- R1 ----
-    if (work) {
-#pragma unroll
-    for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ 64));
-#pragma unroll
-    for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ 64));
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed (this wave's pieces)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- M1 ----
-    if (work) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-      for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::step(fw[a], fa[b], acc[a][b]);
-    __builtin_amdgcn_s_setprio(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (!lag) __builtin_amdgcn_s_barrier();
-  KX_TL_STAMP(2);
-
-  // ---- epilogue staged through LDS in two 64-row halves (8 waves x 64x64 fp32 = 128 KB) ----
-  constexpr int WN = 64, CH = WN / 4;
-  const bool pre = p.stats_out != nullptr;
-  if constexpr (EPI == 1 || EPI == 4) {            // bias / activation (/ statistics) on the accumulators, bf16 tile store
-    if constexpr (EPI == 4) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
-    else lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g);
-    KX_TL_STAMP(3);
-    lean_store_bf16<BM, 256, 8, FM, FN>(p, acc, smem, m0, n0, wm * (BM / 2), wn * WN, wave, lane, g, li);
-    KX_TL_STAMP(4);
-    KX_TL_STAMP(5);
-    KX_TL_COMMIT();
-  } else {
-  if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
-  KX_TL_STAMP(3);
-  GemmParams q = p;
-  q.bias = nullptr; q.stats_out = nullptr;
-  constexpr int HR = BM / 4;                 // rows per epilogue half per wave
-  float* cw = reinterpret_cast<float*>(smem) + wave * (HR * WN);
-  auto park_and_store = [&](auto half_c) {
-    constexpr int half = decltype(half_c)::value;
-    __syncthreads();   // previous half's rows have been read back / the K loop is over
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-      for (int b = 0; b < FM / 2; ++b) {
-        const int ml = b * 16 + li, c = a * 4 + g;
-        *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][half * (FM / 2) + b];
-      }
-    __syncthreads();
-    if (pre) store_loop<KX_ACT_NONE, WN, 32>(q, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
-    else store_loop<ACT, WN, 32>(p, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
-  };
-  park_and_store(std::integral_constant<int, 0>{});
-  KX_TL_STAMP(4);
-  park_and_store(std::integral_constant<int, 1>{});
-  KX_TL_STAMP(5);
-  KX_TL_COMMIT();
-  }  // generic epilogue
-  if (bid + (int)gridDim.x < nwg) __syncthreads();   // the parked rows have been read back before the next tile's fill
-  }  // tiles of this workgroup
-}
-
-template <typename T, int BM, int EPI>
-int launch_p5e(GemmParams& p, hipStream_t s) {
-  const int nwg = p.tiles_m * p.tiles_n;
-  const dim3 grid(p.persistent > 0 ? (nwg < p.persistent ? nwg : p.persistent) : nwg), block(512);
-  // the lean variants are instantiated for the activations the forward uses them with; anything else takes EPI 0
-  if (p.act == KX_ACT_NONE && EPI != 4) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, EPI>), grid, block, 0, s, p);
-  else if (p.act == KX_ACT_GELU_FAST && (EPI == 0 || EPI == 1 || EPI == 4))
-    hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, (EPI == 1 || EPI == 4) ? EPI : 0>), grid, block, 0, s, p);
-  else if (p.act == KX_ACT_QUICK_GELU && (EPI == 0 || EPI == 1))
-    hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_QUICK_GELU, BM, EPI == 1 ? 1 : 0>), grid, block, 0, s, p);
-  else if (EPI != 0) return launch_p5e<T, BM, 0>(p, s);
-  else if (p.act == KX_ACT_NONE) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, 0>), grid, block, 0, s, p);
-  else if (p.act == KX_ACT_GELU) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU, BM, 0>), grid, block, 0, s, p);
-  else { kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG; }
-  KX_CHECK_LAUNCH("kx_gemm(p5)");
-  return KX_OK;
-}
-
-template <typename T, int BM>
-int launch_p5(GemmParams& p, hipStream_t s) {
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + 255) / 256;
-  if (p.lean_epilogue && p.N % 256 == 0) return p.stats_out ? launch_p5e<T, BM, 4>(p, s) : launch_p5e<T, BM, 1>(p, s);
-  return launch_p5e<T, BM, 0>(p, s);
-}
-
-// CUs of the current device (one process drives one GPU; cached after the first call)
-int kx_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
-  return cus;
-}
-
-int launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
-  if (p.ln_out || (p.stats_partials && p.splitk > 1 && !p.ln_g)) {          // row-owning reduce with its fusions
-    const dim3 rg((unsigned)p.M), rb(256);
-    switch (p.act) {
-      case KX_ACT_NONE: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_NONE>, rg, rb, 0, s, p); break;
-      case KX_ACT_GELU: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_GELU>, rg, rb, 0, s, p); break;
-      case KX_ACT_GELU_FAST: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_GELU_FAST>, rg, rb, 0, s, p); break;
-      case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_QUICK_GELU>, rg, rb, 0, s, p); break;
-      default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
-    }
-    KX_CHECK_LAUNCH("kx_gemm(split-K row reduce)");
-    return KX_OK;
-  }
-  const long long work = (long long)p.M * ((p.N + 3) / 4);
-  const dim3 rgrid((unsigned)((work + 255) / 256)), block(256);
-  switch (p.act) {
-    case KX_ACT_NONE: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_NONE>, rgrid, block, 0, s, p); break;
-    case KX_ACT_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_GELU>, rgrid, block, 0, s, p); break;
-    case KX_ACT_GELU_FAST: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_GELU_FAST>, rgrid, block, 0, s, p); break;
-    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<KX_ACT_QUICK_GELU>, rgrid, block, 0, s, p); break;
-    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
-  }
-  KX_CHECK_LAUNCH("kx_gemm(split-K reduce)");
-  return KX_OK;
-}
-
-// -------------------------------------------------------------------------------------------------
-// Weight-streaming kernel for M <= 16 rows (incremental decoding: one token per sequence), ONE launch per GEMM.
-// A decode step is a read-once stream of each W (8-131 MB) against a few KB of activations, and what it costs on
-// this machine is dependent kernel launches (~6 us each: a split-K GEMM + its reduce kernel took 12-16 us whatever
-// the bytes), so this kernel does the whole GEMM and absorbs its neighbours:
-//   * a workgroup owns 16 output columns; its S waves (8 or 16) split K, each streaming its slice of the 16 weight rows
-//     straight from global memory into MFMA A-fragments (lane (g,i): 16 B of row i at k-chunk g, 8 k-steps = 8 KB
-//     per wave in flight; N/16 x S waves per launch keep 8-30 MB in flight).  Nothing of W touches LDS;
-//   * the S partial accumulators meet in LDS and are summed in wave order (deterministic) by wave 0, which runs the
-//     usual fused epilogue (folded-LN consume, bias, q-scale, XPos, activation, residual, fp32/bf16 store) and, as the
-//     producer of a folded sub-LN, emits per-16-column statistics;
-//   * optional LayerNorm prologue (ln_g): the raw fp32 rows are normalised into LDS as bf16 with kx_layernorm's
-//     arithmetic (same lane/column walk, same rounding) — the decode step's separate LayerNorm launches disappear;
-//   * optional statistics prologue (stats_partials): (mean, rstd) of each row from the producer's partials, the
-//     kx_row_stats_finalize arithmetic — those launches disappear too.
-// -------------------------------------------------------------------------------------------------
-template <int ACT>
-__global__ __launch_bounds__(1024) void gemv_fused_kernel(const GemmParams p, int S, int kw, int x_pitch) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, i = lane & 15;
-  float* red = reinterpret_cast<float*>(lds);                    // [S][64] float4
-  float* st = reinterpret_cast<float*>(lds + S * 1024);          // [16][2] (mean, rstd)
-  char* xn = lds + S * 1024 + 128;                               // [M][x_pitch] bf16 (LayerNorm prologue)
-  // The weight stream does not depend on the prologues: put this wave's first 8 KB in flight before them (the
-  // LayerNorm / statistics prologues are three dependent L2 round trips; serialised in front of the loads they
-  // cost more than the stream itself: 17 -> ~9 us per launch at batch 1).
-  constexpr int U = 8;
-  const int n0 = blockIdx.x * 16;
-  const int k0 = wave * kw, klen = min(kw, p.K - k0);           // may be <= 0 for trailing waves of a short K
-  const int nrow = min(n0 + i, p.N - 1);                         // columns past N re-read the last row; never stored
-  const char* wp = p.W + (long long)nrow * p.ldw_b + ((long long)(k0 + 8 * g) << 1);
-  u32x4_t wf[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-    if (32 * u < klen) wf[u] = *reinterpret_cast<const u32x4_t*>(wp + ((32 * u) << 1));
-  if (p.stats_partials) {
-    for (int m = wave; m < p.M; m += S) {
-      const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
-      float sm = 0.f;
-      for (int j = lane; j < p.stats_in_nseg; j += 64) sm += pr[j].x;
-      const float mean = wave_sum(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
-      float m2 = 0.f;
-      for (int j = lane; j < p.stats_in_nseg; j += 64) {
-        const float2 v = pr[j];
-        const float d = v.x / p.stats_in_seg - mean;
-        m2 += v.y + p.stats_in_seg * d * d;
-      }
-      const float var = wave_sum(m2) / (p.stats_in_seg * (float)p.stats_in_nseg);
-      if (lane == 0) { st[2 * m] = mean; st[2 * m + 1] = rsqrtf(var + p.stats_eps); }
-    }
-  }
-  if (p.ln_g) {
-    const int nv = p.K >> 2;                                     // float4 per row
-    // (a register-resident row — one load round trip instead of three — was slower: with 16 waves per workgroup
-    // the 32 extra VGPRs spill)
-    for (int m = wave; m < p.M; m += S) {
-      const float4* xr = reinterpret_cast<const float4*>(p.A + (long long)m * p.lda_b);
-      float sm = 0.f;
-      for (int c = lane; c < nv; c += 64) { const float4 v = xr[c]; sm += (v.x + v.y) + (v.z + v.w); }
-      const float mean = wave_sum(sm) / (float)p.K;
-      float q = 0.f;
-      for (int c = lane; c < nv; c += 64) {
-        const float4 v = xr[c];
-        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-        q += (a * a + b * b) + (cc * cc + d * d);
-      }
-      const float rstd = rsqrtf(wave_sum(q) / (float)p.K + p.ln_eps);
-      for (int c = lane; c < nv; c += 64) {
-        const float4 v = xr[c];
-        const float4 gm = reinterpret_cast<const float4*>(p.ln_g)[c];
-        const float4 bt = reinterpret_cast<const float4*>(p.ln_b)[c];
-        uint2 o;
-        o.x = pack_bf16x2((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y);
-        o.y = pack_bf16x2((v.z - mean) * rstd * gm.z + bt.z, (v.w - mean) * rstd * gm.w + bt.w);
-        *reinterpret_cast<uint2*>(xn + m * x_pitch + c * 8) = o;
-      }
-    }
-  }
-  if (p.ln_g || p.stats_partials) __syncthreads();
-
-  const int xrow = min(i, p.M - 1);                              // fragment columns m >= M: any finite-or-not data,
-  const char* xg = p.ln_g ? xn + xrow * x_pitch + ((k0 + 8 * g) << 1)   //   they only reach outputs that are dropped
-                          : p.A + (long long)xrow * p.lda_b + ((long long)(k0 + 8 * g) << 1);
-  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  for (int kk = 0; kk < klen; kk += 32 * U) {
-    u32x4_t xf[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (kk + 32 * u < klen) {
-        if (kk > 0) wf[u] = *reinterpret_cast<const u32x4_t*>(wp + ((kk + 32 * u) << 1));   // first batch: in flight
-        xf[u] = *reinterpret_cast<const u32x4_t*>(xg + ((kk + 32 * u) << 1));
-      }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (kk + 32 * u < klen) acc = Mma<bf16_t>::step(wf[u], xf[u], acc);
-  }
-  *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
-  __syncthreads();
-  if (wave != 0) return;
-  for (int w = 1; w < S; ++w) acc += *reinterpret_cast<const f32x4_t*>(red + (w * 64 + lane) * 4);
-
-  const int m = i, n = n0 + 4 * g;                               // lane: row m, columns n..n+3
-  const bool live = m < p.M && n < p.N;
-  GemmParams q = p;
-  q.stats_out = nullptr;
-  if (p.stats_partials) q.row_stats = st;                        // LDS through a generic pointer
-  float x[4] = {0.f, 0.f, 0.f, 0.f};
-  if (live) epilogue_compute4<ACT>(q, m, n, acc, x);
-  if (p.stats_out) {
-    // producer of a folded sub-LN: (sum, M2 about the segment mean) of this row's 16 columns — the four lanes
-    // i, i+16, i+32, i+48 hold them (N % 16 == 0, no residual in this mode: enforced on the host)
-    float sm = (x[0] + x[1]) + (x[2] + x[3]);
-    sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
-    const float mu = sm * (1.0f / 16.0f);
-    const float d0 = x[0] - mu, d1 = x[1] - mu, d2 = x[2] - mu, d3 = x[3] - mu;
-    float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    m2 += __shfl_xor(m2, 16, 64); m2 += __shfl_xor(m2, 32, 64);
-    if (live && g == 0)
-      *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (n0 >> 4))) = make_float2(sm, m2);
-  }
-  if (!live) return;
-  const bool full = n + 3 < p.N && p.vec_ok;
-  const long long off = (long long)m * p.ldc + n;
-  if (p.c_bf16) {
-    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
-    if (full) { uint2 o; o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); *reinterpret_cast<uint2*>(c) = o; }
-    else for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = f32_to_bf16(x[j]);
-  } else {
-    float* c = reinterpret_cast<float*>(p.C) + off;
-    if (full) *reinterpret_cast<float4*>(c) = make_float4(x[0], x[1], x[2], x[3]);
-    else for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = x[j];
-  }
-}
-
-int launch_gemv_fused(GemmParams& p, hipStream_t s) {
-  const int S = p.K <= 4096 ? 8 : 16;
-  const int kw = ((p.K + S - 1) / S + 31) / 32 * 32;
-  const int x_pitch = p.ln_g ? p.K * 2 + 16 : 0;
-  const size_t lds = (size_t)S * 1024 + 128 + (size_t)(p.ln_g ? p.M : 0) * x_pitch;
-  const dim3 grid((unsigned)((p.N + 15) / 16)), block(64 * S);
-  static bool attr_set = false;
-  if (!attr_set) {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_QUICK_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  switch (p.act) {
-    case KX_ACT_NONE: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_NONE>, grid, block, lds, s, p, S, kw, x_pitch); break;
-    case KX_ACT_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;
-    case KX_ACT_GELU_FAST: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU_FAST>, grid, block, lds, s, p, S, kw, x_pitch); break;
-    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_QUICK_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;
-    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
-  }
-  KX_CHECK_LAUNCH("kx_gemm(weight streaming)");
-  return KX_OK;
-}
-
-template <typename T, int BM, int BN>
-int launch(GemmParams& p, hipStream_t s) {
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  const dim3 grid(p.tiles_m * p.tiles_n, p.splitk), block(256);
-  if (p.splitk > 1) {
-    // skinny problem: the tile kernels only produce partials (activation-free), the reduce kernel owns the epilogue
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p);
-    KX_CHECK_LAUNCH("kx_gemm(split-K)");
-    return launch_splitk_reduce(p, s);
-  }
-  if constexpr (BM == 160 && sizeof(T) == 2) {     // the ViT's bf16-output GEMMs (qkv, fc1): lean epilogue
-    if (p.lean_epilogue && !p.stats_out && p.N % BN == 0) {
-      if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
-      if (p.act == KX_ACT_QUICK_GELU) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
-      if (p.act == KX_ACT_GELU_FAST) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU_FAST, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
-    }
-  }
-  // the activation is a compile-time property of the kernel: a runtime switch costs ~4 scalar branches per value
-  switch (p.act) {
-    case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p); break;
-    case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU>), grid, block, 0, s, p); break;
-    case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU_FAST>), grid, block, 0, s, p); break;
-    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU>), grid, block, 0, s, p); break;
-    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
-  }
-  KX_CHECK_LAUNCH("kx_gemm");
-  return KX_OK;
-}
-
-}  // namespace
 
 // K slices for a 64x64-tile launch: ~512 workgroups streaming the weights, at most 16 slices, at least two K-tiles per
 // slice, partials [slices, M, N] fp32 within the scratch.  `forced` > 0 overrides the count (tests).
@@ -1443,6 +35,7 @@ static long long splitk_slices(int64_t M, int64_t N, int64_t K, int bk, size_t w
 int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_bytes) {
   auto cdiv = [](long long x, long long y) { return (x + y - 1) / y; };
   if (!ws_bytes || cdiv(M, 128) * cdiv(N, 128) >= 192) return 1;       // the automatic tile choice is not 64x64
+  if (prec == KX_PREC_F16C) return (int)splitk_slices(M, N, 2 * K, 64, ws_bytes, 0);   // 4K-byte rows = 2K 2-byte units
   return (int)splitk_slices(M, N, K, prec == KX_PREC_BF16 ? 64 : 32, ws_bytes, 0);
 }
 
@@ -1452,10 +45,14 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   KX_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "kx_gemm: empty problem M=%lld N=%lld K=%lld", (long long)a->M,
              (long long)a->N, (long long)a->K);
   KX_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "kx_gemm: dimension overflow");
-  const int es = a->prec == KX_PREC_BF16 ? 2 : 4;
-  const int bk = 128 / es;
-  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32, "kx_gemm: bad precision %d", a->prec);
+  const bool f16c = a->prec == KX_PREC_F16C;
+  const int es = (a->prec == KX_PREC_BF16 || f16c) ? 2 : 4;   // KX_F16C rows: lda/ldw/ldc count 2-byte units
+  const int bk = f16c ? 128 : 128 / es;
+  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32 || f16c, "kx_gemm: bad precision %d", a->prec);
   KX_REQUIRE(a->K % bk == 0, "kx_gemm: K=%lld must be a multiple of %d", (long long)a->K, bk);
+  KX_REQUIRE(!f16c || (a->w_scale && a->lda >= 2 * a->K && a->ldw >= 2 * a->K && a->tile != 16 && a->tile != 256 &&
+                       a->tile != 257),
+             "kx_gemm: KX_PREC_F16C needs w_scale, lda/ldw >= 2K (2-byte units) and a tile kernel (not 16 / 256 / 257)");
   KX_REQUIRE((a->lda * es) % 16 == 0 && (a->ldw * es) % 16 == 0, "kx_gemm: lda/ldw must give 16-byte row pitch");
   KX_REQUIRE(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "kx_gemm: A/W must be 16-byte aligned");
   KX_REQUIRE(a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N, "kx_gemm: leading dimension too small");
@@ -1467,13 +64,18 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   GemmParams p;
   p.A = (const char*)a->A; p.W = (const char*)a->W;
   p.lda_b = a->lda * es; p.ldw_b = a->ldw * es;
-  p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->cdt == KX_BF16 || a->cdt == KX_BF16X3; p.c_x3 = a->cdt == KX_BF16X3;
+  p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->cdt == KX_BF16 || a->cdt == KX_BF16X3 || a->cdt == KX_F16C;
+  p.c_x3 = a->cdt == KX_BF16X3; p.c_f16c = a->cdt == KX_F16C;
+  p.nk_main = f16c ? (int)(a->K / 64) : 0x7fffffff; p.wscale = a->w_scale;
+  KX_REQUIRE(a->cdt != KX_F16C || (a->N % 8 == 0 && a->ldc >= 2 * a->N && a->ldc % 8 == 0 && a->tile != 16 &&
+                                    ((uintptr_t)a->C & 15) == 0),
+             "kx_gemm: a KX_F16C output needs N %% 8 == 0, ldc >= 2N (2-byte units), ldc %% 8 == 0 (and is not offered by tile 16)");
   KX_REQUIRE(a->cdt != KX_BF16X3 || (a->N % 8 == 0 && a->ldc >= 3 * a->N && a->ldc % 8 == 0 && a->tile != 16 &&
                                       ((uintptr_t)a->C & 15) == 0),
              "kx_gemm: a KX_BF16X3 output needs N %% 8 == 0, ldc >= 3N, ldc %% 8 == 0 (and is not offered by tile 16)");
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
-  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
-  p.act = (a->act == KX_ACT_GELU && a->prec == KX_PREC_BF16) ? KX_ACT_GELU_FAST : a->act;
+  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)(f16c ? 2 * a->K : a->K);   // f16c: 2-byte units of the 4K-byte row
+  p.act = (a->act == KX_ACT_GELU && (a->prec == KX_PREC_BF16 || f16c)) ? KX_ACT_GELU_FAST : a->act;
   p.qscale = a->qscale; p.qcols = (int)a->qcols;
   p.xq_cs = a->xq_cs; p.xq_ss = a->xq_ss; p.xk_cs = a->xk_cs; p.xk_ss = a->xk_ss;
   p.xpos_T = (int)a->xpos_T; p.xpos_dim = (int)a->xpos_dim;
@@ -1505,7 +107,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     }
     // the lean epilogue covers bf16 outputs (not bf16x3) without residual / folded-LN consume / XPos on
     // 16-byte-aligned rows; launch_p5 also asks for N % 256 == 0.  Everything else keeps the generic loops.
-    p.lean_epilogue = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1 && p.c_bf16 && !p.c_x3 && p.vec8_ok && !a->residual &&
+    p.lean_epilogue = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1 && p.c_bf16 && !p.c_x3 && !p.c_f16c && p.vec8_ok && !a->residual &&
                       !a->row_stats && !a->xpos_dim && a->qcols % 64 == 0 && !(a->stats_out && a->qcols);
     p.fast_epilogue = mode == 2 || (mode == 0 && (a->residual || a->row_stats || a->xpos_dim > 0));
   }
@@ -1524,7 +126,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     const long long t128 = cdiv(a->M, 128) * cdiv(a->N, 128);
     if (t128 < 192) {
       tile = 64;
-    } else if (a->prec != KX_PREC_BF16) {
+    } else if (a->prec == KX_PREC_F32) {
       tile = 128;
     } else {
       const long long t256 = cdiv(a->M, 256) * cdiv(a->N, 128);
@@ -1550,9 +152,14 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
         const double cur = tile == 512 ? (double)cdiv(t512, 256) : 0.6 * (double)cdiv(t256, 256);
         if (c384 < 0.97 * cur) tile = 384;
       }
+      if (f16c && tile == 256) tile = cost(160) <= cost(128) ? 160 : 128;   // no 256x128 ring kernel for KX_F16C rows
     }
   }
-  if (tile == 64 && a->stats_out && !(a->splitk_ws && a->splitk != 1)) tile = 128;   // 64x64 waves own 32 columns only
+  // A 64x64 wave owns 32 columns only: the statistics producer needs the split-K reduce kernel (whose threads walk whole
+  // 64-column segments) — when the call will not actually be split, take 128x128 instead (its waves own 64 columns).
+  if (tile == 64 && a->stats_out &&
+      !(a->splitk_ws && splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk) > 1))
+    tile = 128;
   if (tile == 16) {
     KX_REQUIRE(a->prec == KX_PREC_BF16 && a->M <= 16, "kx_gemm: tile 16 (weight streaming) is bf16, M <= 16 only");
     KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * 2 + 16) <= 128 * 1024 && a->K % 4 == 0),
@@ -1580,7 +187,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     // Skinny problems (batch-1 shapes: M = 114 / 257 / 64) are weight-streaming bound and a 64x64 grid of N/64 x 2
     // workgroups leaves most CUs idle while each one walks all of K serially.  Slice K so that ~512 workgroups
     // stream the weights concurrently; partials are small ([splits][M][N] fp32, L2/MALL resident).
-    const long long sp = splitk_slices(a->M, a->N, a->K, bk, a->splitk_ws_bytes, a->splitk);
+    const long long sp = splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk);
     if (sp > 1) {
       p.splitk = (int)sp;
       p.partial = (float*)a->splitk_ws;
@@ -1599,37 +206,20 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
                "kx_gemm: ln_out needs 16-byte aligned gamma / beta / output");
     KX_REQUIRE(!a->stats_out, "kx_gemm: the row reduce does not produce statistics");
   }
-  const int kind = a->prec != KX_PREC_BF16 ? (tile == 64 ? KX_K_GEMM_F32_64 : KX_K_GEMM_F32_128)
+  const int kind = a->prec == KX_PREC_F32 ? (tile == 64 ? KX_K_GEMM_F32_64 : KX_K_GEMM_F32_128)
                    : (tile == 64 || tile == 16) ? KX_K_GEMM_BF16_64
                    : tile == 160 ? KX_K_GEMM_BF16_160
                    : (tile == 256 || tile == 257) ? KX_K_GEMM_BF16_256X128
                    : (tile == 512 || tile == 384) ? KX_K_GEMM_BF16_256X256 : KX_K_GEMM_BF16_128;
   KxProfScope prof(kind, a->M, a->N, a->K, s);
-  if (a->prec == KX_PREC_BF16) {
-    if (tile == 16) return launch_gemv_fused(p, s);
-    if (tile == 128) return launch<bf16_t, 128, 128>(p, s);
-    if (tile == 64) return launch<bf16_t, 64, 64>(p, s);
-    if (tile == 160) return launch<bf16_t, 160, 128>(p, s);
-    if (tile == 256) return launch_p3<bf16_t, true>(p, s);
-    if (tile == 257) return launch_p3<bf16_t, false>(p, s);   // A/B: same tile and ring, unphased
-    if (tile == 512 || tile == 384) {
-      const int st = kx_tuning_get(KX_TUNE_GEMM_STAGGER);
-      if (st > 0) p.stagger_ticks = st;
-    }
-    if (tile == 512) return launch_p5<bf16_t, 256>(p, s);     // 256x256, 128x64 per wave
-    if (tile == 384) return launch_p5<bf16_t, 192>(p, s);     // 192x256,  96x64 per wave
-  } else {
-    if (tile == 128) return launch<float, 128, 128>(p, s);
-    if (tile == 64) return launch<float, 64, 64>(p, s);
+  if (tile == 512 || tile == 384) {
+    const int st = kx_tuning_get(KX_TUNE_GEMM_STAGGER);
+    if (st > 0) p.stagger_ticks = st;
   }
-  kx_set_error("kx_gemm: unknown tile variant %d", tile);
-  return KX_ERR_UNSUPPORTED;
+  if (a->prec == KX_PREC_BF16) {
+    if (tile == 256 || tile == 257 || tile == 512 || tile == 384) return kx_gemm_launch_phased_bf16(p, tile, s);
+    return kx_gemm_launch_tiles_bf16(p, tile, s);
+  }
+  if (f16c) return kx_gemm_launch_f16c(p, tile, s);
+  return kx_gemm_launch_f32(p, tile, s);
 }
-
-#ifdef KX_TIMELINE
-extern "C" int kx_timeline_read(unsigned long long* out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(kx_tl), 64) != hipSuccess) return 1;
-  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(kx_tl), z, 64) != hipSuccess) return 1; }
-  return 0;
-}
-#endif

@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __res
       o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
       o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
       o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
-      if (OUT == KX_BF16X3) {                      // [hi(cols) | hi(cols) | lo(cols)] per row, see split_bf16x2
+      if (OUT == KX_F16C) {                        // [fp16(cols) | fp8(cols) | fp8 residual(cols)] per row, see f16c_pack4
+        const float o4[4] = {o.x, o.y, o.z, o.w};
+        f16c_store4(reinterpret_cast<char*>(y) + orow * 4ll * cols, 4ll * c, cols, o4);
+      } else if (OUT == KX_BF16X3) {               // [hi(cols) | hi(cols) | lo(cols)] per row, see split_bf16x2
         uint2 hh, ll;
         split_bf16x2(o.x, o.y, hh.x, ll.x); split_bf16x2(o.z, o.w, hh.y, ll.y);
         bf16_t* yr = reinterpret_cast<bf16_t*>(y) + orow * 3ll * cols;
@@ -138,7 +141,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
       o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
       o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
-      if (OUT == KX_BF16X3) {                      // [hi(cols) | hi(cols) | lo(cols)] per row, see split_bf16x2
+      if (OUT == KX_F16C) {                        // [fp16(cols) | fp8(cols) | fp8 residual(cols)] per row, see f16c_pack4
+        const float o4[4] = {o.x, o.y, o.z, o.w};
+        f16c_store4(reinterpret_cast<char*>(y) + orow * 4ll * cols, 4ll * c, cols, o4);
+      } else if (OUT == KX_BF16X3) {               // [hi(cols) | hi(cols) | lo(cols)] per row, see split_bf16x2
         uint2 hh, ll;
         split_bf16x2(o.x, o.y, hh.x, ll.x); split_bf16x2(o.z, o.w, hh.y, ll.y);
         bf16_t* yr = reinterpret_cast<bf16_t*>(y) + orow * 3ll * cols;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const long long* __re
 // pixels[b][c][py*ps+ky][px*ps+kx]; columns >= 3*ps*ps are zero padding up to kpad.
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ pixels, T* __restrict__ patches,
-                                                       int image, int ps, int kpad, int x3) {
+                                                       int image, int ps, int kpad, int fmt) {
   const int G = image / ps;
   const long long prow = blockIdx.x;  // b*G*G + py*G + px
   const int b = (int)(prow / (G * G)), pp = (int)(prow % (G * G));
@@ -228,7 +234,14 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
       v = pixels[(((long long)b * 3 + c) * image + (py * ps + ky)) * image + (px * ps + kx)];
     }
     if constexpr (sizeof(T) == 2) {
-      if (x3) {                                   // KX_BF16X3 row: [hi(kpad) | hi(kpad) | lo(kpad)]
+      if (fmt == 2) {                             // KX_F16C row: [fp16(kpad) | fp8(kpad) | fp8 residual(kpad)]
+        char* pr = reinterpret_cast<char*>(patches) + prow * 4ll * kpad;
+        const _Float16 h = (_Float16)v;
+        reinterpret_cast<_Float16*>(pr)[k] = h;
+        const unsigned e = pack_fp8x4(v, 0.f, 0.f, 0.f), r = pack_fp8x4((v - (float)h) * 2048.0f, 0.f, 0.f, 0.f);
+        reinterpret_cast<unsigned char*>(pr + 2ll * kpad)[k] = (unsigned char)(e & 0xffu);
+        reinterpret_cast<unsigned char*>(pr + 3ll * kpad)[k] = (unsigned char)(r & 0xffu);
+      } else if (fmt == 1) {                      // KX_BF16X3 row: [hi(kpad) | hi(kpad) | lo(kpad)]
         const bf16_t hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
         T* pr = patches + prow * 3ll * kpad;
         pr[k] = hi; pr[kpad + k] = hi; pr[2 * kpad + k] = lo;
@@ -311,11 +324,14 @@ extern "C" int kx_layernorm(const float* x, const float* pre_add, const float* g
 #define KX_LN_BLOCK(OUT)                                                                                             \
   hipLaunchKernelGGL(layernorm_block_kernel<OUT>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta, y,  \
                      (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride, (long long)out_row_offset)
-    if (ydt == KX_BF16X3) KX_LN_BLOCK(KX_BF16X3);
+    if (ydt == KX_F16C) KX_LN_BLOCK(KX_F16C);
+    else if (ydt == KX_BF16X3) KX_LN_BLOCK(KX_BF16X3);
     else if (ydt == KX_BF16) KX_LN_BLOCK(KX_BF16);
     else KX_LN_BLOCK(KX_F32);
 #undef KX_LN_BLOCK
-  } else if (ydt == KX_BF16X3)
+  } else if (ydt == KX_F16C)
+    dispatch_ln<KX_F16C>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
+  else if (ydt == KX_BF16X3)
     dispatch_ln<KX_BF16X3>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
   else if (ydt == KX_BF16)
     dispatch_ln<KX_BF16>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
@@ -375,9 +391,9 @@ int kx_launch_patchify(const float* pixels, void* patches, int64_t B, int image,
   const int G = image / patch;
   const unsigned rows = (unsigned)(B * G * G);
   KxProfScope prof(KX_K_MISC, rows, kpad, 1, s);
-  if (prec == KX_PREC_BF16 || prec == KX_PREC_BF16X3)
+  if (prec == KX_PREC_BF16 || prec == KX_PREC_BF16X3 || prec == KX_PREC_F16C)
     hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, pixels, (bf16_t*)patches, image, patch,
-                       kpad, prec == KX_PREC_BF16X3 ? 1 : 0);
+                       kpad, prec == KX_PREC_BF16X3 ? 1 : prec == KX_PREC_F16C ? 2 : 0);
   else
     hipLaunchKernelGGL(patchify_kernel<float>, dim3(rows), dim3(256), 0, s, pixels, (float*)patches, image, patch,
                        kpad, 0);

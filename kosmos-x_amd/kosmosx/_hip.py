@@ -13,13 +13,14 @@ from pathlib import Path
 
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
+ABI_VERSION = 2   # KX_ABI_VERSION of include/kosmosx_hip.h
 
-KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3 = 0, 1, 2
-KX_F32, KX_BF16, KX_BF16X3 = 0, 1, 2
+KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C = 0, 1, 2, 3
+KX_F32, KX_BF16, KX_BF16X3, KX_F16C = 0, 1, 2, 3
 KX_ACT_NONE, KX_ACT_GELU, KX_ACT_QUICK_GELU = 0, 1, 2
 KX_ATTN_FULL, KX_ATTN_CAUSAL = 0, 1
 ACTS = {"none": KX_ACT_NONE, "gelu": KX_ACT_GELU, "quick_gelu": KX_ACT_QUICK_GELU}
-PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32, "bf16x3": KX_PREC_BF16X3}
+PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32, "bf16x3": KX_PREC_BF16X3, "f16c": KX_PREC_F16C}
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 
@@ -34,7 +35,8 @@ class GemmArgs(C.Structure):
                 ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
                 ("stats_partials", vp), ("stats_in_nseg", i64), ("stats_in_seg", i64), ("stats_eps", f32),
                 ("stats_out_seg", i32),
-                ("ln_out", vp), ("ln_out_dt", i32), ("ln_out_gamma", vp), ("ln_out_beta", vp), ("ln_out_eps", f32)]
+                ("ln_out", vp), ("ln_out_dt", i32), ("ln_out_gamma", vp), ("ln_out_beta", vp), ("ln_out_eps", f32),
+                ("w_scale", vp)]
 
 
 class AttnArgs(C.Structure):
@@ -163,8 +165,8 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.kx_version() != 1:
-        raise RuntimeError(f"libkosmosx_hip.so ABI version {lib.kx_version()} != 1")
+    if lib.kx_version() != ABI_VERSION:
+        raise RuntimeError(f"libkosmosx_hip.so ABI version {lib.kx_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 

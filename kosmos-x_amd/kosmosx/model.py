@@ -49,6 +49,8 @@ def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
     [hi(K) | lo(K) | hi(K)] in bf16 (hi = bf16(w), lo = bf16(w - hi)) that pair with [hi | hi | lo] activation rows —
     see kx_precision in include/kosmosx_hip.h."""
     t = t.detach()
+    if prec == "f16c":
+        return _operand_f16c(t.float())
     if prec != "bf16x3":
         return t.to(_prec_dtype(prec)).contiguous()
     f = t.float()
@@ -57,8 +59,36 @@ def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
     return torch.cat([hi, lo, hi], dim=1).contiguous()
 
 
-def _operand_colsum(wp: torch.Tensor, prec: str) -> torch.Tensor:
+def _operand_f16c(f: torch.Tensor) -> torch.Tensor:
+    """[N,K] fp32 -> the packed KX_F16C weight matrix (kx_precision in include/kosmosx_hip.h): N rows of 4K bytes
+    [h = fp16(w) | r = fp8((w - h) * 2^(s+11)) | e = fp8(w * 2^s)] followed by the N E8M0 scale bytes 127 - s, where s
+    is the row's exponent (max|w| * 2^s in (64, 128]).  Returned as a flat uint8 tensor."""
+    N, K = f.shape
+    if K % 128:
+        raise ValueError(f"f16c operands need K % 128 == 0 (K={K})")
+    amax = f.abs().amax(dim=1).clamp_min(2.0 ** -100)
+    sexp = (7 - torch.ceil(torch.log2(amax))).clamp(-100, 100)          # integer-valued
+    sc = torch.exp2(sexp)[:, None]
+    h = f.to(torch.float16)
+    r = ((f - h.float()) * sc * 2048.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    e = (f * sc).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    rows = torch.cat([h.view(torch.uint8).reshape(N, 2 * K), r.view(torch.uint8), e.view(torch.uint8)], dim=1)
+    scale = (127 - sexp).to(torch.uint8)
+    pad = (-N) % 16
+    if pad:
+        scale = torch.cat([scale, torch.full((pad,), 127, dtype=torch.uint8, device=f.device)])
+    return torch.cat([rows.reshape(-1), scale]).contiguous()
+
+
+def _operand_colsum(wp: torch.Tensor, prec: str, shape=None) -> torch.Tensor:
     """Sum over k of the values a packed operand row represents (what the folded-LayerNorm epilogue subtracts)."""
+    if prec == "f16c":      # the value the GEMM reconstructs is the fp32 weight to 2^-15: h + 2^-(s+11) r
+        N, K = shape
+        rows = wp[: N * 4 * K].view(N, 4 * K)
+        h = rows[:, : 2 * K].contiguous().view(torch.float16).float()
+        r = rows[:, 2 * K: 3 * K].contiguous().view(torch.float8_e4m3fn).float()
+        sexp = 127.0 - wp[N * 4 * K: N * 4 * K + N].float()
+        return (h + r * torch.exp2(-(sexp + 11.0))[:, None]).sum(1)
     if prec != "bf16x3":
         return wp.float().sum(1)
     K = wp.shape[1] // 3
@@ -189,7 +219,7 @@ class CLIPVisionTower(_PackedMixin, nn.Module):
             t = _f32(t); keep.append(t); return t.data_ptr()
 
         kreal = 3 * c.patch * c.patch
-        kpad = (kreal + 63) // 64 * 64
+        kpad = (kreal + 127) // 128 * 128      # whole 128-byte K-tiles in every operand format
         wp = torch.zeros((c.dim, kpad), dtype=torch.float32, device=dev)
         wp[:, :kreal] = self.embeddings.patch_embedding.weight.detach().reshape(c.dim, kreal)
         layers = (H.VitLayer * c.layers)()
@@ -496,8 +526,9 @@ class Decoder(_PackedMixin, nn.Module):
             W' = γ ⊙ W cast to the operand dtype, b' = W·β + b, colsum = Σ_k W'[n,k] of the cast values."""
             wf, g_, b_ = lin.weight.detach().float(), ln.weight.detach().float(), ln.bias.detach().float()
             wp = _operand(wf * g_[None, :], prec)
+            shp = tuple(wf.shape)
             keep.append(wp)
-            return wp.data_ptr(), v(wf @ b_ + lin.bias.detach().float()), v(_operand_colsum(wp, prec))
+            return wp.data_ptr(), v(wf @ b_ + lin.bias.detach().float()), v(_operand_colsum(wp, prec, shp))
 
         layers = (H.DecoderLayer * self.num_layers)()
         for i, L in enumerate(self.layers):

@@ -30,15 +30,36 @@ def _cdt(dtype) -> int:
     raise TypeError(f"unsupported dtype {dtype}")
 
 
+def pack_f16c_rows(x: torch.Tensor) -> torch.Tensor:
+    """[rows, K] fp32 -> KX_F16C activation rows [rows, 4K] uint8: [fp16(x) | fp8(x) | fp8((x - fp16(x)) * 2^11)]
+    (torch conversions; the device producers write the same bytes — kx_precision in include/kosmosx_hip.h)."""
+    x = x.float()
+    h = x.to(torch.float16)
+    e = x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    r = ((x - h.float()) * 2048.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return torch.cat([h.view(torch.uint8).reshape(x.shape[0], -1), e.view(torch.uint8), r.view(torch.uint8)], dim=1).contiguous()
+
+
+def unpack_f16c_rows(rows: torch.Tensor, K: int):
+    """KX_F16C activation rows [rows, 4K] uint8 -> (h, e, r) as fp32 tensors [rows, K] (r still carries its 2^11)."""
+    h = rows[:, : 2 * K].contiguous().view(torch.float16).float()
+    e = rows[:, 2 * K: 3 * K].contiguous().view(torch.float8_e4m3fn).float()
+    r = rows[:, 3 * K: 4 * K].contiguous().view(torch.float8_e4m3fn).float()
+    return h, e, r
+
+
 def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, out=None,
-              rows_per_group=None, out_group_stride=0, out_row_offset=0, x3=False):
-    """x [rows, cols] fp32 -> LN(x (+pre_add)) * gamma + beta.  x3: KX_BF16X3 rows [hi | hi | lo] ([rows, 3*cols] bf16)."""
+              rows_per_group=None, out_group_stride=0, out_row_offset=0, x3=False, f16c=False):
+    """x [rows, cols] fp32 -> LN(x (+pre_add)) * gamma + beta.  x3: KX_BF16X3 rows [hi | hi | lo] ([rows, 3*cols] bf16);
+    f16c: KX_F16C rows ([rows, 4*cols] uint8)."""
     _need_cuda(x, gamma, beta, pre_add, out)
     rows, cols = x.shape
+    if out is None and f16c:
+        out = torch.empty((rows, 4 * cols), dtype=torch.uint8, device=x.device)
     if out is None:
         out = torch.empty((rows, 3 * cols if x3 else cols), dtype=torch.bfloat16 if x3 else out_dtype, device=x.device)
     rc = H.load().kx_layernorm(H.ptr(x), H.ptr(pre_add), H.ptr(gamma), H.ptr(beta), H.ptr(out),
-                               H.KX_BF16X3 if x3 else _cdt(out.dtype),
+                               H.KX_F16C if f16c else H.KX_BF16X3 if x3 else _cdt(out.dtype),
                                rows, cols, float(eps), rows_per_group or rows, out_group_stride, out_row_offset,
                                _stream())
     H.check(rc, "kx_layernorm")
@@ -90,6 +111,33 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
     return out if lnt is None else (out, lnt)
 
 
+def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,
+              xpos=None, xpos_dim=0, tile=0, row_stats=None, colsum=None, stats_out=None, splitk_ws=None, splitk=0):
+    """KX_PREC_F16C GEMM: a_rows [M, 4K] uint8 (KX_F16C activation rows), w_packed = the flat packed weight matrix
+    (N rows of 4K bytes + N scale bytes, model._operand_f16c).  Output fp32 [M, N] or KX_F16C rows [M, 4N] uint8."""
+    _need_cuda(a_rows, w_packed, bias, residual)
+    M = a_rows.shape[0]
+    assert a_rows.dtype == torch.uint8 and a_rows.shape[1] == 4 * K and w_packed.numel() >= N * 4 * K + N
+    out = (torch.empty((M, 4 * N), dtype=torch.uint8, device=a_rows.device) if out_f16c else
+           torch.empty((M, N), dtype=torch.float32, device=a_rows.device))
+    g = H.GemmArgs()
+    g.A, g.lda, g.W, g.ldw = H.ptr(a_rows), a_rows.stride(0) // 2, H.ptr(w_packed), 2 * K
+    g.C, g.ldc, g.cdt = H.ptr(out), (2 * N if out_f16c else out.stride(0)), (H.KX_F16C if out_f16c else H.KX_F32)
+    g.w_scale = w_packed.data_ptr() + N * 4 * K
+    g.bias, g.residual, g.ldr = H.ptr(bias), H.ptr(residual), (residual.stride(0) if residual is not None else 0)
+    g.M, g.N, g.K = M, N, K
+    g.act, g.qscale, g.qcols = H.ACTS[act], float(qscale), qcols
+    if xpos is not None:
+        g.xq_cs, g.xq_ss, g.xk_cs, g.xk_ss = (H.ptr(t) for t in xpos)
+        g.xpos_T, g.xpos_dim = xpos[0].shape[0], xpos_dim
+    g.prec, g.tile = H.KX_PREC_F16C, tile
+    g.row_stats, g.colsum, g.stats_out = H.ptr(row_stats), H.ptr(colsum), H.ptr(stats_out)
+    if splitk_ws is not None:
+        g.splitk_ws, g.splitk_ws_bytes, g.splitk = H.ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size(), splitk
+    H.check(H.load().kx_gemm(C.byref(g), _stream()), "kx_gemm")
+    return out
+
+
 def row_stats_finalize(partials, seg_size, eps=1e-5):
     """partials [rows, nseg, 2] (sum, M2 about the segment mean) -> [rows, 2] (mean, rstd)."""
     _need_cuda(partials)
@@ -100,22 +148,27 @@ def row_stats_finalize(partials, seg_size, eps=1e-5):
     return out
 
 
-def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=False, lse_out=None):
+def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=False, lse_out=None, f16c=False,
+              out_f16c=False):
     """q [B,Tq,H,64], k/v [B,Tk,H,64] (any row/batch strides, last two dims contiguous) -> [B,Tq,H*64]
-    (out_x3, fp32 inputs only: KX_BF16X3 rows [hi | hi | lo], [B,Tq,3*H*64] bf16)."""
+    (out_x3, fp32 inputs only: KX_BF16X3 rows [hi | hi | lo], [B,Tq,3*H*64] bf16).
+    f16c (fp32 inputs): the KX_PREC_F16C kernel — split fp16 (hi, lo) products; out_f16c: KX_F16C rows [B,Tq,4*H*64] uint8."""
     _need_cuda(q, k, v)
     B, Tq, Hh, hd = q.shape
     Tk = k.shape[1]
     assert hd == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and v.stride(2) == 64
     assert k.stride(0) == v.stride(0) and k.stride(1) == v.stride(1)
-    prec = H.KX_PREC_BF16 if q.dtype == torch.bfloat16 else H.KX_PREC_F32
-    out = (torch.empty((B, Tq, 3 * Hh * 64), dtype=torch.bfloat16, device=q.device) if out_x3 else
+    prec = H.KX_PREC_BF16 if q.dtype == torch.bfloat16 else (H.KX_PREC_F16C if f16c or out_f16c else H.KX_PREC_F32)
+    out = (torch.empty((B, Tq, 4 * Hh * 64), dtype=torch.uint8, device=q.device) if out_f16c else
+           torch.empty((B, Tq, 3 * Hh * 64), dtype=torch.bfloat16, device=q.device) if out_x3 else
            torch.empty((B, Tq, Hh * 64), dtype=out_dtype or q.dtype, device=q.device))
     a = H.AttnArgs()
     a.q, a.q_batch_stride, a.q_row_stride = H.ptr(q), q.stride(0), q.stride(1)
     a.k, a.v, a.kv_batch_stride, a.kv_row_stride = H.ptr(k), H.ptr(v), k.stride(0), k.stride(1)
     a.out, a.out_batch_stride, a.out_row_stride = H.ptr(out), out.stride(0), out.stride(1)
-    a.odt = H.KX_BF16X3 if out_x3 else _cdt(out.dtype)
+    if out_f16c:                                   # strides count 2-byte units
+        a.out_batch_stride, a.out_row_stride = out.stride(0) // 2, out.stride(1) // 2
+    a.odt = H.KX_F16C if out_f16c else H.KX_BF16X3 if out_x3 else _cdt(out.dtype)
     a.B, a.H, a.Tq, a.Tk = B, Hh, Tq, Tk
     a.mask, a.prec = (H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL), prec
     a.stats_out = H.ptr(stats_out)

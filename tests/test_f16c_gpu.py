@@ -1,0 +1,222 @@
+"""KX_PREC_F16C ("fp16, compensated": one fp16 product + two fp8 correction products on the block-scaled MFMA), GPU.
+
+Per kernel the reference is EXACT arithmetic (float64) on the very bytes the kernel consumes — the packed (h, e, r)
+pieces are exactly representable — so what is left is fp32 accumulation order; the distance of the FORMAT from the
+un-rounded fp32 product is bounded separately (that is what buys the north star's 1e-3 on the logits).
+End to end the mode is held against the fp32 CPU oracle at 1e-3 (tiny and full size).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from kosmosx import ops  # noqa: E402
+from kosmosx.model import Kosmos, KosmosLanguage, _operand_colsum, _operand_f16c  # noqa: E402
+from oracle import kosmos_oracle as O  # noqa: E402
+from helpers import max_abs, oracle_cfg, oracle_weights, rel_err, tiny_config  # noqa: E402
+
+DEV = "cuda"
+F16C_TOL = 1e-3   # north star, bf16 class
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _w_parts(wp, N, K):
+    rows = wp[: N * 4 * K].view(N, 4 * K).cpu()
+    h = rows[:, : 2 * K].contiguous().view(torch.float16).double()
+    r = rows[:, 2 * K: 3 * K].contiguous().view(torch.float8_e4m3fn).float().double()
+    e = rows[:, 3 * K: 4 * K].contiguous().view(torch.float8_e4m3fn).float().double()
+    s = 127.0 - wp[N * 4 * K: N * 4 * K + N].cpu().double()          # exponent s of each row
+    return h, r, e, s
+
+
+def _exact(a_rows, wp, N, K):
+    """What the kernel is asked to compute, in float64, from the packed bytes."""
+    ah, ae, ar = (t.cpu().double() for t in ops.unpack_f16c_rows(a_rows, K))
+    wh, wr, we, s = _w_parts(wp, N, K)
+    return ah @ wh.t() + (ae @ wr.t() + ar @ we.t()) * torch.exp2(-(s + 11.0))[None, :]
+
+
+def test_f16c_producers_write_the_format_bit_exactly():
+    """LayerNorm, GEMM epilogue and attention KX_F16C outputs == packing their own fp32 outputs (torch conversions:
+    fp16 RNE, e4m3 RNE after the +-448 clamp)."""
+    g = _g(0)
+    x = torch.randn(37, 2048, generator=g) * 3 + 0.5
+    gam, bet = 1 + 0.2 * torch.randn(2048, generator=g), 0.2 * torch.randn(2048, generator=g)
+    y32 = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV))
+    yc = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), f16c=True)
+    assert torch.equal(yc, ops.pack_f16c_rows(y32))
+    x8 = torch.randn(5, 8192, generator=g) * 40                      # block-per-row variant, some |x| beyond fp8's 448
+    g8, b8 = torch.ones(8192) * 200, torch.zeros(8192)
+    assert torch.equal(ops.layernorm(x8.to(DEV), g8.to(DEV), b8.to(DEV), f16c=True),
+                       ops.pack_f16c_rows(ops.layernorm(x8.to(DEV), g8.to(DEV), b8.to(DEV))))
+    M, N, K = 200, 512, 256
+    a = ops.pack_f16c_rows(torch.randn(M, K, generator=g).to(DEV))
+    wp = _operand_f16c((torch.randn(N, K, generator=g) * 0.05).to(DEV))
+    bias = torch.randn(N, generator=g).to(DEV)
+    for tile in (64, 128, 160, 384, 512):
+        c32 = ops.gemm_f16c(a, wp, N, K, bias=bias, act="gelu", tile=tile)
+        cc = ops.gemm_f16c(a, wp, N, K, bias=bias, act="gelu", tile=tile, out_f16c=True)
+        assert torch.equal(cc, ops.pack_f16c_rows(c32)), tile
+    q, k, v = (torch.randn(2, 70, 3, 64, generator=g).to(DEV) for _ in range(3))
+    o32 = ops.attention(q, k, v, True, f16c=True)
+    oc = ops.attention(q, k, v, True, out_f16c=True)
+    assert torch.equal(oc.view(-1, 4 * 192), ops.pack_f16c_rows(o32.view(-1, 192)))
+
+
+SHAPES = [(1, 64, 128), (114, 2048, 2048), (257, 1024, 4096), (130, 264, 128), (300, 1002, 640), (64, 512, 1024),
+          (513, 768, 256), (3648, 512, 2048)]
+
+
+@pytest.mark.parametrize("tile", [0, 64, 128, 160, 384, 512])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_f16c_matches_exact_arithmetic_on_the_packed_operands(shape, tile):
+    M, N, K = shape
+    g = _g(M + N + K)
+    a = ops.pack_f16c_rows((torch.randn(M, K, generator=g) * 1.3).to(DEV))
+    wp = _operand_f16c((torch.randn(N, K, generator=g) * torch.logspace(-2, 0, N)[:, None]).to(DEV))   # row scales 0.01..1
+    ref = _exact(a, wp, N, K)
+    out = ops.gemm_f16c(a, wp, N, K, tile=tile)
+    e = float((out.cpu().double() - ref).abs().max() / ref.pow(2).mean().sqrt())
+    assert e < 2e-5, (shape, tile, e)
+
+
+def test_gemm_f16c_split_k_and_epilogues():
+    g = _g(5)
+    M, N, K = 114, 2048, 2048
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.03
+    a, wp = ops.pack_f16c_rows(x.to(DEV)), _operand_f16c(w.to(DEV))
+    bias, res = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    ref = _exact(a, wp, N, K)
+    want = F.gelu(ref + bias.cpu().double()) + res.cpu().double()
+    for splitk in (0, 2, 7):
+        out = ops.gemm_f16c(a, wp, N, K, bias=bias, residual=res, act="gelu", splitk_ws=ws, splitk=splitk)
+        assert float((out.cpu().double() - want).abs().max()) < 2e-5 * float(want.abs().max()), splitk
+    # folded LayerNorm consumer + statistics producer (the sub-LN pair) on the f16c kernels
+    st = torch.zeros(M, N // 64, 2, device=DEV)
+    for tile in (0, 128, 384, 512):
+        c = ops.gemm_f16c(a, wp, N, K, bias=bias, act="gelu", tile=tile, stats_out=st, splitk_ws=ws if tile == 0 else None)
+        y = F.gelu(ref + bias.cpu().double())
+        seg = y.view(M, N // 64, 64)
+        assert float((st[:, :, 0].cpu().double() - seg.sum(-1)).abs().max()) < 2e-3
+        m2 = (seg - seg.mean(-1, keepdim=True)).pow(2).sum(-1)
+        assert float((st[:, :, 1].cpu().double() - m2).abs().max()) < 2e-3 * float(m2.max())
+        assert float((c.cpu().double() - y).abs().max()) < 2e-5 * float(y.abs().max())
+
+
+def test_f16c_format_error_vs_unrounded_product():
+    """One GEMM: fp16 alone leaves ~2e-4 of the rms, the two fp8 corrections take it to ~5e-6 (bf16: 1.6e-3)."""
+    g = _g(1)
+    M, N, K = 256, 512, 2048
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.02
+    ref = x.double() @ w.double().t()
+    out = ops.gemm_f16c(ops.pack_f16c_rows(x.to(DEV)), _operand_f16c(w.to(DEV)), N, K).cpu().double()
+    rms = ref.pow(2).mean().sqrt()
+    e = float((out - ref).pow(2).mean().sqrt() / rms)
+    e16 = float((x.half().double() @ w.half().double().t() - ref).pow(2).mean().sqrt() / rms)
+    print(f"GEMM K={K}: rms error fp16 {e16:.2e}, f16c {e:.2e}")
+    assert e < 1.5e-5 and e * 8 < e16
+    # the column sums the folded-LayerNorm epilogue subtracts are those of the reconstructed weights
+    cs = _operand_colsum(_operand_f16c(w.to(DEV)), "f16c", (N, K)).cpu().double()
+    assert float((cs - w.double().sum(1)).abs().max()) < 1e-4
+
+
+def _attn_ref(q, k, v, causal):
+    q, k, v = (t.cpu().double().transpose(1, 2) for t in (q, k, v))       # [B,H,T,64]
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        T = s.shape[-1]
+        s = s + torch.triu(torch.full((T, T), float("-inf"), dtype=torch.float64), 1)
+    o = s.softmax(-1) @ v
+    return o.transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
+
+
+ATTN_CASES = [(2, 3, 114, 114, True), (1, 2, 115, 115, True), (2, 2, 257, 257, False), (2, 2, 64, 321, False),
+              (1, 1, 1, 1, True), (1, 2, 9, 9, True), (3, 1, 130, 130, True), (1, 2, 700, 700, True), (1, 1, 5, 77, False)]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_f16c_split_products(case):
+    B, Hh, Tq, Tk, causal = case
+    g = _g(Tq * 7 + Tk)
+    q = (torch.randn(B, Tq, Hh, 64, generator=g) * 0.6).to(DEV)
+    k = (torch.randn(B, Tk, Hh, 64, generator=g) * 1.5).to(DEV)
+    v = torch.randn(B, Tk, Hh, 64, generator=g).to(DEV)
+    ref = _attn_ref(q, k, v, causal)
+    st = torch.zeros(B * Tq, Hh, 2, device=DEV)
+    out = ops.attention(q, k, v, causal, f16c=True, stats_out=st)
+    e = float((out.cpu().double() - ref).abs().max())
+    assert e < 3e-6 * max(1.0, float(ref.abs().max())), (case, e)            # fp32-class: split operands carry 22 bits
+    seg = ref.view(B * Tq, Hh, 64)
+    assert float((st[:, :, 0].cpu().double() - seg.sum(-1)).abs().max()) < 1e-4
+    # plain fp16 operands (what the split is for) would be ~1e-3 here
+    qh, kh = q.half().float(), k.half().float()
+    e16 = float((_attn_ref(qh, kh, v, causal) - ref).abs().max())
+    assert e * 20 < e16 or e16 < 1e-6
+
+
+def test_attention_f16c_softmax_spike_and_strided_views():
+    g = _g(3)
+    qkv = torch.randn(2, 200, 3 * 4 * 64, generator=g).to(DEV)
+    qkv[:, 150, 256:512] *= 12.0                                              # a late key that moves every running max
+    q, k, v = (qkv[:, :, i * 256:(i + 1) * 256].unflatten(2, (4, 64)) for i in range(3))
+    ref = _attn_ref(q, k, v, True)
+    out = ops.attention(q, k, v, True, f16c=True)
+    assert float((out.cpu().double() - ref).abs().max()) < 5e-6 * max(1.0, float(ref.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# end to end
+# ---------------------------------------------------------------------------------------------------------------
+def _inputs(B, Tt, cfg, seed=0):
+    g = _g(seed)
+    return torch.randint(0, cfg.vocab, (B, Tt), generator=g), torch.randn(B, 3, cfg.vit.image, cfg.vit.image, generator=g)
+
+
+@pytest.mark.parametrize("B,Tt", [(1, 10), (3, 2), (2, 50)])
+def test_tiny_f16c_meets_the_bf16_north_star(B, Tt):
+    m = Kosmos._from_config(tiny_config(), seed=0, perturb=0.1).eval()
+    tok, img = _inputs(B, Tt, m.cfg, seed=30 + B)
+    st = {}
+    ref = O.kosmos_forward(oracle_weights(m), tok, img, oracle_cfg(m.cfg), O.Switches(), st)
+    m.precision = "f16c"
+    m = m.to(DEV)
+    out = m(tok.to(DEV), img.to(DEV))
+    e = rel_err(out, ref)
+    print(f"tiny f16c B={B} Tt={Tt}: max|d|/rms vs fp32 oracle = {e:.3e}")
+    assert out.dtype == torch.float32 and e < F16C_TOL, e
+    assert torch.equal(out, m(tok.to(DEV), img.to(DEV)))                      # run-to-run bit equality
+    img_s = m.clip_model.run(img.to(DEV).float(), "f16c", m._ws)
+    assert rel_err(img_s, st["vit"]) < F16C_TOL
+
+
+@pytest.mark.parametrize("B,Tt", [(1, 50), (2, 2), (2, 50), (1, 100)])
+def test_full_size_f16c_meets_1e_3(B, Tt):
+    """C1 (1 image + 50 tokens), T = 66, the M in 129..256 band of ADVICE r1 (B=2,Tt=50: M=228; B=1,Tt=100: M=164)."""
+    from kosmosx.config import DecoderConfig, KosmosConfig
+    m = Kosmos._from_config(KosmosConfig(decoder=DecoderConfig()), seed=0, perturb=0.05).eval()
+    tok, img = _inputs(B, Tt, m.cfg, seed=3)
+    ref = O.kosmos_forward(oracle_weights(m), tok, img, oracle_cfg(m.cfg), O.Switches())
+    m.precision = "f16c"
+    m = m.to(DEV)
+    out = m(tok.to(DEV), img.to(DEV))
+    e = rel_err(out, ref)
+    print(f"full-size f16c B={B} Tt={Tt}: max|d|/rms vs fp32 CPU oracle = {e:.3e}")
+    assert e < F16C_TOL, e
+
+
+def test_full_size_f16c_text_only_T2046():
+    m = KosmosLanguage(vocab_size=32002, dim=2048, _seed=3, _perturb=0.05).eval()
+    tok = torch.randint(0, 32002, (1, 2046), generator=_g(0))
+    ref = O.kosmos_language_forward(oracle_weights(m), tok, O.DecoderCfg(vocab=32002))
+    m.precision = "f16c"
+    m = m.to(DEV)
+    out = m(tok.to(DEV))
+    e = rel_err(out, ref)
+    print(f"KosmosLanguage f16c T=2046: max|d|/rms vs fp32 CPU oracle = {e:.3e}")
+    assert e < F16C_TOL, e

@@ -1,0 +1,114 @@
+"""Error budget of GEMM-operand formats on the CPU oracle (full-size C1: 1 image + 50 tokens).
+
+Every matmul operand of oracle/kosmos_oracle.py passes through ``_r`` / ``linear``; this script swaps those two for
+emulations of candidate operand formats (fp32 accumulate throughout, as the MFMA does) and reports
+max|dlogit|/rms against the un-rounded fp32 oracle — the north star's figure of merit (1e-3 in the bf16 class).
+Formats:  bf16 | fp16 | bf16x3 (hi/lo split, 3 products) | f16c (fp16 product + two fp8-e4m3 correction products)
+Usage:  python tools/precision_study.py [--tiny] [--formats bf16,fp16,f16c] [--attn fp16|split|fp32]
+Test infrastructure only (imports oracle/).
+"""
+import argparse, os, sys, time
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "kosmos-x_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import kosmos_oracle as O  # noqa: E402
+
+F8 = torch.float8_e4m3fn
+
+
+def p2(x):  # power-of-two scale putting max|x| near 2^7 (fp8 e4m3 tops out at 448)
+    m = float(x.abs().max())
+    return 2.0 ** (7 - torch.tensor(m).log2().ceil().item()) if m > 0 else 1.0
+
+
+def f8(x):
+    return x.clamp(-448, 448).to(F8).to(torch.float32)
+
+
+def mm_format(a, w, fmt):
+    """a [.., K] @ w[N, K]^T in the emulated operand format."""
+    if fmt == "fp32":
+        return a @ w.t()
+    if fmt == "bf16":
+        return a.bfloat16().float() @ w.bfloat16().float().t()
+    if fmt == "fp16":
+        return a.half().float() @ w.half().float().t()
+    if fmt == "bf16x3":
+        ah, wh = a.bfloat16().float(), w.bfloat16().float()
+        al, wl = (a - ah).bfloat16().float(), (w - wh).bfloat16().float()
+        return ah @ wh.t() + ah @ wl.t() + al @ wh.t()
+    if fmt in ("f16c", "f16c_static"):
+        ah, wh = a.half().float(), w.half().float()
+        sa = 1.0 if fmt == "f16c_static" else p2(a)
+        sw_ = p2(w)
+        c = 2.0 ** 11
+        a8, ar8 = f8(a * sa), f8((a - ah) * sa * c)
+        w8, wr8 = f8(w * sw_), f8((w - wh) * sw_ * c)
+        return ah @ wh.t() + (a8 @ wr8.t() + ar8 @ w8.t()) / (sa * sw_ * c)
+    if fmt == "f16x2a":   # activation split in two fp16, weight single fp16
+        ah, wh = a.half().float(), w.half().float()
+        al = (a - ah).half().float()
+        return ah @ wh.t() + al @ wh.t()
+    raise ValueError(fmt)
+
+
+class Study:
+    def __init__(self, lin_fmt, attn_fmt):
+        self.lin_fmt, self.attn_fmt = lin_fmt, attn_fmt
+
+    def linear(self, x, w, b, sw):
+        y = mm_format(x.reshape(-1, x.shape[-1]), w, self.lin_fmt).reshape(*x.shape[:-1], w.shape[0])
+        return y if b is None else y + b
+
+    def r(self, x, sw):   # attention operands (q, k, p, v)
+        f = self.attn_fmt
+        if f == "fp32":
+            return x
+        if f == "bf16":
+            return x.bfloat16().float()
+        if f == "fp16":
+            return x.half().float()
+        if f == "split":   # hi+lo pairs carry 16+ bits: the dropped lo*lo term is 2^-18 — emulate as (near) exact
+            h = x.bfloat16().float()
+            return h + (x - h).bfloat16().float()
+        raise ValueError(f)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--formats", default="bf16,fp16,f16x2a,f16c,f16c_static,bf16x3")
+    ap.add_argument("--attn", default="match")
+    ap.add_argument("--text", type=int, default=50)
+    a = ap.parse_args()
+    from kosmosx.model import Kosmos
+    from helpers import oracle_cfg, oracle_weights, tiny_config
+    torch.manual_seed(0)
+    m = (Kosmos._from_config(tiny_config(), seed=0, perturb=0.1) if a.tiny else Kosmos()).eval()
+    w, cfg = oracle_weights(m), oracle_cfg(m.cfg)
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randint(0, m.cfg.vocab, (1, a.text), generator=g)
+    img = torch.randn(1, 3, m.cfg.vit.image, m.cfg.vit.image, generator=g)
+    t0 = time.time()
+    ref = O.kosmos_forward(w, tok, img, cfg, O.Switches())
+    rms = float(ref.pow(2).mean().sqrt())
+    print(f"fp32 oracle: {time.time() - t0:.1f} s, logits rms {rms:.4f}", flush=True)
+    lin0, r0 = O.linear, O._r
+    for fmt in a.formats.split(","):
+        attn = a.attn
+        if attn == "match":
+            attn = {"bf16": "bf16", "fp16": "fp16", "f16x2a": "fp16"}.get(fmt, "split")
+        st = Study(fmt, attn)
+        O.linear, O._r = st.linear, st.r
+        sw = O.Switches(emulate_bf16=True)     # routes the conv through _r as well
+        t0 = time.time()
+        out = O.kosmos_forward(w, tok, img, cfg, sw)
+        O.linear, O._r = lin0, r0
+        d = out - ref
+        print(f"{fmt:12s} attn={attn:6s}: max|d|/rms = {float(d.abs().max()) / rms:.3e}   rms(d)/rms = "
+              f"{float(d.pow(2).mean().sqrt()) / rms:.3e}   ({time.time() - t0:.1f} s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
