@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--text-len", type=int, default=50)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "f16c"])
     ap.add_argument("--no-gather", action="store_true", help="skip the logits all-gather (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
@@ -262,7 +262,7 @@ def main():
     other_modes = None
     if rank == 0 and world == 1 and not force_dist and not args.no_cpu_baseline:
         other_modes = {}
-        for mode in [m for m in ("bf16x3", "fp32") if m != args.precision]:
+        for mode in [m for m in ("f16c", "bf16x3", "fp32", "bf16") if m != args.precision]:
             model.precision = mode
             k = max(3, min(args.steps, 8))
             for _ in range(2):
@@ -333,7 +333,7 @@ def main():
         # max|logit difference| / rms(logits), the figure the tests bound (1e-5 class fp32, 1e-3 bf16x3, 6e-2 bf16)
         ref_logits = O.kosmos_forward(cpu_weights, ctok, cimg, ocfg)
         parity = {}
-        for mode in ("bf16", "bf16x3", "fp32"):
+        for mode in ("bf16", "f16c", "bf16x3", "fp32"):
             model.precision = mode
             with torch.no_grad():
                 got = model(tok[:1], img[:1]).float().cpu()

@@ -199,6 +199,12 @@ int kx_embed_splice(const int64_t* tokens, const float* embed, const float* pos,
                     float* out, int64_t B, int64_t Tt, int64_t n_img, int64_t d, int64_t vocab,
                     int64_t max_pos, int64_t splice_at, int32_t u1_alias, int64_t pos_offset, void* stream);
 
+/* (min, max) of n int64 token ids -> out2[0], out2[1] (device).  The kernels clamp ids for memory safety only; the
+ * Python boundary calls this first and raises IndexError for ids outside [0, vocab), as torch.nn.functional.embedding
+ * does on the reference's CPU path (/root/reference/kosmosx/model.py:238 -> Decoder.forward_embedding). */
+int kx_token_range(const int64_t* tokens, int64_t n, int64_t* out2, void* stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * Stage-level entry points (what kosmosx.model calls).  Weight structs hold device pointers
  * to tensors packed by the Python side from the reference's state_dict key namespace

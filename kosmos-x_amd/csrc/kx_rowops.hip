@@ -294,6 +294,24 @@ __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float* __
   if (lane == 0) reinterpret_cast<float2*>(out)[row] = make_float2(mean, rsqrtf(var + eps));
 }
 
+// (min, max) of n token ids -> out[0], out[1] (pre-set to INT64_MAX / INT64_MIN by the launcher's memset pair): one
+// wave-reduced atomic pair per workgroup.  The Python boundary reads the two values and raises IndexError the way
+// F.embedding does on the CPU (/root/reference/kosmosx/model.py:238: forward_embedding -> bitsandbytes Embedding).
+__global__ __launch_bounds__(256) void token_range_kernel(const long long* __restrict__ tokens, long long n,
+                                                          long long* __restrict__ out) {
+  long long lo = 0x7fffffffffffffffll, hi = -0x7fffffffffffffffll - 1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long t = tokens[i];
+    lo = t < lo ? t : lo; hi = t > hi ? t : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMin(out, lo); atomicMax(out + 1, hi); }
+}
+
 // dst[b, r, :] = src[r, :]
 __global__ __launch_bounds__(256) void rows_bcast_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                          long long rows, int cols) {
@@ -364,6 +382,21 @@ extern "C" int kx_embed_splice(const int64_t* tokens, const float* embed, const 
                      (const long long*)tokens, embed, pos, img, out, (int)Tt, (int)n_img, (int)d, (long long)vocab,
                      (int)splice_at, (int)u1_alias, (int)pos_offset);
   KX_CHECK_LAUNCH("kx_embed_splice");
+  return KX_OK;
+}
+
+extern "C" int kx_token_range(const int64_t* tokens, int64_t n, int64_t* out2, void* stream) {
+  KX_REQUIRE(tokens && out2 && n > 0, "kx_token_range: null pointer / empty input");
+  hipStream_t s = (hipStream_t)stream;
+  static const long long init[2] = {0x7fffffffffffffffll, -0x7fffffffffffffffll - 1};
+  if (hipMemcpyAsync(out2, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) {
+    kx_set_error("kx_token_range: could not initialise the result");
+    return KX_ERR_LAUNCH;
+  }
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(token_range_kernel, dim3(blocks), dim3(256), 0, s, (const long long*)tokens, (long long)n,
+                     (long long*)out2);
+  KX_CHECK_LAUNCH("kx_token_range");
   return KX_OK;
 }
 

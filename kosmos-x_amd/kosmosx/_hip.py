@@ -104,6 +104,7 @@ SYMBOLS = {
     "kx_attention": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "kx_row_stats_finalize": (C.c_int, [vp, i64, i64, i64, f32, vp, vp]),
     "kx_embed_splice": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i64, vp]),
+    "kx_token_range": (C.c_int, [vp, i64, vp, vp]),
     "kx_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "kx_prof_enable": (C.c_int, [C.c_int]),
     "kx_prof_collect": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),

@@ -132,21 +132,41 @@ class _PackedMixin:
 
     def _packed_init(self):
         self._packed = {}
+        self._pack_gen = 0      # bumped on every invalidation: captured hipGraphs (raw pointers into `_packed`) check it
+
+    def _drop_packed(self):
+        self._packed = {}
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1
 
     def invalidate_packed(self):
-        self._packed = {}
+        self._drop_packed()
         for m in self.children():
             if isinstance(m, _PackedMixin):
                 m.invalidate_packed()
 
     def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float() ...
         out = super()._apply(fn, *a, **k)
-        self._packed = {}
+        self._drop_packed()
         return out
 
     def _load_from_state_dict(self, *a, **k):
-        self._packed = {}
+        self._drop_packed()
         return super()._load_from_state_dict(*a, **k)
+
+
+def _validate_token_ids(tokens: torch.Tensor, vocab: int):
+    """IndexError for ids outside [0, vocab) — what F.embedding raises on the reference's CPU path; the kernels only
+    clamp (memory safety).  One tiny reduction kernel + a 16-byte read-back; skipped while a hipGraph is being captured
+    (the graphed forward validates the live inputs before it replays)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    mm = torch.empty(2, dtype=torch.int64, device=tokens.device)
+    H.check(H.load().kx_token_range(tokens.data_ptr(), tokens.numel(), mm.data_ptr(), _stream()), "kx_token_range")
+    lo, hi = mm.tolist()
+    if lo < 0 or hi >= vocab:
+        msg = f"index out of range in self: token id {hi if hi >= vocab else lo} outside the {vocab}-row embedding table"
+        logging.error(msg)
+        raise IndexError(msg)
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -419,37 +439,38 @@ class XPOS(nn.Module):
         self.head_dim, self.scale_base = head_dim, scale_base
         self.register_buffer("scale", (torch.arange(0, head_dim, 2) + 0.4 * head_dim) / (1.4 * head_dim))
 
+    def _closed_form(self, first_abs: int, n_rows: int, min_pos: int, downscale: bool):
+        """Rows for absolute positions a = first_abs .. first_abs + n_rows - 1, from the DEFINITION rather than from
+        torchscale's tensor program (the CPU test reference restates that program; this is a separate derivation so that
+        a slip in either shows up as a difference, tests/test_abi.py::test_xpos_tables_closed_form):
+            table[a, j] = cos|sin(theta) * zeta_j ** (+-(a + min_pos) / scale_base),   zeta_j = (2j + 0.4 hd) / (1.4 hd)
+        The scale is evaluated in float64 as exp(e * log(zeta_j)).  The angle keeps the reference's fp32 semantics —
+        theta = fp32(a) * fp32(1 / 10000 ** (j / (hd/2))), what torchscale's fixed_pos_embedding feeds sin/cos: at
+        a ~ 2000 the fp32 product is 1e-4 rad away from the real-number angle, and the reference's logits include that
+        — and cos / sin of that fp32 angle are taken in float64 and rounded once."""
+        import numpy as np
+        hd, half = self.head_dim, self.head_dim // 2
+        j = np.arange(half, dtype=np.float64)
+        log_zeta = np.log((2.0 * j + 0.4 * hd) / (1.4 * hd))
+        a = np.arange(first_abs, first_abs + n_rows, dtype=np.float64)
+        e = (a + float(min_pos)) / float(self.scale_base)
+        scale = np.exp((-e if downscale else e)[:, None] * log_zeta[None, :]).astype(np.float32)
+        inv_freq = (1.0 / (10000 ** (torch.arange(0, half) / half))).numpy()              # fp32, the definition itself
+        theta = (a.astype(np.float32)[:, None] * inv_freq[None, :]).astype(np.float64)     # fp32 product, exactly
+        cos, sin = np.cos(theta).astype(np.float32), np.sin(theta).astype(np.float32)
+        return torch.from_numpy(cos * scale).contiguous(), torch.from_numpy(sin * scale).contiguous()
+
     def tables_centred(self, n_pos: int, centre_len: int, downscale: bool = False):
         """Rows for absolute positions 0..n_pos-1 with the centring constant of a `centre_len`-token sequence
         (min_pos = -(centre_len)//2).  For n_pos == centre_len this is `tables(centre_len)`; incremental decoding
         keeps the prefill's centring for every later position (the constant cancels in q·k)."""
-        zeta = self.scale.detach().to("cpu", torch.float32)
-        min_pos = -(centre_len) // 2
-        scale = zeta ** torch.arange(min_pos, min_pos + n_pos, 1).to(zeta).div(self.scale_base)[:, None]
-        seq_len, dim = scale.shape
-        inv_freq = 1.0 / (10000 ** (torch.arange(0, dim) / dim))
-        sinusoid = torch.einsum("i , j -> i j", torch.arange(0, seq_len, dtype=torch.float), inv_freq).to(scale)
-        sin, cos = torch.sin(sinusoid), torch.cos(sinusoid)
-        if downscale:
-            scale = 1 / scale
-        return (cos * scale).contiguous(), (sin * scale).contiguous()
+        return self._closed_form(0, n_pos, -(centre_len) // 2, downscale)
 
     def tables(self, length: int, offset: int = 0, downscale: bool = False):
-        """(cos*scale, sin*scale) [length, head_dim/2] fp32 — torchscale XPOS.forward +
-        fixed_pos_embedding, same operation order, evaluated once per sequence length on the host."""
-        zeta = self.scale.detach().to("cpu", torch.float32)
-        min_pos = -(length + offset) // 2
-        max_pos = length + offset + min_pos
-        scale = zeta ** torch.arange(min_pos, max_pos, 1).to(zeta).div(self.scale_base)[:, None]
-        seq_len, dim = scale.shape
-        inv_freq = 1.0 / (10000 ** (torch.arange(0, dim) / dim))
-        sinusoid = torch.einsum("i , j -> i j", torch.arange(0, seq_len, dtype=torch.float), inv_freq).to(scale)
-        sin, cos = torch.sin(sinusoid), torch.cos(sinusoid)
-        if scale.shape[0] > length:
-            scale, sin, cos = scale[-length:], sin[-length:], cos[-length:]
-        if downscale:
-            scale = 1 / scale
-        return (cos * scale).contiguous(), (sin * scale).contiguous()
+        """(cos*scale, sin*scale) [length, head_dim/2] fp32 — what torchscale's XPOS.forward + fixed_pos_embedding
+        produce for a `length`-token call at `offset` (rows = absolute positions offset .. offset+length-1, exponent
+        centred with min_pos = -(length + offset) // 2, Python floor division)."""
+        return self._closed_form(offset, length, -(length + offset) // 2, downscale)
 
 
 class MultiheadAttention(nn.Module):
@@ -580,6 +601,8 @@ class Decoder(_PackedMixin, nn.Module):
                 tokens = tokens.long()  # F.embedding accepts int32/int64 indices
             tokens = tokens.contiguous()
             B, Tt = tokens.shape
+            if getattr(self, "validate_token_ids", True) and tokens.numel():
+                _validate_token_ids(tokens, emb.shape[0])
         else:
             B, Tt = img.shape[0], 0
         n_img = 0 if img is None else img.shape[1]
@@ -900,6 +923,11 @@ class Kosmos(nn.Module):
         key = (tuple(text_tokens.shape), tuple(images.shape), images.dtype, self.precision, text_tokens.device,
                torch.cuda.current_stream(text_tokens.device).cuda_stream)
         ent = self._graphs.get(key)
+        gen = (self.clip_model._pack_gen, self.perceive._pack_gen, self.decoder._pack_gen)
+        if ent is not None and ent[5] != gen:       # weights re-packed since capture (load_state_dict, .to(), an
+            ent = None                              # in-place update + invalidate_packed): the graph's pointers are stale
+        if getattr(self.decoder, "validate_token_ids", True) and text_tokens.numel():
+            _validate_token_ids(text_tokens.long().contiguous(), self.embed.weight.shape[0])
         if ent is None:
             self._forward_impl(text_tokens, images)          # warm-up: packs weights, sizes workspaces, uploads tables
             torch.cuda.synchronize(text_tokens.device)
@@ -908,7 +936,8 @@ class Kosmos(nn.Module):
             cap = torch.cuda.Stream(device=text_tokens.device)
             with torch.cuda.graph(g, stream=cap):
                 s_out = self._forward_impl(s_tok, s_img)
-            ent = self._graphs[key] = (g, s_tok, s_img, s_out, cap)
+            gen = (self.clip_model._pack_gen, self.perceive._pack_gen, self.decoder._pack_gen)
+            ent = self._graphs[key] = (g, s_tok, s_img, s_out, cap, gen)
         g, s_tok, s_img, s_out = ent[:4]
         s_tok.copy_(text_tokens)
         s_img.copy_(images)
@@ -932,7 +961,7 @@ class Kosmos(nn.Module):
             logging.error(f"Failed during text processing: {e}")
             raise
         try:
-            return self.decoder.run(model_input, prec)                              # :250
+            return self.decoder.run(model_input, prec, getattr(self, "logits_dtype", torch.float32))   # :250
         except Exception as e:
             logging.error(f"Failed during model forward pass: {e}")
             raise

@@ -21,34 +21,84 @@ def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
 
 
 class LogitsGatherer:
-    """All-gather of per-rank logits ``[b, T, V]`` into ``[world*b, T, V]`` (rank-major = global batch order
-    when the batch was split with ``shard_range`` into equal shards).
+    """All-gather of per-rank logits ``[b_r, T, V]`` into ``[sum(b_r), T, V]`` (rank-major = global batch order when the
+    batch was split with ``shard_range``).
 
-    On HIP devices the collective is issued on a side stream so that the gather of step k overlaps the
-    compute of step k+1 (the gathered tensor of step k is safe to read after ``wait()``); payload dtype is
-    configurable because xGMI is per-link bound (7 links x ~153 GB/s): bf16 halves the bytes on the wire.
+    * On HIP devices the exchange is issued on a side stream so that the gather of step k overlaps the compute of step
+      k+1; the gathered tensor of step k is safe to read after ``wait()`` and stays valid until ``slots - 1`` further
+      gathers have been issued (``slots`` output buffers are cycled; use pipeline depth + 1).
+    * Payload: xGMI is per-link bound (7 links x ~153 GB/s), so bytes matter.  ``wire_dtype=None`` sends ``local`` as it
+      is — the intended use is a model that already emits bf16 logits straight from the logits GEMM's epilogue
+      (``model.logits_dtype = torch.bfloat16``), so no cast kernel runs; a dtype here casts first.
+    * ``algo="all_gather"``: one ``all_gather_into_tensor`` (RCCL picks ring / tree).  ``algo="direct"``: world - 1
+      grouped send / recv pairs, every peer over its own xGMI link at once — the fully-connected schedule SURVEY 8e
+      computes at ~1/7 of a ring's time for this message (233 MB per rank in bf16 at 32 samples per GPU).
+    * Ragged shards (global batch not divisible by world): rows are padded to the largest shard for ``all_gather`` and
+      the padding is dropped; ``direct`` sends exact sizes.  Shard sizes are exchanged once per distinct local size.
     """
 
     def __init__(self, group=None, wire_dtype: torch.dtype | None = torch.bfloat16, overlap: bool = True,
-                 force: bool = False):
+                 force: bool = False, algo: str = "all_gather", slots: int = 3):
+        if algo not in ("all_gather", "direct"):
+            raise ValueError("algo must be 'all_gather' or 'direct'")
         self.group = group
         self.force = force          # run the collective even with a single rank (exercises the RCCL path in tests)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.wire_dtype = wire_dtype
         self.overlap = overlap
+        self.algo = algo
         self._stream = None
         self._pending = []   # (event, send buffer) kept alive until wait()
         self._slot = 0
-        self._out = [None, None]
+        self._out = [None] * max(2, int(slots))
+        self._sizes = {}     # local rows -> [rows of every rank]
+
+    def _shard_sizes(self, rows: int, device) -> list:
+        sizes = self._sizes.get(rows)
+        if sizes is None:
+            t = torch.tensor([rows], dtype=torch.int64, device=device)
+            allr = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(allr, t, group=self.group)
+            sizes = self._sizes[rows] = [int(x.item()) for x in allr]
+        return sizes
+
+    def _exchange(self, out, wire, sizes):
+        if self.algo == "direct" and self.world > 1:
+            offs = [0]
+            for n in sizes:
+                offs.append(offs[-1] + n)
+            out[offs[self.rank]:offs[self.rank + 1]].copy_(wire)
+            ops = []
+            for d in range(1, self.world):                      # peer order staggered by rank: every link busy at once
+                dst, src = (self.rank + d) % self.world, (self.rank - d) % self.world
+                ops.append(dist.P2POp(dist.isend, wire, dst, self.group))
+                ops.append(dist.P2POp(dist.irecv, out[offs[src]:offs[src + 1]], src, self.group))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            return out
+        if len(set(sizes)) == 1:
+            dist.all_gather_into_tensor(out, wire, group=self.group)
+            return out
+        mx = max(sizes)                                         # ragged: pad to the largest shard, drop the padding
+        padded = wire if wire.shape[0] == mx else torch.cat([wire, wire.new_zeros((mx - wire.shape[0],) + tuple(wire.shape[1:]))])
+        full = wire.new_empty((self.world * mx,) + tuple(wire.shape[1:]))
+        dist.all_gather_into_tensor(full, padded.contiguous(), group=self.group)
+        lo = 0
+        for r, n in enumerate(sizes):
+            out[lo:lo + n].copy_(full[r * mx:r * mx + n])
+            lo += n
+        return out
 
     def gather(self, local: torch.Tensor) -> torch.Tensor:
         if self.world == 1 and not self.force:
             return local
-        wire = local if self.wire_dtype is None else local.to(self.wire_dtype)
+        wire = local if (self.wire_dtype is None or local.dtype == self.wire_dtype) else local.to(self.wire_dtype)
         wire = wire.contiguous()
-        shape = (self.world * wire.shape[0],) + tuple(wire.shape[1:])
+        sizes = self._shard_sizes(wire.shape[0], wire.device) if self.world > 1 else [wire.shape[0]]
+        shape = (sum(sizes),) + tuple(wire.shape[1:])
         slot = self._slot
-        self._slot ^= 1
+        self._slot = (self._slot + 1) % len(self._out)
         out = self._out[slot]
         if out is None or out.shape != shape or out.dtype != wire.dtype or out.device != wire.device:
             out = self._out[slot] = torch.empty(shape, dtype=wire.dtype, device=wire.device)
@@ -57,19 +107,19 @@ class LogitsGatherer:
                 self._stream = torch.cuda.Stream(device=wire.device)
             self._stream.wait_stream(torch.cuda.current_stream(wire.device))
             with torch.cuda.stream(self._stream):
-                dist.all_gather_into_tensor(out, wire, group=self.group)
+                self._exchange(out, wire, sizes)
                 ev = torch.cuda.Event()
                 ev.record(self._stream)
             wire.record_stream(self._stream)
             self._pending.append((ev, wire))
         else:
-            dist.all_gather_into_tensor(out, wire, group=self.group)
+            self._exchange(out, wire, sizes)
         return out
 
     def wait(self):
-        """Make every gather issued so far visible to the current stream."""
-        for ev, _ in self._pending:
-            torch.cuda.current_stream().wait_event(ev)
+        """Make every gather issued so far visible to the current stream of the device that issued it."""
+        for ev, wire in self._pending:
+            torch.cuda.current_stream(wire.device).wait_event(ev)
         self._pending.clear()
 
 

@@ -16,11 +16,13 @@ No CPU fallback; Python only sequences launches.
 """
 from __future__ import annotations
 
+import logging
+
 import torch
 
 from . import grad_ops as G
 from . import ops
-from .model import KosmosLanguage, _a
+from .model import KosmosLanguage, _a, _validate_token_ids
 
 
 def cosine_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5) -> float:
@@ -47,6 +49,12 @@ class LanguageModelTrainer:
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.weight_decay, self.max_grad_norm = weight_decay, max_grad_norm
         self.step_no = 0
+        da = model.decoder.args
+        if max(getattr(da, "dropout", 0.0), getattr(da, "attention_dropout", 0.0), getattr(da, "activation_dropout", 0.0)) > 0:
+            # the reference trains with dropout 0.1 (/root/reference/kosmosx/model.py:175-177); this step is the
+            # deterministic (eval-mode) forward and its exact gradient — said loudly instead of silently
+            logging.warning("LanguageModelTrainer: dropout / attention_dropout > 0 in the config are NOT applied "
+                            "(deterministic forward; SURVEY H1)")
         self.group = process_group
         self._force_collectives = force_collectives
         self._build_flat()
@@ -105,8 +113,12 @@ class LanguageModelTrainer:
                     ffn_ln=ffn.ffn_layernorm if getattr(ffn, "ffn_layernorm", None) is not None else None)
 
     # ------------------------------------------------------------------ one step
-    def step(self, tokens: torch.Tensor, apply_update: bool = True) -> torch.Tensor:
-        """tokens [B,T] int64 on the device.  Returns the mean next-token cross-entropy (a device scalar)."""
+    def step(self, tokens: torch.Tensor, apply_update: bool = True, accumulate: bool = False) -> torch.Tensor:
+        """tokens [B,T] int64 on the device.  Returns the mean next-token cross-entropy (a device scalar).
+        accumulate=True adds this micro-batch's gradients to what the flat gradient buffer already holds (the
+        reference's gradient-accumulation loop: step(b0, apply_update=False), step(b1, apply_update=False,
+        accumulate=True), ..., step(bn, accumulate=True)); by default the buffer is overwritten."""
+        prev_g = self.flat_g.clone() if accumulate else None
         m, dec = self.model, self.model.decoder
         a = dec.args
         if not isinstance(tokens, torch.Tensor) or tokens.dim() != 2 or not tokens.is_cuda:
@@ -117,9 +129,10 @@ class LanguageModelTrainer:
         if T + 2 > self.model.embed_positions.weight.shape[0]:
             raise IndexError(f"index out of range in self: {T} tokens exceed the position table")
         D, F, Hh, V = a.decoder_embed_dim, a.decoder_ffn_embed_dim, a.decoder_attention_heads, a.vocab_size
-        M, eps = B * T, 1e-5
+        M, eps = B * T, float(a.layernorm_eps)
         dev = tokens.device
         tokens = tokens.long().contiguous()
+        _validate_token_ids(tokens, V)                        # ids >= V would silently train against a clamped row
         grads = self.grads                                    # views into the flat gradient buffer
         world = self.zero.world
 
@@ -275,6 +288,9 @@ class LanguageModelTrainer:
         if m.embed.padding_idx is not None:
             grads["embed.weight"][m.embed.padding_idx].zero_()     # nn.Embedding(padding_idx) has no gradient there
 
+        if prev_g is not None:
+            self.flat_g.add_(prev_g)
+            del prev_g
         if apply_update:
             self._update()
         return loss

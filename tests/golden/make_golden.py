@@ -11,6 +11,12 @@
   preprocess.npz   seeded uint8 images of five sizes + the uint8 resize/centre-crop result and the normalisation
                    table recovered from the INSTALLED HF CLIPImageProcessor's pixel_values (Pillow resampler
                    underneath), and the float pixel_values of image 0.
+  kosmos2_text.npz weights + embedded input + last_hidden_state of the INSTALLED HF Kosmos2TextTransformer (Microsoft's
+                   port of the torchscale/fairseq sub-LN decoder: 3 layers, inner_attn_ln / ffn_layernorm, final layer_norm;
+                   no XPos, no multiway) — the whole decoder STACK, not one block.
+  idefics_resampler.npz  weights + context + output of the INSTALLED HF IdeficsPerceiverResampler ("code borrowed from
+                   lucidrains/flamingo-pytorch"), whole module (latents, 2 blocks, residuals, final norm), with its
+                   MLP activation object swapped from ReLU to GELU(erf) — flamingo-pytorch's — nothing else touched.
 Fixtures are data (inputs and expected outputs) — no reference source text is stored.
 """
 import os
@@ -70,6 +76,54 @@ def make_clip():
     np.savez_compressed(HERE / "clip_tiny.npz", pixels=x.numpy(), last_hidden_state=y.numpy(), **out)
 
 
+def make_kosmos2_text():
+    """SURVEY §8c S1, widened from one block to the whole stack (VERDICT r1 next #6b)."""
+    from transformers.models.kosmos2.configuration_kosmos2 import Kosmos2TextConfig
+    from transformers.models.kosmos2.modeling_kosmos2 import Kosmos2TextTransformer
+    cfg = Kosmos2TextConfig(vocab_size=300, embed_dim=128, layers=3, ffn_dim=256, attention_heads=2, dropout=0.0,
+                            attention_dropout=0.0, activation_dropout=0.0, layerdrop=0.0, scale_embedding=False,
+                            layer_norm_eps=1e-5, max_position_embeddings=64, activation_function="gelu")
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(0)
+    hf = Kosmos2TextTransformer(cfg).eval()
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():
+            if "layer_norm" in n_ or "_ln" in n_ or "layernorm" in n_:
+                p_.copy_((1.0 if n_.endswith("weight") else 0.0) + 0.2 * torch.randn(p_.shape, generator=g))
+            else:
+                p_.copy_(torch.randn(p_.shape, generator=g) * (0.2 if n_.endswith("bias") else 0.06))
+        ids = torch.randint(2, 300, (2, 13), generator=g)
+        x = hf.forward_embedding(input_ids=ids)                       # token embedding + sinusoidal positions
+        y = hf(input_ids=ids).last_hidden_state
+    out = {"w:" + k: v.numpy() for k, v in hf.state_dict().items() if v.dtype == torch.float32 and "embed_" not in k}
+    np.savez_compressed(HERE / "kosmos2_text.npz", x=x.numpy(), last_hidden_state=y.numpy(), **out)
+
+
+def make_idefics_resampler():
+    """SURVEY §8c S2, widened from the attention to the whole resampler."""
+    from transformers.models.idefics.configuration_idefics import IdeficsConfig
+    from transformers.models.idefics.perceiver import IdeficsPerceiverResampler
+    cfg = IdeficsConfig()
+    cfg.vision_config.embed_dim = 128
+    cfg.perceiver_config.qk_layer_norms_perceiver = False
+    torch.manual_seed(0)
+    hf = IdeficsPerceiverResampler(cfg, embed_dim=128, depth=2, n_heads=2, head_dim=64, n_latents=8).eval()
+    for _, ff in hf.blocks:
+        ff.act = torch.nn.GELU()                                       # flamingo-pytorch's FeedForward activation
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():
+            if "norm" in n_ or n_.endswith("ln.weight") or n_.endswith("ln.bias"):
+                p_.copy_((1.0 if n_.endswith("weight") else 0.0) + 0.2 * torch.randn(p_.shape, generator=g))
+            else:
+                p_.copy_(torch.randn(p_.shape, generator=g) * (1.0 if n_ == "latents" else 0.08))
+        ctx = torch.randn(3, 17, 128, generator=g)
+        y = hf(ctx)
+    out = {"w:" + k: v.numpy() for k, v in hf.state_dict().items()}
+    np.savez_compressed(HERE / "idefics_resampler.npz", context=ctx.numpy(), out=y.numpy(), **out)
+
+
 def make_kosmos():
     from helpers import oracle_cfg, oracle_weights, tiny_config
     from kosmosx.model import Kosmos
@@ -97,7 +151,8 @@ def make_xpos():
 
 if __name__ == "__main__":
     only = sys.argv[1:]            # e.g. `make_golden.py preprocess` regenerates one fixture
-    for name, fn in (("clip", make_clip), ("kosmos", make_kosmos), ("xpos", make_xpos), ("preprocess", make_preprocess)):
+    for name, fn in (("clip", make_clip), ("kosmos", make_kosmos), ("xpos", make_xpos), ("preprocess", make_preprocess),
+                     ("kosmos2_text", make_kosmos2_text), ("idefics_resampler", make_idefics_resampler)):
         if not only or name in only:
             fn()
     for f in sorted(HERE.glob("*.npz")):

@@ -154,3 +154,42 @@ def test_state_dict_namespace_matches_the_reference():
             c.decoder.decoder_ffn_embed_dim, c.decoder.decoder_attention_heads) == (32002, 2048, 24, 2048, 8192, 32)
     assert (c.vit.layers, c.vit.dim, c.vit.heads, c.vit.ffn, c.vit.tokens) == (24, 1024, 16, 4096, 257)
     assert (c.perceiver.depth, c.perceiver.latents, c.perceiver.heads, c.perceiver.media_embeds) == (2, 64, 8, 257)
+
+
+def test_xpos_tables_closed_form():
+    """The product derives its XPos tables from the definition in float64 (model.XPOS._closed_form); the oracle restates
+    torchscale's fp32 tensor program (oracle.xpos_tables).  Two derivations, one answer to fp32 rounding — for every
+    length/offset the forward and the incremental path use, odd and even (Python floor division in min_pos)."""
+    import numpy as np
+    import torch
+    from pathlib import Path
+    from kosmosx.model import XPOS
+    from oracle import kosmos_oracle as O
+    xp = XPOS(64)
+    for T, off in ((1, 0), (2, 0), (9, 0), (114, 0), (115, 0), (2046, 0), (1, 113), (1, 114), (7, 30)):
+        for down in (False, True):
+            pc, ps = xp.tables(T, off, down)
+            oc, os_ = O.xpos_tables(T, 64, 512, off, down)
+            scale = float(oc.abs().max())
+            assert float((pc - oc).abs().max()) < 4e-7 * max(1.0, scale) and float((ps - os_).abs().max()) < 4e-7 * max(1.0, scale)
+    z = np.load(Path(__file__).resolve().parent / "golden" / "xpos_tables.npz")
+    for T in (1, 2, 9, 114, 115):
+        assert np.abs(xp.tables(T, 0, False)[0].numpy() - z[f"q_cs_{T}"]).max() < 4e-7 * 4
+        assert np.abs(xp.tables(T, 0, True)[1].numpy() - z[f"k_ss_{T}"]).max() < 4e-7 * 4
+    # incremental decoding: rows of tables_centred(n, centre) == rows of tables(centre) where they overlap
+    a, b = xp.tables_centred(200, 114, True), xp.tables(114, 0, True)
+    assert torch.equal(a[0][:114], b[0]) and torch.equal(a[1][:114], b[1])
+    # the relative-position property on the product's own tables: <xpos_q(q)_i, xpos_k(k)_m> depends on i - m only
+    g = torch.Generator().manual_seed(0)
+    q, k = torch.randn(64, generator=g), torch.randn(64, generator=g)
+
+    def rot(x, cs, ss, p):
+        x1, x2 = x[0::2], x[1::2]
+        return torch.stack((x1 * cs[p] - x2 * ss[p], x2 * cs[p] + x1 * ss[p]), -1).flatten()
+    vals = []
+    for L in (64, 115, 2046):
+        qc, qs = xp.tables(L, 0, False)
+        kc, ks = xp.tables(L, 0, True)
+        for i, m in ((10, 3), (40, 33), (57, 50)):
+            vals.append(float(rot(q, qc, qs, i) @ rot(k, kc, ks, m)))
+    assert max(vals) - min(vals) < 2e-4 * abs(vals[0]), vals

@@ -158,3 +158,42 @@ def test_zero_shard_regions_cover_the_parameters_once():
                     seen[a:b] += 1
                     assert (b <= n_decay) if dec else (a >= n_decay)
             assert int(seen.min()) == 1 and int(seen.max()) == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# LogitsGatherer variants: the direct (grouped send/recv, one xGMI link per peer) schedule and ragged shards
+# ---------------------------------------------------------------------------------------------
+def _gather_worker(rank, world, port, algo, total, q):
+    for p in (str(ROOT), str(ROOT / "kosmos-x_amd"), str(ROOT / "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KOSMOSX_NO_LOGGING_CONFIG="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kosmosx.parallel import LogitsGatherer, shard_range
+    full = torch.arange(total * 3 * 5, dtype=torch.float32).reshape(total, 3, 5)
+    lo, hi = shard_range(total, rank, world)
+    ga = LogitsGatherer(wire_dtype=None, algo=algo, slots=3)
+    outs = [ga.gather(full[lo:hi] + k).clone() for k in range(4)]     # more gathers than slots: buffers are recycled
+    ga.wait()
+    if rank == 0:
+        q.put(outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo", ["all_gather", "direct"])
+@pytest.mark.parametrize("world,total", [(2, 8), (2, 7), (3, 8)])
+def test_logits_gatherer_algorithms_and_ragged_shards(algo, world, total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, algo, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    full = torch.arange(total * 3 * 5, dtype=torch.float32).reshape(total, 3, 5)
+    for k, o in enumerate(outs):
+        assert torch.equal(o, full + k), (algo, world, total, k)
