@@ -3,6 +3,8 @@
 // orchestration: no allocation, no synchronisation, everything asynchronous on the caller's stream
 // (hipGraph-capturable).  Scratch comes from one caller-owned workspace carved deterministically.
 #include <stdarg.h>
+#include <atomic>
+#include <mutex>
 #include <vector>
 #include "kx_common.h"
 
@@ -30,14 +32,16 @@ extern "C" int kx_last_error(char* buf, size_t n) {
 // ---------------------------------------------------------------------------------------------
 // tuning knobs (kernel-variant A/B from one process; defaults are the shipped configuration)
 // ---------------------------------------------------------------------------------------------
-static int g_tuning[KX_TUNE_COUNT] = {0};
-int kx_tuning_get(int key) { return (key >= 0 && key < KX_TUNE_COUNT) ? g_tuning[key] : 0; }
+// Process-wide A/B switches (not part of the forward's state: defaults are the shipped configuration).  Atomics, so that
+// a tool flipping a knob from one thread while another thread launches is a data-race-free read of either value.
+static std::atomic<int> g_tuning[KX_TUNE_COUNT];
+int kx_tuning_get(int key) { return (key >= 0 && key < KX_TUNE_COUNT) ? g_tuning[key].load(std::memory_order_relaxed) : 0; }
 extern "C" int kx_set_tuning(int key, int value) {
   if (key < 0 || key >= KX_TUNE_COUNT) {
     kx_set_error("kx_set_tuning: unknown key %d", key);
     return KX_ERR_INVALID_ARG;
   }
-  g_tuning[key] = value;
+  g_tuning[key].store(value, std::memory_order_relaxed);
   return KX_OK;
 }
 
@@ -45,10 +49,15 @@ extern "C" int kx_set_tuning(int key, int value) {
 // launch timing
 // ---------------------------------------------------------------------------------------------
 namespace {
+// Launch timing is a process-wide recorder (one list of records, in launch order per thread): every access takes
+// g_prof_mu, so launches from several host threads / streams interleave safely; the enable flag is an atomic that
+// the fast path (profiling off) reads without the lock.
 struct ProfRec { int kind; int64_t a, b, c; hipEvent_t e0, e1; };
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;
-bool g_prof_enabled = false;
+std::mutex g_prof_mu;
+std::atomic<bool> g_prof_enabled{false};
+thread_local size_t g_prof_open = 0;      // index of this thread's record between kx_prof_begin and kx_prof_end
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
   hipEvent_t e;
@@ -56,20 +65,27 @@ hipEvent_t prof_event() {
   return e;
 }
 }  // namespace
-bool kx_prof_on() { return g_prof_enabled; }
+bool kx_prof_on() { return g_prof_enabled.load(std::memory_order_relaxed); }
 void kx_prof_begin(int kind, int64_t a, int64_t b, int64_t c, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r{kind, a, b, c, prof_event(), prof_event()};
   (void)hipEventRecord(r.e0, s);
+  g_prof_open = g_prof.size();
   g_prof.push_back(r);
 }
-void kx_prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().e1, s); }
+void kx_prof_end(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_open < g_prof.size()) (void)hipEventRecord(g_prof[g_prof_open].e1, s);
+}
 extern "C" int kx_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
   g_prof.clear();
-  g_prof_enabled = on != 0;
+  g_prof_enabled.store(on != 0, std::memory_order_relaxed);
   return KX_OK;
 }
 extern "C" int kx_prof_collect(kx_prof_record* out, int max_records) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   int n = 0;
   for (auto& r : g_prof) {
     if (n >= max_records) break;

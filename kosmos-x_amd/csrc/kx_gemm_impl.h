@@ -4,6 +4,8 @@
 // kx_gemm_f16c.hip (KX_F16C).  kx_gemm.hip keeps the argument checks and the variant choice.
 #pragma once
 #include "kx_common.h"
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 struct GemmParams {
@@ -1331,16 +1333,17 @@ int launch_p5(GemmParams& p, hipStream_t s) {
   return launch_p5e<T, BM, 0>(p, s);
 }
 
-// CUs of the current device (one process drives one GPU; cached after the first call)
+// CUs of the current device, cached per device ordinal (relaxed atomics: racing first calls store the same value)
 int kx_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev].store(n, std::memory_order_relaxed);
   }
-  return cus;
+  return n;
 }
 
 int launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
@@ -1511,14 +1514,13 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
   const int x_pitch = p.ln_g ? p.K * 2 + 16 : 0;
   const size_t lds = (size_t)S * 1024 + 128 + (size_t)(p.ln_g ? p.M : 0) * x_pitch;
   const dim3 grid((unsigned)((p.N + 15) / 16)), block(64 * S);
-  static bool attr_set = false;
-  if (!attr_set) {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_QUICK_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  });
   switch (p.act) {
     case KX_ACT_NONE: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_NONE>, grid, block, lds, s, p, S, kw, x_pitch); break;
     case KX_ACT_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;

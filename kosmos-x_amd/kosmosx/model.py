@@ -404,25 +404,34 @@ class PositionalEmbedding(nn.Embedding):
 
 
 class MultiwayNetwork(nn.Module):
-    """torchscale MultiwayNetwork with split_position == -1: forward == A.  The B copy is never
-    allocated; it is emitted into / accepted from state_dicts as an alias of A (B = deepcopy(A) at init)."""
+    """torchscale MultiwayNetwork with split_position == -1: forward == A.  The B copy is dead weight on
+    this path and is never allocated on the device.  state_dict round trip: a checkpoint whose B tensors differ from A
+    (torchscale initialises B = deepcopy(A), training can move them apart) keeps them — parked on the host in
+    `_b_store`, re-emitted unchanged on save; without stored tensors B is emitted as an alias of A."""
 
     def __init__(self, module: nn.Module):
         super().__init__()
         self.A = module
         self.split_position = -1
+        self._b_store = {}
         self._register_state_dict_hook(MultiwayNetwork._emit_b)
-        self._register_load_state_dict_pre_hook(MultiwayNetwork._drop_b, with_module=True)
+        self._register_load_state_dict_pre_hook(MultiwayNetwork._keep_b, with_module=True)
 
     @staticmethod
     def _emit_b(module, state_dict, prefix, local_metadata):
         for k in [k for k in state_dict if k.startswith(prefix + "A.")]:
-            state_dict[prefix + "B." + k[len(prefix) + 2:]] = state_dict[k]
+            suffix = k[len(prefix) + 2:]
+            state_dict[prefix + "B." + suffix] = module._b_store.get(suffix, state_dict[k])
 
     @staticmethod
-    def _drop_b(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    def _keep_b(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        store = {}
         for k in [k for k in state_dict if k.startswith(prefix + "B.")]:
-            del state_dict[k]
+            suffix = k[len(prefix) + 2:]
+            v, a = state_dict.pop(k), state_dict.get(prefix + "A." + suffix)
+            if a is None or v.shape != a.shape or not torch.equal(v.detach().cpu(), a.detach().cpu()):
+                store[suffix] = v.detach().to("cpu").clone()
+        module._b_store = store
 
 
 def _mw(multiway: bool, module: nn.Module) -> nn.Module:

@@ -23,7 +23,8 @@ def test_safetensors_and_pt_round_trip(tmp_path):
 
 
 def test_reference_style_checkpoint_with_materialised_b_copies_loads(tmp_path):
-    """A torchscale checkpoint carries real (trained-apart) B tensors: they are accepted and ignored."""
+    """A torchscale checkpoint carries real (trained-apart) B tensors: the forward ignores them, the state_dict keeps them
+    (host-side, never uploaded) and writes them back unchanged."""
     a = Kosmos._from_config(tiny_config(), seed=3)
     sd = {k: v.clone() for k, v in a.state_dict().items()}
     for k in sd:
@@ -34,4 +35,20 @@ def test_reference_style_checkpoint_with_materialised_b_copies_loads(tmp_path):
     b = Kosmos._from_config(tiny_config(), seed=4)
     load_checkpoint(b, path)
     assert torch.equal(b.state_dict()["decoder.layers.0.ffn.A.fc1.weight"], sd["decoder.layers.0.ffn.A.fc1.weight"])
-    assert torch.equal(b.state_dict()["decoder.layers.0.ffn.B.fc1.weight"], sd["decoder.layers.0.ffn.A.fc1.weight"])
+    assert torch.equal(b.state_dict()["decoder.layers.0.ffn.B.fc1.weight"], sd["decoder.layers.0.ffn.B.fc1.weight"])
+    assert not torch.equal(sd["decoder.layers.0.ffn.B.fc1.weight"], sd["decoder.layers.0.ffn.A.fc1.weight"])
+    # save -> load keeps them too (both file formats), and no device memory is spent on them
+    for name in ("rt.pt", "rt.safetensors"):
+        p2 = str(tmp_path / name)
+        save_checkpoint(b, p2, include_multiway_b=True)
+        c = Kosmos._from_config(tiny_config(), seed=5)
+        load_checkpoint(c, p2)
+        assert all(torch.equal(c.state_dict()[k], sd[k]) for k in sd), name
+    assert not any(".B." in n for n, _ in b.named_parameters())
+    # a checkpoint whose B copies equal A stores nothing
+    d = Kosmos._from_config(tiny_config(), seed=6)
+    load_checkpoint(d, str(tmp_path / "ref.pt"))
+    sd2 = {k: v.clone() for k, v in a.state_dict().items()}
+    torch.save(sd2, str(tmp_path / "same.pt"))
+    load_checkpoint(d, str(tmp_path / "same.pt"))
+    assert all(len(m._b_store) == 0 for m in d.modules() if hasattr(m, "_b_store"))

@@ -161,3 +161,29 @@ def test_hip_resampler_matches_hf_idefics_fixture(prec, tol):
     e = float((out.cpu() - ref).abs().max() / ref.pow(2).mean().sqrt())
     print(f"HIP resampler vs HF IdeficsPerceiverResampler fixture [{prec}]: max|d|/rms = {e:.3e}")
     assert e < tol, e
+
+
+@pytest.mark.gpu
+def test_hf_clip_checkpoint_through_load_checkpoint_matches_hf_output(tmp_path):
+    """a file holding HF CLIPVisionModel's state_dict under the reference's `clip_model.` prefix goes
+    through kosmosx.checkpoint.load_checkpoint into a Kosmos with that tower shape, and the HIP tower reproduces HF's
+    last_hidden_state (clip_tiny.npz carries weights and output of the installed HF implementation)."""
+    from helpers import tiny_config
+    from kosmosx.checkpoint import load_checkpoint
+    from kosmosx.config import VitConfig
+    from kosmosx.model import Kosmos
+    z = np.load(G / "clip_tiny.npz")
+    cfg = tiny_config()
+    cfg.vit = VitConfig(image=28, patch=14, dim=128, heads=2, ffn=128, layers=1, act="gelu")
+    cfg.perceiver.media_embeds = 5
+    m = Kosmos._from_config(cfg, seed=0).eval()
+    sd = {"clip_model." + k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    path = str(tmp_path / "clip_only.pt")
+    torch.save(sd, path)
+    res = load_checkpoint(m, path, strict=False)
+    assert not res.unexpected_keys and not any(k.startswith("clip_model.") and "position_ids" not in k for k in res.missing_keys)
+    m = m.to("cuda")
+    m.precision = "fp32"
+    out = m.clip_model(pixel_values=torch.from_numpy(z["pixels"]).cuda())["last_hidden_state"]
+    ref = torch.from_numpy(z["last_hidden_state"])
+    assert float((out.cpu() - ref).abs().max() / ref.pow(2).mean().sqrt()) < 2e-5

@@ -53,16 +53,42 @@ def mm_format(a, w, fmt):
     raise ValueError(fmt)
 
 
+FAMILIES = ["vit.qkv", "vit.out", "vit.fc1", "vit.fc2", "perceiver", "image_proj", "dec.qkv", "dec.out", "dec.fc1",
+            "dec.fc2", "logits"]
+
+
+def family_of(name: str) -> str:
+    if name.startswith("clip_model."):
+        return ("vit.qkv" if any(t in name for t in ("q_proj", "k_proj", "v_proj")) else "vit.out" if "out_proj" in name
+                else "vit.fc1" if "fc1" in name else "vit.fc2" if "fc2" in name else "vit.other")
+    if name.startswith("perceive."):
+        return "perceiver"
+    if name.startswith("image_proj"):
+        return "image_proj"
+    if name.startswith("output_projection"):
+        return "logits"
+    if name.startswith("decoder."):
+        return ("dec.qkv" if any(t in name for t in ("q_proj", "k_proj", "v_proj")) else "dec.out" if "out_proj" in name
+                else "dec.fc1" if "fc1" in name else "dec.fc2" if "fc2" in name else "dec.other")
+    return "other"
+
+
 class Study:
-    def __init__(self, lin_fmt, attn_fmt):
+    def __init__(self, lin_fmt, attn_fmt, weights=None, override=None):
+        """override = {family: format}: those GEMM families use another operand format (error-budget runs)."""
         self.lin_fmt, self.attn_fmt = lin_fmt, attn_fmt
+        self.override = override or {}
+        self.fam = {id(v): family_of(k) for k, v in (weights or {}).items()}
 
     def linear(self, x, w, b, sw):
-        y = mm_format(x.reshape(-1, x.shape[-1]), w, self.lin_fmt).reshape(*x.shape[:-1], w.shape[0])
+        fmt = self.override.get(self.fam.get(id(w), "other"), self.lin_fmt)
+        y = mm_format(x.reshape(-1, x.shape[-1]), w, fmt).reshape(*x.shape[:-1], w.shape[0])
         return y if b is None else y + b
 
     def r(self, x, sw):   # attention operands (q, k, p, v)
         f = self.attn_fmt
+        if x.dim() == 4 and x.shape[1] == 16 and "vit.attn" in self.override:   # the ViT's [B,16,257,*] operands
+            f = self.override["vit.attn"]
         if f == "fp32":
             return x
         if f == "bf16":
@@ -81,6 +107,9 @@ def main():
     ap.add_argument("--formats", default="bf16,fp16,f16x2a,f16c,f16c_static,bf16x3")
     ap.add_argument("--attn", default="match")
     ap.add_argument("--text", type=int, default=50)
+    ap.add_argument("--mix", default="", help="one run with several families overridden: fam=fmt,fam=fmt (vit.attn too)")
+    ap.add_argument("--budget", default="", help="error budget: run BASE with ONE GEMM family at a time in this cheaper "
+                                                 "format, e.g. --budget fp16 (base format = first of --formats)")
     a = ap.parse_args()
     from kosmosx.model import Kosmos
     from helpers import oracle_cfg, oracle_weights, tiny_config
@@ -95,6 +124,31 @@ def main():
     rms = float(ref.pow(2).mean().sqrt())
     print(f"fp32 oracle: {time.time() - t0:.1f} s, logits rms {rms:.4f}", flush=True)
     lin0, r0 = O.linear, O._r
+    if a.mix:
+        base = a.formats.split(",")[0]
+        ov = dict(kv.split("=") for kv in a.mix.split(","))
+        st = Study(base, "split", w, ov)
+        O.linear, O._r = st.linear, st.r
+        out = O.kosmos_forward(w, tok, img, cfg, O.Switches(emulate_bf16=True))
+        O.linear, O._r = lin0, r0
+        d = out - ref
+        print(f"{base} with {ov}: max|d|/rms = {float(d.abs().max()) / rms:.3e}   rms(d)/rms = {float(d.pow(2).mean().sqrt()) / rms:.3e}")
+        return
+    if a.budget:
+        base = a.formats.split(",")[0]
+        print(f"error budget: everything {base} (attention split), one GEMM family at a time in {a.budget}")
+        tot = 0.0
+        for fam in FAMILIES:
+            st = Study(base, "split", w, {fam: a.budget})
+            O.linear, O._r = st.linear, st.r
+            out = O.kosmos_forward(w, tok, img, cfg, O.Switches(emulate_bf16=True))
+            O.linear, O._r = lin0, r0
+            d = out - ref
+            e_max, e_rms = float(d.abs().max()) / rms, float(d.pow(2).mean().sqrt()) / rms
+            tot += e_rms ** 2
+            print(f"  {fam:11s} in {a.budget}: max|d|/rms = {e_max:.3e}   rms(d)/rms = {e_rms:.3e}", flush=True)
+        print(f"  root-sum-square of the family rms errors: {tot ** 0.5:.3e}")
+        return
     for fmt in a.formats.split(","):
         attn = a.attn
         if attn == "match":
