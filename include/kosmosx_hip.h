@@ -59,9 +59,15 @@ typedef enum {
  * activation-side scale is the constant 2^-11.  A packed weight matrix is N such rows followed by the N scale bytes
  * (kx_gemm_args.w_scale).  fp8 conversions saturate at +-448; values must fit fp16 (|a| < 65504).  K % 128 == 0.
  * Attention takes fp32 q/k/v and multiplies fp16 (hi, lo) pairs: three products per score / output, P split the same
- * way.  The residual stream, statistics and accumulators stay fp32. */
-typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3 } kx_precision;
-typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3 } kx_dtype;
+ * way.  The residual stream, statistics and accumulators stay fp32.
+ *
+ * KX_PREC_F16: plain fp16 operands (dtype KX_F16, 2 bytes per value) on the fp16 MFMA — the bf16 pipeline with three
+ * more mantissa bits at the same speed.  On its own it leaves 4.6e-3 on the logits, but the error budget is very uneven
+ * (tools/precision_study.py --budget fp16): the whole CLIP tower in plain fp16 moves the logits by 2.5e-4, every decoder
+ * GEMM family by 1.4-2.7e-3.  The model-level mode "mixed" therefore runs the tower in KX_PREC_F16 and the Perceiver and
+ * decoder in KX_PREC_F16C.  Values must fit fp16 (|x| < 65504). */
+typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3, KX_PREC_F16 = 4 } kx_precision;
+typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3, KX_F16 = 4 } kx_dtype;
 typedef enum { KX_ACT_NONE = 0, KX_ACT_GELU = 1, KX_ACT_QUICK_GELU = 2 } kx_act;
 typedef enum { KX_ATTN_FULL = 0, KX_ATTN_CAUSAL = 1 } kx_attn_mask;
 

@@ -186,7 +186,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 constexpr int VSTR = 80;   // V tile row pitch in elements (160 B)
 
-template <bool CAUSAL>
+// F16: the same kernel on fp16 operands (KX_PREC_F16: q, k, v, P and a 2-byte output in fp16)
+template <bool F16>
+__device__ __forceinline__ f32x4_t mma16(u32x4_t a, u32x4_t b, f32x4_t c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned pack16x2(float lo, float hi) { return F16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
+
+template <bool CAUSAL, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * VSTR];
@@ -269,9 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
               *reinterpret_cast<const u32x4_t*>(&Ks[buf][krow * 64 + (((ks * 4 + g) ^ (krow & 7)) << 3)]);
 #pragma unroll
           for (int qb = 0; qb < 2; ++qb)
-            st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                                 __builtin_bit_cast(bf16x8_t, qf[qb][ks]), st[qb][kb],
-                                                                 0, 0, 0);
+            st[qb][kb] = mma16<F16>(kf, qf[qb][ks], st[qb][kb]);
         }
       }
       // ---- online softmax per query block (query = lane&15; its keys sit in 4 lanes x 16 registers) ----
@@ -325,21 +332,21 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
           for (int r = 0; r < 4; ++r) st[qb][kb][r] = __builtin_amdgcn_exp2f(fmaf(st[qb][kb][r], LOG2E, mneg[qb]));
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          pf[qb][c][0] = pack_bf16x2(st[qb][2 * c][0], st[qb][2 * c][1]);
-          pf[qb][c][1] = pack_bf16x2(st[qb][2 * c][2], st[qb][2 * c][3]);
-          pf[qb][c][2] = pack_bf16x2(st[qb][2 * c + 1][0], st[qb][2 * c + 1][1]);
-          pf[qb][c][3] = pack_bf16x2(st[qb][2 * c + 1][2], st[qb][2 * c + 1][3]);
+          pf[qb][c][0] = pack16x2<F16>(st[qb][2 * c][0], st[qb][2 * c][1]);
+          pf[qb][c][1] = pack16x2<F16>(st[qb][2 * c][2], st[qb][2 * c][3]);
+          pf[qb][c][2] = pack16x2<F16>(st[qb][2 * c + 1][0], st[qb][2 * c + 1][1]);
+          pf[qb][c][3] = pack16x2<F16>(st[qb][2 * c + 1][2], st[qb][2 * c + 1][3]);
         }
       }
       // ---- l += 1^T P^T on the matrix pipe (4 MFMAs replace 32 VALU adds per lane; the kernel is VALU-bound) ----
       {
-        const u32x4_t ones = (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        constexpr unsigned ONE2 = F16 ? 0x3c003c00u : 0x3f803f80u;      // (1.0, 1.0) in fp16 / bf16
+        const u32x4_t ones = (u32x4_t){ONE2, ONE2, ONE2, ONE2};
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
           for (int c = 0; c < 2; ++c)
-            lt[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones),
-                                                             __builtin_bit_cast(bf16x8_t, pf[qb][c]), lt[qb], 0, 0, 0);
+            lt[qb] = mma16<F16>(ones, pf[qb][c], lt[qb]);
       }
       // ---- O^T += V^T P^T : V fragment by transpose-read, k index (g,v) <-> key 32c + 16(v>>2) + 4g + (v&3) ----
 #pragma unroll
@@ -353,9 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
           const u32x4_t vf = (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]};
 #pragma unroll
           for (int qb = 0; qb < 2; ++qb)
-            ot[qb][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf),
-                                                                __builtin_bit_cast(bf16x8_t, pf[qb][c]), ot[qb][d],
-                                                                0, 0, 0);
+            ot[qb][d] = mma16<F16>(vf, pf[qb][c], ot[qb][d]);
         }
     }
     if (t + 1 < ntiles) lstore(buf ^ 1);
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
       for (int d = 0; d < 4; ++d) {
         const float o0 = ot[qb][d][0] * inv, o1 = ot[qb][d][1] * inv, o2 = ot[qb][d][2] * inv, o3 = ot[qb][d][3] * inv;
         if (p.o_bf16) {
-          uint2 pk; pk.x = pack_bf16x2(o0, o1); pk.y = pack_bf16x2(o2, o3);
+          uint2 pk; pk.x = pack16x2<F16>(o0, o1); pk.y = pack16x2<F16>(o2, o3);
           *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + ooff + d * 16) = pk;
         } else {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + ooff + d * 16) = make_float4(o0, o1, o2, o3);
@@ -866,8 +871,12 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   KX_REQUIRE(a->B > 0 && a->H > 0 && a->Tq > 0 && a->Tk > 0, "kx_attention: empty problem");
   KX_REQUIRE(a->H < 65536 && a->B < 65536, "kx_attention: B/H exceed the grid limits");
   KX_REQUIRE(a->mask != KX_ATTN_CAUSAL || a->Tq == a->Tk, "kx_attention: the causal mask needs Tq == Tk");
-  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32 || a->prec == KX_PREC_F16C, "kx_attention: bad precision");
-  const int es = a->prec == KX_PREC_BF16 ? 2 : 4;                 // KX_PREC_F16C takes fp32 q, k, v
+  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32 || a->prec == KX_PREC_F16C || a->prec == KX_PREC_F16,
+             "kx_attention: bad precision");
+  const bool f16 = a->prec == KX_PREC_F16;                        // fp16 q, k, v on the v2 kernel
+  const int es = (a->prec == KX_PREC_BF16 || f16) ? 2 : 4;        // KX_PREC_F16C takes fp32 q, k, v
+  KX_REQUIRE(!f16 || ((a->odt == KX_F16 || a->odt == KX_F32) && !a->lse_out), "kx_attention: KX_PREC_F16 writes KX_F16 or fp32 (no lse)");
+  KX_REQUIRE(a->odt != KX_F16 || f16, "kx_attention: a KX_F16 output comes from KX_PREC_F16");
   KX_REQUIRE((a->q_row_stride * es) % 16 == 0 && (a->kv_row_stride * es) % 16 == 0 &&
                  (a->q_batch_stride * es) % 16 == 0 && (a->kv_batch_stride * es) % 16 == 0,
              "kx_attention: strides must keep 16-byte alignment");
@@ -877,7 +886,7 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   AttnParams p;
   p.q = (const char*)a->q; p.qbs = a->q_batch_stride; p.qrs = a->q_row_stride;
   p.k = (const char*)a->k; p.v = (const char*)a->v; p.kbs = a->kv_batch_stride; p.krs = a->kv_row_stride;
-  p.out = a->out; p.obs = a->out_batch_stride; p.ors = a->out_row_stride; p.o_bf16 = a->odt == KX_BF16;
+  p.out = a->out; p.obs = a->out_batch_stride; p.ors = a->out_row_stride; p.o_bf16 = a->odt == KX_BF16 || a->odt == KX_F16;
   p.o_x3 = a->odt == KX_BF16X3;
   p.o_f16c = a->odt == KX_F16C;
   KX_REQUIRE(!p.o_f16c || (a->prec == KX_PREC_F16C && a->out_row_stride >= 2 * a->H * 64),
@@ -901,6 +910,12 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
       hipLaunchKernelGGL(attn_f16s_kernel<true>, dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
     else
       hipLaunchKernelGGL(attn_f16s_kernel<false>, dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+  } else if (f16) {
+    const unsigned nx = (unsigned)((a->Tq + 127) / 128);
+    if (a->mask == KX_ATTN_CAUSAL)
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<true, true>), dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, true>), dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
   } else if (a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1) {   // v1, kept for A/B
     dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, p);
@@ -908,9 +923,9 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   } else if (a->prec == KX_PREC_BF16) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     if (a->mask == KX_ATTN_CAUSAL)   // causal workgroups take query-block pairs (x, nx-1-x)
-      hipLaunchKernelGGL(attn_bf16_v2_kernel<true>, dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<true, false>), dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
     else
-      hipLaunchKernelGGL(attn_bf16_v2_kernel<false>, dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false>), dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
   } else if (kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1) {
     dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_f32_mfma_kernel<true>, grid, dim3(256), 0, s, p);

@@ -120,15 +120,19 @@ struct Carver {
 };
 // GEMM-operand activations: bf16 (2 B), fp32 (4 B), bf16x3 (3 x 2 B per value: [hi | hi | lo] rows) or f16c (4 B per
 // value: [fp16 | fp8 | fp8 residual] rows) — kx_precision doc
-inline size_t esz(int prec) { return prec == KX_PREC_BF16 ? 2 : prec == KX_PREC_BF16X3 ? 6 : 4; }
+inline size_t esz(int prec) { return (prec == KX_PREC_BF16 || prec == KX_PREC_F16) ? 2 : prec == KX_PREC_BF16X3 ? 6 : 4; }
 inline int cdt(int prec) {
-  return prec == KX_PREC_BF16 ? KX_BF16 : prec == KX_PREC_BF16X3 ? KX_BF16X3 : prec == KX_PREC_F16C ? KX_F16C : KX_F32;
+  return prec == KX_PREC_BF16 ? KX_BF16 : prec == KX_PREC_F16 ? KX_F16 : prec == KX_PREC_BF16X3 ? KX_BF16X3
+         : prec == KX_PREC_F16C ? KX_F16C : KX_F32;
 }
 // q/k/v (attention inputs) and the attention arithmetic: bf16x3 keeps them in fp32 on the exact-f32 matrix instruction,
 // f16c keeps them in fp32 and multiplies split fp16 (hi, lo) pairs (attn_f16s_kernel)
-inline size_t qes(int prec) { return prec == KX_PREC_BF16 ? 2 : 4; }
-inline int qdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : KX_F32; }
-inline int aprec(int prec) { return prec == KX_PREC_BF16 ? KX_PREC_BF16 : prec == KX_PREC_F16C ? KX_PREC_F16C : KX_PREC_F32; }
+// plain fp16 (KX_PREC_F16) is the bf16 pipeline on fp16 values: fp16 q/k/v, the v2 attention kernel on fp16 MFMAs
+inline size_t qes(int prec) { return (prec == KX_PREC_BF16 || prec == KX_PREC_F16) ? 2 : 4; }
+inline int qdt(int prec) { return prec == KX_PREC_BF16 ? KX_BF16 : prec == KX_PREC_F16 ? KX_F16 : KX_F32; }
+inline int aprec(int prec) {
+  return prec == KX_PREC_BF16 ? KX_PREC_BF16 : prec == KX_PREC_F16 ? KX_PREC_F16 : prec == KX_PREC_F16C ? KX_PREC_F16C : KX_PREC_F32;
+}
 // operand row length in 2-byte units per value (the unit lda / ldc / attention output strides count for these formats)
 inline int64_t kmul(int prec) { return prec == KX_PREC_BF16X3 ? 3 : prec == KX_PREC_F16C ? 2 : 1; }
 
@@ -386,7 +390,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
                                 void* vcache, int64_t Tmax) {
   KX_REQUIRE(w && x && logits && workspace, "kx_decoder_forward: null pointer");
   KX_REQUIRE(!kcache == !vcache, "kx_decoder_prefill: kcache and vcache must be given together");
-  KX_REQUIRE(!kcache || (prec != KX_PREC_BF16X3 && prec != KX_PREC_F16C),
+  KX_REQUIRE(!kcache || (prec != KX_PREC_BF16X3 && prec != KX_PREC_F16C && prec != KX_PREC_F16),
              "kx_decoder_prefill: incremental decoding is offered in bf16 and fp32");
   KX_REQUIRE(!kcache || T <= Tmax, "kx_decoder_prefill: %lld tokens do not fit a %lld-row cache", (long long)T,
              (long long)Tmax);
@@ -500,7 +504,7 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
                                       void* vcache, int64_t Tmax, void* logits, int32_t ldt, void* workspace,
                                       size_t workspace_bytes, int32_t prec, void* stream) {
   KX_REQUIRE(w && x && logits && workspace && kcache && vcache, "kx_decoder_decode_step: null pointer");
-  KX_REQUIRE(prec != KX_PREC_BF16X3 && prec != KX_PREC_F16C,
+  KX_REQUIRE(prec != KX_PREC_BF16X3 && prec != KX_PREC_F16C && prec != KX_PREC_F16,
              "kx_decoder_decode_step: incremental decoding is offered in bf16 and fp32");
   KX_REQUIRE(B > 0 && t >= 0 && t < Tmax, "kx_decoder_decode_step: position %lld outside the cache of %lld rows",
              (long long)t, (long long)Tmax);

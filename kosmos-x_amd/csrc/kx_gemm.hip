@@ -36,7 +36,7 @@ int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_byt
   auto cdiv = [](long long x, long long y) { return (x + y - 1) / y; };
   if (!ws_bytes || cdiv(M, 128) * cdiv(N, 128) >= 192) return 1;       // the automatic tile choice is not 64x64
   if (prec == KX_PREC_F16C) return (int)splitk_slices(M, N, 2 * K, 64, ws_bytes, 0);   // 4K-byte rows = 2K 2-byte units
-  return (int)splitk_slices(M, N, K, prec == KX_PREC_BF16 ? 64 : 32, ws_bytes, 0);
+  return (int)splitk_slices(M, N, K, (prec == KX_PREC_BF16 || prec == KX_PREC_F16) ? 64 : 32, ws_bytes, 0);
 }
 
 extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
@@ -46,9 +46,13 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
              (long long)a->N, (long long)a->K);
   KX_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "kx_gemm: dimension overflow");
   const bool f16c = a->prec == KX_PREC_F16C;
-  const int es = (a->prec == KX_PREC_BF16 || f16c) ? 2 : 4;   // KX_F16C rows: lda/ldw/ldc count 2-byte units
+  const bool f16 = a->prec == KX_PREC_F16;                    // plain fp16 rows on the KX_F16C kernels, no correction tiles
+  const int es = (a->prec == KX_PREC_BF16 || f16c || f16) ? 2 : 4;   // KX_F16C rows: lda/ldw/ldc count 2-byte units
   const int bk = f16c ? 128 : 128 / es;
-  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32 || f16c, "kx_gemm: bad precision %d", a->prec);
+  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32 || f16c || f16, "kx_gemm: bad precision %d", a->prec);
+  KX_REQUIRE(!f16 || (a->tile != 16 && a->tile != 256 && a->tile != 257), "kx_gemm: KX_PREC_F16 runs the tile kernels 64/128/160/384/512");
+  KX_REQUIRE(a->cdt != KX_F16 || f16 || f16c, "kx_gemm: KX_F16 outputs come from the fp16 kernels (KX_PREC_F16 / KX_PREC_F16C)");
+  KX_REQUIRE(a->cdt != KX_BF16 || !f16, "kx_gemm: KX_PREC_F16 writes KX_F16 or fp32");
   KX_REQUIRE(a->K % bk == 0, "kx_gemm: K=%lld must be a multiple of %d", (long long)a->K, bk);
   KX_REQUIRE(!f16c || (a->w_scale && a->lda >= 2 * a->K && a->ldw >= 2 * a->K && a->tile != 16 && a->tile != 256 &&
                        a->tile != 257),
@@ -64,8 +68,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   GemmParams p;
   p.A = (const char*)a->A; p.W = (const char*)a->W;
   p.lda_b = a->lda * es; p.ldw_b = a->ldw * es;
-  p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->cdt == KX_BF16 || a->cdt == KX_BF16X3 || a->cdt == KX_F16C;
-  p.c_x3 = a->cdt == KX_BF16X3; p.c_f16c = a->cdt == KX_F16C;
+  p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->cdt == KX_BF16 || a->cdt == KX_BF16X3 || a->cdt == KX_F16C || a->cdt == KX_F16;
+  p.c_x3 = a->cdt == KX_BF16X3; p.c_f16c = a->cdt == KX_F16C; p.c_f16 = a->cdt == KX_F16;
   p.nk_main = f16c ? (int)(a->K / 64) : 0x7fffffff; p.wscale = a->w_scale;
   KX_REQUIRE(a->cdt != KX_F16C || (a->N % 8 == 0 && a->ldc >= 2 * a->N && a->ldc % 8 == 0 && a->tile != 16 &&
                                     ((uintptr_t)a->C & 15) == 0),
@@ -75,7 +79,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
              "kx_gemm: a KX_BF16X3 output needs N %% 8 == 0, ldc >= 3N, ldc %% 8 == 0 (and is not offered by tile 16)");
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)(f16c ? 2 * a->K : a->K);   // f16c: 2-byte units of the 4K-byte row
-  p.act = (a->act == KX_ACT_GELU && (a->prec == KX_PREC_BF16 || f16c)) ? KX_ACT_GELU_FAST : a->act;
+  p.act = (a->act == KX_ACT_GELU && (a->prec == KX_PREC_BF16 || f16c || f16)) ? KX_ACT_GELU_FAST : a->act;
   p.qscale = a->qscale; p.qcols = (int)a->qcols;
   p.xq_cs = a->xq_cs; p.xq_ss = a->xq_ss; p.xk_cs = a->xk_cs; p.xk_ss = a->xk_ss;
   p.xpos_T = (int)a->xpos_T; p.xpos_dim = (int)a->xpos_dim;
@@ -107,7 +111,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     }
     // the lean epilogue covers bf16 outputs (not bf16x3) without residual / folded-LN consume / XPos on
     // 16-byte-aligned rows; launch_p5 also asks for N % 256 == 0.  Everything else keeps the generic loops.
-    p.lean_epilogue = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1 && p.c_bf16 && !p.c_x3 && !p.c_f16c && p.vec8_ok && !a->residual &&
+    p.lean_epilogue = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1 && p.c_bf16 && !p.c_x3 && !p.c_f16c &&
+                      ((f16 || f16c) ? p.c_f16 : !p.c_f16) && p.vec8_ok && !a->residual &&
                       !a->row_stats && !a->xpos_dim && a->qcols % 64 == 0 && !(a->stats_out && a->qcols);
     p.fast_epilogue = mode == 2 || (mode == 0 && (a->residual || a->row_stats || a->xpos_dim > 0));
   }
@@ -152,7 +157,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
         const double cur = tile == 512 ? (double)cdiv(t512, 256) : 0.6 * (double)cdiv(t256, 256);
         if (c384 < 0.97 * cur) tile = 384;
       }
-      if (f16c && tile == 256) tile = cost(160) <= cost(128) ? 160 : 128;   // no 256x128 ring kernel for KX_F16C rows
+      if ((f16c || f16) && tile == 256) tile = cost(160) <= cost(128) ? 160 : 128;   // no 256x128 ring kernel for fp16 rows
     }
   }
   // A 64x64 wave owns 32 columns only: the statistics producer needs the split-K reduce kernel (whose threads walk whole
@@ -220,6 +225,6 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     if (tile == 256 || tile == 257 || tile == 512 || tile == 384) return kx_gemm_launch_phased_bf16(p, tile, s);
     return kx_gemm_launch_tiles_bf16(p, tile, s);
   }
-  if (f16c) return kx_gemm_launch_f16c(p, tile, s);
+  if (f16c || f16) return kx_gemm_launch_f16c(p, tile, s);
   return kx_gemm_launch_f32(p, tile, s);
 }

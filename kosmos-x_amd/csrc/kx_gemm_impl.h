@@ -13,6 +13,7 @@ struct GemmParams {
   long long lda_b, ldw_b;  // row pitch in BYTES
   void* C; long long ldc; int c_bf16;
   int c_x3;   // KX_BF16X3 output: [hi(N) | hi(N) | lo(N)] per row (c_bf16 is set too)
+  int c_f16;  // KX_F16 output (c_bf16 is set too: same 2-byte layout, fp16 conversion)
   int c_f16c; // KX_F16C output: [fp16(N) | fp8(N) | fp8 residual(N)] per row, ldc in 2-byte units (c_bf16 is set too)
   // KX_PREC_F16C operands: K-tiles [0, nk_main) hold fp16 (16x16x32 f16 MFMA), tiles [nk_main, nk) the fp8 correction
   // segments (block-scaled 16x16x128 MFMA, weight-row scale bytes from wscale, activation scale 2^-11)
@@ -50,6 +51,14 @@ namespace {
 // Keeps a value in a scalar VGPR across this point: stops the SLP vectoriser from pairing the XPos products into
 // v_pk_mul_f32 / v_pk_fma_f32 with op_sel operand swizzles (see store_loop_fast).
 #define KX_NO_PACK(x) asm volatile("" : "+v"(x))
+
+// 2-byte outputs of the generic store paths: bf16 or (c_f16) fp16
+__device__ __forceinline__ unsigned pack16(const GemmParams& p, float lo, float hi) {
+  return p.c_f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi);
+}
+__device__ __forceinline__ bf16_t cvt16(const GemmParams& p, float x) {
+  return p.c_f16 ? __builtin_bit_cast(bf16_t, (_Float16)x) : f32_to_bf16(x);
+}
 
 // Everything of the fused epilogue except the store: x[0..3] = columns n..n+3 of row m (in range: m < M, n < N).
 template <int ACT>
@@ -140,10 +149,10 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   } else if (p.c_bf16) {
     bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
     if (full && p.vec_ok) {
-      uint2 o; o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]);
+      uint2 o; o.x = pack16(p, x[0], x[1]); o.y = pack16(p, x[2], x[3]);
       *reinterpret_cast<uint2*>(c) = o;
     } else {
-      for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = f32_to_bf16(x[j]);
+      for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = cvt16(p, x[j]);
     }
   } else {
     float* c = reinterpret_cast<float*>(p.C) + off;
@@ -176,8 +185,8 @@ __device__ __forceinline__ void epilogue8_bf16(const GemmParams& p, int m, int n
       *reinterpret_cast<uint4*>(c + 2 * (long long)p.N) = l;
     } else {
       uint4 o;
-      o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]);
-      o.z = pack_bf16x2(y[0], y[1]); o.w = pack_bf16x2(y[2], y[3]);
+      o.x = pack16(p, x[0], x[1]); o.y = pack16(p, x[2], x[3]);
+      o.z = pack16(p, y[0], y[1]); o.w = pack16(p, y[2], y[3]);
       *reinterpret_cast<uint4*>(c) = o;
     }
   } else {
@@ -282,8 +291,8 @@ __device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float
             *reinterpret_cast<uint4*>(c + 2 * (long long)p.N) = l;
           } else {
             uint4 o;
-            o.x = pack_bf16x2(x[0][0], x[0][1]); o.y = pack_bf16x2(x[0][2], x[0][3]);
-            o.z = pack_bf16x2(x[1][0], x[1][1]); o.w = pack_bf16x2(x[1][2], x[1][3]);
+            o.x = pack16(p, x[0][0], x[0][1]); o.y = pack16(p, x[0][2], x[0][3]);
+            o.z = pack16(p, x[1][0], x[1][1]); o.w = pack16(p, x[1][2], x[1][3]);
             *reinterpret_cast<uint4*>(c) = o;
           }
         } else {
@@ -443,7 +452,7 @@ __device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc
   }
 }
 
-template <int BM, int BN, int NW, int FM, int FN>   // tile BM x BN, NW waves, wave sub-tile at (row_w0, col_w0)
+template <int BM, int BN, int NW, int FM, int FN, bool F16 = false>   // tile BM x BN, NW waves, wave sub-tile at (row_w0, col_w0); F16: fp16 values
 __device__ __forceinline__ void lean_store_bf16(const GemmParams& p, const f32x4_t (&acc)[FN][FM], char* smem, int m0,
                                                 int n0, int row_w0, int col_w0, int wave, int lane, int g, int li) {
   constexpr int RB = BN * 2, CPR = BN / 8;        // bytes and 16-byte chunks per tile row
@@ -457,8 +466,8 @@ __device__ __forceinline__ void lean_store_bf16(const GemmParams& p, const f32x4
     for (int a = 0; a < FN; ++a) {
       const int chunk = ((col_w0 >> 3) + a * 2 + (g >> 1)) ^ (rt & 7);
       uint2 v;
-      v.x = pack_bf16x2(acc[a][b][0], acc[a][b][1]);
-      v.y = pack_bf16x2(acc[a][b][2], acc[a][b][3]);
+      v.x = F16 ? pack_f16x2(acc[a][b][0], acc[a][b][1]) : pack_bf16x2(acc[a][b][0], acc[a][b][1]);
+      v.y = F16 ? pack_f16x2(acc[a][b][2], acc[a][b][3]) : pack_bf16x2(acc[a][b][2], acc[a][b][3]);
       *reinterpret_cast<uint2*>(smem + rt * RB + chunk * 16 + (g & 1) * 8) = v;
     }
   }
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   [[maybe_unused]] int wsc[FN];
   if constexpr (kIsF16c<T>) {
 #pragma unroll
-    for (int a = 0; a < FN; ++a) wsc[a] = p.wscale[min(n0 + wn * (BN / 2) + a * 16 + li, p.N - 1)];
+    for (int a = 0; a < FN; ++a) wsc[a] = p.wscale ? p.wscale[min(n0 + wn * (BN / 2) + a * 16 + li, p.N - 1)] : 127;
   }
   const int nk_all = p.K / (ROWB / (int)sizeof(T));
   const int kchunk = (nk_all + p.splitk - 1) / p.splitk;
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;
   if constexpr (EPI == 1) {           // bias + activation on the accumulators, the tile parked once as bf16, full-row stores
     lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g);
-    lean_store_bf16<BM, BN, 4, FM, FN>(p, acc, smem, m0, n0, wm * WM, wn * WN, wave, lane, g, li);
+    lean_store_bf16<BM, BN, 4, FM, FN, kIsF16c<T>>(p, acc, smem, m0, n0, wm * WM, wn * WN, wave, lane, g, li);
     return;
   }
   constexpr int CH = WN / 4;          // 16-byte chunks per sub-tile row (16 or 8)
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
         split_bf16x2(x[j][0], x[j][1], hh.x, ll.x); split_bf16x2(x[j][2], x[j][3], hh.y, ll.y);
         *reinterpret_cast<uint2*>(c) = hh; *reinterpret_cast<uint2*>(c + p.N) = hh; *reinterpret_cast<uint2*>(c + 2ll * p.N) = ll;
       } else if (p.c_bf16) {
-        uint2 o; o.x = pack_bf16x2(x[j][0], x[j][1]); o.y = pack_bf16x2(x[j][2], x[j][3]);
+        uint2 o; o.x = pack16(p, x[j][0], x[j][1]); o.y = pack16(p, x[j][2], x[j][3]);
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
       } else {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off) = make_float4(x[j][0], x[j][1], x[j][2], x[j][3]);
@@ -768,6 +777,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
       uint2 hh, ll;
       split_bf16x2(o0, o1, hh.x, ll.x); split_bf16x2(o2, o3, hh.y, ll.y);
       *reinterpret_cast<uint2*>(c) = hh; *reinterpret_cast<uint2*>(c + p.N) = hh; *reinterpret_cast<uint2*>(c + 2ll * p.N) = ll;
+    } else if (p.ln_out_dt == KX_F16) {
+      uint2 o; o.x = pack_f16x2(o0, o1); o.y = pack_f16x2(o2, o3);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.ln_out) + (long long)m * p.N + n) = o;
     } else if (p.ln_out_dt == KX_BF16) {
       uint2 o; o.x = pack_bf16x2(o0, o1); o.y = pack_bf16x2(o2, o3);
       *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.ln_out) + (long long)m * p.N + n) = o;
@@ -1131,7 +1143,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   // scratch inside the MFMA phases, with a vmcnt(0) that also drained the next tile's LDS-DMA).
   auto kloop = [&](auto work_c) __attribute__((always_inline)) {
   constexpr bool W = decltype(work_c)::value;
-  const int nk1 = kIsF16c<T> ? p.nk_main : nk;     // KX_F16C: the fp16 tiles; the fp8 correction tiles follow below
+  const int nk1 = kIsF16c<T> ? min(p.nk_main, nk) : nk;     // KX_F16C: the fp16 tiles; the fp8 correction tiles follow below
   for (int kt = 0; kt < nk1; ++kt) {
     const char* base = smem + (kt & 1) * STAGE;
     u32x4_t fa[FM], fw[FN];
@@ -1192,7 +1204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     constexpr int FH = FM / 2;
     int wsc[FN];
 #pragma unroll
-    for (int a = 0; a < FN; ++a) wsc[a] = p.wscale[min(n0 + wn * 64 + a * 16 + lk, p.N - 1)];
+    for (int a = 0; a < FN; ++a) wsc[a] = p.wscale ? p.wscale[min(n0 + wn * 64 + a * 16 + lk, p.N - 1)] : 127;
     for (int kt = nk1; kt < nk; ++kt) {
       const char* base = smem + (kt & 1) * STAGE;
       u32x4_t fw0[FN], fw1[FN], fa0[FH], fa1[FH];
@@ -1271,7 +1283,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     if constexpr (EPI == 4) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
     else lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g);
     KX_TL_STAMP(3);
-    lean_store_bf16<BM, 256, 8, FM, FN>(p, acc, smem, m0, n0, wm * (BM / 2), wn * WN, wave, lane, g, li);
+    lean_store_bf16<BM, 256, 8, FM, FN, kIsF16c<T>>(p, acc, smem, m0, n0, wm * (BM / 2), wn * WN, wave, lane, g, li);
     KX_TL_STAMP(4);
     KX_TL_STAMP(5);
     KX_TL_COMMIT();
@@ -1543,7 +1555,7 @@ int launch(GemmParams& p, hipStream_t s) {
     KX_CHECK_LAUNCH("kx_gemm(split-K)");
     return launch_splitk_reduce(p, s);
   }
-  if constexpr (BM == 160 && sizeof(T) == 2 && !kIsF16c<T>) {     // the ViT's bf16-output GEMMs (qkv, fc1): lean epilogue
+  if constexpr (BM == 160 && sizeof(T) == 2) {     // the ViT's bf16 / fp16-output GEMMs (qkv, fc1): lean epilogue
     if (p.lean_epilogue && !p.stats_out && p.N % BN == 0) {
       if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
       if (p.act == KX_ACT_QUICK_GELU) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }

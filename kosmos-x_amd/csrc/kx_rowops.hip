@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __res
         reinterpret_cast<uint2*>(yr)[c] = hh;
         reinterpret_cast<uint2*>(yr + cols)[c] = hh;
         reinterpret_cast<uint2*>(yr + 2ll * cols)[c] = ll;
+      } else if (OUT == KX_F16) {
+        uint2 pk; pk.x = pack_f16x2(o.x, o.y); pk.y = pack_f16x2(o.z, o.w);
+        reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + orow * (long long)cols)[c] = pk;
       } else if (OUT == KX_BF16) {
         uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
         reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + orow * (long long)cols)[c] = pk;
@@ -151,6 +154,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         reinterpret_cast<uint2*>(yr)[c] = hh;
         reinterpret_cast<uint2*>(yr + cols)[c] = hh;
         reinterpret_cast<uint2*>(yr + 2ll * cols)[c] = ll;
+      } else if (OUT == KX_F16) {
+        uint2 pk; pk.x = pack_f16x2(o.x, o.y); pk.y = pack_f16x2(o.z, o.w);
+        reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + orow * (long long)cols)[c] = pk;
       } else if (OUT == KX_BF16) {
         uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
         reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + orow * (long long)cols)[c] = pk;
@@ -241,6 +247,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         const unsigned e = pack_fp8x4(v, 0.f, 0.f, 0.f), r = pack_fp8x4((v - (float)h) * 2048.0f, 0.f, 0.f, 0.f);
         reinterpret_cast<unsigned char*>(pr + 2ll * kpad)[k] = (unsigned char)(e & 0xffu);
         reinterpret_cast<unsigned char*>(pr + 3ll * kpad)[k] = (unsigned char)(r & 0xffu);
+      } else if (fmt == 3) {                      // KX_F16
+        patches[prow * kpad + k] = __builtin_bit_cast(bf16_t, (_Float16)v);
       } else if (fmt == 1) {                      // KX_BF16X3 row: [hi(kpad) | hi(kpad) | lo(kpad)]
         const bf16_t hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
         T* pr = patches + prow * 3ll * kpad;
@@ -343,12 +351,15 @@ extern "C" int kx_layernorm(const float* x, const float* pre_add, const float* g
   hipLaunchKernelGGL(layernorm_block_kernel<OUT>, dim3((unsigned)rows), dim3(256), 0, s, x, pre_add, gamma, beta, y,  \
                      (int)cols, eps, (long long)rows_per_group, (long long)out_group_stride, (long long)out_row_offset)
     if (ydt == KX_F16C) KX_LN_BLOCK(KX_F16C);
+    else if (ydt == KX_F16) KX_LN_BLOCK(KX_F16);
     else if (ydt == KX_BF16X3) KX_LN_BLOCK(KX_BF16X3);
     else if (ydt == KX_BF16) KX_LN_BLOCK(KX_BF16);
     else KX_LN_BLOCK(KX_F32);
 #undef KX_LN_BLOCK
   } else if (ydt == KX_F16C)
     dispatch_ln<KX_F16C>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
+  else if (ydt == KX_F16)
+    dispatch_ln<KX_F16>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
   else if (ydt == KX_BF16X3)
     dispatch_ln<KX_BF16X3>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
   else if (ydt == KX_BF16)
@@ -424,9 +435,9 @@ int kx_launch_patchify(const float* pixels, void* patches, int64_t B, int image,
   const int G = image / patch;
   const unsigned rows = (unsigned)(B * G * G);
   KxProfScope prof(KX_K_MISC, rows, kpad, 1, s);
-  if (prec == KX_PREC_BF16 || prec == KX_PREC_BF16X3 || prec == KX_PREC_F16C)
+  if (prec == KX_PREC_BF16 || prec == KX_PREC_BF16X3 || prec == KX_PREC_F16C || prec == KX_PREC_F16)
     hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, pixels, (bf16_t*)patches, image, patch,
-                       kpad, prec == KX_PREC_BF16X3 ? 1 : prec == KX_PREC_F16C ? 2 : 0);
+                       kpad, prec == KX_PREC_BF16X3 ? 1 : prec == KX_PREC_F16C ? 2 : prec == KX_PREC_F16 ? 3 : 0);
   else
     hipLaunchKernelGGL(patchify_kernel<float>, dim3(rows), dim3(256), 0, s, pixels, (float*)patches, image, patch,
                        kpad, 0);

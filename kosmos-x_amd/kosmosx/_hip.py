@@ -15,12 +15,22 @@ _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
 ABI_VERSION = 2   # KX_ABI_VERSION of include/kosmosx_hip.h
 
-KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C = 0, 1, 2, 3
-KX_F32, KX_BF16, KX_BF16X3, KX_F16C = 0, 1, 2, 3
+KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16 = 0, 1, 2, 3, 4
+KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16 = 0, 1, 2, 3, 4
 KX_ACT_NONE, KX_ACT_GELU, KX_ACT_QUICK_GELU = 0, 1, 2
 KX_ATTN_FULL, KX_ATTN_CAUSAL = 0, 1
 ACTS = {"none": KX_ACT_NONE, "gelu": KX_ACT_GELU, "quick_gelu": KX_ACT_QUICK_GELU}
-PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32, "bf16x3": KX_PREC_BF16X3, "f16c": KX_PREC_F16C}
+PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32, "bf16x3": KX_PREC_BF16X3, "f16c": KX_PREC_F16C, "f16": KX_PREC_F16}
+# model-level modes: the stage precisions above plus "mixed" — the error-budgeted mix (CLIP tower in plain fp16, Perceiver
+# and decoder in f16c; kx_precision in include/kosmosx_hip.h, tools/precision_study.py --budget)
+MODEL_PRECS = list(PRECS) + ["mixed"]
+
+
+def stage_precision(prec: str, stage: str) -> str:
+    """The arithmetic a stage ("vit", "perceiver", "decoder") runs in under the model-level mode `prec`."""
+    if prec == "mixed":
+        return "f16" if stage == "vit" else "f16c"
+    return prec
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 

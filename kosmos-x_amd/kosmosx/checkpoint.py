@@ -54,7 +54,8 @@ def load_checkpoint(model: torch.nn.Module, path: str, strict: bool = True):
         if alias in own and alias not in sd and src in sd:
             sd[alias] = sd[src]
     for k in [k for k in own if ".B." in k and k not in sd]:   # B copies are optional on disk
-        sd[k] = sd[k.replace(".B.", ".A.")]
+        if k.replace(".B.", ".A.") in sd:                        # (a partial file — e.g. the CLIP tower alone — has neither)
+            sd[k] = sd[k.replace(".B.", ".A.")]
     res = model.load_state_dict(sd, strict=strict)
     if hasattr(model, "invalidate_packed"):
         model.invalidate_packed()

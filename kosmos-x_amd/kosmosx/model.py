@@ -41,7 +41,7 @@ def _stream() -> int:
 
 
 def _prec_dtype(prec: str):
-    return torch.float32 if prec == "fp32" else torch.bfloat16
+    return torch.float32 if prec == "fp32" else torch.float16 if prec == "f16" else torch.bfloat16
 
 
 def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
@@ -97,8 +97,8 @@ def _operand_colsum(wp: torch.Tensor, prec: str, shape=None) -> torch.Tensor:
 
 def _default_precision() -> str:
     p = os.environ.get("KOSMOSX_PRECISION", "bf16")
-    if p not in H.PRECS:
-        raise ValueError(f"KOSMOSX_PRECISION must be one of {list(H.PRECS)}")
+    if p not in H.MODEL_PRECS:
+        raise ValueError(f"KOSMOSX_PRECISION must be one of {H.MODEL_PRECS}")
     return p
 
 
@@ -265,6 +265,7 @@ class CLIPVisionTower(_PackedMixin, nn.Module):
         return self._packed[key]
 
     def run(self, pixels: torch.Tensor, prec: str, ws: _Workspace) -> torch.Tensor:
+        prec = H.stage_precision(prec, "vit")
         """pixels [B,3,H,W] any real dtype (HF casts to the weight dtype; SURVEY H2) -> [B,tokens,dim] fp32."""
         _require_cuda(pixels, "images")
         c = self.cfg
@@ -369,6 +370,7 @@ class PerceiverResampler(_PackedMixin, nn.Module):
             want_latents: bool = False):
         """x [B,m,dim] fp32 -> (projected [B,latents,out_dim] or None, latents [B,latents,dim] or None)."""
         _require_cuda(x, "media")
+        prec = H.stage_precision(prec, "perceiver")
         w, _, _ = self._pack(prec, image_proj)
         lib = H.load()
         x = x.to(torch.float32).contiguous()
@@ -602,6 +604,7 @@ class Decoder(_PackedMixin, nn.Module):
               alias: bool | None = None, pos_offset: int = 0) -> torch.Tensor:
         """Fused forward_embedding/cat/forward_embedding of /root/reference/kosmosx/model.py:238-244
         (img given) or the single forward_embedding of :319 (img None)."""
+        prec = H.stage_precision(prec, "decoder")
         _, _, _, emb, pos = self._pack(prec)
         lib = H.load()
         if tokens is not None:
@@ -629,6 +632,7 @@ class Decoder(_PackedMixin, nn.Module):
 
     def run(self, x: torch.Tensor, prec: str, logits_dtype=torch.float32) -> torch.Tensor:
         """x [B,T,dim] fp32 residual stream (CONSUMED) -> logits [B,T,vocab]."""
+        prec = H.stage_precision(prec, "decoder")
         w, _, _, _, _ = self._pack(prec)
         lib = H.load()
         B, T, _ = x.shape
@@ -647,6 +651,7 @@ class Decoder(_PackedMixin, nn.Module):
         """torchscale's incremental_state protocol: the first call runs the whole prefix and fills the KV cache,
         every later call is given the token history (only its last token and its length are used, as upstream's
         `tokens[:, -1:]`) and appends one position.  ``state`` is an opaque dict owned by the caller."""
+        prec = H.stage_precision(prec, "decoder")
         w, _, _, emb, pos = self._pack(prec)
         lib = H.load()
         D, L = self.args.decoder_embed_dim, self.num_layers

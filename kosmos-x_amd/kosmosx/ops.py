@@ -27,6 +27,8 @@ def _cdt(dtype) -> int:
         return H.KX_F32
     if dtype == torch.bfloat16:
         return H.KX_BF16
+    if dtype == torch.float16:
+        return H.KX_F16
     raise TypeError(f"unsupported dtype {dtype}")
 
 
@@ -78,7 +80,7 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
     _need_cuda(a, w, bias, residual, out)
     M, K = a.shape
     N = w.shape[0]
-    prec = H.KX_PREC_BF16 if w.dtype == torch.bfloat16 else H.KX_PREC_F32
+    prec = H.KX_PREC_BF16 if w.dtype == torch.bfloat16 else H.KX_PREC_F16 if w.dtype == torch.float16 else H.KX_PREC_F32
     if a.dtype != w.dtype and ln is None:
         raise TypeError("gemm operands must share a dtype")
     if out is None:
@@ -158,7 +160,8 @@ def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=Fals
     Tk = k.shape[1]
     assert hd == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and v.stride(2) == 64
     assert k.stride(0) == v.stride(0) and k.stride(1) == v.stride(1)
-    prec = H.KX_PREC_BF16 if q.dtype == torch.bfloat16 else (H.KX_PREC_F16C if f16c or out_f16c else H.KX_PREC_F32)
+    prec = (H.KX_PREC_BF16 if q.dtype == torch.bfloat16 else H.KX_PREC_F16 if q.dtype == torch.float16
+            else (H.KX_PREC_F16C if f16c or out_f16c else H.KX_PREC_F32))
     out = (torch.empty((B, Tq, 4 * Hh * 64), dtype=torch.uint8, device=q.device) if out_f16c else
            torch.empty((B, Tq, 3 * Hh * 64), dtype=torch.bfloat16, device=q.device) if out_x3 else
            torch.empty((B, Tq, Hh * 64), dtype=out_dtype or q.dtype, device=q.device))

@@ -220,3 +220,86 @@ def test_full_size_f16c_text_only_T2046():
     e = rel_err(out, ref)
     print(f"KosmosLanguage f16c T=2046: max|d|/rms vs fp32 CPU oracle = {e:.3e}")
     assert e < F16C_TOL, e
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# plain fp16 (KX_PREC_F16) kernels and the error-budgeted "mixed" mode (CLIP tower fp16, Perceiver + decoder f16c)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [0, 64, 128, 160, 384, 512])
+@pytest.mark.parametrize("shape", [(114, 2048, 2048), (257, 1024, 4096), (300, 1002, 640), (8224, 512, 1024)])
+def test_gemm_f16_plain(shape, tile):
+    """fp16 operands are exact in fp32: the reference is the fp32 product of the fp16-rounded operands."""
+    M, N, K = shape
+    g = _g(M + N + K + 1)
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).half()
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), tile=tile)
+    assert float((out.cpu().double() - ref).abs().max() / ref.pow(2).mean().sqrt()) < 2e-5, (shape, tile)
+    if N % 8 == 0:      # fp16 output (lean epilogue on the 160x128 kernel) == rounding the fp32 output
+        o16 = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act="gelu", tile=tile, out_dtype=torch.float16)
+        o32 = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act="gelu", tile=tile)
+        assert o16.dtype == torch.float16
+        d = (o16.float() - o32).abs()
+        assert float(d.max()) <= float(o32.abs().max()) * 2 ** -11 and float((o16 == o32.half()).float().mean()) > 0.999
+
+
+@pytest.mark.parametrize("case", [(2, 3, 114, 114, True), (2, 2, 257, 257, False), (2, 2, 64, 321, False), (1, 2, 700, 700, True)])
+def test_attention_f16_plain(case):
+    B, Hh, Tq, Tk, causal = case
+    g = _g(Tq + 3 * Tk)
+    q = (torch.randn(B, Tq, Hh, 64, generator=g) * 0.4).half()
+    k, v = torch.randn(B, Tk, Hh, 64, generator=g).half(), torch.randn(B, Tk, Hh, 64, generator=g).half()
+    ref = _attn_ref(q, k, v, causal)
+    st = torch.zeros(B * Tq, Hh, 2, device=DEV)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), causal, out_dtype=torch.float32, stats_out=st)
+    assert float((out.cpu().double() - ref).abs().max()) < 2e-3          # P travels as fp16 (2^-12 per element)
+    o16 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), causal)
+    assert o16.dtype == torch.float16 and float((o16.float().cpu().double() - ref).abs().max()) < 4e-3
+    # bf16 on the same (fp16-representable) inputs is 8x coarser
+    ob = ops.attention(q.bfloat16().to(DEV), k.bfloat16().to(DEV), v.bfloat16().to(DEV), causal, out_dtype=torch.float32)
+    assert float((out.cpu().double() - ref).abs().max()) < float((ob.cpu().double() - ref).abs().max())
+
+
+def test_layernorm_f16_output():
+    g = _g(9)
+    x = torch.randn(33, 1024, generator=g) * 2 + 0.1
+    gam, bet = 1 + 0.1 * torch.randn(1024, generator=g), 0.1 * torch.randn(1024, generator=g)
+    y32 = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV))
+    y16 = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out_dtype=torch.float16)
+    assert y16.dtype == torch.float16 and torch.equal(y16, y32.half())
+
+
+@pytest.mark.parametrize("B,Tt", [(1, 10), (2, 50)])
+def test_tiny_mixed_meets_the_bf16_north_star(B, Tt):
+    m = Kosmos._from_config(tiny_config(), seed=0, perturb=0.1).eval()
+    tok, img = _inputs(B, Tt, m.cfg, seed=40 + B)
+    st = {}
+    ref = O.kosmos_forward(oracle_weights(m), tok, img, oracle_cfg(m.cfg), O.Switches(), st)
+    m.precision = "mixed"
+    m = m.to(DEV)
+    out = m(tok.to(DEV), img.to(DEV))
+    e = rel_err(out, ref)
+    print(f"tiny mixed B={B} Tt={Tt}: max|d|/rms vs fp32 oracle = {e:.3e}")
+    assert e < F16C_TOL, e
+    assert torch.equal(out, m(tok.to(DEV), img.to(DEV)))
+    ev = rel_err(m.clip_model.run(img.to(DEV).float(), "f16", m._ws), st["vit"])
+    print(f"  tower alone in plain fp16: {ev:.3e}")
+    assert ev < 5e-3
+
+
+@pytest.mark.parametrize("B,Tt", [(1, 50), (2, 50), (4, 20)])
+def test_full_size_mixed_meets_1e_3(B, Tt):
+    """The error-budgeted mode at full size: CLIP tower in plain fp16 (2.5e-4 of logit error on the CPU study), Perceiver
+    and decoder in f16c — within the north star's 1e-3 of the fp32 CPU path."""
+    from kosmosx.config import DecoderConfig, KosmosConfig
+    m = Kosmos._from_config(KosmosConfig(decoder=DecoderConfig()), seed=0, perturb=0.05).eval()
+    tok, img = _inputs(B, Tt, m.cfg, seed=5)
+    ref = O.kosmos_forward(oracle_weights(m), tok, img, oracle_cfg(m.cfg), O.Switches())
+    m.precision = "mixed"
+    m = m.to(DEV)
+    out = m(tok.to(DEV), img.to(DEV))
+    e = rel_err(out, ref)
+    print(f"full-size mixed B={B} Tt={Tt}: max|d|/rms vs fp32 CPU oracle = {e:.3e}")
+    assert e < F16C_TOL, e
