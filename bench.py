@@ -66,26 +66,32 @@ def parse():
     return ap.parse_args()
 
 
-_PMC_KEYS = {"gemm_bf16_160x128": "gemm_kernel<bf16,160,128", "gemm_bf16_128x128": "gemm_kernel<bf16,128,128",
-             "gemm_bf16_64x64": "gemm_kernel<bf16,64,64", "gemm_bf16_256x128_phased": "gemm_kernel_p3<bf16",
-             "gemm_bf16_256x256_phased": "gemm_kernel_p5<bf16", "attn_bf16": "attn_bf16_v2_kernel"}
+_PMC_KEYS = {"gemm_bf16_160x128": "gemm_kernel<{T},160,128", "gemm_bf16_128x128": "gemm_kernel<{T},128,128",
+             "gemm_bf16_64x64": "gemm_kernel<{T},64,64", "gemm_bf16_256x128_phased": "gemm_kernel_p3<{T}",
+             "gemm_bf16_256x256_phased": "gemm_kernel_p5<{T}", "attn_bf16": "attn_"}
+_PMC_FILES = {"bf16": ("profiles/r01_v_pmc.json", "bf16", "profiles/r01_v_pmc_summary.md"),
+              "mixed": ("profiles/r02_a_pmc.json", "f16c_t", "profiles/r02_a_pmc_summary.md")}
 
 
 def pmc_traffic(kernel, args):
     """roofline.traffic: HBM-side bytes per launch of the dominant kernel.  PMC counters need rocprofv3 around the
     process, so they are not collected here: the value comes from the committed PMC pass of this same command
-    (tools/pmc_round.sh -> tools/pmc_summary.py -> profiles/r01_v_pmc.json; FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950
-    correction) and is only reported for the default workload it was measured on; otherwise null."""
-    f = Path(__file__).resolve().parent / "profiles" / "r01_v_pmc.json"
+    (tools/pmc_round.sh -> tools/pmc_summary.py -> profiles/r0N_*_pmc.json; FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950
+    correction) and is only reported for the default workload and the precision it was measured on; otherwise null."""
+    ent = _PMC_FILES.get(args.precision)
     key = _PMC_KEYS.get(kernel)
-    if not (f.exists() and key and args.batch == 32 and args.text_len == 50 and args.precision == "bf16"):
+    if not (ent and key and args.batch == 32 and args.text_len == 50):
         return {"traffic": None}
+    f = Path(__file__).resolve().parent / ent[0]
+    if not f.exists():
+        return {"traffic": None}
+    key = key.format(T=ent[1])
     rows = [v for k, v in json.loads(f.read_text()).items() if k.startswith(key)]
     n = sum(v["launches"] for v in rows)
     if not n:
         return {"traffic": None}
     t = sum(v["launches"] * (v["fetch_bytes_x2"] + v["write_bytes"]) for v in rows) / n
-    return {"traffic": round(t), "traffic_unit": "bytes/launch", "traffic_source": "profiles/r01_v_pmc_summary.md"}
+    return {"traffic": round(t), "traffic_unit": "bytes/launch", "traffic_source": ent[2] + " (committed PMC pass of this command, not this run)"}
 
 
 def kernel_report(records, steps):

@@ -954,7 +954,7 @@ struct DecodeParams {
   const char* qkv; long long qkv_row;        // [B, 3*D] rows: q | k | v of the new token (elements)
   char* kcache; char* vcache;                // [B, Tmax, D]
   long long cache_batch, cache_row;          // element strides
-  void* out; long long out_row; int o_bf16;  // [B, D]
+  void* out; long long out_row; int o_bf16, o_f16c;  // [B, D] (o_f16c: KX_F16C rows of D values, out_row in 2-byte units)
   float* stats_out;                          // [B, H, 2] or null
   int H, D, t;                               // t = number of tokens already cached (the new one goes to row t)
 };
@@ -1046,7 +1046,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
       if (lane == 0) *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)b * p.H + h)) = make_float2(sm, m2);
     }
     const long long ooff = (long long)b * p.out_row + (long long)h * 64 + lane;
-    if (p.o_bf16) reinterpret_cast<bf16_t*>(p.out)[ooff] = f32_to_bf16(ov);
+    if (p.o_f16c) {                                   // [fp16 | fp8 | fp8 residual] planes of the row, one value per lane
+      char* row = reinterpret_cast<char*>(p.out) + (long long)b * p.out_row * 2;
+      const long long n = (long long)h * 64 + lane, D = p.D;
+      const _Float16 hv = (_Float16)ov;
+      reinterpret_cast<_Float16*>(row)[n] = hv;
+      reinterpret_cast<unsigned char*>(row + 2 * D)[n] = (unsigned char)(pack_fp8x4(ov, 0.f, 0.f, 0.f) & 0xffu);
+      reinterpret_cast<unsigned char*>(row + 3 * D)[n] = (unsigned char)(pack_fp8x4((ov - (float)hv) * 2048.0f, 0.f, 0.f, 0.f) & 0xffu);
+    } else if (p.o_bf16) reinterpret_cast<bf16_t*>(p.out)[ooff] = f32_to_bf16(ov);
     else reinterpret_cast<float*>(p.out)[ooff] = ov;
   }
 }
@@ -1085,13 +1092,15 @@ extern "C" int kx_attention_decode(const void* qkv, void* kcache, void* vcache, 
   KX_REQUIRE(qkv && kcache && vcache && out, "kx_attention_decode: null pointer");
   KX_REQUIRE(B > 0 && H > 0 && t >= 0 && t < Tmax, "kx_attention_decode: position %lld outside the cache of %lld rows",
              (long long)t, (long long)Tmax);
-  KX_REQUIRE(prec == KX_PREC_BF16 || prec == KX_PREC_F32, "kx_attention_decode: bad precision");
+  KX_REQUIRE(prec == KX_PREC_BF16 || prec == KX_PREC_F32 || prec == KX_PREC_F16C, "kx_attention_decode: bad precision");
+  KX_REQUIRE((odt == KX_F16C) == (prec == KX_PREC_F16C) || odt == KX_F32,
+             "kx_attention_decode: KX_PREC_F16C (fp32 q / cache, exact softmax) writes KX_F16C rows or fp32");
   KX_REQUIRE(B < 65536 && H < 65536, "kx_attention_decode: B/H exceed the grid limits");
   DecodeParams p;
   const int64_t D = H * 64;
   p.qkv = (const char*)qkv; p.qkv_row = 3 * D;
   p.kcache = (char*)kcache; p.vcache = (char*)vcache; p.cache_batch = Tmax * D; p.cache_row = D;
-  p.out = out; p.out_row = D; p.o_bf16 = odt == KX_BF16; p.stats_out = stats_out;
+  p.out = out; p.out_row = odt == KX_F16C ? 2 * D : D; p.o_bf16 = odt == KX_BF16; p.o_f16c = odt == KX_F16C; p.stats_out = stats_out;
   p.H = (int)H; p.D = (int)D; p.t = (int)t;
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(prec == KX_PREC_BF16 ? KX_K_ATTN_BF16 : KX_K_ATTN_F32, B * H, 1, t + 1, s);

@@ -390,8 +390,8 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
                                 void* vcache, int64_t Tmax) {
   KX_REQUIRE(w && x && logits && workspace, "kx_decoder_forward: null pointer");
   KX_REQUIRE(!kcache == !vcache, "kx_decoder_prefill: kcache and vcache must be given together");
-  KX_REQUIRE(!kcache || (prec != KX_PREC_BF16X3 && prec != KX_PREC_F16C && prec != KX_PREC_F16),
-             "kx_decoder_prefill: incremental decoding is offered in bf16 and fp32");
+  KX_REQUIRE(!kcache || (prec != KX_PREC_BF16X3 && prec != KX_PREC_F16),
+             "kx_decoder_prefill: incremental decoding is offered in bf16, fp32 and f16c (fp32 cache)");
   KX_REQUIRE(!kcache || T <= Tmax, "kx_decoder_prefill: %lld tokens do not fit a %lld-row cache", (long long)T,
              (long long)Tmax);
   KX_REQUIRE(B > 0 && T > 0, "kx_decoder_forward: empty input");
@@ -421,7 +421,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, qdt(prec), M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
                 w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? T : 0, w->xpos ? D : 0));
     if (kcache) {   // incremental decoding: keep this layer's (XPos-rotated) keys and values
-      const size_t layer_bytes = (size_t)B * Tmax * D * es;
+      const size_t layer_bytes = (size_t)B * Tmax * D * qes(prec);
       KX_TRY(kx_launch_kv_prefill(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, B, T, D, Tmax,
                                   prec, s));
     }
@@ -504,8 +504,8 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
                                       void* vcache, int64_t Tmax, void* logits, int32_t ldt, void* workspace,
                                       size_t workspace_bytes, int32_t prec, void* stream) {
   KX_REQUIRE(w && x && logits && workspace && kcache && vcache, "kx_decoder_decode_step: null pointer");
-  KX_REQUIRE(prec != KX_PREC_BF16X3 && prec != KX_PREC_F16C && prec != KX_PREC_F16,
-             "kx_decoder_decode_step: incremental decoding is offered in bf16 and fp32");
+  KX_REQUIRE(prec != KX_PREC_BF16X3 && prec != KX_PREC_F16,
+             "kx_decoder_decode_step: incremental decoding is offered in bf16, fp32 and f16c (fp32 cache)");
   KX_REQUIRE(B > 0 && t >= 0 && t < Tmax, "kx_decoder_decode_step: position %lld outside the cache of %lld rows",
              (long long)t, (long long)Tmax);
   KX_REQUIRE(w->dim == w->heads * 64, "kx_decoder_decode_step: head_dim must be 64");
@@ -521,7 +521,7 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
   SplitkScope sk(d.splitk, KX_SPLITK_WS);
   const int ct = cdt(prec);
   const size_t es = esz(prec);
-  const size_t layer_bytes = (size_t)B * Tmax * D * es;
+  const size_t layer_bytes = (size_t)B * Tmax * D * qes(prec);   // the cache holds q/k/v-typed values (fp32 for f16c)
   // One token per sequence in bf16, up to 16 sequences: the step is 120 dependent launches of weight-streaming work,
   // and launches are what it costs (~6 us each) — tile 16 does each GEMM in one launch and takes the LayerNorm and
   // statistics-finalize kernels in as prologues: 5 launches per layer instead of 13.
@@ -556,7 +556,7 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
     const kx_decoder_layer& L = w->layer[i];
     KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
     // XPos rows of absolute position t (xpos_T = 1: every batch row is the same position)
-    KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
+    KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, qdt(prec), M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
                 w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? 1 : 0, w->xpos ? D : 0));
     KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, ct,
                                w->subln ? d.partials : nullptr, B, w->heads, t, Tmax, prec, stream));

@@ -31,7 +31,7 @@ def test_oracle_incremental_equals_full_forward():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 6e-2), ("f16c", 1e-3), ("mixed", 1e-3)])
 def test_hip_prefill_and_decode_steps_match_full_forward(prec, tol):
     lm = _lm(seed=6)
     w = oracle_weights(lm)

@@ -183,7 +183,7 @@ def test_hf_clip_checkpoint_through_load_checkpoint_matches_hf_output(tmp_path):
     res = load_checkpoint(m, path, strict=False)
     assert not res.unexpected_keys and not any(k.startswith("clip_model.") and "position_ids" not in k for k in res.missing_keys)
     m = m.to("cuda")
-    m.precision = "fp32"
+    m.clip_model.precision = "fp32"
     out = m.clip_model(pixel_values=torch.from_numpy(z["pixels"]).cuda())["last_hidden_state"]
     ref = torch.from_numpy(z["last_hidden_state"])
     assert float((out.cpu() - ref).abs().max() / ref.pow(2).mean().sqrt()) < 2e-5

@@ -19,7 +19,7 @@ if [[ "$WHAT" == all || "$WHAT" == gemm ]]; then
 fi
 if [[ "$WHAT" == all || "$WHAT" == prof ]]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OLDPWD/gpurun_out/prof" -o kx -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --prof-steps 0 > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OLDPWD/gpurun_out/prof" -o kx -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extra --prof-steps 0 > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1)
   find gpurun_out/prof -name "*stats*" | head; 
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && head -30 "$f"
   # keep the merge-back small: drop the raw trace, keep the stats

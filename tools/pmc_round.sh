@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp KOSMOSX_NO_LOGGING_CONFIG=1
 mkdir -p gpurun_out/pmc
-CMD="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0"
+CMD="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --prof-steps 0"
 run() { # name, counters
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $2 -f csv -d "$OLDPWD/gpurun_out/pmc/$1" -o pmc -- $CMD > "$OLDPWD/gpurun_out/pmc/$1.log" 2>&1)
   ls gpurun_out/pmc/$1 2>/dev/null | head -5
