@@ -155,6 +155,14 @@ typedef struct {
   /* KX_PREC_F16C only: [N] E8M0 scale bytes of the weight rows (see kx_precision).  A, W are KX_F16C rows: lda/ldw (and
    * ldc for a KX_F16C output) count 2-byte units (>= 2K, >= 2N), K is the number of values per row (K % 128 == 0). */
   const uint8_t* w_scale;
+  /* Folded PRE-LayerNorm, producer side (the residual GEMMs out_proj / fc2: fp32 C with `residual`, N % 64 == 0, a tile
+   * kernel of 128 rows or more, no split-K): besides C = x_new the epilogue writes x_new a second time as the operand
+   * rows of the GEMM that follows the next LayerNorm (ln_operand_dt = KX_BF16 / KX_F16 / KX_F16C, dense [M, N]) and the
+   * partial statistics (sum, M2 about the segment mean) of every 64-column segment to ln_operand_stats [M, N/64, 2].
+   * kx_row_stats_finalize(seg_size 64) turns them into the (mean, rstd) the consumer takes as `row_stats` together with
+   * gamma-folded weights, `colsum` and bias' = W·beta + b — torchscale's self_attn_layer_norm / final_layer_norm /
+   * decoder.layer_norm and CLIP's layer_norm1/2 then cost no pass over the residual stream. */
+  void* ln_operand_out; int32_t ln_operand_dt; float* ln_operand_stats;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 
@@ -223,6 +231,12 @@ typedef struct {
   const float *ln2_g, *ln2_b;                 /* layer_norm2 */
   const void* w1;   const float* b1;          /* mlp.fc1 */
   const void* w2;   const float* b2;          /* mlp.fc2 */
+  /* Optional (all NULL = off): layer_norm1 / layer_norm2 FOLDED into the GEMMs that consume them, packed like the
+   * decoder's sub-LNs below — w := gamma ⊙ W, b := W·beta + b, colsum[n] := Σ_k w[n,k].  With them (and 64 | dim,
+   * a batch large enough for the tile kernels) the residual GEMMs emit the operand rows + statistics themselves
+   * (kx_gemm_args.ln_operand_out) and no LayerNorm kernel runs between the layers. */
+  const void* wqkv_f; const float* bqkv_f; const float* wqkv_colsum;
+  const void* w1_f;   const float* b1_f;   const float* w1_colsum;
 } kx_vit_layer;
 
 typedef struct {
@@ -282,6 +296,9 @@ typedef struct {
   const void* w1;   const float* b1;          /* ffn.A.fc1 */
   const void* w2;   const float* b2;          /* ffn.A.fc2 (sub-LN folded) */
   const float* w2_colsum;
+  /* Optional (all NULL = off): self_attn_layer_norm folded into qkv, final_layer_norm into fc1 (same packing rule) */
+  const void* wqkv_f; const float* bqkv_f; const float* wqkv_colsum;
+  const void* w1_f;   const float* b1_f;   const float* w1_colsum;
 } kx_decoder_layer;
 
 typedef struct {
@@ -289,6 +306,8 @@ typedef struct {
   const kx_decoder_layer* layer;              /* host array [layers] */
   const float *ln_g, *ln_b;                   /* decoder.layer_norm */
   const void* wout;                           /* output_projection.weight [vocab, dim] */
+  /* Optional: decoder.layer_norm folded into the output projection (bout_f = Wout·beta, [vocab]) */
+  const void* wout_f; const float* bout_f; const float* wout_colsum;
 } kx_decoder_weights;
 
 /* Decoder.forward(x, passed_x=x)[0] (/root/reference/kosmosx/model.py:250, :320; torchscale

@@ -143,11 +143,16 @@ struct RowFusion {
   float eps = 0.f;
 };
 
+// folded pre-LayerNorm, producer side of a residual GEMM (kx_gemm_args.ln_operand_out)
+struct LnOp { void* out; int dt; float* stats; };
+inline bool fold_prec(int prec) { return prec == KX_PREC_BF16 || prec == KX_PREC_F16 || prec == KX_PREC_F16C; }
+
 int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t ldc, int cdtype, int64_t M, int64_t N,
          const float* bias, const float* residual, int act, float qscale, int64_t qcols, int prec, hipStream_t s,
          const float* xq_cs = nullptr, const float* xq_ss = nullptr, const float* xk_cs = nullptr,
          const float* xk_ss = nullptr, int64_t xT = 0, int64_t xdim = 0, const float* row_stats = nullptr,
-         const float* colsum = nullptr, float* stats_out = nullptr, const RowFusion* rf = nullptr) {
+         const float* colsum = nullptr, float* stats_out = nullptr, const RowFusion* rf = nullptr,
+         const LnOp* lo = nullptr) {
   kx_gemm_args g;
   memset(&g, 0, sizeof(g));
   // bf16x3: the same bf16 kernels over the 3K-wide split operands ([hi|hi|lo] activations x [hi|lo|hi] weights)
@@ -167,6 +172,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
     g.stats_partials = rf->partials; g.stats_in_nseg = rf->nseg; g.stats_in_seg = rf->seg; g.stats_eps = rf->eps;
     g.ln_out = rf->ln_out; g.ln_out_dt = rf->ln_dt; g.ln_out_gamma = rf->ln_g; g.ln_out_beta = rf->ln_b; g.ln_out_eps = rf->eps;
   }
+  if (lo) { g.ln_operand_out = lo->out; g.ln_operand_dt = lo->dt; g.ln_operand_stats = lo->stats; }
   return kx_gemm(&g, (void*)s);
 }
 
@@ -209,7 +215,7 @@ int ln(const float* x, const float* pre, const float* g, const float* b, void* y
 }
 
 // ---------------- ViT ----------------
-struct VitBufs { void *patches, *h, *qkv, *att, *ff, *splitk; float *patch_out, *xpre; size_t total; };
+struct VitBufs { void *patches, *h, *qkv, *att, *ff, *splitk; float *patch_out, *xpre, *partials2, *stats2; size_t total; };
 VitBufs vit_plan(const kx_vit_weights* w, int64_t B, int prec, char* base) {
   const int64_t G = w->image / w->patch, P = G * G, S = P + 1, M = B * S, MP = B * P;
   const size_t es = esz(prec);
@@ -222,6 +228,8 @@ VitBufs vit_plan(const kx_vit_weights* w, int64_t B, int prec, char* base) {
   v.qkv = c.take((size_t)M * 3 * w->dim * qes(prec));
   v.att = c.take((size_t)M * w->dim * es);
   v.ff = c.take((size_t)M * w->ffn * es);
+  v.partials2 = (float*)c.take((size_t)M * ((w->dim + 63) / 64) * 2 * 4);    // folded layer_norm1/2: per-64-column partials
+  v.stats2 = (float*)c.take((size_t)M * 2 * 4);
   v.splitk = c.take(KX_SPLITK_WS);
   v.total = c.off;
   return v;
@@ -248,7 +256,7 @@ PerBufs per_plan(const kx_perceiver_weights* w, int64_t B, int64_t m, int prec, 
 }
 
 // ---------------- Decoder ----------------
-struct DecBufs { void *h, *qkv, *att, *g, *splitk; float *partials, *stats; size_t total; };
+struct DecBufs { void *h, *qkv, *att, *g, *splitk; float *partials, *stats, *partials2, *stats2; size_t total; };
 DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, char* base) {
   const int64_t M = B * T;
   const size_t es = esz(prec);
@@ -263,6 +271,8 @@ DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, ch
   const int64_t nseg = w->ffn / 16 > w->heads ? w->ffn / 16 : w->heads;
   d.partials = (float*)c.take((size_t)M * nseg * 2 * 4);
   d.stats = (float*)c.take((size_t)M * 2 * 4);
+  d.partials2 = (float*)c.take((size_t)M * ((w->dim + 63) / 64) * 2 * 4);   // folded pre-LayerNorms (residual-stream rows)
+  d.stats2 = (float*)c.take((size_t)M * 2 * 4);
   d.splitk = c.take(KX_SPLITK_WS);
   d.total = c.off;
   return d;
@@ -300,11 +310,20 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
   // At batch 1 (M = 257) the GEMMs are split-K and the layer is a chain of dependent ~12 us launches: the residual
   // GEMMs' row-owning reduce kernels also write the LayerNorm that follows (layer_norm2 / the next layer's layer_norm1).
   const bool fuse_o = row_reduce_available(M, D, D, prec), fuse_2 = row_reduce_available(M, D, w->ffn, prec);
+  // Folded layer_norm1 / layer_norm2 (large batches, the tile kernels): the residual GEMMs write the operand rows and the
+  // row statistics of what they finish, qkv / fc1 multiply by gamma-folded weights — no LayerNorm kernel between layers.
+  const bool fold = w->layers > 0 && w->layer[0].wqkv_f && fold_prec(prec) && !fuse_o && !fuse_2 && D % 64 == 0 &&
+                    kx_tuning_get(KX_TUNE_GEMM_TILE) == 0 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1;
+  const LnOp lop{v.h, ct, v.partials2};
   bool h_ready = false;                                   // v.h already holds layer_norm1(out) of this layer
   for (int i = 0; i < w->layers; ++i) {
     const kx_vit_layer& L = w->layer[i];
-    if (!h_ready) KX_TRY(ln(out, nullptr, L.ln1_g, L.ln1_b, v.h, ct, M, D, w->eps, s));
-    KX_TRY(gemm(v.h, D, L.wqkv, D, v.qkv, 3 * D, qdt(prec), M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s));
+    const bool st1 = fold && i > 0;                        // v.h = un-normalised rows + v.stats2 from the previous fc2
+    if (fold && i == 0) KX_TRY(ln(out, nullptr, nullptr, nullptr, v.h, ct, M, D, w->eps, s));   // unit affine: the fold carries gamma / beta
+    else if (!fold && !h_ready) KX_TRY(ln(out, nullptr, L.ln1_g, L.ln1_b, v.h, ct, M, D, w->eps, s));
+    KX_TRY(gemm(v.h, D, fold ? L.wqkv_f : L.wqkv, D, v.qkv, 3 * D, qdt(prec), M, 3 * D, fold ? L.bqkv_f : L.bqkv, nullptr, 0,
+                0.125f, D, prec, s, nullptr, nullptr, nullptr, nullptr, 0, 0, st1 ? v.stats2 : nullptr,
+                st1 ? L.wqkv_colsum : nullptr));
     kx_attn_args a;
     memset(&a, 0, sizeof(a));
     a.q = v.qkv; a.q_batch_stride = S * 3 * D; a.q_row_stride = 3 * D;
@@ -316,13 +335,17 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
     RowFusion ro, r2;
     ro.ln_out = v.h; ro.ln_dt = ct; ro.ln_g = L.ln2_g; ro.ln_b = L.ln2_b; ro.eps = w->eps;
     KX_TRY(gemm(v.att, D, L.wo, D, out, D, KX_F32, M, D, L.bo, out, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr, 0,
-                0, nullptr, nullptr, nullptr, fuse_o ? &ro : nullptr));
-    if (!fuse_o) KX_TRY(ln(out, nullptr, L.ln2_g, L.ln2_b, v.h, ct, M, D, w->eps, s));
-    KX_TRY(gemm(v.h, D, L.w1, D, v.ff, w->ffn, ct, M, w->ffn, L.b1, nullptr, w->act, 1.f, 0, prec, s));
+                0, nullptr, nullptr, nullptr, fuse_o ? &ro : nullptr, fold ? &lop : nullptr));
+    if (fold) KX_TRY(kx_row_stats_finalize(v.partials2, M, D / 64, 64, w->eps, v.stats2, stream));
+    else if (!fuse_o) KX_TRY(ln(out, nullptr, L.ln2_g, L.ln2_b, v.h, ct, M, D, w->eps, s));
+    KX_TRY(gemm(v.h, D, fold ? L.w1_f : L.w1, D, v.ff, w->ffn, ct, M, w->ffn, fold ? L.b1_f : L.b1, nullptr, w->act, 1.f, 0,
+                prec, s, nullptr, nullptr, nullptr, nullptr, 0, 0, fold ? v.stats2 : nullptr, fold ? L.w1_colsum : nullptr));
     const bool next = fuse_2 && i + 1 < w->layers;
     if (next) { r2.ln_out = v.h; r2.ln_dt = ct; r2.ln_g = w->layer[i + 1].ln1_g; r2.ln_b = w->layer[i + 1].ln1_b; r2.eps = w->eps; }
+    const bool emit = fold && i + 1 < w->layers;           // the last layer's output is the tower's output: nothing follows
     KX_TRY(gemm(v.ff, w->ffn, L.w2, w->ffn, out, D, KX_F32, M, D, L.b2, out, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
-                nullptr, 0, 0, nullptr, nullptr, nullptr, next ? &r2 : nullptr));
+                nullptr, 0, 0, nullptr, nullptr, nullptr, next ? &r2 : nullptr, emit ? &lop : nullptr));
+    if (emit) KX_TRY(kx_row_stats_finalize(v.partials2, M, D / 64, 64, w->eps, v.stats2, stream));
     h_ready = next;
   }
   return KX_OK;
@@ -413,13 +436,23 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
   // folded-LN statistics straight from the producer's partials and write the LayerNorm that follows (final_layer_norm,
   // the next layer's self_attn_layer_norm, the decoder's last LayerNorm) — 9 launches per layer instead of 13.
   const bool fuse_o = row_reduce_available(M, D, D, prec), fuse_2 = row_reduce_available(M, D, F, prec);
+  // Folded self_attn_layer_norm / final_layer_norm / decoder.layer_norm (large M, the tile kernels): out_proj and fc2 —
+  // the GEMMs that finish a row of the residual stream — also write it as the next GEMM's operand (d.h) with its partial
+  // statistics; qkv / fc1 / the output projection multiply by gamma-folded weights and apply rstd*(acc - mean*colsum) +
+  // (W beta + b).  One LayerNorm launch is left (layer 0, unit affine) instead of 2 L + 1.
+  const bool fold = w->layers > 0 && w->layer[0].wqkv_f && w->wout_f && fold_prec(prec) && !fuse_o && !fuse_2 && D % 64 == 0 &&
+                    kx_tuning_get(KX_TUNE_GEMM_TILE) == 0 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1;
+  const LnOp lop{d.h, ct, d.partials2};
   bool h_ready = false;                                   // d.h already holds the LayerNorm this layer starts with
   for (int i = 0; i < w->layers; ++i) {
     const kx_decoder_layer& L = w->layer[i];
     // x = x + out_proj(inner_attn_ln(attn(xpos(q), xpos(k), v)))   on self_attn_layer_norm(x)
-    if (!h_ready) KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
-    KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, qdt(prec), M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
-                w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? T : 0, w->xpos ? D : 0));
+    const bool st1 = fold && i > 0;                        // d.h = un-normalised rows of x + d.stats2 from the previous fc2
+    if (fold && i == 0) KX_TRY(ln(x, nullptr, nullptr, nullptr, d.h, ct, M, D, w->eps, s));     // unit affine
+    else if (!fold && !h_ready) KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
+    KX_TRY(gemm(d.h, D, fold ? L.wqkv_f : L.wqkv, D, d.qkv, 3 * D, qdt(prec), M, 3 * D, fold ? L.bqkv_f : L.bqkv, nullptr, 0,
+                0.125f, D, prec, s, w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? T : 0, w->xpos ? D : 0,
+                st1 ? d.stats2 : nullptr, st1 ? L.wqkv_colsum : nullptr));
     if (kcache) {   // incremental decoding: keep this layer's (XPos-rotated) keys and values
       const size_t layer_bytes = (size_t)B * Tmax * D * qes(prec);
       KX_TRY(kx_launch_kv_prefill(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, B, T, D, Tmax,
@@ -446,22 +479,27 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
       } else {
         KX_TRY(kx_row_stats_finalize(d.partials, M, w->heads, 64, w->eps, d.stats, stream));
         KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
-                    0, 0, d.stats, L.wo_colsum, nullptr));
+                    0, 0, d.stats, L.wo_colsum, nullptr, nullptr, fold ? &lop : nullptr));
       }
     } else {
       KX_TRY(kx_attention(&a, stream));
       KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr, 0,
-                  0, nullptr, nullptr, nullptr, fuse_o ? &ro : nullptr));
+                  0, nullptr, nullptr, nullptr, fuse_o ? &ro : nullptr, fold ? &lop : nullptr));
     }
     // x = x + fc2(ffn_layernorm(gelu(fc1(final_layer_norm(x)))))
-    if (!fuse_o) KX_TRY(ln(x, nullptr, L.fl_g, L.fl_b, d.h, ct, M, D, w->eps, s));
+    if (fold) KX_TRY(kx_row_stats_finalize(d.partials2, M, D / 64, 64, w->eps, d.stats2, stream));
+    else if (!fuse_o) KX_TRY(ln(x, nullptr, L.fl_g, L.fl_b, d.h, ct, M, D, w->eps, s));
     const bool last = i + 1 == w->layers;
     r2.ln_out = d.h; r2.ln_dt = ct; r2.eps = w->eps;
     r2.ln_g = last ? w->ln_g : w->layer[i + 1].sa_g; r2.ln_b = last ? w->ln_b : w->layer[i + 1].sa_b;
+    const void* w1 = fold ? L.w1_f : L.w1;
+    const float* b1 = fold ? L.b1_f : L.b1;
+    const float* rs1 = fold ? d.stats2 : nullptr;
+    const float* cs1 = fold ? L.w1_colsum : nullptr;
     if (w->subln) {
       // ffn_layernorm folded into fc2 the same way; fc1's epilogue emits the row statistics of gelu(fc1)
-      KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
-                  nullptr, 0, 0, nullptr, nullptr, d.partials));
+      KX_TRY(gemm(d.h, D, w1, D, d.g, F, ct, M, F, b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
+                  nullptr, 0, 0, rs1, cs1, d.partials));
       if (fuse_2) {
         r2.partials = d.partials; r2.nseg = F / 64; r2.seg = 64;
         KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
@@ -469,14 +507,21 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
       } else {
         KX_TRY(kx_row_stats_finalize(d.partials, M, F / 64, 64, w->eps, d.stats, stream));
         KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
-                    0, 0, d.stats, L.w2_colsum, nullptr));
+                    0, 0, d.stats, L.w2_colsum, nullptr, nullptr, fold ? &lop : nullptr));
       }
     } else {
-      KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s));
+      KX_TRY(gemm(d.h, D, w1, D, d.g, F, ct, M, F, b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
+                  0, 0, rs1, cs1));
       KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr, 0, 0,
-                  nullptr, nullptr, nullptr, fuse_2 ? &r2 : nullptr));
+                  nullptr, nullptr, nullptr, fuse_2 ? &r2 : nullptr, fold ? &lop : nullptr));
     }
+    if (fold) KX_TRY(kx_row_stats_finalize(d.partials2, M, D / 64, 64, w->eps, d.stats2, stream));
     h_ready = fuse_2;                                     // d.h = the next layer's (or the final) LayerNorm of x
+  }
+  if (fold) {                                             // decoder.layer_norm folded into the output projection
+    KX_TRY(gemm(d.h, D, w->wout_f, D, logits, w->vocab, ldt, M, w->vocab, w->bout_f, nullptr, 0, 1.f, 0, prec, s, nullptr,
+                nullptr, nullptr, nullptr, 0, 0, d.stats2, w->wout_colsum));
+    return KX_OK;
   }
   if (!h_ready) KX_TRY(ln(x, nullptr, w->ln_g, w->ln_b, d.h, ct, M, D, w->eps, s));
   KX_TRY(gemm(d.h, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab, nullptr, nullptr, 0, 1.f, 0, prec, s));

@@ -88,14 +88,22 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   KX_REQUIRE(!a->colsum || ((uintptr_t)a->colsum & 15) == 0, "kx_gemm: colsum must be 16-byte aligned");
   KX_REQUIRE(!a->stats_out || a->stats_out_seg == 16 || a->N % 64 == 0, "kx_gemm: stats_out needs N %% 64 == 0 (N=%lld)",
              (long long)a->N);
-  KX_REQUIRE(!a->stats_out || (!a->row_stats && a->qcols == 0 && a->xpos_dim == 0),
-             "kx_gemm: stats_out combines with bias and activation only");
+  KX_REQUIRE(!a->stats_out || (a->qcols == 0 && a->xpos_dim == 0),
+             "kx_gemm: stats_out combines with the folded-LN consume, bias and activation only");
   KX_REQUIRE(!a->stats_out || !a->residual, "kx_gemm: stats_out is taken before the residual add; pass one of them");
   p.vec_ok = (a->ldc % 4 == 0) && (!a->residual || a->ldr % 4 == 0) &&
              (((uintptr_t)a->C & 15) == 0) && (!a->residual || ((uintptr_t)a->residual & 15) == 0);
   p.vec8_ok = p.vec_ok && (a->ldc % 8 == 0) && (a->N % 8 == 0);
   KX_REQUIRE(!a->bias || ((uintptr_t)a->bias & 15) == 0, "kx_gemm: bias must be 16-byte aligned");
   p.splitk = 1; p.partial = nullptr;
+  p.lnop_out = a->ln_operand_out; p.lnop_dt = a->ln_operand_dt; p.lnop_stats = a->ln_operand_stats;
+  KX_REQUIRE(!a->ln_operand_out == !a->ln_operand_stats, "kx_gemm: ln_operand_out and ln_operand_stats go together");
+  KX_REQUIRE(!a->ln_operand_out ||
+                 (a->residual && a->cdt == KX_F32 && a->N % 64 == 0 && p.vec_ok && !a->stats_out && !a->ln_out &&
+                  (a->ln_operand_dt == KX_BF16 || a->ln_operand_dt == KX_F16 || a->ln_operand_dt == KX_F16C) &&
+                  ((uintptr_t)a->ln_operand_out & 15) == 0 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1),
+             "kx_gemm: ln_operand_out needs an fp32 output with residual, N %% 64 == 0, aligned rows, a 2-byte / KX_F16C "
+             "operand dtype and the prefetching store loop");
   p.stagger_ticks = 0;
   p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
   p.stats_partials = nullptr; p.stats_in_nseg = 0; p.stats_in_seg = p.stats_eps = 0.f;
@@ -162,6 +170,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   }
   // A 64x64 wave owns 32 columns only: the statistics producer needs the split-K reduce kernel (whose threads walk whole
   // 64-column segments) — when the call will not actually be split, take 128x128 instead (its waves own 64 columns).
+  if (tile == 64 && a->ln_operand_out) tile = 128;        // the producer lives in the 64-column store loops
   if (tile == 64 && a->stats_out &&
       !(a->splitk_ws && splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk) > 1))
     tile = 128;

@@ -28,6 +28,9 @@ struct GemmParams {
   // folded sub-LayerNorm (see kx_gemm_args): consume per-row (mean, rstd) + column sums, produce partial statistics
   const float* row_stats; const float* colsum;
   float* stats_out; int stats_nseg;
+  // folded PRE-LayerNorm, producer side (residual GEMMs: out_proj, fc2): besides C = x_new (fp32), write x_new as the
+  // next GEMM's operand rows (bf16 / fp16 / KX_F16C, [M, N]) and its per-(row, 64-column) partial statistics
+  void* lnop_out; int lnop_dt; float* lnop_stats;
   // split-K (skinny problems): blockIdx.y = K slice; raw fp32 partials go to `partial` [splitk][M][N], the fused
   // epilogue runs in splitk_reduce_kernel, which sums the slices in a fixed order (deterministic)
   int splitk; float* partial;
@@ -300,6 +303,32 @@ __device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float
               make_float4(x[0][0], x[0][1], x[0][2], x[0][3]);
         }
       }
+      if constexpr (CPL == 4 && WN == 64) {
+        if (p.lnop_stats) {
+          // The 16 lanes of a row hold the 64 finished values of one statistics segment: (sum, M2 about the segment
+          // mean) by 8 lane exchanges, and the same values go out a second time as the next GEMM's operand — the
+          // LayerNorm that follows this residual GEMM needs no pass of its own (its gamma / beta are folded into the
+          // consumer's weights, the (mean, rstd) into its epilogue).  Rows past M take part in the exchanges only.
+          float sm = (x[0][0] + x[0][1]) + (x[0][2] + x[0][3]);
+          sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
+          const float mu = sm * (1.0f / 64.0f);
+          const float d0 = x[0][0] - mu, d1 = x[0][1] - mu, d2 = x[0][2] - mu, d3 = x[0][3] - mu;
+          float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64); m2 += __shfl_xor(m2, 8, 64);
+          if (m < p.M) {
+            if (cl == 0)
+              *reinterpret_cast<float2*>(p.lnop_stats + 2 * ((long long)m * (p.N >> 6) + (n >> 6))) = make_float2(sm, m2);
+            if (p.lnop_dt == KX_F16C) {
+              f16c_store4(reinterpret_cast<char*>(p.lnop_out) + (long long)m * p.N * 4, n, p.N, x[0]);
+            } else {
+              uint2 o;
+              if (p.lnop_dt == KX_F16) { o.x = pack_f16x2(x[0][0], x[0][1]); o.y = pack_f16x2(x[0][2], x[0][3]); }
+              else { o.x = pack_bf16x2(x[0][0], x[0][1]); o.y = pack_bf16x2(x[0][2], x[0][3]); }
+              *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.lnop_out) + (long long)m * p.N + n) = o;
+            }
+          }
+        }
+      }
     }
   }
 }
@@ -349,16 +378,24 @@ __device__ __forceinline__ void prepass_bias_act_stats(const GemmParams& p, f32x
   for (int sg = 0; sg < FN / 4; ++sg) {
     const int nseg0 = ncol0 + sg * 64;
     if (nseg0 >= p.N) return;                     // whole segment outside (N % 64 == 0)
-    float4 bias[4];
+    float4 bias[4], csum[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
       bias[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nseg0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      csum[a] = p.row_stats ? *reinterpret_cast<const float4*>(p.colsum + nseg0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
+      // folded pre-LayerNorm consume (rstd * (acc - mean * colsum)); (mean, rstd) = (0, 1) is an exact no-op, so the
+      // arithmetic stays straight-line (see lean_bias_act on why)
+      const float2 rs = p.row_stats ? *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)min(mrow0 + b * 16 + li, p.M - 1))
+                                    : make_float2(0.f, 1.f);
       float sm = 0.f;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         f32x4_t v = acc[sg * 4 + a][b];
+        v[0] = rs.y * (v[0] - rs.x * csum[a].x); v[1] = rs.y * (v[1] - rs.x * csum[a].y);
+        v[2] = rs.y * (v[2] - rs.x * csum[a].z); v[3] = rs.y * (v[3] - rs.x * csum[a].w);
         v[0] = apply_act<ACT>(v[0] + bias[a].x); v[1] = apply_act<ACT>(v[1] + bias[a].y);
         v[2] = apply_act<ACT>(v[2] + bias[a].z); v[3] = apply_act<ACT>(v[3] + bias[a].w);
         acc[sg * 4 + a][b] = v;
@@ -430,18 +467,28 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // epilogue keep the generic loops: an accumulator-level fp32 path measured the same 71k cycles (it waits on the
 // residual loads either way) and the XPos variant still spilled.
 template <int ACT, int FM, int FN>
-__device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc)[FN][FM], int ncol0, int g) {
+__device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc)[FN][FM], int ncol0, int g, int mrow0, int li) {
   // Straight-line on purpose: a run-time branch whose two sides both rewrite the 128 accumulator registers made the
   // compiler keep two copies of them (spills) — which is also why the variants are separate kernel instantiations.
   // q-scale: a wave's 64 columns lie on one side of the boundary (qcols % 64 == 0, checked by kx_gemm) -> one scalar
   const float qsc = ncol0 < p.qcols ? p.qscale : 1.0f;
+  // folded pre-LayerNorm consume: rstd * (acc - mean * colsum) first; without row statistics (mean, rstd) = (0, 1) and
+  // colsum = 0 make it an exact no-op — same straight-line code either way
+  float2 rs[FM];
+#pragma unroll
+  for (int b = 0; b < FM; ++b)
+    rs[b] = p.row_stats ? *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)min(mrow0 + b * 16 + li, p.M - 1))
+                        : make_float2(0.f, 1.f);
 #pragma unroll
   for (int a = 0; a < FN; ++a) {
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + ncol0 + a * 16 + 4 * g);
+    if (p.row_stats) cs = *reinterpret_cast<const float4*>(p.colsum + ncol0 + a * 16 + 4 * g);
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
       f32x4_t v = acc[a][b];
+      v[0] = rs[b].y * (v[0] - rs[b].x * cs.x); v[1] = rs[b].y * (v[1] - rs[b].x * cs.y);
+      v[2] = rs[b].y * (v[2] - rs[b].x * cs.z); v[3] = rs[b].y * (v[3] - rs[b].x * cs.w);
       v[0] = (v[0] + bias.x) * qsc; v[1] = (v[1] + bias.y) * qsc; v[2] = (v[2] + bias.z) * qsc; v[3] = (v[3] + bias.w) * qsc;
       if constexpr (ACT != KX_ACT_NONE) {
 #pragma unroll
@@ -620,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   // exists once, inside a rolled loop.
   constexpr int WM = BM / 2, WN = BN / 2;
   if constexpr (EPI == 1) {           // bias + activation on the accumulators, the tile parked once as bf16, full-row stores
-    lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g);
+    lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g, m0 + wm * WM, li);
     lean_store_bf16<BM, BN, 4, FM, FN, kIsF16c<T>>(p, acc, smem, m0, n0, wm * WM, wn * WN, wave, lane, g, li);
     return;
   }
@@ -631,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, g, li);
   }
   GemmParams q = p;                   // what is left for the store loop after the pre-pass
-  q.bias = nullptr; q.stats_out = nullptr;
+  q.bias = nullptr; q.stats_out = nullptr; q.row_stats = nullptr;
   __syncthreads();                    // every wave is done reading the last stage
   float* cw = reinterpret_cast<float*>(smem) + wave * (WM * WN);
 #pragma unroll
@@ -983,7 +1030,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
   const bool pre = p.stats_out != nullptr;
   if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, g, li);
   GemmParams q = p;
-  q.bias = nullptr; q.stats_out = nullptr;
+  q.bias = nullptr; q.stats_out = nullptr; q.row_stats = nullptr;
   float* cw = reinterpret_cast<float*>(smem) + wave * (WM * WN);
 #pragma unroll
   for (int a = 0; a < FN; ++a)
@@ -1281,7 +1328,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const bool pre = p.stats_out != nullptr;
   if constexpr (EPI == 1 || EPI == 4) {            // bias / activation (/ statistics) on the accumulators, bf16 tile store
     if constexpr (EPI == 4) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
-    else lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g);
+    else lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g, m0 + wm * (BM / 2), li);
     KX_TL_STAMP(3);
     lean_store_bf16<BM, 256, 8, FM, FN, kIsF16c<T>>(p, acc, smem, m0, n0, wm * (BM / 2), wn * WN, wave, lane, g, li);
     KX_TL_STAMP(4);
@@ -1291,7 +1338,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   if (pre) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
   KX_TL_STAMP(3);
   GemmParams q = p;
-  q.bias = nullptr; q.stats_out = nullptr;
+  q.bias = nullptr; q.stats_out = nullptr; q.row_stats = nullptr;
   constexpr int HR = BM / 4;                 // rows per epilogue half per wave
   float* cw = reinterpret_cast<float*>(smem) + wave * (HR * WN);
   auto park_and_store = [&](auto half_c) {

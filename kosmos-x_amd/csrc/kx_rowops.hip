@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __res
   for (int i = 0; i < 8; ++i) {
     const int c = threadIdx.x + i * 256;
     if (c < nv) {
-      const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
-      const float4 bt = reinterpret_cast<const float4*>(beta)[c];
+      const float4 gm = gamma ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 bt = beta ? reinterpret_cast<const float4*>(beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 o;
       o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
       o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
-      const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
-      const float4 bt = reinterpret_cast<const float4*>(beta)[c];
+      const float4 gm = gamma ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 bt = beta ? reinterpret_cast<const float4*>(beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 o;
       o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
       o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void rows_bcast_kernel(const float* __restrict
 extern "C" int kx_layernorm(const float* x, const float* pre_add, const float* gamma, const float* beta, void* y,
                             kx_dtype ydt, int64_t rows, int64_t cols, float eps, int64_t rows_per_group,
                             int64_t out_group_stride, int64_t out_row_offset, void* stream) {
-  KX_REQUIRE(x && gamma && beta && y, "kx_layernorm: null pointer");
+  KX_REQUIRE(x && y, "kx_layernorm: null pointer");     // gamma / beta may be NULL: unit scale / zero shift
   KX_REQUIRE(rows > 0 && rows < (1ll << 31), "kx_layernorm: rows=%lld out of range", (long long)rows);
   KX_REQUIRE(cols > 0 && cols % 4 == 0 && cols <= 8192, "kx_layernorm: cols=%lld must be a multiple of 4 and <= 8192",
              (long long)cols);

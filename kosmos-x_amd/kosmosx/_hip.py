@@ -46,7 +46,7 @@ class GemmArgs(C.Structure):
                 ("stats_partials", vp), ("stats_in_nseg", i64), ("stats_in_seg", i64), ("stats_eps", f32),
                 ("stats_out_seg", i32),
                 ("ln_out", vp), ("ln_out_dt", i32), ("ln_out_gamma", vp), ("ln_out_beta", vp), ("ln_out_eps", f32),
-                ("w_scale", vp)]
+                ("w_scale", vp), ("ln_operand_out", vp), ("ln_operand_dt", i32), ("ln_operand_stats", vp)]
 
 
 class AttnArgs(C.Structure):
@@ -59,7 +59,7 @@ class AttnArgs(C.Structure):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b",
-                                  "w1", "b1", "w2", "b2")]
+                                  "w1", "b1", "w2", "b2", "wqkv_f", "bqkv_f", "wqkv_colsum", "w1_f", "b1_f", "w1_colsum")]
 
 
 class VitWeights(C.Structure):
@@ -81,13 +81,14 @@ class PerceiverWeights(C.Structure):
 
 class DecoderLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("sa_g", "sa_b", "wqkv", "bqkv", "wo", "bo", "wo_colsum", "fl_g", "fl_b",
-                                  "w1", "b1", "w2", "b2", "w2_colsum")]
+                                  "w1", "b1", "w2", "b2", "w2_colsum", "wqkv_f", "bqkv_f", "wqkv_colsum",
+                                  "w1_f", "b1_f", "w1_colsum")]
 
 
 class DecoderWeights(C.Structure):
     _fields_ = [("layers", i32), ("dim", i32), ("heads", i32), ("ffn", i32), ("vocab", i32), ("act", i32),
                 ("subln", i32), ("xpos", i32), ("eps", f32), ("layer", C.POINTER(DecoderLayer)),
-                ("ln_g", vp), ("ln_b", vp), ("wout", vp)]
+                ("ln_g", vp), ("ln_b", vp), ("wout", vp), ("wout_f", vp), ("bout_f", vp), ("wout_colsum", vp)]
 
 
 class ProfRecord(C.Structure):

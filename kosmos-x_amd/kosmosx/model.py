@@ -95,6 +95,25 @@ def _operand_colsum(wp: torch.Tensor, prec: str, shape=None) -> torch.Tensor:
     return (wp[:, :K].float() + wp[:, K:2 * K].float()).sum(1)
 
 
+FOLD_PRECS = ("bf16", "f16", "f16c")      # stage precisions whose pre-LayerNorms are folded into qkv / fc1 / logits
+
+
+def _fold_pre_ln() -> bool:
+    """Opt-in (KOSMOSX_FOLD_PRE_LN=1).  Measured at B = 32: the 95 LayerNorm launches it removes cost
+    1.5 ms, the residual epilogues' second store + lane exchanges, the consumers' row-statistics loads and the 96
+    statistics-finalize launches it adds cost 2.3 ms — a 2 % loss on the headline and on C3, so it ships off."""
+    return os.environ.get("KOSMOSX_FOLD_PRE_LN", "0") == "1"
+
+
+def _fold_ln_linear(ln_w, ln_b, w, b, prec: str):
+    """LayerNorm(gamma, beta) followed by Linear(W, b), folded (kx_decoder_layer in include/kosmosx_hip.h):
+    W' = gamma ⊙ W as the operand of `prec`, b' = W·beta + b (fp32), colsum[n] = Σ_k W'[n,k] of the packed values."""
+    wf, g_, b_ = w.detach().float(), ln_w.detach().float(), ln_b.detach().float()
+    wp = _operand(wf * g_[None, :], prec)
+    bias = wf @ b_ + (b.detach().float() if b is not None else 0.0)
+    return wp, bias.contiguous(), _operand_colsum(wp, prec, tuple(wf.shape)).contiguous()
+
+
 def _default_precision() -> str:
     # "mixed": the fastest arithmetic that holds the north star's 1e-3 on the logits (see kx_precision in the header)
     p = os.environ.get("KOSMOSX_PRECISION", "mixed")
@@ -255,6 +274,13 @@ class CLIPVisionTower(_PackedMixin, nn.Module):
             e.ln2_g, e.ln2_b = v(L.layer_norm2.weight), v(L.layer_norm2.bias)
             e.w1, e.b1 = op(L.mlp.fc1.weight), v(L.mlp.fc1.bias)
             e.w2, e.b2 = op(L.mlp.fc2.weight), v(L.mlp.fc2.bias)
+            if prec in FOLD_PRECS and _fold_pre_ln():      # layer_norm1 -> qkv, layer_norm2 -> fc1
+                for dst, ln, wt, bt in (("wqkv", L.layer_norm1, wqkv, bqkv), ("w1", L.layer_norm2, L.mlp.fc1.weight, L.mlp.fc1.bias)):
+                    t3 = _fold_ln_linear(ln.weight, ln.bias, wt, bt, prec)
+                    keep.extend(t3)
+                    setattr(e, dst + "_f", t3[0].data_ptr())
+                    setattr(e, "b" + dst[1:] + "_f", t3[1].data_ptr())
+                    setattr(e, dst + "_colsum", t3[2].data_ptr())
         w = H.VitWeights()
         w.image, w.patch, w.dim, w.heads, w.ffn, w.layers = c.image, c.patch, c.dim, c.heads, c.ffn, c.layers
         w.act, w.eps, w.kpad = H.ACTS[c.act], c.eps, kpad
@@ -579,6 +605,15 @@ class Decoder(_PackedMixin, nn.Module):
                 e.w2, e.b2 = op(ffn.fc2.weight), v(ffn.fc2.bias)
             e.fl_g, e.fl_b = v(_a(L.final_layer_norm).weight), v(_a(L.final_layer_norm).bias)
             e.w1, e.b1 = op(ffn.fc1.weight), v(ffn.fc1.bias)
+            if prec in FOLD_PRECS and _fold_pre_ln():      # self_attn_layer_norm -> qkv, final_layer_norm -> fc1
+                sl, fl = _a(L.self_attn_layer_norm), _a(L.final_layer_norm)
+                t3 = _fold_ln_linear(sl.weight, sl.bias, torch.cat([q.weight, k.weight, vv.weight], 0),
+                                     torch.cat([q.bias, k.bias, vv.bias], 0), prec)
+                keep.extend(t3)
+                e.wqkv_f, e.bqkv_f, e.wqkv_colsum = (t.data_ptr() for t in t3)
+                t3 = _fold_ln_linear(fl.weight, fl.bias, ffn.fc1.weight, ffn.fc1.bias, prec)
+                keep.extend(t3)
+                e.w1_f, e.b1_f, e.w1_colsum = (t.data_ptr() for t in t3)
         w = H.DecoderWeights()
         w.layers, w.dim, w.heads, w.ffn = self.num_layers, a.decoder_embed_dim, a.decoder_attention_heads, a.decoder_ffn_embed_dim
         w.vocab, w.act = self.output_projection.weight.shape[0], H.ACTS[a.activation_fn]
@@ -586,6 +621,10 @@ class Decoder(_PackedMixin, nn.Module):
         w.layer = C.cast(layers, C.POINTER(H.DecoderLayer))
         w.ln_g, w.ln_b = v(self.layer_norm.weight), v(self.layer_norm.bias)
         w.wout = op(self.output_projection.weight)
+        if prec in FOLD_PRECS and _fold_pre_ln():          # decoder.layer_norm -> output_projection
+            t3 = _fold_ln_linear(self.layer_norm.weight, self.layer_norm.bias, self.output_projection.weight, None, prec)
+            keep.extend(t3)
+            w.wout_f, w.bout_f, w.wout_colsum = (t.data_ptr() for t in t3)
         emb, pos = _f32(self.embed_tokens.weight), _f32(self.embed_positions.weight)
         keep += [emb, pos]
         self._packed[key] = (w, layers, keep, emb, pos)

@@ -71,7 +71,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, o
 def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
          xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None, splitk_ws=None,
          splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0, out_x3=False,
-         ln_out=None):
+         ln_out=None, ln_operand=None):
     """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32].
     tile=16 (weight streaming, bf16, M <= 16) extras: ln = (gamma, beta, eps) with `a` the raw fp32 rows;
     stats_partials [M,nseg,2] instead of row_stats; stats_out_seg=16.
@@ -109,12 +109,29 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
         lnt = torch.empty((M, N), dtype=ln_out[3], device=a.device)
         g.ln_out, g.ln_out_dt = H.ptr(lnt), _cdt(ln_out[3])
         g.ln_out_gamma, g.ln_out_beta, g.ln_out_eps = H.ptr(ln_out[0]), H.ptr(ln_out[1]), float(ln_out[2])
+    lop = None
+    if ln_operand is not None:      # dtype of the operand copy: torch.bfloat16 / torch.float16 / "f16c"
+        lop = _ln_operand_buffers(g, ln_operand, M, N, a.device)
     H.check(H.load().kx_gemm(C.byref(g), _stream()), "kx_gemm")
+    if lop is not None:
+        return (out,) + lop
     return out if lnt is None else (out, lnt)
 
 
+def _ln_operand_buffers(g, dt, M, N, device):
+    """Folded pre-LayerNorm producer outputs: (operand copy of the finished rows, partial statistics [M, N/64, 2])."""
+    if dt == "f16c":
+        cp, g.ln_operand_dt = torch.empty((M, 4 * N), dtype=torch.uint8, device=device), H.KX_F16C
+    else:
+        cp, g.ln_operand_dt = torch.empty((M, N), dtype=dt, device=device), _cdt(dt)
+    st = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=device)
+    g.ln_operand_out, g.ln_operand_stats = H.ptr(cp), H.ptr(st)
+    return cp, st
+
+
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,
-              xpos=None, xpos_dim=0, tile=0, row_stats=None, colsum=None, stats_out=None, splitk_ws=None, splitk=0):
+              xpos=None, xpos_dim=0, tile=0, row_stats=None, colsum=None, stats_out=None, splitk_ws=None, splitk=0,
+              ln_operand=None):
     """KX_PREC_F16C GEMM: a_rows [M, 4K] uint8 (KX_F16C activation rows), w_packed = the flat packed weight matrix
     (N rows of 4K bytes + N scale bytes, model._operand_f16c).  Output fp32 [M, N] or KX_F16C rows [M, 4N] uint8."""
     _need_cuda(a_rows, w_packed, bias, residual)
@@ -136,8 +153,9 @@ def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_
     g.row_stats, g.colsum, g.stats_out = H.ptr(row_stats), H.ptr(colsum), H.ptr(stats_out)
     if splitk_ws is not None:
         g.splitk_ws, g.splitk_ws_bytes, g.splitk = H.ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size(), splitk
+    lop = _ln_operand_buffers(g, ln_operand, M, N, a_rows.device) if ln_operand is not None else None
     H.check(H.load().kx_gemm(C.byref(g), _stream()), "kx_gemm")
-    return out
+    return out if lop is None else (out,) + lop
 
 
 def row_stats_finalize(partials, seg_size, eps=1e-5):
