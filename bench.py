@@ -53,6 +53,8 @@ def parse():
                          "fp16 MFMA + two fp8 correction MFMAs); bf16 is reported next to it with its parity")
     ap.add_argument("--no-extra", action="store_true", help="skip the c3 / batch-1 / training legs (headline only)")
     ap.add_argument("--no-gather", action="store_true", help="skip the logits all-gather (N > 1)")
+    ap.add_argument("--gather-algo", default="direct", choices=["all_gather", "direct"],
+                    help="direct: world-1 grouped send/recv pairs, one xGMI link per peer; all_gather: RCCL's collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3, help="instrumented steps for the roofline leg")
@@ -250,8 +252,10 @@ def main():
     B, Tt = args.batch, args.text_len
     tok = torch.randint(0, cfg.vocab, (B, Tt), generator=g).to(dev)
     img = torch.randn(B, 3, cfg.vit.image, cfg.vit.image, generator=g).to(dev)
-    gatherer = (LogitsGatherer(wire_dtype=torch.bfloat16, force=force_dist)
+    gatherer = (LogitsGatherer(wire_dtype=None, force=force_dist, algo=args.gather_algo, slots=max(1, args.pipeline) + 1)
                 if ((world > 1 or force_dist) and not args.no_gather) else None)
+    if gatherer is not None:
+        model.logits_dtype = torch.bfloat16       # the logits GEMM's epilogue writes the wire format itself: no cast kernel
 
     S = max(1, args.streams)
     side = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
@@ -494,7 +498,8 @@ def main():
                                    "24L/2048d sub-LN XPos decoder, random-init weights (BASELINE.json configs[3] per-GPU share)",
                        "batch_per_gpu": B, "global_batch": world * B, "seq_len": Tt + cfg.perceiver.latents,
                        "text_len": Tt, "parallelism": f"dp{world}",
-                       "logits_gather": (None if gatherer is None else "RCCL all-gather, bf16 wire, overlapped"),
+                       "logits_gather": (None if gatherer is None else f"RCCL {args.gather_algo}, bf16 logits straight from the GEMM epilogue, "
+                                                               "issued on a side stream (overlaps the next step)"),
                        "micro_batch_streams": S, "pipelined_steps": P, "hip_graph": bool(args.graph)},
             "algorithmic_gflop_per_sample": round(fl["total"] / 1e9, 2),
             "model_tflops": round(fl["total"] * total / elapsed / 1e12, 2),
