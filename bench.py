@@ -513,6 +513,11 @@ def main():
             "gemm_shapes": gemm_shapes,
             "build_seconds": round(t_build, 1),
         }
+        try:                                    # RCCL's banner sits in libc's stdout buffer: flush it BEFORE the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         dist.barrier()                      # rank 0 finishes its instrumented leg before anyone tears down

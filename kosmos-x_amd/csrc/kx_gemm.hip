@@ -94,6 +94,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   p.vec_ok = (a->ldc % 4 == 0) && (!a->residual || a->ldr % 4 == 0) &&
              (((uintptr_t)a->C & 15) == 0) && (!a->residual || ((uintptr_t)a->residual & 15) == 0);
   p.vec8_ok = p.vec_ok && (a->ldc % 8 == 0) && (a->N % 8 == 0);
+  p.vec2_ok = a->cdt == KX_F32 && (a->ldc % 2 == 0) && (((uintptr_t)a->C & 7) == 0);
   KX_REQUIRE(!a->bias || ((uintptr_t)a->bias & 15) == 0, "kx_gemm: bias must be 16-byte aligned");
   p.splitk = 1; p.partial = nullptr;
   p.lnop_out = a->ln_operand_out; p.lnop_dt = a->ln_operand_dt; p.lnop_stats = a->ln_operand_stats;
