@@ -123,6 +123,13 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     p.lean_epilogue = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1 && p.c_bf16 && !p.c_x3 && !p.c_f16c &&
                       ((f16 || f16c) ? p.c_f16 : !p.c_f16) && p.vec8_ok && !a->residual &&
                       !a->row_stats && !a->xpos_dim && a->qcols % 64 == 0 && !(a->stats_out && a->qcols);
+    // the decoder's qkv GEMM in bf16: bias + q-scale + XPos, no folded-LN consume / residual / statistics, whole heads per wave
+    // A/B only (tuning key 4 = 3): measured SLOWER than the row-major store loop it was meant to replace — C3 qkv 36.5 ms
+    // (1084 TFLOP/s) on the generic loop, 49.3 ms with the tables read from global in accumulator layout, 44.5 ms with
+    // them staged through LDS (the 256-row variant pushes half of its rotated accumulators through scratch).
+    p.lean_xpos = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) == 3 && a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && p.vec8_ok &&
+                  a->xpos_dim > 0 && !a->residual && !a->row_stats && !a->stats_out && a->act == KX_ACT_NONE &&
+                  a->qcols % 256 == 0 && a->xpos_dim % 256 == 0;
     p.fast_epilogue = mode == 2 || (mode == 0 && (a->residual || a->row_stats || a->xpos_dim > 0));
   }
   hipStream_t s = (hipStream_t)stream;

@@ -40,6 +40,7 @@ struct GemmParams {
   int stagger_ticks;
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
   int lean_epilogue;    // 256-column kernel: accumulator-level epilogue + pure data movement (see lean_store_*)
+  int lean_xpos;        // 256-column kernel, bf16 output: q-scale + XPos at accumulator level too (lean_bias_qscale_xpos)
   int persistent;       // 256x256 kernel: > 0 = launch this many workgroups, each walking its tiles itself
   int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
   // weight-streaming variant (gemv_fused_kernel) only
@@ -500,6 +501,58 @@ __device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc
       }
       acc[a][b] = v;
     }
+  }
+}
+
+// q-scale + XPos at accumulator level (the decoder's qkv GEMM, EPI 5 of the 256-column kernel): lane (g, li) of
+// fragment (a, b) holds row b*16+li and columns ncol0 + a*16 + 4g .. +3 = two rotary pairs j = a*8 + 2g, +1 of the
+// wave's head (a wave's 64 columns are one head; the tile's 256 columns lie on one side of the q | k | v boundaries), so
+// the rotation is lane-local.  The table rows of the tile's BM positions are first staged into the (idle) staging LDS —
+// [BM][cos*scale (32) | sin*scale (32) | pad 4] floats, one coalesced 128-byte read per (row, table) — because read
+// straight from global by the accumulator layout they are 16 partial cache lines per wave instruction: that version ran
+// the qkv GEMM at 800 instead of 1080 TFLOP/s (the generic row-major store loop, 32 k cycles per tile, was faster).
+// The v tiles skip all of it.
+constexpr int XPOS_PITCH = 68;   // floats per staged row: 272 B = 16-byte aligned rows, bank-skewed by 4
+template <int BM>
+__device__ __forceinline__ void stage_xpos_rows(const GemmParams& p, float* tab, int m0, int n0, int tid) {
+  const float* cs = n0 < p.xpos_dim ? p.xq_cs : p.xk_cs;
+  const float* ss = n0 < p.xpos_dim ? p.xq_ss : p.xk_ss;
+  for (int t = tid; t < BM * 2; t += 512) {
+    const int row = t >> 1, half = t & 1;
+    const int pos = min(m0 + row, p.M - 1) % p.xpos_T;
+    const float4* src = reinterpret_cast<const float4*>((half ? ss : cs) + pos * 32);
+    float4* dst = reinterpret_cast<float4*>(tab + row * XPOS_PITCH + half * 32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[q] = src[q];
+  }
+}
+template <int FM, int FN>
+__device__ __forceinline__ void lean_bias_qscale_xpos(const GemmParams& p, f32x4_t (&acc)[FN][FM], int ncol0, int g,
+                                                      int row_w0, int li, const float* tab, bool rot) {
+  static_assert(FN == 4, "a wave owns one 64-column head");
+  const float qsc = ncol0 < p.qcols ? p.qscale : 1.0f;
+  float4 bias[FN];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+    bias[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + ncol0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const float* tr = tab + (row_w0 + b * 16 + li) * XPOS_PITCH + 2 * g;
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      // v columns: the identity rotation (1, 0) — exact — keeps the arithmetic straight-line
+      const float2 c = rot ? *reinterpret_cast<const float2*>(tr + a * 8) : make_float2(1.f, 1.f);
+      const float2 sn = rot ? *reinterpret_cast<const float2*>(tr + 32 + a * 8) : make_float2(0.f, 0.f);
+      f32x4_t v = acc[a][b];
+      const float x0 = (v[0] + bias[a].x) * qsc, x1 = (v[1] + bias[a].y) * qsc;
+      const float x2 = (v[2] + bias[a].z) * qsc, x3 = (v[3] + bias[a].w) * qsc;
+      float t0 = (-x1) * sn.x, t1 = x0 * sn.x, t2 = (-x3) * sn.y, t3 = x2 * sn.y;
+      KX_NO_PACK(t0); KX_NO_PACK(t1); KX_NO_PACK(t2); KX_NO_PACK(t3);
+      v[0] = x0 * c.x + t0; v[1] = x1 * c.x + t1;
+      v[2] = x2 * c.y + t2; v[3] = x3 * c.y + t3;
+      acc[a][b] = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the next rows' table reads from being hoisted (they pushed accumulators to scratch)
   }
 }
 
@@ -1330,8 +1383,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const int lane = lane_e, g = lane_e >> 4, li = lane_e & 15;
   constexpr int WN = 64, CH = WN / 4;
   const bool pre = p.stats_out != nullptr;
-  if constexpr (EPI == 1 || EPI == 4) {            // bias / activation (/ statistics) on the accumulators, bf16 tile store
-    if constexpr (EPI == 4) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
+  if constexpr (EPI == 1 || EPI == 4 || EPI == 5) {   // bias / activation (/ statistics, / XPos) on the accumulators, bf16 tile store
+    if constexpr (EPI == 5) {
+      const bool rot = n0 < 2 * p.xpos_dim;                 // tile-uniform: xpos_dim % 256 == 0 (kx_gemm checks)
+      float* tab = reinterpret_cast<float*>(smem);
+      __syncthreads();                                      // the K loop's last fragment reads are done
+      if (rot) stage_xpos_rows<BM>(p, tab, m0, n0, threadIdx.x);
+      __syncthreads();
+      lean_bias_qscale_xpos<FM, FN>(p, acc, n0 + wn * WN, g, wm * (BM / 2), li, tab, rot);
+    } else if constexpr (EPI == 4) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
     else lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g, m0 + wm * (BM / 2), li);
     KX_TL_STAMP(3);
     lean_store_bf16<BM, 256, 8, FM, FN, kIsF16c<T>>(p, acc, smem, m0, n0, wm * (BM / 2), wn * WN, wave, lane, g, li);
@@ -1375,6 +1435,7 @@ int launch_p5e(GemmParams& p, hipStream_t s) {
   const dim3 grid(p.persistent > 0 ? (nwg < p.persistent ? nwg : p.persistent) : nwg), block(512);
   // the lean variants are instantiated for the activations the forward uses them with; anything else takes EPI 0
   if (p.act == KX_ACT_NONE && EPI != 4) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, EPI>), grid, block, 0, s, p);
+  else if (EPI == 5) return launch_p5e<T, BM, 0>(p, s);
   else if (p.act == KX_ACT_GELU_FAST && (EPI == 0 || EPI == 1 || EPI == 4))
     hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, (EPI == 1 || EPI == 4) ? EPI : 0>), grid, block, 0, s, p);
   else if (p.act == KX_ACT_QUICK_GELU && (EPI == 0 || EPI == 1))
@@ -1392,6 +1453,7 @@ int launch_p5(GemmParams& p, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + 255) / 256;
   if constexpr (kIsF16c<T>) return launch_p5e<T, BM, 0>(p, s);   // KX_F16C outputs take the generic store loops
+  else if (p.lean_xpos && p.N % 256 == 0) return launch_p5e<T, BM, 5>(p, s);
   else if (p.lean_epilogue && p.N % 256 == 0) return p.stats_out ? launch_p5e<T, BM, 4>(p, s) : launch_p5e<T, BM, 1>(p, s);
   return launch_p5e<T, BM, 0>(p, s);
 }

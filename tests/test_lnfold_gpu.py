@@ -139,3 +139,30 @@ def test_full_size_batch16_with_folded_pre_layernorms(prec, tol):
     d = rel_err(out, out0)
     print(f"   folded vs unfolded: {d:.3e}")
     assert d < (tol if prec != "bf16" else 6e-2)
+
+
+@pytest.mark.parametrize("tile", [384, 512])
+@pytest.mark.parametrize("M,T", [(3648, 114), (4092, 2046), (700, 115)])
+def test_qkv_xpos_epilogue_at_accumulator_level_equals_the_store_loop(tile, M, T):
+    """EPI 5 of the 256-column kernel (bias + q-scale + XPos on the accumulators, lean bf16 store) against the generic
+    store loop of the 128x128 kernel: same arithmetic, so the bf16 outputs agree to the last bit almost everywhere."""
+    from kosmosx.model import XPOS
+    g = _g(M + tile)
+    D, K = 512, 256
+    x = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(3 * D, K, generator=g) * 0.06).bfloat16().to(DEV)
+    bias = torch.randn(3 * D, generator=g).to(DEV)
+    xp = XPOS(64)
+    tabs = tuple(t.to(DEV) for t in (*xp.tables(T, 0, False), *xp.tables(T, 0, True)))
+    kw = dict(bias=bias, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D, out_dtype=torch.bfloat16)
+    from kosmosx import _hip as H
+    ref = ops.gemm(x, w, tile=128, **kw)
+    ref32 = ops.gemm(x, w, tile=128, **{**kw, "out_dtype": torch.float32})
+    H.load().kx_set_tuning(4, 3)          # the variant is A/B only: it measured slower than the store loop (kx_gemm.hip)
+    try:
+        out = ops.gemm(x, w, tile=tile, **kw)
+        assert torch.equal(out, ops.gemm(x, w, tile=tile, **kw))
+    finally:
+        H.load().kx_set_tuning(4, 0)
+    assert float((out.float() - ref32).abs().max()) <= float(ref32.abs().max()) * 2 ** -8
+    assert float((out == ref).float().mean()) > 0.9995
