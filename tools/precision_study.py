@@ -68,6 +68,12 @@ def family_of(name: str) -> str:
     if name.startswith("output_projection"):
         return "logits"
     if name.startswith("decoder."):
+        import os, re
+        m = re.match(r"decoder\.layers\.(\d+)\.", name)
+        split = int(os.environ.get("KX_STUDY_LAYER_SPLIT", "0"))          # >0: families "dec.lo.*" (layers < split) / "dec.hi.*"
+        if split and m:
+            return ("dec.lo." if int(m.group(1)) < split else "dec.hi.") + ("qkv" if any(t in name for t in ("q_proj", "k_proj", "v_proj"))
+                    else "out" if "out_proj" in name else "fc1" if "fc1" in name else "fc2" if "fc2" in name else "other")
         return ("dec.qkv" if any(t in name for t in ("q_proj", "k_proj", "v_proj")) else "dec.out" if "out_proj" in name
                 else "dec.fc1" if "fc1" in name else "dec.fc2" if "fc2" in name else "dec.other")
     return "other"
