@@ -53,8 +53,10 @@ def parse():
                          "fp16 MFMA + two fp8 correction MFMAs); bf16 is reported next to it with its parity")
     ap.add_argument("--no-extra", action="store_true", help="skip the c3 / batch-1 / training legs (headline only)")
     ap.add_argument("--no-gather", action="store_true", help="skip the logits all-gather (N > 1)")
-    ap.add_argument("--gather-algo", default="direct", choices=["all_gather", "direct"],
-                    help="direct: world-1 grouped send/recv pairs, one xGMI link per peer; all_gather: RCCL's collective")
+    ap.add_argument("--gather-algo", default="all_gather", choices=["all_gather", "direct"],
+                    help="all_gather (default): RCCL's collective — its ring time at 8 GPUs (~10 ms for 233 MB per rank) hides "
+                         "under the 30 ms step it overlaps; direct: world-1 grouped send/recv pairs, one xGMI link per peer "
+                         "(~1.5 ms by SURVEY 8e's arithmetic; gloo-tested only — no multi-GPU node has been available)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3, help="instrumented steps for the roofline leg")

@@ -435,6 +435,10 @@ int kx_embed_backward(const int64_t* tokens, const float* dx, int64_t B, int64_t
  * clip_grad_norm_'s factor min(1, max_norm / (norm + 1e-6)) to the gradient on the fly. */
 int kx_adamw(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float weight_decay, int64_t step, const float* grad_norm_sq, float max_norm, void* stream);
+/* lion_pytorch.Lion step (the optimizer the reference's train.py:547-556 selects) on one flat fp32 tensor:
+ * p *= 1 - lr*wd;  p -= lr * sign(beta1*m + (1-beta1)*g);  m = beta2*m + (1-beta2)*g;  optional clip factor as kx_adamw. */
+int kx_lion(float* param, const float* grad, float* m, int64_t n, float lr, float beta1, float beta2, float weight_decay,
+            const float* grad_norm_sq, float max_norm, void* stream);
 /* Attention backward (head_dim 64): q/k/v/dq/dk/dv are column blocks of fused [B*T, 3D] buffers (row / batch strides in
  * elements, the same for the inputs and the fp32 gradients), out/dout [B,T,D] fp32; lse [B,H,T] from kx_attention
  * (lse_out); delta [B,H,T] scratch.  qkv_dt: dtype of q/k/v (KX_F32, or KX_BF16 with bf16 products).

@@ -495,6 +495,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   p[i] = pi;
 }
 
+// ---- Lion (lion_pytorch.Lion.step, the optimizer /root/reference/train.py:547-556 asks for): decoupled decay, update =
+//      sign(b1*m + (1-b1)*g), m <- b2*m + (1-b2)*g; the clip factor is applied to g on the fly as in adamw_kernel ----
+__global__ __launch_bounds__(256) void lion_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   long long n, float lr, float b1, float b2, float wd,
+                                                   const float* __restrict__ gnorm_sq, float max_norm) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float clip = 1.0f;
+  if (gnorm_sq) clip = fminf(1.0f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));
+  const float gi = g[i] * clip, mi = m[i];
+  const float u = b1 * mi + (1.0f - b1) * gi;
+  const float sg = u > 0.f ? 1.0f : (u < 0.f ? -1.0f : 0.0f);
+  p[i] = p[i] * (1.0f - lr * wd) - lr * sg;
+  m[i] = b2 * mi + (1.0f - b2) * gi;
+}
+
 // ---- causal / full attention backward, fp32, head_dim 64 — FIRST VERSION (tuning key 2 = 1), on the VALU.  Workgroup = (key tile of 64, head, batch); it owns dK, dV
 //  of its keys and walks the query tiles; dQ rows are accumulated by a second pass that owns query tiles (no atomics).
 //  P = exp(S - lse), dP = dO·Vᵀ, dS = P ⊙ (dP - delta), delta[q] = sum_d dO[q,d]*O[q,d].
@@ -1328,6 +1344,17 @@ extern "C" int kx_adamw(float* param, const float* grad, float* m, float* v, int
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, m, v, (long long)n, lr,
                      beta1, beta2, eps, weight_decay, bc1, bc2, grad_norm_sq, max_norm);
   KX_CHECK_LAUNCH("kx_adamw");
+  return KX_OK;
+}
+
+extern "C" int kx_lion(float* param, const float* grad, float* m, int64_t n, float lr, float beta1, float beta2,
+                       float weight_decay, const float* grad_norm_sq, float max_norm, void* stream) {
+  KX_REQUIRE(param && grad && m && n > 0, "kx_lion: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, n, 0, 27, s);
+  hipLaunchKernelGGL(lion_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, m, (long long)n, lr, beta1,
+                     beta2, weight_decay, grad_norm_sq, max_norm);
+  KX_CHECK_LAUNCH("kx_lion");
   return KX_OK;
 }
 

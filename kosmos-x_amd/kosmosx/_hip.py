@@ -150,6 +150,7 @@ SYMBOLS = {
     "kx_xpos_backward": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, f32, vp]),
     "kx_embed_backward": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, vp, vp, vp]),
     "kx_adamw": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, f32, vp]),
+    "kx_lion": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp]),
     "kx_attention_backward": (C.c_int, [vp, vp, vp, i32] + [vp] * 7 + [i64] * 7 + [i32, i32, vp]),
 }
 

@@ -147,6 +147,13 @@ def adamw_(param, grad, m, v, step, lr, betas=(0.9, 0.95), eps=1e-8, weight_deca
                               float(max_norm), _stream()), "kx_adamw")
 
 
+def lion_(param, grad, m, lr, betas=(0.9, 0.99), weight_decay=0.0, grad_norm_sq=None, max_norm=1.0):
+    """lion_pytorch.Lion.step on flat fp32 tensors (the optimizer /root/reference/train.py:547-556 asks for)."""
+    _need_cuda(param, grad, m, grad_norm_sq)
+    H.check(H.load().kx_lion(H.ptr(param), H.ptr(grad), H.ptr(m), param.numel(), float(lr), float(betas[0]), float(betas[1]),
+                             float(weight_decay), H.ptr(grad_norm_sq), float(max_norm), _stream()), "kx_lion")
+
+
 def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True, bf16_products=False):
     """qkv [B*T, 3D] (q pre-scaled and XPos-rotated; fp32, or bf16 with bf16_products), out/dout [B,T,D] fp32, lse [B,H,T]
     -> dqkv [B*T, 3D] fp32."""

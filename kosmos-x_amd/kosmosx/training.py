@@ -39,7 +39,10 @@ def cosine_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_s
 class LanguageModelTrainer:
     def __init__(self, model: KosmosLanguage, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.1, max_grad_norm: float = 1.0, precision: str = "fp32", process_group=None,
-                 force_collectives: bool = False, checkpoint_activations: bool = False):
+                 force_collectives: bool = False, checkpoint_activations: bool = False, optimizer: str = "adamw"):
+        if optimizer not in ("adamw", "lion"):       # BASELINE configs[4] says Adam; the reference script itself selects Lion
+            raise ValueError("optimizer must be 'adamw' or 'lion'")
+        self.optimizer = optimizer
         if precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError("precision must be fp32, bf16 or bf16x3")
         self.precision = precision
@@ -310,6 +313,10 @@ class LanguageModelTrainer:
         step = self.step_no
 
         def adamw(p, g, m, v, decayed, gsq):
+            if self.optimizer == "lion":             # one moment only (v stays untouched)
+                G.lion_(p, g, m, self.lr, self.betas, self.weight_decay if decayed else 0.0, grad_norm_sq=gsq,
+                        max_norm=self.max_grad_norm)
+                return
             G.adamw_(p, g, m, v, step, self.lr, self.betas, self.eps, self.weight_decay if decayed else 0.0,
                      grad_norm_sq=gsq, max_norm=self.max_grad_norm)
 

@@ -107,6 +107,20 @@ def test_embed_backward_and_adamw():
         gd = gr.to(DEV)
         G.adamw_(p, gd, m, v, step, 1e-2, (0.9, 0.95), 1e-8, 0.1, grad_norm_sq=G.reduce_sum(gd, squares=True), max_norm=1.0)
         assert rel_err(p, ref.detach()) < 1e-5, step
+    # Lion (lion_pytorch.Lion.step restated in torch: the package is absent; /root/reference/train.py:547-556 selects it)
+    pr = p0.clone(); mr = torch.zeros_like(pr)
+    p = p0.clone().to(DEV); m = torch.zeros_like(p)
+    lr, b1, b2, wd = 1e-3, 0.9, 0.95, 0.1
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g) * 3
+        clip = min(1.0, 1.0 / (float(gr.norm()) + 1e-6))
+        gc = gr * clip
+        pr = pr * (1 - lr * wd)
+        pr = pr - lr * torch.sign(mr * b1 + gc * (1 - b1))
+        mr = mr * b2 + gc * (1 - b2)
+        gd = gr.to(DEV)
+        G.lion_(p, gd, m, lr, (b1, b2), wd, grad_norm_sq=G.reduce_sum(gd, squares=True), max_norm=1.0)
+        assert rel_err(p, pr) < 1e-6 and rel_err(m, mr) < 1e-5, step
 
 
 @pytest.mark.parametrize("B,Hh,T,causal", [(2, 2, 9, True), (1, 3, 114, True), (2, 1, 130, False), (1, 2, 200, True)])
