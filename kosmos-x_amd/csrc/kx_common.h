@@ -129,12 +129,45 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
 #define KX_ACT_GELU_FAST 3  /* internal: chosen by kx_gemm for KX_ACT_GELU when prec == bf16 */
+// GELU without transcendentals for the accumulator-level epilogues of the plain-bf16 256-column kernel, where the matrix
+// pipe idles while the VALU works (v_rcp_f32 / v_exp_f32 issue at a quarter of the fma rate, and every instruction
+// below has a packed two-value form): x * (0.5 + u * Q(u^2)), u = clamp(x, +-3*sqrt2) / (3*sqrt2), Q = degree-8 minimax
+// fit of 0.5 * erf(3u) / u weighted by the error on the GELU output (tools/fit_gelu_poly.py).  |error| <= 5.5e-5 on the
+// output for every x (fp32 Horner included) — a fortieth of bf16's rounding step at 1.0; bf16 outputs only.
+#define KX_ACT_GELU_POLY 4  /* internal: gemm_kernel_p5's lean epilogues, bf16 operands and bf16 output */
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t pk_splat(float a) { return (f32x2_t){a, a}; }
+__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
+  constexpr float C = 4.242640495300293f, RC = 0.2357022613286972f;
+  f32x2_t u;
+  u.x = __builtin_amdgcn_fmed3f(x.x, -C, C); u.y = __builtin_amdgcn_fmed3f(x.y, -C, C);
+  u = u * pk_splat(RC);
+  const f32x2_t t = u * u;
+  f32x2_t q = pk_fma(pk_splat(2.1510443687438965f), t, pk_splat(-11.833083152770996f));
+  q = pk_fma(q, t, pk_splat(28.841842651367188f));
+  q = pk_fma(q, t, pk_splat(-41.43374252319336f));
+  q = pk_fma(q, t, pk_splat(39.49993133544922f));
+  q = pk_fma(q, t, pk_splat(-26.727092742919922f));
+  q = pk_fma(q, t, pk_splat(13.36419677734375f));
+  q = pk_fma(q, t, pk_splat(-5.055159568786621f));
+  q = pk_fma(q, t, pk_splat(1.692056655883789f));
+  return x * pk_fma(q, u, pk_splat(0.5f));
+}
+__device__ __forceinline__ float gelu_poly(float x) { return gelu_poly2((f32x2_t){x, x}).x; }
 template <int ACT>
 __device__ __forceinline__ float apply_act(float x) {
   if constexpr (ACT == KX_ACT_GELU) return gelu_erf(x);
   else if constexpr (ACT == KX_ACT_GELU_FAST) return gelu_erf_fast(x);
+  else if constexpr (ACT == KX_ACT_GELU_POLY) return gelu_poly(x);
   else if constexpr (ACT == KX_ACT_QUICK_GELU) return quick_gelu(x);
   else return x;
+}
+template <int ACT>
+__device__ __forceinline__ f32x2_t apply_act2(f32x2_t x) {
+  if constexpr (ACT == KX_ACT_GELU_POLY) return gelu_poly2(x);
+  else if constexpr (ACT == KX_ACT_NONE) return x;
+  else return (f32x2_t){apply_act<ACT>(x.x), apply_act<ACT>(x.y)};
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -130,7 +130,9 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     p.lean_xpos = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) == 3 && a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && p.vec8_ok &&
                   a->xpos_dim > 0 && !a->residual && !a->row_stats && !a->stats_out && a->act == KX_ACT_NONE &&
                   a->qcols % 256 == 0 && a->xpos_dim % 256 == 0;
-    p.fast_epilogue = mode == 2 || (mode == 0 && (a->residual || a->row_stats || a->xpos_dim > 0));
+    // A/B: tuning key 4 = 4 keeps the A&S erf in the lean epilogues
+    p.gelu_poly = mode != 4 && a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && a->act == KX_ACT_GELU;
+    p.fast_epilogue = mode == 2 || (mode != 1 && (a->residual || a->row_stats || a->xpos_dim > 0));
   }
   hipStream_t s = (hipStream_t)stream;
   // Kernel-variant choice (measured on MI355X with tools/gemm_bench.py and in situ with bench.py):
@@ -236,7 +238,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   KxProfScope prof(kind, a->M, a->N, a->K, s);
   if (tile == 512 || tile == 384) {
     const int st = kx_tuning_get(KX_TUNE_GEMM_STAGGER);
-    if (st > 0) p.stagger_ticks = st;
+    if (st >= 200000) { if (a->residual) p.stagger_ticks = st - 200000; }   // A/B: only the in-place residual epilogues
+    else if (st > 0) p.stagger_ticks = st;
   }
   if (a->prec == KX_PREC_BF16) {
     if (tile == 256 || tile == 257 || tile == 512 || tile == 384) return kx_gemm_launch_phased_bf16(p, tile, s);

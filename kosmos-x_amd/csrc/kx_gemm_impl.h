@@ -41,6 +41,7 @@ struct GemmParams {
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
   int lean_epilogue;    // 256-column kernel: accumulator-level epilogue + pure data movement (see lean_store_*)
   int lean_xpos;        // 256-column kernel, bf16 output: q-scale + XPos at accumulator level too (lean_bias_qscale_xpos)
+  int gelu_poly;        // 256-column kernel, lean epilogues: KX_ACT_GELU_FAST may run as KX_ACT_GELU_POLY (plain bf16 in / out)
   int persistent;       // 256x256 kernel: > 0 = launch this many workgroups, each walking its tiles itself
   int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
   // weight-streaming variant (gemv_fused_kernel) only
@@ -236,23 +237,28 @@ __device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float
     cs[v] = (nv < p.xpos_dim ? p.xq_cs : p.xk_cs) + j;
     ss[v] = (nv < p.xpos_dim ? p.xq_ss : p.xk_ss) + j;
   }
-  for (int r0 = 0; r0 < rows; r0 += CHUNK) {
-    float4 res[U][NV];
-    float2 rs[U], xc[U][NV], xs[U][NV];
+  // Rolling prefetch: the operands of pass i + U are requested as soon as pass i has consumed its slot, so U passes of
+  // loads stay in flight for the whole sub-tile — requesting CHUNK rows, draining them, then requesting the next CHUNK
+  // exposed one full load latency per chunk (four per 256x256 tile of the in-place fp32 residual epilogue).
+  float4 res[U][NV];
+  float2 rs[U], xc[U][NV], xs[U][NV];
+  auto request = [&](int u, int r) __attribute__((always_inline)) {
+    const int m = min(mbase + r + rl, p.M - 1);                      // clamped for the loads; the store is predicated
+    if (has_rs) rs[u] = *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)m);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int m = min(mbase + r0 + u * RPI + rl, p.M - 1);       // clamped for the loads; the store is predicated
-      if (has_rs) rs[u] = *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)m);
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        if (has_res) res[u][v] = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n + 4 * v);
-        if (xp[v]) {
-          const int pos = m % p.xpos_T;
-          xc[u][v] = *reinterpret_cast<const float2*>(cs[v] + pos * 32);
-          xs[u][v] = *reinterpret_cast<const float2*>(ss[v] + pos * 32);
-        }
+    for (int v = 0; v < NV; ++v) {
+      if (has_res) res[u][v] = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n + 4 * v);
+      if (xp[v]) {
+        const int pos = m % p.xpos_T;
+        xc[u][v] = *reinterpret_cast<const float2*>(cs[v] + pos * 32);
+        xs[u][v] = *reinterpret_cast<const float2*>(ss[v] + pos * 32);
       }
     }
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) request(u, u * RPI);
+  for (int r0 = 0; r0 < rows; r0 += CHUNK) {
+    const bool more = r0 + CHUNK < rows;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int ml = r0 + u * RPI + rl, m = (r0 + u * RPI < rows) ? mbase + ml : p.M;   // past `rows`: no store
@@ -285,6 +291,7 @@ __device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float
         }
         if (has_res) { y[0] += res[u][v].x; y[1] += res[u][v].y; y[2] += res[u][v].z; y[3] += res[u][v].w; }
       }
+      if (more) request(u, r0 + CHUNK + u * RPI);                    // slot u is free again
       if (m < p.M) {
         if constexpr (CPL == 8) {
           bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n;
@@ -383,11 +390,15 @@ __device__ __forceinline__ void prepass_bias_act_stats(const GemmParams& p, f32x
   for (int sg = 0; sg < FN / 4; ++sg) {
     const int nseg0 = ncol0 + sg * 64;
     if (nseg0 >= p.N) return;                     // whole segment outside (N % 64 == 0)
-    float4 bias[4], csum[4];
+    // packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two values per VALU issue) on explicit
+    // two-element vectors whose halves are register-pair aligned — the matrix pipe is idle for as long as this takes
+    f32x2_t bias[4][2], csum[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      bias[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nseg0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-      csum[a] = p.row_stats ? *reinterpret_cast<const float4*>(p.colsum + nseg0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + nseg0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 cv = p.row_stats ? *reinterpret_cast<const float4*>(p.colsum + nseg0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bias[a][0] = (f32x2_t){bv.x, bv.y}; bias[a][1] = (f32x2_t){bv.z, bv.w};
+      csum[a][0] = (f32x2_t){cv.x, cv.y}; csum[a][1] = (f32x2_t){cv.z, cv.w};
     }
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
@@ -395,27 +406,29 @@ __device__ __forceinline__ void prepass_bias_act_stats(const GemmParams& p, f32x
       // arithmetic stays straight-line (see lean_bias_act on why)
       const float2 rs = p.row_stats ? *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)min(mrow0 + b * 16 + li, p.M - 1))
                                     : make_float2(0.f, 1.f);
-      float sm = 0.f;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        f32x4_t v = acc[sg * 4 + a][b];
-        v[0] = rs.y * (v[0] - rs.x * csum[a].x); v[1] = rs.y * (v[1] - rs.x * csum[a].y);
-        v[2] = rs.y * (v[2] - rs.x * csum[a].z); v[3] = rs.y * (v[3] - rs.x * csum[a].w);
-        v[0] = apply_act<ACT>(v[0] + bias[a].x); v[1] = apply_act<ACT>(v[1] + bias[a].y);
-        v[2] = apply_act<ACT>(v[2] + bias[a].z); v[3] = apply_act<ACT>(v[3] + bias[a].w);
-        acc[sg * 4 + a][b] = v;
-        sm += (v[0] + v[1]) + (v[2] + v[3]);
-      }
-      sm += __shfl_xor(sm, 16, 64);
-      sm += __shfl_xor(sm, 32, 64);
-      const float mu = sm * (1.0f / 64.0f);
-      float m2 = 0.f;
+      const f32x2_t nmean = pk_splat(-rs.x), rstd = pk_splat(rs.y);
+      f32x2_t sm2 = pk_splat(0.f);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const f32x4_t v = acc[sg * 4 + a][b];
-        const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
-        m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        f32x2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+        lo = apply_act2<ACT>(pk_fma(rstd, pk_fma(nmean, csum[a][0], lo), bias[a][0]));
+        hi = apply_act2<ACT>(pk_fma(rstd, pk_fma(nmean, csum[a][1], hi), bias[a][1]));
+        acc[sg * 4 + a][b] = (f32x4_t){lo.x, lo.y, hi.x, hi.y};
+        sm2 += lo + hi;
       }
+      float sm = sm2.x + sm2.y;
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const f32x2_t nmu = pk_splat(sm * (-1.0f / 64.0f));
+      f32x2_t m22 = pk_splat(0.f);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const f32x4_t v = acc[sg * 4 + a][b];
+        const f32x2_t d0 = (f32x2_t){v[0], v[1]} + nmu, d1 = (f32x2_t){v[2], v[3]} + nmu;
+        m22 = pk_fma(d0, d0, m22); m22 = pk_fma(d1, d1, m22);
+      }
+      float m2 = m22.x + m22.y;
       m2 += __shfl_xor(m2, 16, 64);
       m2 += __shfl_xor(m2, 32, 64);
       const int m = mrow0 + b * 16 + li;
@@ -484,22 +497,22 @@ __device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc
   for (int b = 0; b < FM; ++b)
     rs[b] = p.row_stats ? *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)min(mrow0 + b * 16 + li, p.M - 1))
                         : make_float2(0.f, 1.f);
+  const f32x2_t qs2 = pk_splat(qsc);
 #pragma unroll
   for (int a = 0; a < FN; ++a) {
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + ncol0 + a * 16 + 4 * g);
     if (p.row_stats) cs = *reinterpret_cast<const float4*>(p.colsum + ncol0 + a * 16 + 4 * g);
+    // packed fp32 arithmetic, see prepass_bias_act_stats
+    const f32x2_t b0 = {bias.x, bias.y}, b1 = {bias.z, bias.w}, c0 = {cs.x, cs.y}, c1 = {cs.z, cs.w};
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
-      f32x4_t v = acc[a][b];
-      v[0] = rs[b].y * (v[0] - rs[b].x * cs.x); v[1] = rs[b].y * (v[1] - rs[b].x * cs.y);
-      v[2] = rs[b].y * (v[2] - rs[b].x * cs.z); v[3] = rs[b].y * (v[3] - rs[b].x * cs.w);
-      v[0] = (v[0] + bias.x) * qsc; v[1] = (v[1] + bias.y) * qsc; v[2] = (v[2] + bias.z) * qsc; v[3] = (v[3] + bias.w) * qsc;
-      if constexpr (ACT != KX_ACT_NONE) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = apply_act<ACT>(v[q]);
-      }
-      acc[a][b] = v;
+      const f32x4_t v = acc[a][b];
+      const f32x2_t nmean = pk_splat(-rs[b].x), rstd = pk_splat(rs[b].y);
+      f32x2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+      lo = apply_act2<ACT>(pk_fma(rstd, pk_fma(nmean, c0, lo), b0) * qs2);
+      hi = apply_act2<ACT>(pk_fma(rstd, pk_fma(nmean, c1, hi), b1) * qs2);
+      acc[a][b] = (f32x4_t){lo.x, lo.y, hi.x, hi.y};
     }
   }
 }
@@ -1436,8 +1449,16 @@ int launch_p5e(GemmParams& p, hipStream_t s) {
   // the lean variants are instantiated for the activations the forward uses them with; anything else takes EPI 0
   if (p.act == KX_ACT_NONE && EPI != 4) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, EPI>), grid, block, 0, s, p);
   else if (EPI == 5) return launch_p5e<T, BM, 0>(p, s);
-  else if (p.act == KX_ACT_GELU_FAST && (EPI == 0 || EPI == 1 || EPI == 4))
-    hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, (EPI == 1 || EPI == 4) ? EPI : 0>), grid, block, 0, s, p);
+  else if (p.act == KX_ACT_GELU_FAST && (EPI == 0 || EPI == 1 || EPI == 4)) {
+    constexpr int E = (EPI == 1 || EPI == 4) ? EPI : 0;
+    // plain bf16 in, plain bf16 out, accumulator-level epilogue: the transcendental-free packed GELU (KX_ACT_GELU_POLY)
+    if constexpr (!kIsF16c<T> && E != 0) {
+      if (p.gelu_poly) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_POLY, BM, E>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, E>), grid, block, 0, s, p);
+    } else {
+      hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, E>), grid, block, 0, s, p);
+    }
+  }
   else if (p.act == KX_ACT_QUICK_GELU && (EPI == 0 || EPI == 1))
     hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_QUICK_GELU, BM, EPI == 1 ? 1 : 0>), grid, block, 0, s, p);
   else if (EPI != 0) return launch_p5e<T, BM, 0>(p, s);

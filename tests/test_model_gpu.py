@@ -15,6 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from kosmosx import _hip  # noqa: E402
 from kosmosx.config import Switches  # noqa: E402
 from kosmosx.model import Kosmos, KosmosLanguage  # noqa: E402
 from oracle import kosmos_oracle as O  # noqa: E402
@@ -296,6 +297,26 @@ def test_language_full_size_max_length(full_lang):
     # one token more overflows the position table exactly like the reference (example_lang.py's 2048 raises)
     with pytest.raises(IndexError):
         lm(torch.zeros(1, 2047, dtype=torch.long, device=DEV))
+
+
+def test_c3_rows_polynomial_gelu_epilogue_stays_within_bf16_noise():
+    """At C3's row count the decoder's fc1 runs the 256-column kernel's lean epilogue, whose GELU is the packed
+    transcendental-free polynomial (KX_ACT_GELU_POLY, |err| <= 5.5e-5); tuning key 4 = 4 keeps the A&S erf there."""
+    lm = KosmosLanguage(vocab_size=512, dim=2048, depth=2, _seed=5, _perturb=0.05).eval().to(DEV)
+    lm.precision = "bf16"
+    tok = torch.randint(0, 512, (17, 2046), generator=torch.Generator().manual_seed(6)).to(DEV)   # 34,782 rows
+    lib = _hip.load()
+    out = lm(tok).float()
+    again = lm(tok).float()
+    try:
+        lib.kx_set_tuning(4, 4)
+        erf = lm(tok).float()
+    finally:
+        lib.kx_set_tuning(4, 0)
+    assert torch.equal(out, again) and torch.isfinite(out).all()
+    d = float((out - erf).abs().max() / erf.pow(2).mean().sqrt())
+    print(f"C3 rows, 2 layers: polynomial vs A&S GELU epilogue: max|d|/rms = {d:.3e}")
+    assert d < 2e-2
 
 
 @pytest.mark.parametrize("Tt", [2, 1982])
