@@ -50,13 +50,12 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   const int es = (a->prec == KX_PREC_BF16 || f16c || f16) ? 2 : 4;   // KX_F16C rows: lda/ldw/ldc count 2-byte units
   const int bk = f16c ? 128 : 128 / es;
   KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32 || f16c || f16, "kx_gemm: bad precision %d", a->prec);
-  KX_REQUIRE(!f16 || (a->tile != 16 && a->tile != 256 && a->tile != 257), "kx_gemm: KX_PREC_F16 runs the tile kernels 64/128/160/384/512");
+  KX_REQUIRE(!f16 || (a->tile != 16 && a->tile != 257), "kx_gemm: KX_PREC_F16 runs the tile kernels 64/128/160/256/384/512");
   KX_REQUIRE(a->cdt != KX_F16 || f16 || f16c, "kx_gemm: KX_F16 outputs come from the fp16 kernels (KX_PREC_F16 / KX_PREC_F16C)");
   KX_REQUIRE(a->cdt != KX_BF16 || !f16, "kx_gemm: KX_PREC_F16 writes KX_F16 or fp32");
   KX_REQUIRE(a->K % bk == 0, "kx_gemm: K=%lld must be a multiple of %d", (long long)a->K, bk);
-  KX_REQUIRE(!f16c || (a->w_scale && a->lda >= 2 * a->K && a->ldw >= 2 * a->K && a->tile != 16 && a->tile != 256 &&
-                       a->tile != 257),
-             "kx_gemm: KX_PREC_F16C needs w_scale, lda/ldw >= 2K (2-byte units) and a tile kernel (not 16 / 256 / 257)");
+  KX_REQUIRE(!f16c || (a->w_scale && a->lda >= 2 * a->K && a->ldw >= 2 * a->K && a->tile != 16 && a->tile != 257),
+             "kx_gemm: KX_PREC_F16C needs w_scale, lda/ldw >= 2K (2-byte units) and a tile kernel (not 16 / 257)");
   KX_REQUIRE((a->lda * es) % 16 == 0 && (a->ldw * es) % 16 == 0, "kx_gemm: lda/ldw must give 16-byte row pitch");
   KX_REQUIRE(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "kx_gemm: A/W must be 16-byte aligned");
   KX_REQUIRE(a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N, "kx_gemm: leading dimension too small");
@@ -175,7 +174,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
         const double cur = tile == 512 ? (double)cdiv(t512, 256) : 0.6 * (double)cdiv(t256, 256);
         if (c384 < 0.97 * cur) tile = 384;
       }
-      if ((f16c || f16) && tile == 256) tile = cost(160) <= cost(128) ? 160 : 128;   // no 256x128 ring kernel for fp16 rows
+      // A/B: tuning key 4 = 6 keeps the 128 / 160-row kernels for fp16 rows where bf16 takes the 256x128 ring
+      if ((f16c || f16) && tile == 256 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) == 6) tile = cost(160) <= cost(128) ? 160 : 128;
     }
   }
   // A 64x64 wave owns 32 columns only: the statistics producer needs the split-K reduce kernel (whose threads walk whole

@@ -1000,6 +1000,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
   __builtin_amdgcn_s_barrier();
   int slot = 0;
   if constexpr (!PHASED) {
+    static_assert(!kIsF16c<T>, "the unphased ring (A/B) is bf16 only");
     for (int kt = 0; kt < nk; ++kt) {
       const bool more = kt + 2 < nk;
       if (more) stage(slot == 0 ? 2 : slot - 1, kt + 2);   // (kt+2)%3: the slot tile kt-1 just vacated
@@ -1038,7 +1039,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
     // stages and keeps the barrier cadence — under the board's power cap wasted MFMAs cost clock, not just slots
     const bool work = !p.skip_idle_waves || m0 + wm * 64 < p.M;
     if (lag) __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk1 = kIsF16c<T> ? min(p.nk_main, nk) : nk;   // KX_F16C: the fp16 tiles; the fp8 correction tiles follow
+    for (int kt = 0; kt < nk1; ++kt) {
       const bool more = kt + 2 < nk;
       const char* base = smem + slot * STAGE;
       u32x4_t fa[FM], fw[FN];
@@ -1091,6 +1093,75 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       slot = slot == 2 ? 0 : slot + 1;
+    }
+    if constexpr (kIsF16c<T>) {
+      // fp8 correction tiles on the same ring, phases and barriers (see gemm_kernel_p5): one scaled MFMA contracts a
+      // whole 128-byte row, so the two MFMA phases split the wave's FM activation fragments instead of the two k-steps
+      constexpr int FH = FM / 2;
+      int wsc[FN];
+#pragma unroll
+      for (int a = 0; a < FN; ++a) wsc[a] = p.wscale ? p.wscale[min(n0 + wn * 64 + a * 16 + li, p.N - 1)] : 127;
+      for (int kt = nk1; kt < nk; ++kt) {
+        const bool more = kt + 2 < nk;
+        const char* base = smem + slot * STAGE;
+        u32x4_t fw0[FN], fw1[FN], fa0[FH], fa1[FH];
+        // ---- R0 ----
+        if (more) stage(slot == 0 ? 2 : slot - 1, kt + 2);
+        if (work) {
+#pragma unroll
+          for (int a = 0; a < FN; ++a) {
+            fw0[a] = *reinterpret_cast<const u32x4_t*>(base + offW[a]);
+            fw1[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ 64));
+          }
+#pragma unroll
+          for (int b = 0; b < FH; ++b) {
+            fa0[b] = *reinterpret_cast<const u32x4_t*>(base + offA[b]);
+            fa1[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ 64));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M0 ----
+        if (work) {
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FH; ++b) acc[a][b] = mma_fp8(fw0[a], fw1[a], fa0[b], fa1[b], acc[a][b], wsc[a]);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- R1 ----
+        if (work) {
+#pragma unroll
+          for (int b = 0; b < FH; ++b) {
+            fa0[b] = *reinterpret_cast<const u32x4_t*>(base + offA[FH + b]);
+            fa1[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[FH + b] ^ 64));
+          }
+        }
+        if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M1 ----
+        if (work) {
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FH; ++b) acc[a][FH + b] = mma_fp8(fw0[a], fw1[a], fa0[b], fa1[b], acc[a][FH + b], wsc[a]);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == 2 ? 0 : slot + 1;
+      }
     }
     if (!lag) __builtin_amdgcn_s_barrier();
   }

@@ -57,7 +57,7 @@ def test_f16c_producers_write_the_format_bit_exactly():
     a = ops.pack_f16c_rows(torch.randn(M, K, generator=g).to(DEV))
     wp = _operand_f16c((torch.randn(N, K, generator=g) * 0.05).to(DEV))
     bias = torch.randn(N, generator=g).to(DEV)
-    for tile in (64, 128, 160, 384, 512):
+    for tile in (64, 128, 160, 256, 384, 512):
         c32 = ops.gemm_f16c(a, wp, N, K, bias=bias, act="gelu", tile=tile)
         cc = ops.gemm_f16c(a, wp, N, K, bias=bias, act="gelu", tile=tile, out_f16c=True)
         assert torch.equal(cc, ops.pack_f16c_rows(c32)), tile
@@ -71,7 +71,7 @@ SHAPES = [(1, 64, 128), (114, 2048, 2048), (257, 1024, 4096), (130, 264, 128), (
           (513, 768, 256), (3648, 512, 2048)]
 
 
-@pytest.mark.parametrize("tile", [0, 64, 128, 160, 384, 512])
+@pytest.mark.parametrize("tile", [0, 64, 128, 160, 256, 384, 512])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_f16c_matches_exact_arithmetic_on_the_packed_operands(shape, tile):
     M, N, K = shape
@@ -99,7 +99,7 @@ def test_gemm_f16c_split_k_and_epilogues():
         assert float((out.cpu().double() - want).abs().max()) < 2e-5 * float(want.abs().max()), splitk
     # folded LayerNorm consumer + statistics producer (the sub-LN pair) on the f16c kernels
     st = torch.zeros(M, N // 64, 2, device=DEV)
-    for tile in (0, 128, 384, 512):
+    for tile in (0, 128, 256, 384, 512):
         c = ops.gemm_f16c(a, wp, N, K, bias=bias, act="gelu", tile=tile, stats_out=st, splitk_ws=ws if tile == 0 else None)
         y = F.gelu(ref + bias.cpu().double())
         seg = y.view(M, N // 64, 64)
@@ -225,7 +225,7 @@ def test_full_size_f16c_text_only_T2046():
 # ---------------------------------------------------------------------------------------------------------------
 # plain fp16 (KX_PREC_F16) kernels and the error-budgeted "mixed" mode (CLIP tower fp16, Perceiver + decoder f16c)
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [0, 64, 128, 160, 384, 512])
+@pytest.mark.parametrize("tile", [0, 64, 128, 160, 256, 384, 512])
 @pytest.mark.parametrize("shape", [(114, 2048, 2048), (257, 1024, 4096), (300, 1002, 640), (8224, 512, 1024)])
 def test_gemm_f16_plain(shape, tile):
     """fp16 operands are exact in fp32: the reference is the fp32 product of the fp16-rounded operands."""
