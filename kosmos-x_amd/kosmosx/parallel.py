@@ -167,17 +167,32 @@ class ZeroShardedOptimizer:
         """flat_p / flat_g: [padded]; m / v: [shard] (this rank's moments).  adamw(p, g, m, v, decayed, gnorm_sq) updates
         in place; sumsq(x) -> 1-element tensor.  Returns the global squared gradient norm (1-element tensor)."""
         distributed = self.world > 1 or (force and dist.is_initialized())
+        # gloo with device tensors (several ranks sharing one GPU: the whole-trainer test on a 1-GPU box): the collectives
+        # run on host copies.  RCCL (the product path) takes the device tensors as they are.
+        staged = distributed and flat_g.is_cuda and dist.get_backend(self.group) == "gloo"
         if distributed:
-            g_shard = torch.empty(self.shard, dtype=flat_g.dtype, device=flat_g.device)
-            dist.reduce_scatter_tensor(g_shard, flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            src = flat_g.cpu() if staged else flat_g
+            g_shard = torch.empty(self.shard, dtype=flat_g.dtype, device=src.device)
+            dist.reduce_scatter_tensor(g_shard, src, op=dist.ReduceOp.SUM, group=self.group)
+            g_shard = g_shard.to(flat_g.device)
         else:
             g_shard = flat_g[self.lo:self.hi]
         gsq = sumsq(g_shard)
         if distributed:
-            dist.all_reduce(gsq, op=dist.ReduceOp.SUM, group=self.group)
+            if staged:
+                h = gsq.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                gsq.copy_(h)
+            else:
+                dist.all_reduce(gsq, op=dist.ReduceOp.SUM, group=self.group)
         for a, b, decayed in self.regions():
             s = slice(a - self.lo, b - self.lo)
             adamw(flat_p[a:b], g_shard[s], m[s], v[s], decayed, gsq)
         if distributed:
-            dist.all_gather_into_tensor(flat_p, flat_p[self.lo:self.hi].clone(), group=self.group)
+            if staged:
+                full = torch.empty(self.padded, dtype=flat_p.dtype)
+                dist.all_gather_into_tensor(full, flat_p[self.lo:self.hi].cpu(), group=self.group)
+                flat_p.copy_(full)
+            else:
+                dist.all_gather_into_tensor(flat_p, flat_p[self.lo:self.hi].clone(), group=self.group)
         return gsq

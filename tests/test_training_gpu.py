@@ -128,6 +128,75 @@ def test_sharded_update_over_rccl_single_rank_matches_local_update():
     assert torch.equal(ta.flat_p, tb.flat_p)
 
 
+def _two_rank_trainer_worker(rank, world, port, q):
+    """One data-parallel rank of the WHOLE trainer (forward, backward, reduce-scatter, clip, AdamW slice, all-gather);
+    both ranks share the box's one GPU, so the process group is gloo (RCCL refuses two ranks per device)."""
+    import os
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for p in (str(root), str(root / "kosmos-x_amd"), str(root / "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KOSMOSX_NO_LOGGING_CONFIG="1")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        lm = _tiny_lm(seed=2).to(DEV)                       # same seed on every rank = replicated start
+        tr = LanguageModelTrainer(lm, lr=1e-3)
+        assert tr.zero.world == world and tr.m.numel() * world == tr.flat_p.numel()      # 1/world of the moments per rank
+        g = torch.Generator().manual_seed(9)
+        losses = []
+        for _ in range(2):
+            tok = torch.randint(2, 1002, (2 * world, 24), generator=g)
+            losses.append(float(tr.step(tok[2 * rank:2 * rank + 2].to(DEV))))
+        torch.cuda.synchronize()
+        q.put((rank, losses, {n: p.detach().cpu().numpy() for n, p in lm.named_parameters()}))   # by value
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_whole_trainer_on_two_ranks_matches_single_process_autograd():
+    """LanguageModelTrainer.step on two data-parallel ranks (each half of the batch) against
+    single-process autograd + torch.optim.AdamW on the full batch: the mean of the rank losses, and every parameter after
+    two clipped steps — identical on both ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, losses, params = q.get(timeout=600)
+        got[r] = (losses, {n: torch.from_numpy(v) for n, v in params.items()})
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    lm = _tiny_lm(seed=2)
+    cfg = O.DecoderCfg(layers=2, dim=256, ffn=512, heads=4, vocab=1002, max_pos=128)
+    w = _leaf_weights(lm)
+    opt = TO.make_optimizer(w, lr=1e-3)
+    g = torch.Generator().manual_seed(9)
+    for step in range(2):
+        tok = torch.randint(2, 1002, (4, 24), generator=g)
+        ref_loss = float(TO.train_step(w, opt, tok, cfg))
+        mean = 0.5 * (got[0][0][step] + got[1][0][step])     # equal shards: the mean of the rank means
+        assert abs(mean - ref_loss) < 1e-4 * abs(ref_loss), (step, mean, ref_loss)
+    for n in w:
+        if n not in got[0][1]:
+            continue
+        assert torch.equal(got[0][1][n], got[1][1][n]), n    # the all-gather leaves every rank with the same parameters
+        d = got[0][1][n] - w[n].detach()
+        assert float(d.pow(2).mean().sqrt() / w[n].detach().pow(2).mean().sqrt()) < 2e-5, n
+        assert float(d.abs().max()) <= 2.1 * 1e-3 * 2, n
+
+
 def test_trainer_argument_errors():
     lm = _tiny_lm().to(DEV)
     tr = LanguageModelTrainer(lm)
