@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KX_ABI_VERSION 2
+#define KX_ABI_VERSION 3
 
 typedef enum {
   KX_OK = 0,
@@ -418,6 +418,20 @@ int kx_layernorm_backward(const float* x, const float* gamma, const float* dy, c
 /* exact (erf) GELU forward on a kept pre-activation, and its backward: dpre = dg * (Phi(pre) + pre*phi(pre)) */
 int kx_gelu_forward(const float* pre, float* out, int64_t n, void* stream);
 int kx_gelu_backward(const float* pre, const float* dg, float* dpre, int64_t n, void* stream);
+/* HF QuickGELUActivation (CLIP's MLP, modeling_clip.py: x * sigmoid(1.702 x)) on a kept pre-activation, and its backward */
+int kx_quick_gelu_forward(const float* pre, float* out, int64_t n, void* stream);
+int kx_quick_gelu_backward(const float* pre, const float* dg, float* dpre, int64_t n, void* stream);
+/* out[r][c] = x[r][c] + vec[c]: flamingo PerceiverResampler's `x + media_pos_emb[:times]` kept as a tensor (the
+ * backward of norm_media needs it); cols % 4 == 0, 16-byte aligned buffers */
+int kx_add_rowvec(const float* x, const float* vec, float* out, int64_t rows, int64_t cols, void* stream);
+/* The vision tower's embeddings as stand-alone steps for the op-by-op training forward (HF CLIPVisionEmbeddings):
+ * kx_patchify: pixels [B,3,image,image] fp32 -> patch rows [B*(image/patch)^2, kpad] (fp32 for KX_PREC_F32, bf16 for
+ * KX_PREC_BF16), columns (channel, dy, dx) as nn.Conv2d's weight.flatten(1), zero padded to kpad;
+ * kx_vit_assemble: x[b] = cat(class_embedding, patch_out[b]) + position_embedding, [B, tokens, dim] fp32. */
+int kx_patchify(const float* pixels, void* patches, int64_t B, int32_t image, int32_t patch, int32_t kpad, int32_t prec,
+                void* stream);
+int kx_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x, int64_t B, int32_t tokens,
+                    int32_t dim, void* stream);
 /* F.cross_entropy rows: loss_rows[r] = logsumexp(logits[r]) - logits[r][target[r]] (0 for targets outside [0,V):
  * ignore_index); dlogits (optional) = (softmax - onehot) * scale. */
 int kx_cross_entropy(const float* logits, int64_t rows, int64_t V, int64_t ld, const int64_t* target, float scale,

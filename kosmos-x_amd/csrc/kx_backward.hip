@@ -342,6 +342,28 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
   dpre[i] = dg[i] * (cdf + x * pdf);
 }
 
+// ---- QuickGELU (HF CLIP: x * sigmoid(1.702 x)) forward on a saved pre-activation, and its backward ----
+__global__ __launch_bounds__(256) void quick_gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float x = pre[i]; out[i] = x / (1.0f + expf(-1.702f * x)); }
+}
+__global__ __launch_bounds__(256) void quick_gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dg,
+                                                             float* __restrict__ dpre, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = pre[i], sg = 1.0f / (1.0f + expf(-1.702f * x));
+  dpre[i] = dg[i] * (sg + 1.702f * x * sg * (1.0f - sg));
+}
+
+// ---- out[r][c] = x[r][c] + vec[c] (flamingo's x + media_pos_emb[:times] kept as a tensor for the backward) ----
+__global__ __launch_bounds__(256) void add_rowvec_kernel(const float* __restrict__ x, const float* __restrict__ vec,
+                                                         float* __restrict__ out, long long n4, int cols4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(vec)[i % cols4];
+  reinterpret_cast<float4*>(out)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
 // ---- cross-entropy: one workgroup per row; loss_r = lse - logit[target]; dlogits = (softmax - onehot) * scale ----
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, long long ld, int V,
                                                             const long long* __restrict__ target, float scale,
@@ -1271,6 +1293,36 @@ extern "C" int kx_gelu_forward(const float* pre, float* out, int64_t n, void* st
   KxProfScope prof(KX_K_MISC, n, 0, 27, s);
   hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, out, (long long)n);
   KX_CHECK_LAUNCH("kx_gelu_forward");
+  return KX_OK;
+}
+
+extern "C" int kx_quick_gelu_forward(const float* pre, float* out, int64_t n, void* stream) {
+  KX_REQUIRE(pre && out && n > 0, "kx_quick_gelu_forward: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, n, 0, 28, s);
+  hipLaunchKernelGGL(quick_gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, out, (long long)n);
+  KX_CHECK_LAUNCH("kx_quick_gelu_forward");
+  return KX_OK;
+}
+
+extern "C" int kx_quick_gelu_backward(const float* pre, const float* dg, float* dpre, int64_t n, void* stream) {
+  KX_REQUIRE(pre && dg && dpre && n > 0, "kx_quick_gelu_backward: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, n, 0, 29, s);
+  hipLaunchKernelGGL(quick_gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, dg, dpre, (long long)n);
+  KX_CHECK_LAUNCH("kx_quick_gelu_backward");
+  return KX_OK;
+}
+
+extern "C" int kx_add_rowvec(const float* x, const float* vec, float* out, int64_t rows, int64_t cols, void* stream) {
+  KX_REQUIRE(x && vec && out && rows > 0 && cols > 0 && cols % 4 == 0 &&
+                 (((uintptr_t)x | (uintptr_t)vec | (uintptr_t)out) & 15) == 0,
+             "kx_add_rowvec: null pointer, bad shape, cols %% 4 != 0 or unaligned buffers");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, rows, cols, 30, s);
+  const long long n4 = (long long)rows * cols / 4;
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, vec, out, n4, (int)(cols / 4));
+  KX_CHECK_LAUNCH("kx_add_rowvec");
   return KX_OK;
 }
 

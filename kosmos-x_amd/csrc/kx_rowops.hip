@@ -453,3 +453,19 @@ int kx_launch_vit_assemble(const float* patch_out, const float* cls, const float
   KX_CHECK_LAUNCH("vit_assemble");
   return KX_OK;
 }
+
+// The vision tower's first two steps as stand-alone entry points (the training step runs the tower op by op and keeps
+// the patch matrix for the patch-embedding weight gradient)
+extern "C" int kx_patchify(const float* pixels, void* patches, int64_t B, int32_t image, int32_t patch, int32_t kpad,
+                           int32_t prec, void* stream) {
+  KX_REQUIRE(pixels && patches && B > 0 && patch > 0 && image > 0 && image % patch == 0 && kpad >= 3 * patch * patch &&
+                 (prec == KX_PREC_F32 || prec == KX_PREC_BF16),
+             "kx_patchify: null pointer, image %% patch != 0, kpad < 3*patch*patch or a precision other than fp32 / bf16");
+  return kx_launch_patchify(pixels, patches, B, image, patch, kpad, prec, (hipStream_t)stream);
+}
+
+extern "C" int kx_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x, int64_t B,
+                               int32_t tokens, int32_t dim, void* stream) {
+  KX_REQUIRE(patch_out && cls && pos && x && B > 0 && tokens > 1 && dim > 0, "kx_vit_assemble: bad arguments");
+  return kx_launch_vit_assemble(patch_out, cls, pos, x, B, tokens, dim, (hipStream_t)stream);
+}

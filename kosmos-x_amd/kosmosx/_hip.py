@@ -13,7 +13,7 @@ from pathlib import Path
 
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
-ABI_VERSION = 2   # KX_ABI_VERSION of include/kosmosx_hip.h
+ABI_VERSION = 3   # KX_ABI_VERSION of include/kosmosx_hip.h
 
 KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16 = 0, 1, 2, 3, 4
 KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16 = 0, 1, 2, 3, 4
@@ -151,6 +151,11 @@ SYMBOLS = {
     "kx_embed_backward": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, vp, vp, vp]),
     "kx_adamw": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, f32, vp]),
     "kx_lion": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp]),
+    "kx_quick_gelu_forward": (C.c_int, [vp, vp, i64, vp]),
+    "kx_quick_gelu_backward": (C.c_int, [vp, vp, vp, i64, vp]),
+    "kx_add_rowvec": (C.c_int, [vp, vp, vp, i64, i64, vp]),
+    "kx_patchify": (C.c_int, [vp, vp, i64, i32, i32, i32, i32, vp]),
+    "kx_vit_assemble": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, vp]),
     "kx_attention_backward": (C.c_int, [vp, vp, vp, i32] + [vp] * 7 + [i64] * 7 + [i32, i32, vp]),
 }
 

@@ -120,6 +120,50 @@ def reduce_sum(x, squares=False, out=None, accumulate=False):
     return out
 
 
+def quick_gelu(pre: torch.Tensor) -> torch.Tensor:
+    """HF QuickGELUActivation on a kept pre-activation (CLIP's MLP)."""
+    _need_cuda(pre)
+    out = torch.empty_like(pre)
+    H.check(H.load().kx_quick_gelu_forward(H.ptr(pre), H.ptr(out), pre.numel(), _stream()), "kx_quick_gelu_forward")
+    return out
+
+
+def quick_gelu_backward(pre, dg):
+    _need_cuda(pre, dg)
+    out = torch.empty_like(pre)
+    H.check(H.load().kx_quick_gelu_backward(H.ptr(pre), H.ptr(dg), H.ptr(out), pre.numel(), _stream()), "kx_quick_gelu_backward")
+    return out
+
+
+def add_rowvec(x: torch.Tensor, vec: torch.Tensor) -> torch.Tensor:
+    """x [rows, cols] + vec [cols] (every row)."""
+    _need_cuda(x, vec)
+    out = torch.empty_like(x)
+    H.check(H.load().kx_add_rowvec(H.ptr(x), H.ptr(vec), H.ptr(out), x.shape[0], x.shape[1], _stream()), "kx_add_rowvec")
+    return out
+
+
+def patchify(pixels: torch.Tensor, patch: int, kpad: int, bf16: bool = False) -> torch.Tensor:
+    """pixels [B,3,S,S] fp32 -> patch rows [B*(S/patch)^2, kpad] (columns as Conv2d.weight.flatten(1), zero padded)."""
+    _need_cuda(pixels)
+    B, _, S, _ = pixels.shape
+    rows = B * (S // patch) ** 2
+    out = torch.empty((rows, kpad), dtype=torch.bfloat16 if bf16 else torch.float32, device=pixels.device)
+    H.check(H.load().kx_patchify(H.ptr(pixels), H.ptr(out), B, S, patch, kpad, H.KX_PREC_BF16 if bf16 else H.KX_PREC_F32,
+                                 _stream()), "kx_patchify")
+    return out
+
+
+def vit_assemble(patch_out: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, B: int) -> torch.Tensor:
+    """cat(class_embedding, patch_out[b]) + position_embedding -> [B, tokens, dim] fp32."""
+    _need_cuda(patch_out, cls, pos)
+    tokens, dim = pos.shape
+    x = torch.empty((B, tokens, dim), dtype=torch.float32, device=pos.device)
+    H.check(H.load().kx_vit_assemble(H.ptr(patch_out), H.ptr(cls), H.ptr(pos), H.ptr(x), B, tokens, dim, _stream()),
+            "kx_vit_assemble")
+    return x
+
+
 def xpos_backward_(dqkv, D, T, tables, qscale):
     """In place on the fused [M,3D] gradient: undo XPos on the q and k blocks, apply the q scale."""
     _need_cuda(dqkv)

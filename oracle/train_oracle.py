@@ -1,4 +1,4 @@
-"""CPU restatement of the training step on the text decoder — TEST INFRASTRUCTURE.
+"""CPU restatement of the training step (text decoder and multimodal model) — TEST INFRASTRUCTURE.
 
 Only tests/, __graft_entry__.smoke() and benchmark cpu_baseline legs may import this module.
 
@@ -25,6 +25,26 @@ def lm_loss(w: dict, tokens: torch.Tensor, cfg: O.DecoderCfg, sw: O.Switches | N
     return F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), tokens[:, 1:].reshape(-1))
 
 
+def mm_loss(w: dict, tokens: torch.Tensor, images: torch.Tensor, cfg: O.KosmosCfg, sw: O.Switches | None = None) -> torch.Tensor:
+    """The same loss on the multimodal model (Kosmos.forward, /root/reference/kosmosx/model.py:208-253, with autograd on):
+    the sequence is t0 t1 | image x L | t2 ...; position p predicts position p+1 wherever p+1 holds a TEXT token — the
+    Tt-1 predicting positions per sample of lm_loss."""
+    sw = sw or O.Switches()
+    img = O.vit_forward(w, images, cfg.vit, sw)
+    img = O.perceiver_forward(w, img, cfg.perceiver, sw).squeeze(1)
+    img = O.linear(img, w["image_proj.weight"], None, sw)
+    x, embed = O.forward_embedding_tokens(w, tokens, cfg.decoder)
+    first = x if sw.u1_inplace_alias else embed
+    mi = torch.cat([first[:, 0:2], img, first[:, 2:]], dim=1)
+    T, L = mi.shape[1], img.shape[1]
+    mi = 1.0 * mi + w["embed_positions.weight"][O.positions_for(T)][None]
+    logits = O.decoder_forward(w, mi, cfg.decoder, sw)
+    seq = torch.full((tokens.shape[0], T), -100, dtype=torch.long)
+    seq[:, :2] = tokens[:, :2]
+    seq[:, 2 + L:] = tokens[:, 2:]
+    return F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), seq[:, 1:].reshape(-1), ignore_index=-100)
+
+
 def backward(loss: torch.Tensor, w: dict, padding_idx: int = 1):
     """loss.backward() with nn.Embedding(padding_idx) semantics: the padding row receives no gradient (the forward
     oracle embeds with a bare F.embedding; the reference's embedding module is built with padding_idx = 1)."""
@@ -45,9 +65,9 @@ def make_optimizer(w: dict, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0
                              lr=lr, betas=betas, eps=eps)
 
 
-def train_step(w: dict, opt, tokens, cfg, max_norm=1.0):
+def train_step(w: dict, opt, tokens, cfg, max_norm=1.0, images=None, sw=None):
     opt.zero_grad()
-    loss = lm_loss(w, tokens, cfg)
+    loss = lm_loss(w, tokens, cfg) if images is None else mm_loss(w, tokens, images, cfg, sw)
     backward(loss, w)
     torch.nn.utils.clip_grad_norm_(list(w.values()), max_norm)
     opt.step()
