@@ -65,6 +65,7 @@ class LanguageModelTrainer:
                             "(deterministic forward; SURVEY H1)")
         self.group = process_group
         self._force_collectives = force_collectives
+        self._xpos_cache = {}
         self._build_flat()
 
     # ------------------------------------------------------------------ flat fp32 buffers (parameters, gradients, moments)
@@ -108,6 +109,20 @@ class LanguageModelTrainer:
     def _leading_groups(self):
         """(decay, nodecay) name lists that must come first, in an order that keeps fused gradients adjacent."""
         return [], []
+
+    def _pspan(self, first: str, rows: int, cols: int | None = None):
+        """The PARAMETER view matching _gspan: q | k | v weights (biases) are one [3D, D] ([3D]) matrix of the flat
+        buffer — the fused projection needs no per-step torch.cat."""
+        o = self.offset[first]
+        t = self.flat_p[o:o + rows * (cols or 1)]
+        return t.view(rows, cols) if cols else t
+
+    def _xpos_tables(self, xp, T, dev):
+        """XPos tables of a sequence length, built once on the host (closed form, fp64) and kept on the device."""
+        key = (T, str(dev))
+        if key not in self._xpos_cache:
+            self._xpos_cache[key] = [t.to(dev) for t in (*xp.tables(T, 0, False), *xp.tables(T, 0, True))]
+        return self._xpos_cache[key]
 
     def _invalidate(self):
         self.model.decoder.invalidate_packed()              # the inference path's operand copies are stale now
@@ -179,17 +194,16 @@ class LanguageModelTrainer:
         D, Hh, V = a.decoder_embed_dim, a.decoder_attention_heads, a.vocab_size
         M, eps, dev = B * T, float(a.layernorm_eps), x.device
         xp = dec.layers[0].self_attn.xpos
-        tabs = None
-        if xp is not None:
-            tabs = [t.to(dev) for t in (*xp.tables(T, 0, False), *xp.tables(T, 0, True))]
+        tabs = self._xpos_tables(xp, T, dev) if xp is not None else None
+        mwn = ".A" if a.multiway else ""
 
-        def layer_forward(L, x):
+        def layer_forward(L, x, li):
             """One decoder layer; returns the layer output and everything its backward needs."""
             P = self._layer_params(L)
             s = {"x_in": x}
             h1 = ops.layernorm(x, P["sa_ln"].weight.detach(), P["sa_ln"].bias.detach(), eps, out_dtype=o.ln_dt)
-            wqkv = torch.cat([P["q"].weight, P["k"].weight, P["v"].weight], 0).detach()
-            bqkv = torch.cat([P["q"].bias, P["k"].bias, P["v"].bias], 0).detach()
+            wqkv = self._pspan(f"decoder.layers.{li}.self_attn.q_proj{mwn}.weight", 3 * D, D)    # q | k | v, adjacent
+            bqkv = self._pspan(f"decoder.layers.{li}.self_attn.q_proj{mwn}.bias", 3 * D)
             # bf16 mode: q, k, v live in bf16 (flash kernel with bf16 products forward and backward, fp32 statistics)
             wqkv_a, wqkv_t = o.pairW(wqkv)
             qkv = ops.gemm(o.opA(h1), wqkv_a, bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0,
@@ -214,9 +228,9 @@ class LanguageModelTrainer:
         # checkpoint_activations: keep only each layer's input (4 bytes x d per token instead of ~21x that) and run the
         # layer's forward again right before its backward — one third more GEMM work for batches that do not fit otherwise
         saved = []
-        for L in dec.layers:
+        for li, L in enumerate(dec.layers):
             x_in = x
-            x, s = layer_forward(L, x)
+            x, s = layer_forward(L, x, li)
             saved.append({"x_in": x_in} if self.checkpoint_activations else s)
             del s
         hf = ops.layernorm(x, dec.layer_norm.weight.detach(), dec.layer_norm.bias.detach(), eps, out_dtype=o.ln_dt)
@@ -256,7 +270,7 @@ class LanguageModelTrainer:
         for li in range(len(dec.layers) - 1, -1, -1):
             L, s = dec.layers[li], saved[li]
             if self.checkpoint_activations:
-                _, s = fw["layer_forward"](L, s["x_in"])
+                _, s = fw["layer_forward"](L, s["x_in"], li)
             saved[li] = None
             P, pfx = self._layer_params(L), f"decoder.layers.{li}."
             # x_out = x_mid + fc2(ffn_ln(gelu(fc1(fl_ln(x_mid)))))
@@ -423,8 +437,8 @@ class KosmosTrainer(LanguageModelTrainer):
             sa = L.self_attn
             s = {"x_in": x}
             y1 = ops.layernorm(x, L.layer_norm1.weight.detach(), L.layer_norm1.bias.detach(), eps, out_dtype=o.ln_dt)
-            wqkv = torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach()
-            bqkv = torch.cat([sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias], 0).detach()
+            pfx = f"clip_model.encoder.layers.{len(saved)}.self_attn.q_proj."
+            wqkv, bqkv = self._pspan(pfx + "weight", 3 * dv, dv), self._pspan(pfx + "bias", 3 * dv)   # q | k | v, adjacent
             wqkv_a, wqkv_t = o.pairW(wqkv)
             qkv = ops.gemm(o.opA(y1), wqkv_a, bqkv, qscale=0.125, qcols=dv)               # HF: (q_proj(x)) * head_dim**-0.5
             del wqkv_a
@@ -517,7 +531,7 @@ class KosmosTrainer(LanguageModelTrainer):
             g = G.gelu(y1)
             lat2, w3_t = o.lin(g, ff[3].weight, residual=lat)
             # the backward's data gradient of norm_latents comes from q AND from the latent rows of kv: one GEMM on cat(Wq, Wkv)
-            _, wqkv_lat_t = o.pairW(torch.cat([at.to_q.weight, at.to_kv.weight], 0).detach())
+            _, wqkv_lat_t = o.pairW(self._pspan(f"perceive.layers.{len(saved)}.0.to_q.weight", 3 * inner, dim))   # Wq | Wkv, adjacent
             s.update(kv_in=kv_in, ln_l=ln_l, q=q, kv=kv, wkv_t=wkv_t, wqkv_lat_t=wqkv_lat_t, lse=lse, att=att, wo_t=wo_t,
                      lat_mid=lat, y=y, y1=y1, w1_t=w1_t, g=g, w3_t=w3_t)
             saved.append(s)

@@ -128,6 +128,40 @@ def test_sharded_update_over_rccl_single_rank_matches_local_update():
     assert torch.equal(ta.flat_p, tb.flat_p)
 
 
+def test_full_size_gradient_families_match_autograd():
+    """parity of gradient families at the REAL size (24 layers, 2048-d, vocab 32002; B=1, T=24 so the
+    CPU autograd reference stays at seconds): first / last layer fc2, q | k | v, the sub-LayerNorms, the output projection
+    and the embedding rows the batch touches."""
+    lm = KosmosLanguage(vocab_size=32002, dim=2048, _seed=7, _perturb=0.05).eval()
+    tok = torch.randint(2, 32002, (1, 24), generator=torch.Generator().manual_seed(8))
+    cfg = O.DecoderCfg(vocab=32002)
+    w = _leaf_weights(lm)
+    ref_loss = TO.lm_loss(w, tok, cfg)
+    TO.backward(ref_loss, w)
+    tr = LanguageModelTrainer(lm.to(DEV))
+    loss = tr.step(tok.to(DEV), apply_update=False)
+    assert abs(float(loss) - float(ref_loss.detach())) < 2e-5 * abs(float(ref_loss.detach()))
+    fam = ["output_projection.weight", "embed.weight", "embed_positions.weight", "decoder.layer_norm.weight"]
+    for li in (0, 11, 23):
+        p = f"decoder.layers.{li}."
+        fam += [p + "ffn.A.fc2.weight", p + "ffn.A.fc1.weight", p + "self_attn.q_proj.A.weight", p + "self_attn.k_proj.A.weight",
+                p + "self_attn.v_proj.A.weight", p + "self_attn.out_proj.A.weight", p + "self_attn.inner_attn_ln.A.weight",
+                p + "ffn.A.ffn_layernorm.weight", p + "self_attn_layer_norm.A.bias"]
+    worst = 0.0
+    for name in fam:
+        g, r = tr.grads[name].cpu(), w[name].grad
+        if name == "embed.weight":                        # sparse: the rows of the batch's tokens (the rest is exactly zero)
+            rows = tok.unique()
+            assert float(g.abs().sum()) == float(g[rows].abs().sum())
+            g, r = g[rows], r[rows]
+        elif name == "embed_positions.weight":
+            g, r = g[2:26], r[2:26]
+        e = float((g - r).abs().max() / (r.pow(2).mean().sqrt() + 1e-6))
+        worst = max(worst, e)
+        assert e < 1e-3, (name, e)
+    print(f"24L/2048d gradient families vs autograd: worst max|d|/rms = {worst:.2e}")
+
+
 def _two_rank_trainer_worker(rank, world, port, q):
     """One data-parallel rank of the WHOLE trainer (forward, backward, reduce-scatter, clip, AdamW slice, all-gather);
     both ranks share the box's one GPU, so the process group is gloo (RCCL refuses two ranks per device)."""
