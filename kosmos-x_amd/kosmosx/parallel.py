@@ -196,3 +196,101 @@ class ZeroShardedOptimizer:
             else:
                 dist.all_gather_into_tensor(flat_p, flat_p[self.lo:self.hi].clone(), group=self.group)
         return gsq
+
+
+class Zero3Layout:
+    """ZeRO-stage-3 layout of the training step (BASELINE configs[4]; /root/reference/config/zero3.json:26-45 shards
+    parameters, gradients and optimizer state): the parameters are cut into GROUPS (one per decoder layer + one for the
+    rest); every group's flat fp32 buffer [decayed | others | padding] is cut into `world` equal slices and a rank keeps
+    slice `rank` of EVERY group — its master parameters, gradients and both Adam moments are 1/world of the model.  A group
+    exists in full only while it is used:
+
+        acquire(g)   all-gather the group's slices into a scratch buffer (the layer's weights for forward / recompute)
+        release(g)   reduce-scatter the group's full gradient buffer (SUM; the loss scale carries 1/world) into the
+                     rank's gradient slice and drop both scratch buffers
+
+    so a step moves each parameter three times (gather for forward, gather for the recompute before backward, reduce-
+    scatter of its gradient) — DeepSpeed stage 3's traffic — and the optimizer needs no collective but the norm.
+    The collectives are injected like ZeroShardedOptimizer's (device tensors on RCCL, host copies on gloo)."""
+
+    def __init__(self, groups, group=None):
+        """groups: list of lists of (name, numel, decayed) in buffer order (decayed entries first within a group)."""
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.offset, self.gof = {}, {}            # name -> offset inside its group's full buffer / group index
+        self.total, self.n_decay, self.shard, self.padded, self.goff = [], [], [], [], []
+        off_shard = 0
+        for gi, items in enumerate(groups):
+            off, nd, seen_other = 0, 0, False
+            for name, numel, decayed in items:
+                if decayed:
+                    assert not seen_other, "decayed parameters come first inside a group"
+                    nd += numel
+                else:
+                    seen_other = True
+                self.offset[name], self.gof[name] = off, gi
+                off += numel
+            sh = (off + self.world - 1) // self.world
+            sh = (sh + 3) // 4 * 4                       # 16-byte aligned slices
+            self.total.append(off); self.n_decay.append(nd); self.shard.append(sh); self.padded.append(sh * self.world)
+            self.goff.append(off_shard)
+            off_shard += sh
+        self.shard_total = off_shard
+
+    def shard_slice(self, gi):
+        """This rank's slice of group gi inside its shard buffers."""
+        return slice(self.goff[gi], self.goff[gi] + self.shard[gi])
+
+    def regions(self):
+        """[(start, stop, decayed?)] of the rank's shard buffer (padding excluded)."""
+        out = []
+        for gi in range(len(self.total)):
+            lo, hi = self.rank * self.shard[gi], (self.rank + 1) * self.shard[gi]          # group coordinates
+            base = self.goff[gi] - lo
+            a, b = lo, min(hi, self.n_decay[gi])
+            if b > a:
+                out.append((base + a, base + b, True))
+            a, b = max(lo, self.n_decay[gi]), min(hi, self.total[gi])
+            if b > a:
+                out.append((base + a, base + b, False))
+        return out
+
+    def _staged(self, t):
+        return self.world > 1 and t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def gather(self, gi, shard_p):
+        """-> the group's full parameter buffer [padded] from every rank's slice."""
+        mine = shard_p[self.shard_slice(gi)]
+        if self.world == 1:
+            return mine.clone()
+        if self._staged(mine):
+            full = torch.empty(self.padded[gi], dtype=mine.dtype)
+            dist.all_gather_into_tensor(full, mine.cpu(), group=self.group)
+            return full.to(mine.device)
+        full = torch.empty(self.padded[gi], dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group)
+        return full
+
+    def scatter_grad(self, gi, full_g, shard_g):
+        """reduce-scatter(SUM) of the group's full gradient buffer into this rank's gradient slice."""
+        dst = shard_g[self.shard_slice(gi)]
+        if self.world == 1:
+            dst.copy_(full_g)
+        elif self._staged(full_g):
+            out = torch.empty(self.shard[gi], dtype=full_g.dtype)
+            dist.reduce_scatter_tensor(out, full_g.cpu(), op=dist.ReduceOp.SUM, group=self.group)
+            dst.copy_(out)
+        else:
+            dist.reduce_scatter_tensor(dst, full_g, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_reduce_scalar(self, t):
+        if self.world == 1:
+            return t
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t

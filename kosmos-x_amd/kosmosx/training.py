@@ -22,6 +22,7 @@ attention over cat(media, latents)), the tower (pre-LN blocks, QuickGELU) down t
 from __future__ import annotations
 
 import logging
+import math
 
 import torch
 
@@ -44,14 +45,19 @@ def cosine_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_s
 class LanguageModelTrainer:
     def __init__(self, model: KosmosLanguage, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.1, max_grad_norm: float = 1.0, precision: str = "fp32", process_group=None,
-                 force_collectives: bool = False, checkpoint_activations: bool = False, optimizer: str = "adamw"):
+                 force_collectives: bool = False, checkpoint_activations: bool = False, optimizer: str = "adamw",
+                 zero_stage: int = 1):
         if optimizer not in ("adamw", "lion"):       # BASELINE configs[4] says Adam; the reference script itself selects Lion
             raise ValueError("optimizer must be 'adamw' or 'lion'")
         self.optimizer = optimizer
         if precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError("precision must be fp32, bf16 or bf16x3")
         self.precision = precision
-        self.checkpoint_activations = checkpoint_activations
+        if zero_stage not in (1, 3):
+            raise ValueError("zero_stage must be 1 (optimizer state sharded) or 3 (parameters, gradients and state sharded)")
+        self.zero_stage = zero_stage
+        # stage 3 keeps a layer's weights only while the layer runs: its backward recomputes the layer after a second gather
+        self.checkpoint_activations = checkpoint_activations or zero_stage == 3
         if not next(model.parameters()).is_cuda:
             raise RuntimeError("LanguageModelTrainer needs the model on a HIP device: there is no CPU fallback")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
@@ -89,6 +95,8 @@ class LanguageModelTrainer:
                 continue
             (decay if (name.endswith(".weight") and p.dim() == 2 and not name.startswith("embed")) else nodecay).append(name)
         self.names = decay + nodecay
+        if self.zero_stage == 3:
+            return self._build_sharded(params, decay, nodecay)
         n_decay = sum(params[n].numel() for n in decay)
         total = sum(params[n].numel() for n in self.names)
         self.zero = ZeroShardedOptimizer(total, n_decay, self.group)
@@ -106,6 +114,79 @@ class LanguageModelTrainer:
             off += p.numel()
         self.grads = {n: self.flat_g[self.offset[n]:self.offset[n] + params[n].numel()].view(params[n].shape) for n in self.names}
 
+    # ------------------------------------------------------------------ ZeRO stage 3: parameters, gradients, moments sharded
+    def _build_sharded(self, params, decay, nodecay):
+        """Groups: 0 = everything outside the decoder layers (embeddings, output projection, final LayerNorm; the tower and
+        resampler of Kosmos), 1 + i = decoder layer i.  See kosmosx.parallel.Zero3Layout."""
+        from .parallel import Zero3Layout
+        nl = len(self.model.decoder.layers)
+        gi_of = lambda n: 1 + int(n.split(".")[2]) if n.startswith("decoder.layers.") else 0
+        groups = [[] for _ in range(1 + nl)]
+        for n in decay:
+            groups[gi_of(n)].append((n, params[n].numel(), True))
+        for n in nodecay:
+            groups[gi_of(n)].append((n, params[n].numel(), False))
+        z = self.zero = Zero3Layout(groups, self.group)
+        dev = next(self.model.parameters()).device
+        self.shard_p = torch.zeros(z.shard_total, dtype=torch.float32, device=dev)
+        self.shard_g = torch.zeros(z.shard_total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(z.shard_total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(z.shard_total, dtype=torch.float32, device=dev)
+        self.offset = z.offset
+        self._params = params
+        self._shapes = {n: tuple(params[n].shape) for n in self.names}
+        self._group_names = [[n for n, _, _ in g] for g in groups]
+        self._pfull, self._gfull = {}, {}
+        self._nothing = torch.empty(0, dtype=torch.float32, device=dev)
+        for gi, items in enumerate(groups):                # the rank's slice of every group, from the replicated start
+            full = torch.zeros(z.padded[gi], dtype=torch.float32, device=dev)
+            for n, numel, _ in items:
+                full[z.offset[n]:z.offset[n] + numel].copy_(params[n].data.reshape(-1))
+            self.shard_p[z.shard_slice(gi)].copy_(full[z.rank * z.shard[gi]:(z.rank + 1) * z.shard[gi]])
+            for n, _, _ in items:
+                params[n].data = self._nothing             # the full tensors are gone: 1/world of the model stays resident
+        self.grads = _ShardedGradViews(self)
+
+    def _acquire(self, gi, grads=False):
+        """Materialise group gi: all-gather its parameters (and, for the backward, a zeroed full gradient buffer)."""
+        if self.zero_stage != 3:
+            return
+        z = self.zero
+        if gi not in self._pfull:
+            full = self._pfull[gi] = z.gather(gi, self.shard_p)
+            for n in self._group_names[gi]:
+                p = self._params[n]
+                shape = self._shapes[n]
+                p.data = full[z.offset[n]:z.offset[n] + math.prod(shape)].view(shape)
+        if grads and gi not in self._gfull:
+            self._gfull[gi] = torch.zeros(z.padded[gi], dtype=torch.float32, device=self.shard_p.device)
+
+    def _release(self, gi):
+        """Reduce-scatter group gi's gradients (if any were produced) into the rank's slice and drop the full buffers."""
+        if self.zero_stage != 3:
+            return
+        if gi in self._gfull:
+            self.zero.scatter_grad(gi, self._gfull.pop(gi), self.shard_g)
+        if gi in self._pfull:
+            del self._pfull[gi]
+            for n in self._group_names[gi]:
+                self._params[n].data = self._nothing
+
+    def _grad_buffer(self):
+        return self.shard_g if self.zero_stage == 3 else self.flat_g
+
+    def gather_parameters(self):
+        """Stage 3: all-gather every group and leave the model holding full tensors (evaluation, checkpointing — DeepSpeed's
+        GatheredParameters).  The next step() works from the rank's slices again."""
+        if self.zero_stage != 3:
+            return
+        for gi in range(len(self._group_names)):
+            full = self.zero.gather(gi, self.shard_p)
+            for n in self._group_names[gi]:
+                shape = self._shapes[n]
+                self._params[n].data = full[self.offset[n]:self.offset[n] + math.prod(shape)].view(shape).clone()
+        self._invalidate()
+
     def _leading_groups(self):
         """(decay, nodecay) name lists that must come first, in an order that keeps fused gradients adjacent."""
         return [], []
@@ -114,7 +195,7 @@ class LanguageModelTrainer:
         """The PARAMETER view matching _gspan: q | k | v weights (biases) are one [3D, D] ([3D]) matrix of the flat
         buffer — the fused projection needs no per-step torch.cat."""
         o = self.offset[first]
-        t = self.flat_p[o:o + rows * (cols or 1)]
+        t = (self._pfull[self.zero.gof[first]] if self.zero_stage == 3 else self.flat_p)[o:o + rows * (cols or 1)]
         return t.view(rows, cols) if cols else t
 
     def _xpos_tables(self, xp, T, dev):
@@ -131,7 +212,7 @@ class LanguageModelTrainer:
         """A gradient view that starts at parameter `first` and spans adjacent parameters (fused q|k|v)."""
         o = self.offset[first]
         n = rows * (cols or 1)
-        t = self.flat_g[o:o + n]
+        t = (self._gfull[self.zero.gof[first]] if self.zero_stage == 3 else self.flat_g)[o:o + n]
         return t.view(rows, cols) if cols else t
 
     # ------------------------------------------------------------------ parameters
@@ -230,7 +311,9 @@ class LanguageModelTrainer:
         saved = []
         for li, L in enumerate(dec.layers):
             x_in = x
+            self._acquire(1 + li)                          # stage 3: this layer's weights exist from here ...
             x, s = layer_forward(L, x, li)
+            self._release(1 + li)                          # ... to here
             saved.append({"x_in": x_in} if self.checkpoint_activations else s)
             del s
         hf = ops.layernorm(x, dec.layer_norm.weight.detach(), dec.layer_norm.bias.detach(), eps, out_dtype=o.ln_dt)
@@ -269,6 +352,7 @@ class LanguageModelTrainer:
         mw = ".A" if a.multiway else ""
         for li in range(len(dec.layers) - 1, -1, -1):
             L, s = dec.layers[li], saved[li]
+            self._acquire(1 + li, grads=True)              # stage 3: second gather, for the recompute and the backward
             if self.checkpoint_activations:
                 _, s = fw["layer_forward"](L, s["x_in"], li)
             saved[li] = None
@@ -302,6 +386,8 @@ class LanguageModelTrainer:
             x_in = s["x_in"]
             del dq_a, dq_t, s
             dx = self._ln_bwd(x_in, pfx + f"self_attn_layer_norm{mw}", P["sa_ln"].weight, dh1, eps, dres=dx)
+            del P
+            self._release(1 + li)                          # reduce-scatter the layer's gradients, drop its weights
         return dx
 
     def step(self, tokens: torch.Tensor, apply_update: bool = True, accumulate: bool = False) -> torch.Tensor:
@@ -309,11 +395,12 @@ class LanguageModelTrainer:
         accumulate=True adds this micro-batch's gradients to what the flat gradient buffer already holds (the
         reference's gradient-accumulation loop: step(b0, apply_update=False), step(b1, apply_update=False,
         accumulate=True), ..., step(bn, accumulate=True)); by default the buffer is overwritten."""
-        prev_g = self.flat_g.clone() if accumulate else None
+        prev_g = self._grad_buffer().clone() if accumulate else None
         m, dec = self.model, self.model.decoder
         a = dec.args
         if not isinstance(tokens, torch.Tensor) or tokens.dim() != 2 or not tokens.is_cuda:
             raise TypeError("tokens must be a [B, T] integer tensor on the HIP device (no CPU fallback)")
+        self._acquire(0, grads=True)                       # stage 3: embeddings, output projection, final LayerNorm for the step
         B, T = tokens.shape
         if T < 2:
             raise ValueError("next-token training needs at least two positions per sequence")
@@ -343,9 +430,10 @@ class LanguageModelTrainer:
                          out_embed=self.grads["embed.weight"], out_pos=self.grads["embed_positions.weight"])
         if m.embed.padding_idx is not None:
             self.grads["embed.weight"][m.embed.padding_idx].zero_()     # nn.Embedding(padding_idx) has no gradient there
+        self._release(0)
 
         if prev_g is not None:
-            self.flat_g.add_(prev_g)
+            self._grad_buffer().add_(prev_g)
             del prev_g
         if apply_update:
             self._update()
@@ -373,9 +461,34 @@ class LanguageModelTrainer:
             G.adamw_(p, g, m, v, step, self.lr, self.betas, self.eps, self.weight_decay if decayed else 0.0,
                      grad_norm_sq=gsq, max_norm=self.max_grad_norm)
 
+        if self.zero_stage == 3:                            # every buffer is already the rank's slice: only the norm travels
+            gsq = self.grad_norm_sq = self.zero.all_reduce_scalar(G.reduce_sum(self.shard_g, squares=True))
+            for lo, hi, decayed in self.zero.regions():
+                adamw(self.shard_p[lo:hi], self.shard_g[lo:hi], self.m[lo:hi], self.v[lo:hi], decayed, gsq)
+            self._invalidate()
+            return
         self.grad_norm_sq = self.zero.step(self.flat_p, self.flat_g, self.m, self.v, adamw,
                                            lambda t: G.reduce_sum(t, squares=True), force=self._force_collectives)
         self._invalidate()
+
+
+class _ShardedGradViews:
+    """grads[name] of the stage-3 trainer: a view into the full gradient buffer of the parameter's group, which exists
+    between _acquire(group, grads=True) and _release(group)."""
+
+    def __init__(self, trainer):
+        self.t = trainer
+
+    def __contains__(self, name):
+        return name in self.t.offset
+
+    def __getitem__(self, name):
+        t = self.t
+        gi = t.zero.gof[name]
+        if gi not in t._gfull:
+            raise KeyError(f"the gradient buffer of {name!r} (group {gi}) is not materialised outside its layer's backward")
+        shape = t._shapes[name]
+        return t._gfull[gi][t.offset[name]:t.offset[name] + math.prod(shape)].view(shape)
 
 
 class KosmosTrainer(LanguageModelTrainer):
@@ -610,11 +723,12 @@ class KosmosTrainer(LanguageModelTrainer):
     def step(self, tokens: torch.Tensor, images: torch.Tensor, apply_update: bool = True, accumulate: bool = False) -> torch.Tensor:
         """tokens [B,Tt] int64, images [B,3,S,S] on the device.  Returns the mean cross-entropy over the B*(Tt-1) text
         positions of the spliced sequence (a device scalar)."""
-        prev_g = self.flat_g.clone() if accumulate else None
+        prev_g = self._grad_buffer().clone() if accumulate else None
         m, dec = self.model, self.model.decoder
         a = dec.args
         if not isinstance(tokens, torch.Tensor) or tokens.dim() != 2 or not tokens.is_cuda:
             raise TypeError("tokens must be a [B, T] integer tensor on the HIP device (no CPU fallback)")
+        self._acquire(0, grads=True)                       # stage 3: tower, resampler, embeddings, output projection
         if not isinstance(images, torch.Tensor) or images.dim() != 4 or not images.is_cuda or images.shape[0] != tokens.shape[0]:
             raise TypeError("images must be a [B, 3, S, S] tensor on the HIP device with the batch of `tokens`")
         B, Tt = tokens.shape
@@ -665,9 +779,10 @@ class KosmosTrainer(LanguageModelTrainer):
         del dx, dx_text
         d_xv = self._perceiver_backward(o, d_img, fp)
         self._vit_backward(o, d_xv, fv)
+        self._release(0)
 
         if prev_g is not None:
-            self.flat_g.add_(prev_g)
+            self._grad_buffer().add_(prev_g)
             del prev_g
         if apply_update:
             self._update()

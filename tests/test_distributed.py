@@ -197,3 +197,53 @@ def test_logits_gatherer_algorithms_and_ragged_shards(algo, world, total):
     full = torch.arange(total * 3 * 5, dtype=torch.float32).reshape(total, 3, 5)
     for k, o in enumerate(outs):
         assert torch.equal(o, full + k), (algo, world, total, k)
+
+
+def _zero3_worker(rank, world, port, q):
+    for p in (str(ROOT), str(ROOT / "kosmos-x_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KOSMOSX_NO_LOGGING_CONFIG="1")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kosmosx.parallel import Zero3Layout
+    groups = [[("a", 10, True), ("b", 7, False)], [("c", 33, True), ("d", 1, False), ("e", 5, False)], [("f", 4, False)]]
+    z = Zero3Layout(groups)
+    full = [torch.arange(z.padded[g], dtype=torch.float32) + 1000 * g for g in range(3)]     # the replicated start
+    for g in range(3):
+        full[g][z.total[g]:] = 0
+    shard_p = torch.cat([full[g][rank * z.shard[g]:(rank + 1) * z.shard[g]] for g in range(3)])
+    assert shard_p.numel() == z.shard_total
+    ok = all(torch.equal(z.gather(g, shard_p), full[g]) for g in range(3))                     # all-gather restores a group
+    shard_g = torch.zeros(z.shard_total)
+    for g in range(3):
+        z.scatter_grad(g, full[g] * (rank + 1), shard_g)                                       # SUM over ranks: x (1 + 2)
+    ok = ok and all(torch.equal(shard_g[z.shard_slice(g)], 3 * full[g][rank * z.shard[g]:(rank + 1) * z.shard[g]]) for g in range(3))
+    regs = []
+    for lo, hi, decayed in z.regions():                    # shard-buffer coordinates -> (group, element range inside the group)
+        g = max(i for i in range(3) if z.goff[i] <= lo)
+        assert hi <= z.goff[g] + z.shard[g]
+        regs.append((g, lo - z.goff[g] + rank * z.shard[g], hi - z.goff[g] + rank * z.shard[g], decayed))
+    q.put((rank, ok, regs, z.n_decay, z.total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero3_layout_gathers_scatters_and_covers_every_parameter_once():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero3_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    covered = {}
+    for rank, ok, regs, n_decay, total in got:
+        assert ok
+        for g, lo, hi, decayed in regs:
+            for e in range(lo, hi):
+                assert (g, e) not in covered and e < total[g] and decayed == (e < n_decay[g])
+                covered[(g, e)] = rank
+    assert len(covered) == 17 + 39 + 4                                                # every real element, once

@@ -1,5 +1,7 @@
 """Training step on the device against autograd + torch.optim.AdamW on the CPU oracle: the loss,
 EVERY parameter gradient, and the parameters after two clipped AdamW steps."""
+import math
+
 import pytest
 import torch
 
@@ -162,7 +164,7 @@ def test_full_size_gradient_families_match_autograd():
     print(f"24L/2048d gradient families vs autograd: worst max|d|/rms = {worst:.2e}")
 
 
-def _two_rank_trainer_worker(rank, world, port, q):
+def _two_rank_trainer_worker(rank, world, port, q, zero_stage=1):
     """One data-parallel rank of the WHOLE trainer (forward, backward, reduce-scatter, clip, AdamW slice, all-gather);
     both ranks share the box's one GPU, so the process group is gloo (RCCL refuses two ranks per device)."""
     import os
@@ -177,13 +179,22 @@ def _two_rank_trainer_worker(rank, world, port, q):
     try:
         torch.cuda.set_device(0)
         lm = _tiny_lm(seed=2).to(DEV)                       # same seed on every rank = replicated start
-        tr = LanguageModelTrainer(lm, lr=1e-3)
-        assert tr.zero.world == world and tr.m.numel() * world == tr.flat_p.numel()      # 1/world of the moments per rank
+        tr = LanguageModelTrainer(lm, lr=1e-3, zero_stage=zero_stage)
+        n_params = sum(p.numel() for p in lm.parameters()) if zero_stage == 1 else sum(math.prod(s) for s in tr._shapes.values())
+        if zero_stage == 1:
+            assert tr.zero.world == world and tr.m.numel() * world == tr.flat_p.numel()  # 1/world of the moments per rank
+        else:                                               # 1/world of parameters, gradients and both moments per rank
+            for t in (tr.shard_p, tr.shard_g, tr.m, tr.v):
+                assert n_params / world <= t.numel() <= n_params / world + 16 * (1 + len(lm.decoder.layers))
+            assert all(p.numel() == 0 for p in lm.parameters())
         g = torch.Generator().manual_seed(9)
         losses = []
         for _ in range(2):
             tok = torch.randint(2, 1002, (2 * world, 24), generator=g)
             losses.append(float(tr.step(tok[2 * rank:2 * rank + 2].to(DEV))))
+        if zero_stage == 3:
+            assert not tr._pfull and not tr._gfull and all(p.numel() == 0 for p in lm.parameters())   # nothing full is left
+            tr.gather_parameters()
         torch.cuda.synchronize()
         q.put((rank, losses, {n: p.detach().cpu().numpy() for n, p in lm.named_parameters()}))   # by value
         dist.barrier()
@@ -191,10 +202,12 @@ def _two_rank_trainer_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_whole_trainer_on_two_ranks_matches_single_process_autograd():
+@pytest.mark.parametrize("zero_stage", [1, 3])
+def test_whole_trainer_on_two_ranks_matches_single_process_autograd(zero_stage):
     """LanguageModelTrainer.step on two data-parallel ranks (each half of the batch) against
     single-process autograd + torch.optim.AdamW on the full batch: the mean of the rank losses, and every parameter after
-    two clipped steps — identical on both ranks."""
+    two clipped steps — identical on both ranks.  zero_stage 3: parameters, gradients and moments sharded
+    (config/zero3.json), a layer's weights gathered for its forward and again for its recompute + backward."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -202,7 +215,7 @@ def test_whole_trainer_on_two_ranks_matches_single_process_autograd():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_trainer_worker, args=(r, 2, port, q, zero_stage)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict()
@@ -229,6 +242,22 @@ def test_whole_trainer_on_two_ranks_matches_single_process_autograd():
         d = got[0][1][n] - w[n].detach()
         assert float(d.pow(2).mean().sqrt() / w[n].detach().pow(2).mean().sqrt()) < 2e-5, n
         assert float(d.abs().max()) <= 2.1 * 1e-3 * 2, n
+
+
+def test_zero_stage_3_single_rank_is_bitwise_the_replicated_step():
+    """Stage 3 on one rank runs the same kernels on the same values (gather = copy, reduce-scatter = copy): identical
+    losses and parameters after two steps, with activation recompute on both sides."""
+    tok = torch.randint(2, 1002, (2, 24), generator=torch.Generator().manual_seed(11)).to(DEV)
+    a, b = _tiny_lm(seed=4).to(DEV), _tiny_lm(seed=4).to(DEV)
+    ta = LanguageModelTrainer(a, lr=1e-3, precision="bf16", checkpoint_activations=True)
+    tb = LanguageModelTrainer(b, lr=1e-3, precision="bf16", zero_stage=3)
+    assert [float(ta.step(tok)) for _ in range(2)] == [float(tb.step(tok)) for _ in range(2)]
+    tb.gather_parameters()
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    assert all(torch.equal(pa[n], pb[n]) for n in pa)
+    out = b(tok)                                           # gathered parameters serve the inference path
+    assert torch.isfinite(out).all()
+    assert abs(float(tb.step(tok)) - float(ta.step(tok))) == 0.0      # and the next step shards them again
 
 
 def test_trainer_argument_errors():

@@ -103,6 +103,19 @@ def test_bf16_products_multimodal_gradients():
         assert worst < rms_tol, (prec, worst)
 
 
+def test_zero_stage_3_multimodal_step_is_bitwise_the_replicated_step():
+    cfg = tiny_config()
+    tok, img = _batch(cfg, 2, 10, 41)
+    a = Kosmos._from_config(cfg, seed=7, perturb=0.1).eval().to(DEV)
+    b = Kosmos._from_config(cfg, seed=7, perturb=0.1).eval().to(DEV)
+    ta = KosmosTrainer(a, lr=1e-3, checkpoint_activations=True)
+    tb = KosmosTrainer(b, lr=1e-3, zero_stage=3)
+    assert float(ta.step(tok.to(DEV), img.to(DEV))) == float(tb.step(tok.to(DEV), img.to(DEV)))
+    tb.gather_parameters()
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    assert all(torch.equal(pa[n], pb[n]) for n in pa)
+
+
 def test_trainer_argument_errors():
     cfg = tiny_config()
     m = Kosmos._from_config(cfg, seed=6).eval().to(DEV)
