@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KX_ABI_VERSION 3
+#define KX_ABI_VERSION 4
 
 typedef enum {
   KX_OK = 0,
@@ -184,6 +184,11 @@ typedef struct {
                                                  of the 64 output values, for the folded inner_attn_ln */
   float* lse_out;                             /* optional [B,H,Tq] fp32: log-sum-exp of each query's scores: what
                                                  kx_attention_backward needs to rebuild P */
+  /* ABI 4, training only (torchscale MultiheadAttention's dropout_module on the probabilities; the reference trains with
+   * attention_dropout = 0.1, kosmosx/model.py:177): dropout_p > 0 keeps probability (b,h,q,k) iff Philox4x32-10(seed;
+   * ((b*H + h)*Tq + q)*Tk + k, site) says so and scales it by 1/(1-p); the softmax normaliser stays un-dropped.  fp32
+   * q/k/v only (the wave-per-query kernel); zero = off. */
+  float dropout_p; int32_t dropout_site; uint64_t dropout_seed;
 } kx_attn_args;
 int kx_attention(const kx_attn_args* args, void* stream);
 
@@ -462,6 +467,19 @@ int kx_attention_backward(const void* q, const void* k, const void* v, int32_t q
                           const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B, int64_t H, int64_t T,
                           int64_t qkv_row_stride, int64_t qkv_batch_stride, int64_t out_row_stride,
                           int64_t out_batch_stride, int32_t mask, int32_t prec, void* stream);
+
+/* kx_attention_backward for a forward that ran with kx_attn_args.dropout_p > 0 (same seed / site; fp32 q/k/v) */
+int kx_attention_backward_dropout(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                  const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B, int64_t H,
+                                  int64_t T, int64_t qkv_row_stride, int64_t qkv_batch_stride, int64_t out_row_stride,
+                                  int64_t out_batch_stride, int32_t mask, float dropout_p, uint64_t seed, int32_t site,
+                                  void* stream);
+/* Inverted dropout of the training step (torchscale dropout_module after the embedding, after out_proj and after fc2,
+ * reference dropout = 0.1, kosmosx/model.py:175): y = (residual +) keep(i) * x / (1 - p), keep = Philox4x32-10(seed; i, site).
+ * Applied to a gradient it is its own backward.  kx_dropout_mask exports the keep bytes (what the CPU autograd reference
+ * multiplies by — test infrastructure). */
+int kx_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, int32_t site, void* stream);
+int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t site, void* stream);
 
 /* Kernel-variant selection for in-process A/B measurement (tools/gemm_bench.py, tools/ln_bench.py).  Defaults (all 0) are the
  * shipped configuration.  key 0: LayerNorm variant (0 wave-per-row, 1 workgroup-per-row);

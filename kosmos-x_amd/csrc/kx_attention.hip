@@ -23,6 +23,7 @@ struct AttnParams {
   int B, H, Tq, Tk;
   float* stats_out;   // [B*Tq, H, 2] partial LayerNorm statistics of the output rows (folded inner_attn_ln), or null
   float* lse_out;     // [B, H, Tq] log-sum-exp of the scores (fp32 matrix-core kernel; for the backward pass), or null
+  float drop_inv_keep; unsigned drop_thresh; unsigned long long drop_seed; unsigned drop_site;   // attention dropout (training)
 };
 
 constexpr int KSTR = 72;  // LDS row stride (elements) for the 64-wide K / Vᵀ tiles: 144 B, 16-B aligned rows
@@ -692,10 +693,17 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
   float sum = 0.f;
   for (int key = lane; key < kmax; key += 64) {
     const float e = expf(sc[key] - mx);
-    sc[key] = e;
+    // attention dropout (training): the normaliser sums the un-dropped probabilities, the output the kept ones / (1-p)
+    float keep = 1.0f;
+    if (p.drop_thresh)
+      keep = kx_dropout_keep(p.drop_seed, p.drop_site,
+                             (((unsigned long long)b * p.H + h) * p.Tq + qc) * (unsigned long long)p.Tk + key, p.drop_thresh)
+                 ? p.drop_inv_keep : 0.f;
+    sc[key] = e * keep;
     sum += e;
   }
   sum = wave_sum(sum);
+  if (p.lse_out && lane == 0 && qi < p.Tq) p.lse_out[((long long)b * p.H + h) * p.Tq + qi] = mx + logf(sum);
   __syncthreads();
   float o = 0.f;
   for (int key = 0; key < kmax; ++key) o = fmaf(sc[key], vp[(long long)key * p.krs + lane], o);
@@ -898,8 +906,14 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
   p.stats_out = a->stats_out;
   p.lse_out = a->lse_out;
-  KX_REQUIRE(!a->lse_out || kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1,
-             "kx_attention: lse_out is not produced by the first-version (A/B) kernels");
+  const bool drop = a->dropout_p > 0.f;
+  KX_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (!drop || (a->prec == KX_PREC_F32 && a->odt == KX_F32 && !a->stats_out)),
+             "kx_attention: dropout_p must be in [0, 1) and needs fp32 q/k/v, an fp32 output and no stats_out");
+  p.drop_thresh = drop ? (unsigned)fminf(4294967295.0f, a->dropout_p * 4294967296.0f) : 0u;
+  p.drop_inv_keep = 1.0f / (1.0f - a->dropout_p);
+  p.drop_seed = a->dropout_seed; p.drop_site = (unsigned)a->dropout_site;
+  KX_REQUIRE(!a->lse_out || drop || kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1 || a->prec == KX_PREC_F32,
+             "kx_attention: lse_out is not produced by the first-version (A/B) bf16 kernel");
   KX_REQUIRE(!a->stats_out || !(a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1),
              "kx_attention: stats_out is not implemented by the v1 A/B kernel");
   hipStream_t s = (hipStream_t)stream;
@@ -926,11 +940,11 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
       hipLaunchKernelGGL((attn_bf16_v2_kernel<true, false>), dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
     else
       hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false>), dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
-  } else if (kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1) {
+  } else if (kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1 && !drop) {
     dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_f32_mfma_kernel<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_f32_mfma_kernel<false>, grid, dim3(256), 0, s, p);
-  } else {                                                                      // wave-per-query VALU kernel, kept for A/B
+  } else {                                            // wave-per-query VALU kernel: A/B, and the one that carries attention dropout
     dim3 grid((unsigned)((a->Tq + 3) / 4), (unsigned)a->H, (unsigned)a->B);
     const size_t lds = 4 * (64 + (size_t)a->Tk) * sizeof(float);
     KX_REQUIRE(lds <= 64 * 1024, "kx_attention(f32): Tk=%lld exceeds the LDS score buffer", (long long)a->Tk);

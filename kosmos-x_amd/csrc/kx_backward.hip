@@ -364,6 +364,26 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(const float* __restrict
   reinterpret_cast<float4*>(out)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
+// ---- dropout: y = (residual +) keep(i) * x / (1 - p); its own backward (the mask is a function of the index) ----
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ residual,
+                                                      float* __restrict__ y, long long n4, float inv_keep, unsigned thresh,
+                                                      unsigned long long seed, unsigned site) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  unsigned w[4];
+  philox4x32_10((unsigned long long)i, site, seed, w);
+  const float4 a = reinterpret_cast<const float4*>(x)[i];
+  float4 o = residual ? reinterpret_cast<const float4*>(residual)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  o.x += w[0] >= thresh ? a.x * inv_keep : 0.f; o.y += w[1] >= thresh ? a.y * inv_keep : 0.f;
+  o.z += w[2] >= thresh ? a.z * inv_keep : 0.f; o.w += w[3] >= thresh ? a.w * inv_keep : 0.f;
+  reinterpret_cast<float4*>(y)[i] = o;
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned char* __restrict__ keep, long long n, unsigned thresh,
+                                                           unsigned long long seed, unsigned site) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keep[i] = kx_dropout_keep(seed, site, (unsigned long long)i, thresh) ? 1 : 0;
+}
+
 // ---- cross-entropy: one workgroup per row; loss_r = lse - logit[target]; dlogits = (softmax - onehot) * scale ----
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, long long ld, int V,
                                                             const long long* __restrict__ target, float scale,
@@ -545,7 +565,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ lse, const float* __restrict__ delta,
                                                        float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                        int T, int H, long long row_stride /* elements between tokens: 3D */,
-                                                       long long batch_stride, long long do_row, long long do_batch) {
+                                                       long long batch_stride, long long do_row, long long do_batch,
+                                                       float inv_keep = 1.0f, unsigned drop_thresh = 0u,
+                                                       unsigned long long drop_seed = 0ull, unsigned drop_site = 0u) {
   __shared__ float A[64 * AP], Bm[64 * AP], Cm[64 * AP], Dm[64 * AP];   // role depends on MODE, see below
   __shared__ float Ps[64 * AP];
   const int own0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -613,8 +635,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const int kj = k0 + 4 * tx + j;
         const bool ok = qi < T && kj < T && (!CAUSAL || kj <= qi);
         const float pv = ok ? expf(s[i][j] - l) : 0.f;
-        s[i][j] = pv * (dp[i][j] - dl);               // dS
-        dp[i][j] = pv;                                // P
+        // attention dropout (drop_thresh > 0): O = (P ⊙ M / (1-p)) V, so dV takes the dropped P and dP arrives through
+        // the same mask; delta = rowsum(dO ⊙ O) already holds the dropped output
+        float keep = 1.0f;
+        if (drop_thresh)
+          keep = kx_dropout_keep(drop_seed, drop_site, (((unsigned long long)b * H + h) * T + qi) * (unsigned long long)T + kj,
+                                 drop_thresh) ? inv_keep : 0.f;
+        s[i][j] = pv * (dp[i][j] * keep - dl);        // dS
+        dp[i][j] = pv * keep;                         // P (dropped) for dV
       }
     }
     float* dSs = Ps;
@@ -1464,5 +1492,66 @@ extern "C" int kx_attention_backward(const void* qv_, const void* kv_, const voi
   else { KX_ATTN_BWD(0, false); KX_ATTN_BWD(1, false); }
 #undef KX_ATTN_BWD
   KX_CHECK_LAUNCH("kx_attention_backward");
+  return KX_OK;
+}
+
+// The same backward with attention dropout (training): fp32 q/k/v, the VALU passes (the only ones that carry the
+// mask today — the matrix-core variants of the deterministic step are untouched), mask = Philox(seed, site) over the
+// element index ((b*H + h)*T + q)*T + k, exactly as the forward (kx_attn_args.dropout_*).
+extern "C" int kx_attention_backward_dropout(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                             const float* lse, float* dq, float* dk, float* dv, float* delta, int64_t B,
+                                             int64_t H, int64_t T, int64_t qkv_row_stride, int64_t qkv_batch_stride,
+                                             int64_t out_row_stride, int64_t out_batch_stride, int32_t mask, float dropout_p,
+                                             uint64_t seed, int32_t site, void* stream) {
+  KX_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta, "kx_attention_backward_dropout: null pointer");
+  KX_REQUIRE(B > 0 && H > 0 && T > 0 && B < 65536 && H < 65536 && dropout_p >= 0.f && dropout_p < 1.f,
+             "kx_attention_backward_dropout: bad shape or dropout_p outside [0, 1)");
+  KX_REQUIRE(qkv_row_stride % 4 == 0 && out_row_stride % 4 == 0 && qkv_batch_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
+                 (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+             "kx_attention_backward_dropout: pointers and strides must keep 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_ATTN_F32, B * H, T, -T, s);
+  const long long nw = (long long)B * T * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, out, dout, delta, (int)B, (int)T,
+                     (int)H, (long long)out_row_stride, (long long)out_batch_stride);
+  const dim3 grid((unsigned)((T + 63) / 64), (unsigned)H, (unsigned)B);
+  const unsigned thresh = dropout_p > 0.f ? (unsigned)fminf(4294967295.0f, dropout_p * 4294967296.0f) : 0u;
+  const float inv_keep = 1.0f / (1.0f - dropout_p);
+#define KX_ATTN_BWD_D(MODE, CAUSAL)                                                                                      \
+  hipLaunchKernelGGL((attn_bwd_kernel<MODE, CAUSAL>), grid, dim3(256), 0, s, q, k, v, dout, lse, (const float*)delta, dq, dk, \
+                     dv, (int)T, (int)H, (long long)qkv_row_stride, (long long)qkv_batch_stride, (long long)out_row_stride, \
+                     (long long)out_batch_stride, inv_keep, thresh, (unsigned long long)seed, (unsigned)site)
+  if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD_D(0, true); KX_ATTN_BWD_D(1, true); }
+  else { KX_ATTN_BWD_D(0, false); KX_ATTN_BWD_D(1, false); }
+#undef KX_ATTN_BWD_D
+  KX_CHECK_LAUNCH("kx_attention_backward_dropout");
+  return KX_OK;
+}
+
+// y = (residual +) dropout(x): inverted dropout with the Philox mask of (seed, site); applied to a gradient it is its own
+// backward.  n % 4 == 0, 16-byte aligned buffers; y may alias x.
+extern "C" int kx_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, int32_t site,
+                          void* stream) {
+  KX_REQUIRE(x && y && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f &&
+                 (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0,
+             "kx_dropout: null pointer, n %% 4 != 0, p outside [0, 1) or unaligned buffers");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_MISC, n, 0, 31, s);
+  const long long n4 = n / 4;
+  const unsigned thresh = p > 0.f ? (unsigned)fminf(4294967295.0f, p * 4294967296.0f) : 0u;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, residual, y, n4, 1.0f / (1.0f - p),
+                     thresh, (unsigned long long)seed, (unsigned)site);
+  KX_CHECK_LAUNCH("kx_dropout");
+  return KX_OK;
+}
+
+// test hook: the keep mask (1 byte per element) of (seed, site) — what the CPU autograd reference multiplies by
+extern "C" int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t site, void* stream) {
+  KX_REQUIRE(keep && n > 0 && p >= 0.f && p < 1.f, "kx_dropout_mask: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned thresh = p > 0.f ? (unsigned)fminf(4294967295.0f, p * 4294967296.0f) : 0u;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keep, (long long)n, thresh,
+                     (unsigned long long)seed, (unsigned)site);
+  KX_CHECK_LAUNCH("kx_dropout_mask");
   return KX_OK;
 }

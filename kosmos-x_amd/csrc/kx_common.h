@@ -169,6 +169,31 @@ __device__ __forceinline__ f32x2_t apply_act2(f32x2_t x) {
   else if constexpr (ACT == KX_ACT_NONE) return x;
   else return (f32x2_t){apply_act<ACT>(x.x), apply_act<ACT>(x.y)};
 }
+// ---- counter-based dropout masks (training, SURVEY H1: the reference trains with dropout = attention_dropout = 0.1) ----
+// Philox4x32-10 (Salmon et al., SC'11) keyed by the step's 64-bit seed; counter = (element index / 4 [64 bit], site, 0):
+// element i of site s keeps iff word (i & 3) of its block is >= thresh = round(p * 2^32).  A pure function of (seed, site,
+// element index): the forward, its recompute, every backward pass and the test hook that exports masks for the CPU
+// autograd reference see the same mask whatever their thread layout.
+__device__ __forceinline__ void philox4x32_10(unsigned long long ctr_lo, unsigned ctr_site, unsigned long long key,
+                                              unsigned (&out)[4]) {
+  unsigned c0 = (unsigned)ctr_lo, c1 = (unsigned)(ctr_lo >> 32), c2 = ctr_site, c3 = 0u;
+  unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ unsigned kx_dropout_thresh(float p) { return (unsigned)fminf(4294967295.0f, p * 4294967296.0f); }
+__device__ __forceinline__ bool kx_dropout_keep(unsigned long long seed, unsigned site, unsigned long long idx, unsigned thresh) {
+  unsigned w[4];
+  philox4x32_10(idx >> 2, site, seed, w);
+  return w[idx & 3] >= thresh;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

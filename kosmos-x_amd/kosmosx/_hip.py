@@ -13,7 +13,7 @@ from pathlib import Path
 
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
-ABI_VERSION = 3   # KX_ABI_VERSION of include/kosmosx_hip.h
+ABI_VERSION = 4   # KX_ABI_VERSION of include/kosmosx_hip.h
 
 KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16 = 0, 1, 2, 3, 4
 KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16 = 0, 1, 2, 3, 4
@@ -54,7 +54,7 @@ class AttnArgs(C.Structure):
                 ("k", vp), ("v", vp), ("kv_batch_stride", i64), ("kv_row_stride", i64),
                 ("out", vp), ("out_batch_stride", i64), ("out_row_stride", i64), ("odt", i32),
                 ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64), ("mask", i32), ("prec", i32), ("stats_out", vp),
-                ("lse_out", vp)]
+                ("lse_out", vp), ("dropout_p", f32), ("dropout_site", i32), ("dropout_seed", C.c_uint64)]
 
 
 class VitLayer(C.Structure):
@@ -151,6 +151,9 @@ SYMBOLS = {
     "kx_embed_backward": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, vp, vp, vp]),
     "kx_adamw": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, f32, vp]),
     "kx_lion": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp]),
+    "kx_attention_backward_dropout": (C.c_int, [vp] * 10 + [i64] * 7 + [i32, f32, C.c_uint64, i32, vp]),
+    "kx_dropout": (C.c_int, [vp, vp, vp, i64, f32, C.c_uint64, i32, vp]),
+    "kx_dropout_mask": (C.c_int, [vp, i64, f32, C.c_uint64, i32, vp]),
     "kx_quick_gelu_forward": (C.c_int, [vp, vp, i64, vp]),
     "kx_quick_gelu_backward": (C.c_int, [vp, vp, vp, i64, vp]),
     "kx_add_rowvec": (C.c_int, [vp, vp, vp, i64, i64, vp]),

@@ -198,7 +198,23 @@ def lion_(param, grad, m, lr, betas=(0.9, 0.99), weight_decay=0.0, grad_norm_sq=
                              float(weight_decay), H.ptr(grad_norm_sq), float(max_norm), _stream()), "kx_lion")
 
 
-def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True, bf16_products=False):
+def dropout(x: torch.Tensor, p: float, seed: int, site: int, residual: torch.Tensor | None = None) -> torch.Tensor:
+    """(residual +) keep * x / (1 - p) with the Philox mask of (seed, site); on a gradient: the dropout backward."""
+    _need_cuda(x, residual)
+    y = torch.empty_like(x)
+    H.check(H.load().kx_dropout(H.ptr(x), H.ptr(residual), H.ptr(y), x.numel(), float(p), int(seed), int(site), _stream()),
+            "kx_dropout")
+    return y
+
+
+def dropout_mask(n: int, p: float, seed: int, site: int, device) -> torch.Tensor:
+    """The keep mask (uint8 [n]) of (seed, site): test hook for the CPU autograd reference."""
+    m = torch.empty(n, dtype=torch.uint8, device=device)
+    H.check(H.load().kx_dropout_mask(H.ptr(m), n, float(p), int(seed), int(site), _stream()), "kx_dropout_mask")
+    return m
+
+
+def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True, bf16_products=False, dropout=None):
     """qkv [B*T, 3D] (q pre-scaled and XPos-rotated; fp32, or bf16 with bf16_products), out/dout [B,T,D] fp32, lse [B,H,T]
     -> dqkv [B*T, 3D] fp32."""
     _need_cuda(qkv, out, dout, lse)
@@ -210,6 +226,15 @@ def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True, bf16_products
     es = qkv.element_size()
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es
     dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * 4, dqkv.data_ptr() + 2 * D * 4
+    if dropout is not None:                        # (p, seed, site) of the forward's attention dropout
+        if qkv.dtype != torch.float32:
+            raise TypeError("attention dropout runs on fp32 q/k/v")
+        H.check(H.load().kx_attention_backward_dropout(q, k, v, H.ptr(out), H.ptr(dout), H.ptr(lse), dq, dk, dv, H.ptr(delta), B,
+                                                       Hh, T, 3 * D, T * 3 * D, D, T * D,
+                                                       H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL, float(dropout[0]),
+                                                       int(dropout[1]), int(dropout[2]), _stream()),
+                "kx_attention_backward_dropout")
+        return dqkv
     H.check(H.load().kx_attention_backward(q, k, v, H.KX_BF16 if qkv.dtype == torch.bfloat16 else H.KX_F32, H.ptr(out),
                                            H.ptr(dout), H.ptr(lse), dq, dk, dv, H.ptr(delta), B, Hh, T, 3 * D, T * 3 * D, D,
                                            T * D, H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL,

@@ -169,7 +169,7 @@ def row_stats_finalize(partials, seg_size, eps=1e-5):
 
 
 def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=False, lse_out=None, f16c=False,
-              out_f16c=False):
+              out_f16c=False, dropout=None):
     """q [B,Tq,H,64], k/v [B,Tk,H,64] (any row/batch strides, last two dims contiguous) -> [B,Tq,H*64]
     (out_x3, fp32 inputs only: KX_BF16X3 rows [hi | hi | lo], [B,Tq,3*H*64] bf16).
     f16c (fp32 inputs): the KX_PREC_F16C kernel — split fp16 (hi, lo) products; out_f16c: KX_F16C rows [B,Tq,4*H*64] uint8."""
@@ -194,6 +194,8 @@ def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=Fals
     a.mask, a.prec = (H.KX_ATTN_CAUSAL if causal else H.KX_ATTN_FULL), prec
     a.stats_out = H.ptr(stats_out)
     a.lse_out = H.ptr(lse_out)
+    if dropout is not None:                        # (p, seed, site): attention dropout of the training step, fp32 only
+        a.dropout_p, a.dropout_seed, a.dropout_site = float(dropout[0]), int(dropout[1]), int(dropout[2])
     H.check(H.load().kx_attention(C.byref(a), _stream()), "kx_attention")
     return out
 

@@ -46,7 +46,7 @@ class LanguageModelTrainer:
     def __init__(self, model: KosmosLanguage, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.1, max_grad_norm: float = 1.0, precision: str = "fp32", process_group=None,
                  force_collectives: bool = False, checkpoint_activations: bool = False, optimizer: str = "adamw",
-                 zero_stage: int = 1):
+                 zero_stage: int = 1, train_mode: bool = False, dropout_seed: int = 0):
         if optimizer not in ("adamw", "lion"):       # BASELINE configs[4] says Adam; the reference script itself selects Lion
             raise ValueError("optimizer must be 'adamw' or 'lion'")
         self.optimizer = optimizer
@@ -64,10 +64,18 @@ class LanguageModelTrainer:
         self.weight_decay, self.max_grad_norm = weight_decay, max_grad_norm
         self.step_no = 0
         da = model.decoder.args
-        if max(getattr(da, "dropout", 0.0), getattr(da, "attention_dropout", 0.0), getattr(da, "activation_dropout", 0.0)) > 0:
-            # the reference trains with dropout 0.1 (/root/reference/kosmosx/model.py:175-177); this step is the
-            # deterministic (eval-mode) forward and its exact gradient — said loudly instead of silently
-            logging.warning("LanguageModelTrainer: dropout / attention_dropout > 0 in the config are NOT applied "
+        # train_mode = the reference's model.train() (/root/reference/train.py:642; dropout = attention_dropout = 0.1,
+        # kosmosx/model.py:175-177): torchscale's dropout_module after the embedding, on the attention probabilities, after
+        # out_proj and after fc2, masks from Philox4x32-10(seed = (dropout_seed, step call), site, element).  Default False: the
+        # deterministic (eval-mode) forward and its exact gradient.
+        self.train_mode = train_mode
+        self.p_drop = float(getattr(da, "dropout", 0.0)) if train_mode else 0.0
+        self.p_attn = float(getattr(da, "attention_dropout", 0.0)) if train_mode else 0.0
+        if train_mode and float(getattr(da, "activation_dropout", 0.0)) > 0:
+            raise NotImplementedError("activation_dropout > 0 is not on the reference's path (torchscale default 0.0)")
+        self._dropout_seed, self._calls, self._seed = int(dropout_seed), 0, 0
+        if not train_mode and max(getattr(da, "dropout", 0.0), getattr(da, "attention_dropout", 0.0)) > 0:
+            logging.warning("LanguageModelTrainer: train_mode=False — the config's dropout / attention_dropout are NOT applied "
                             "(deterministic forward; SURVEY H1)")
         self.group = process_group
         self._force_collectives = force_collectives
@@ -171,6 +179,32 @@ class LanguageModelTrainer:
             del self._pfull[gi]
             for n in self._group_names[gi]:
                 self._params[n].data = self._nothing
+
+    def _begin_call(self):
+        """One dropout seed per step() call: (dropout_seed, call index) — the recompute and the backward reuse it."""
+        self._seed = ((self._dropout_seed & 0xFFFFFFFF) << 32) | (self._calls & 0xFFFFFFFF)
+        self._calls += 1
+
+    def dropout_masks(self, B, T):
+        """Test hook: {site: keep / (1 - p) tensor} of the NEXT step() call for a [B, T] (spliced) sequence, in the shapes
+        oracle/kosmos_oracle.decoder_layer multiplies by."""
+        a = self.model.decoder.args
+        D, Hh, dev = a.decoder_embed_dim, a.decoder_attention_heads, self._nothing_dev()
+        seed = ((self._dropout_seed & 0xFFFFFFFF) << 32) | (self._calls & 0xFFFFFFFF)
+        out = {}
+        if self.p_drop > 0:
+            out[0] = G.dropout_mask(B * T * D, self.p_drop, seed, 0, dev).view(B, T, D).float() / (1.0 - self.p_drop)
+        for li in range(len(self.model.decoder.layers)):
+            if self.p_attn > 0:
+                out[1 + 3 * li] = (G.dropout_mask(B * Hh * T * T, self.p_attn, seed, 1 + 3 * li, dev).view(B * Hh, T, T).float()
+                                   / (1.0 - self.p_attn))
+            if self.p_drop > 0:
+                for site in (2 + 3 * li, 3 + 3 * li):
+                    out[site] = G.dropout_mask(B * T * D, self.p_drop, seed, site, dev).view(B, T, D).float() / (1.0 - self.p_drop)
+        return out
+
+    def _nothing_dev(self):
+        return (self.shard_p if self.zero_stage == 3 else self.flat_p).device
 
     def _grad_buffer(self):
         return self.shard_g if self.zero_stage == 3 else self.flat_g
@@ -287,21 +321,32 @@ class LanguageModelTrainer:
             bqkv = self._pspan(f"decoder.layers.{li}.self_attn.q_proj{mwn}.bias", 3 * D)
             # bf16 mode: q, k, v live in bf16 (flash kernel with bf16 products forward and backward, fp32 statistics)
             wqkv_a, wqkv_t = o.pairW(wqkv)
+            adrop = (self.p_attn, self._seed, 1 + 3 * li) if self.p_attn > 0 else None
             qkv = ops.gemm(o.opA(h1), wqkv_a, bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0,
-                           out_dtype=torch.bfloat16 if self.precision == "bf16" else torch.float32)
+                           out_dtype=torch.bfloat16 if self.precision == "bf16" and adrop is None else torch.float32)
             del wqkv_a
             q3, k3, v3 = (qkv[:, i * D:(i + 1) * D].unflatten(0, (B, T)).unflatten(2, (Hh, 64)) for i in range(3))
             lse = torch.empty((B, Hh, T), dtype=torch.float32, device=dev)
-            att = ops.attention(q3, k3, v3, True, out_dtype=torch.float32, lse_out=lse).reshape(M, D)
+            att = ops.attention(q3, k3, v3, True, out_dtype=torch.float32, lse_out=lse, dropout=adrop).reshape(M, D)
             a_n = att if P["inner_ln"] is None else ops.layernorm(att, P["inner_ln"].weight.detach(),
                                                                    P["inner_ln"].bias.detach(), eps, out_dtype=o.ln_dt)
-            x, wo_t = o.lin(a_n, P["o"].weight, P["o"].bias, residual=x)
+            if self.p_drop > 0:                            # x + dropout(out_proj(.)): torchscale DecoderLayer
+                ao, wo_t = o.lin(a_n, P["o"].weight, P["o"].bias)
+                x = G.dropout(ao, self.p_drop, self._seed, 2 + 3 * li, residual=x)
+                del ao
+            else:
+                x, wo_t = o.lin(a_n, P["o"].weight, P["o"].bias, residual=x)
             h2 = ops.layernorm(x, P["fl_ln"].weight.detach(), P["fl_ln"].bias.detach(), eps, out_dtype=o.ln_dt)
             pre, w1_t = o.lin(h2, P["fc1"].weight, P["fc1"].bias)
             g = G.gelu(pre)
             g_n = g if P["ffn_ln"] is None else ops.layernorm(g, P["ffn_ln"].weight.detach(), P["ffn_ln"].bias.detach(), eps,
                                                               out_dtype=o.ln_dt)
-            y, w2_t = o.lin(g_n, P["fc2"].weight, P["fc2"].bias, residual=x)
+            if self.p_drop > 0:                            # x + dropout(fc2(.)): torchscale FeedForwardNetwork
+                fo, w2_t = o.lin(g_n, P["fc2"].weight, P["fc2"].bias)
+                y = G.dropout(fo, self.p_drop, self._seed, 3 + 3 * li, residual=x)
+                del fo
+            else:
+                y, w2_t = o.lin(g_n, P["fc2"].weight, P["fc2"].bias, residual=x)
             s.update(h1=h1, wqkv_t=wqkv_t, wo_t=wo_t, w1_t=w1_t, w2_t=w2_t, qkv=qkv, lse=lse, att=att, a_n=a_n, x_mid=x,
                      h2=h2, pre=pre, g=g, g_n=g_n)
             return y, s
@@ -357,8 +402,9 @@ class LanguageModelTrainer:
                 _, s = fw["layer_forward"](L, s["x_in"], li)
             saved[li] = None
             P, pfx = self._layer_params(L), f"decoder.layers.{li}."
-            # x_out = x_mid + fc2(ffn_ln(gelu(fc1(fl_ln(x_mid)))))
-            dx_a, dx_t = o.pairA(dx, grads[pfx + f"ffn{mw}.fc2.bias"])
+            # x_out = x_mid + [dropout](fc2(ffn_ln(gelu(fc1(fl_ln(x_mid))))))
+            dy = G.dropout(dx, self.p_drop, self._seed, 3 + 3 * li) if self.p_drop > 0 else dx
+            dx_a, dx_t = o.pairA(dy, grads[pfx + f"ffn{mw}.fc2.bias"])
             o.wgrad(dx_t, s["g_n"], out=grads[pfx + f"ffn{mw}.fc2.weight"])
             dgn = o.dgrad(dx_a, s["w2_t"])
             del dx_a, dx_t
@@ -369,15 +415,18 @@ class LanguageModelTrainer:
             dh2 = o.dgrad(dp_a, s["w1_t"])
             del dp_a, dp_t
             dx = self._ln_bwd(s["x_mid"], pfx + f"final_layer_norm{mw}", P["fl_ln"].weight, dh2, eps, dres=dx)
-            # x_mid = x_in + out_proj(inner_ln(attention(xpos(q), xpos(k), v)))
-            dx_a, dx_t = o.pairA(dx, grads[pfx + f"self_attn.out_proj{mw}.bias"])
+            # x_mid = x_in + [dropout](out_proj(inner_ln(attention(xpos(q), xpos(k), v))))
+            dy = G.dropout(dx, self.p_drop, self._seed, 2 + 3 * li) if self.p_drop > 0 else dx
+            dx_a, dx_t = o.pairA(dy, grads[pfx + f"self_attn.out_proj{mw}.bias"])
+            del dy
             o.wgrad(dx_t, s["a_n"], out=grads[pfx + f"self_attn.out_proj{mw}.weight"])
             dan = o.dgrad(dx_a, s["wo_t"])
             del dx_a, dx_t
             datt = dan if P["inner_ln"] is None else self._ln_bwd(s["att"], pfx + f"self_attn.inner_attn_ln{mw}",
                                                                    P["inner_ln"].weight, dan, eps)
+            adrop = (self.p_attn, self._seed, 1 + 3 * li) if self.p_attn > 0 else None
             dqkv = G.attention_backward(s["qkv"], s["att"].reshape(B, T, D), datt.reshape(B, T, D), s["lse"], B, T, Hh, True,
-                                        bf16_products=self.precision == "bf16")
+                                        bf16_products=self.precision == "bf16" and adrop is None, dropout=adrop)
             G.xpos_backward_(dqkv, D, T, tabs, 0.125)
             # q | k | v are adjacent in the flat layout: one GEMM output / one column sum covers the three
             dq_a, dq_t = o.pairA(dqkv, self._gspan(pfx + f"self_attn.q_proj{mw}.bias", 3 * D))
@@ -414,7 +463,10 @@ class LanguageModelTrainer:
         o = self._make_ops()
 
         # ---------------- forward, keeping what the backward needs ----------------
+        self._begin_call()
         x = ops.embed_splice(tokens, m.embed.weight.detach(), m.embed_positions.weight.detach()).reshape(M, D)
+        if self.p_drop > 0:                                # forward_embedding: x = dropout_module(x)
+            x = G.dropout(x, self.p_drop, self._seed, 0)
         logits, fw = self._decoder_forward(o, x, B, T)
         del x
 
@@ -426,6 +478,8 @@ class LanguageModelTrainer:
 
         # ---------------- backward: every parameter gradient is written into its view of the flat buffer ----------------
         dx = self._decoder_backward(o, dlogits, fw)
+        if self.p_drop > 0:
+            dx = G.dropout(dx, self.p_drop, self._seed, 0)
         G.embed_backward(tokens, dx.reshape(B, T, D), V, m.embed_positions.weight.shape[0],
                          out_embed=self.grads["embed.weight"], out_pos=self.grads["embed_positions.weight"])
         if m.embed.padding_idx is not None:
@@ -745,11 +799,14 @@ class KosmosTrainer(LanguageModelTrainer):
         alias = bool(m.switches.u1_inplace_alias)
 
         # ---------------- forward ----------------
+        self._begin_call()
         xv, fv = self._vit_forward(o, images)
         img, fp = self._perceiver_forward(o, xv, B, fv["S"])
         del xv
         x = ops.embed_splice(tokens, m.embed.weight.detach(), m.embed_positions.weight.detach(), img=img.view(B, Lq, D),
                              u1_alias=alias).reshape(B * T, D)
+        if self.p_drop > 0:                                # the second forward_embedding's [0] is taken after dropout_module
+            x = G.dropout(x, self.p_drop, self._seed, 0)
         logits, fw = self._decoder_forward(o, x, B, T)
         del x, img
 
@@ -763,7 +820,10 @@ class KosmosTrainer(LanguageModelTrainer):
         del logits
 
         # ---------------- backward ----------------
-        dx = self._decoder_backward(o, dlogits, fw).view(B, T, D)
+        dx = self._decoder_backward(o, dlogits, fw)
+        if self.p_drop > 0:
+            dx = G.dropout(dx, self.p_drop, self._seed, 0)
+        dx = dx.view(B, T, D)
         del dlogits, fw
         # text rows: embedding rows, and (forward_embedding()[1] aliases x) the positions of the text-only pass
         dx_text = torch.cat([dx[:, :2], dx[:, 2 + Lq:]], 1).contiguous()

@@ -273,7 +273,11 @@ def apply_xpos(x, cs, ss):
 # a9-a13: Decoder (torchscale, recalled) with the passed_x patch
 # --------------------------------------------------------------------------------------
 def decoder_layer(w: dict, x: torch.Tensor, i: int, cfg: DecoderCfg, sw: Switches, prefix="decoder.",
-                  mw=".A"):
+                  mw=".A", drop: dict | None = None):
+    """drop (training mode; None = eval): {site: keep/(1-p) tensor} at torchscale's dropout_module calls —
+    site 1+3i: the attention probabilities [B*H, T, T] (MultiheadAttention, attention_dropout), 2+3i: the attention
+    block's output before the residual add, 3+3i: fc2's output before the residual add (DecoderLayer / FeedForwardNetwork,
+    dropout).  Site 0 (after the embedding) is applied by the caller."""
     p = f"{prefix}layers.{i}."
     B, T, D = x.shape
     H = cfg.heads
@@ -296,11 +300,15 @@ def decoder_layer(w: dict, x: torch.Tensor, i: int, cfg: DecoderCfg, sw: Switche
     mask = torch.triu(torch.zeros([T, T]).float().fill_(float("-inf")), 1)
     a = torch.nan_to_num(a) + mask[None]
     a = F.softmax(a, dim=-1, dtype=torch.float32)
+    if drop is not None and (1 + 3 * i) in drop:
+        a = a * drop[1 + 3 * i]
     o = torch.bmm(_r(a, sw), _r(v, sw))
     o = o.transpose(0, 1).reshape(T, B, D).transpose(0, 1)
     if cfg.subln:
         o = layer_norm(o, w[p + f"self_attn.inner_attn_ln{mw}.weight"], w[p + f"self_attn.inner_attn_ln{mw}.bias"], cfg.eps)
     o = linear(o, w[p + f"self_attn.out_proj{mw}.weight"], w[p + f"self_attn.out_proj{mw}.bias"], sw)
+    if drop is not None and (2 + 3 * i) in drop:
+        o = o * drop[2 + 3 * i]
     x = r * 1.0 + o                                                      # residual_connection, alpha = 1
     r = x
     y = layer_norm(x, w[p + f"final_layer_norm{mw}.weight"], w[p + f"final_layer_norm{mw}.bias"], cfg.eps)
@@ -309,15 +317,17 @@ def decoder_layer(w: dict, x: torch.Tensor, i: int, cfg: DecoderCfg, sw: Switche
     y = act_fn(y.float(), cfg.act)
     if cfg.subln:
         y = layer_norm(y, w[p + f"ffn{mw}.ffn_layernorm.weight"], w[p + f"ffn{mw}.ffn_layernorm.bias"], cfg.eps)
-    y = linear(y, w[p + f"ffn{mw}.fc2.weight"], w[p + f"ffn{mw}.fc2.bias"], sw)
-    return r * 1.0 + y.view(B, T, D)
+    y = linear(y, w[p + f"ffn{mw}.fc2.weight"], w[p + f"ffn{mw}.fc2.bias"], sw).view(B, T, D)
+    if drop is not None and (3 + 3 * i) in drop:
+        y = y * drop[3 + 3 * i]
+    return r * 1.0 + y
 
 
 def decoder_forward(w: dict, x: torch.Tensor, cfg: DecoderCfg, sw: Switches, prefix="decoder.",
-                    features_only: bool = False) -> torch.Tensor:
+                    features_only: bool = False, drop: dict | None = None) -> torch.Tensor:
     """Decoder.forward(..., passed_x=x)[0]: 24 layers, final LayerNorm, output_projection."""
     for i in range(cfg.layers):
-        x = decoder_layer(w, x, i, cfg, sw, prefix)
+        x = decoder_layer(w, x, i, cfg, sw, prefix, drop=drop)
     x = layer_norm(x, w[prefix + "layer_norm.weight"], w[prefix + "layer_norm.bias"], cfg.eps)
     if features_only:
         return x

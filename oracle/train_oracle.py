@@ -18,14 +18,19 @@ import torch.nn.functional as F
 from . import kosmos_oracle as O
 
 
-def lm_loss(w: dict, tokens: torch.Tensor, cfg: O.DecoderCfg, sw: O.Switches | None = None) -> torch.Tensor:
+def lm_loss(w: dict, tokens: torch.Tensor, cfg: O.DecoderCfg, sw: O.Switches | None = None, drop: dict | None = None) -> torch.Tensor:
+    """drop: training-mode dropout masks {site: keep/(1-p)} (kosmos_oracle.decoder_layer; site 0 = torchscale
+    forward_embedding's dropout_module on x, the value Decoder.forward consumes)."""
     sw = sw or O.Switches()
     x, _ = O.forward_embedding_tokens(w, tokens, cfg)
-    logits = O.decoder_forward(w, x, cfg, sw)
+    if drop is not None and 0 in drop:
+        x = x * drop[0]
+    logits = O.decoder_forward(w, x, cfg, sw, drop=drop)
     return F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), tokens[:, 1:].reshape(-1))
 
 
-def mm_loss(w: dict, tokens: torch.Tensor, images: torch.Tensor, cfg: O.KosmosCfg, sw: O.Switches | None = None) -> torch.Tensor:
+def mm_loss(w: dict, tokens: torch.Tensor, images: torch.Tensor, cfg: O.KosmosCfg, sw: O.Switches | None = None,
+            drop: dict | None = None) -> torch.Tensor:
     """The same loss on the multimodal model (Kosmos.forward, /root/reference/kosmosx/model.py:208-253, with autograd on):
     the sequence is t0 t1 | image x L | t2 ...; position p predicts position p+1 wherever p+1 holds a TEXT token — the
     Tt-1 predicting positions per sample of lm_loss."""
@@ -38,7 +43,9 @@ def mm_loss(w: dict, tokens: torch.Tensor, images: torch.Tensor, cfg: O.KosmosCf
     mi = torch.cat([first[:, 0:2], img, first[:, 2:]], dim=1)
     T, L = mi.shape[1], img.shape[1]
     mi = 1.0 * mi + w["embed_positions.weight"][O.positions_for(T)][None]
-    logits = O.decoder_forward(w, mi, cfg.decoder, sw)
+    if drop is not None and 0 in drop:                     # the second forward_embedding returns [0]: after dropout_module
+        mi = mi * drop[0]                                  # (the first call's [1] is taken before it: no mask there)
+    logits = O.decoder_forward(w, mi, cfg.decoder, sw, drop=drop)
     seq = torch.full((tokens.shape[0], T), -100, dtype=torch.long)
     seq[:, :2] = tokens[:, :2]
     seq[:, 2 + L:] = tokens[:, 2:]

@@ -260,6 +260,81 @@ def test_zero_stage_3_single_rank_is_bitwise_the_replicated_step():
     assert abs(float(tb.step(tok)) - float(ta.step(tok))) == 0.0      # and the next step shards them again
 
 
+def test_dropout_ops_masks_are_a_function_of_seed_site_and_index():
+    """kx_dropout / kx_dropout_mask / attention dropout: Philox4x32-10 masks — the exported mask is the one the kernels
+    apply, the keep rate is 1 - p, another site or seed gives another mask, and the attention forward / backward with the
+    mask equal autograd through softmax * mask."""
+    from kosmosx import grad_ops as G, ops
+    x = torch.randn(4096 * 64, generator=torch.Generator().manual_seed(0)).to(DEV) + 3.0
+    keep = G.dropout_mask(x.numel(), 0.1, 1234, 7, DEV)
+    y = G.dropout(x, 0.1, 1234, 7)
+    assert torch.equal(y, torch.where(keep.bool(), x * (1.0 / (1.0 - 0.1)), torch.zeros_like(x)))
+    assert abs(float(keep.float().mean()) - 0.9) < 3e-3
+    assert not torch.equal(keep, G.dropout_mask(x.numel(), 0.1, 1234, 8, DEV))
+    assert not torch.equal(keep, G.dropout_mask(x.numel(), 0.1, 1235, 7, DEV))
+    assert torch.equal(keep[:1000], G.dropout_mask(1000, 0.1, 1234, 7, DEV))          # a function of the index, not of n
+    r = torch.randn_like(x)
+    assert torch.equal(G.dropout(x, 0.1, 1234, 7, residual=r), r + y)
+    # attention: B=2, H=3, T=70 (partial tiles), causal, p = 0.25
+    B, Hh, T, D = 2, 3, 70, 192
+    g = torch.Generator().manual_seed(1)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 0.5).to(DEV)
+    dout = torch.randn(B, T, D, generator=g).to(DEV)
+    q3, k3, v3 = (qkv[:, i * D:(i + 1) * D].unflatten(0, (B, T)).unflatten(2, (Hh, 64)) for i in range(3))
+    lse = torch.empty(B, Hh, T, device=DEV)
+    out = ops.attention(q3, k3, v3, True, out_dtype=torch.float32, lse_out=lse, dropout=(0.25, 99, 4))
+    mask = G.dropout_mask(B * Hh * T * T, 0.25, 99, 4, DEV).view(B, Hh, T, T).float().cpu() / 0.75
+    qr = qkv.detach().cpu().clone().requires_grad_()
+    qq, kk, vv = (qr[:, i * D:(i + 1) * D].view(B, T, Hh, 64).transpose(1, 2) for i in range(3))
+    sc = qq @ kk.transpose(-1, -2) + torch.triu(torch.full((T, T), float("-inf")), 1)
+    pr = torch.softmax(sc, -1)
+    ref = ((pr * mask) @ vv).transpose(1, 2).reshape(B, T, D)
+    assert float((out.cpu() - ref.detach()).abs().max()) < 2e-5
+    assert float((lse.cpu() - torch.logsumexp(sc, -1).detach()).abs().max()) < 2e-5
+    ref.backward(dout.cpu())
+    dqkv = G.attention_backward(qkv, out, dout, lse, B, T, Hh, True, dropout=(0.25, 99, 4))
+    assert float((dqkv.cpu() - qr.grad).abs().max() / qr.grad.pow(2).mean().sqrt()) < 1e-4
+
+
+@pytest.mark.parametrize("zero_stage", [1, 3])
+def test_train_mode_dropout_matches_autograd_with_the_same_masks(zero_stage):
+    """train_mode=True (the reference's model.train(): dropout = attention_dropout = 0.1): the loss, every gradient and the
+    parameters after two steps against autograd over the oracle given the masks the kernels draw (dropout_masks())."""
+    lm = _tiny_lm(seed=6)
+    cfg = O.DecoderCfg(layers=2, dim=256, ffn=512, heads=4, vocab=1002, max_pos=128)
+    w = _leaf_weights(lm)
+    opt = TO.make_optimizer(w, lr=1e-3)
+    tr = LanguageModelTrainer(lm.to(DEV), lr=1e-3, train_mode=True, dropout_seed=5, zero_stage=zero_stage)
+    g = torch.Generator().manual_seed(12)
+    seen = []
+    for step in range(2):
+        tok = torch.randint(2, 1002, (2, 30), generator=g)
+        drop = {k: v.cpu() for k, v in tr.dropout_masks(2, 30).items()}
+        assert set(drop) == {0, 1, 2, 3, 4, 5, 6}
+        seen.append(drop[2])
+        opt.zero_grad()
+        ref = TO.lm_loss(w, tok, cfg, drop=drop)
+        TO.backward(ref, w)
+        loss = tr.step(tok.to(DEV), apply_update=False)
+        assert abs(float(loss) - float(ref.detach())) < 2e-5 * abs(float(ref.detach())), (step, float(loss), float(ref.detach()))
+        if zero_stage == 1:
+            for name in dict(lm.named_parameters()):
+                if ".B." in name:
+                    continue
+                e = float((tr.grads[name].cpu() - w[name].grad).abs().max() / (w[name].grad.pow(2).mean().sqrt() + 1e-3))
+                assert e < 3e-4, (step, name, e)
+        torch.nn.utils.clip_grad_norm_(list(w.values()), 1.0)
+        opt.step()
+        tr._update()
+    assert not torch.equal(seen[0], seen[1])               # a new mask every step
+    tr.gather_parameters()
+    params = dict(lm.named_parameters())
+    for n in w:
+        if n in params:
+            d = params[n].detach().cpu() - w[n].detach()
+            assert float(d.pow(2).mean().sqrt() / w[n].detach().pow(2).mean().sqrt()) < 2e-5, n
+
+
 def test_trainer_argument_errors():
     lm = _tiny_lm().to(DEV)
     tr = LanguageModelTrainer(lm)

@@ -116,6 +116,29 @@ def test_zero_stage_3_multimodal_step_is_bitwise_the_replicated_step():
     assert all(torch.equal(pa[n], pb[n]) for n in pa)
 
 
+def test_multimodal_train_mode_dropout_matches_autograd_with_the_same_masks():
+    cfg = tiny_config()
+    m = Kosmos._from_config(cfg, seed=8, perturb=0.1).eval()
+    tok, img = _batch(cfg, 2, 9, 51)
+    w = _leaves(m)
+    tr = KosmosTrainer(m.to(DEV), train_mode=True, dropout_seed=3)
+    T = 9 + cfg.perceiver.latents
+    drop = {k: v.cpu() for k, v in tr.dropout_masks(2, T).items()}
+    ref = TO.mm_loss(w, tok, img, oracle_cfg(cfg), oracle_switches(m.switches), drop=drop)
+    TO.backward(ref, w)
+    loss = tr.step(tok.to(DEV), img.to(DEV), apply_update=False)
+    assert abs(float(loss) - float(ref.detach())) < 2e-5 * abs(float(ref.detach()))
+    worst = 0.0
+    for name in dict(m.named_parameters()):
+        if ".B." in name or w[name].grad is None:
+            continue
+        g, r = tr.grads[name].cpu(), w[name].grad.reshape(tr.grads[name].shape)
+        e = float((g - r).abs().max() / (r.pow(2).mean().sqrt() + 1e-3))
+        worst = max(worst, e)
+        assert e < 3e-4, (name, e)
+    print(f"multimodal train-mode step: worst gradient max|d|/rms = {worst:.2e}")
+
+
 def test_trainer_argument_errors():
     cfg = tiny_config()
     m = Kosmos._from_config(cfg, seed=6).eval().to(DEV)
