@@ -187,7 +187,7 @@ class LanguageModelTrainer:
 
     def dropout_masks(self, B, T):
         """Test hook: {site: keep / (1 - p) tensor} of the NEXT step() call for a [B, T] (spliced) sequence, in the shapes
-        oracle/kosmos_oracle.decoder_layer multiplies by."""
+        CPU autograd reference of the tests multiplies by."""
         a = self.model.decoder.args
         D, Hh, dev = a.decoder_embed_dim, a.decoder_attention_heads, self._nothing_dev()
         seed = ((self._dropout_seed & 0xFFFFFFFF) << 32) | (self._calls & 0xFFFFFFFF)
