@@ -479,8 +479,24 @@ def main():
             model.invalidate_packed()                 # drop this mode's operand copies (3-10 GB each)
         model.precision = args.precision
         parity_all = parity
+        # The yardstick for the fp32 tolerance (north star: 1e-5): the SAME oracle evaluated in float64.  Two fp32
+        # implementations of a 50-layer model differ by their summation orders; what each is away from the exact result
+        # says whether the HIP fp32 path is any further from the truth than the CPU fp32 path it is compared with.
+        with O.working_dtype(torch.float64):
+            ref64 = O.kosmos_forward({k: (v.double() if v.is_floating_point() else v) for k, v in cpu_weights.items()},
+                                     ctok, cimg.double(), ocfg)
+        rms64 = ref64.pow(2).mean().sqrt()
+        model.precision = "fp32"
+        with torch.no_grad():
+            got32 = model(tok, img)[:1].double().cpu()
+        model.invalidate_packed()
+        model.precision = args.precision
+        fp32_vs_64 = {"hip_fp32": float(f"{float((got32 - ref64).abs().max() / rms64):.3e}"),
+                      "cpu_fp32_oracle": float(f"{float((ref_logits.double() - ref64).abs().max() / rms64):.3e}"),
+                      "note": "max|d|/rms against the float64 evaluation of the same oracle (sample 0)"}
         cpu_baseline = {"value": round(n / t_cpu, 4), "unit": "samples/s", "cores": best_n,
                         "parity_max_abs_over_rms": {k: float(f"{v:.3e}") for k, v in parity.items()},
+                        "fp32_vs_float64": fp32_vs_64,
                         "host_threads_available": ncpu, "kind": "port",
                         "sample": f"{n} x (1 image + {Tt} tokens) forward, fp32 torch CPU oracle (oracle/kosmos_oracle.py), "
                                   f"batch 1, {t_cpu:.1f} s"}

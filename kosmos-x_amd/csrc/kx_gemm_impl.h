@@ -678,6 +678,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     offW[a] = A_BYTES + row * ROWB + ((g ^ (row & 7)) << 4);
   }
 
+  [[maybe_unused]] f32x4_t blk[std::is_same<T, float>::value ? FN : 1][std::is_same<T, float>::value ? FM : 1];
+  if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b) blk[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
   [[maybe_unused]] int wsc[FN];
   if constexpr (kIsF16c<T>) {
 #pragma unroll
@@ -713,6 +720,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
           for (int b = 0; b < FM; ++b) acc[a][b] = mma_fp8(fw0[a], fw1[a], fa0[b], fa1[b], acc[a][b], wsc[a]);
         continue;
       }
+    }
+    if constexpr (std::is_same<T, float>::value) {
+      // fp32 (the 1e-5 parity mode): BLOCKED summation.  One accumulator chained over all of K rounds K/4 times in a row
+      // (a 16x16x4 MFMA adds its four products exactly, then rounds once): measured 8e-7 (K = 2048) / 1.6e-6 (K = 8192)
+      // of the output rms against float64, 3-6x torch's CPU GEMM (2.7e-7, blocked by its vector lanes) — after 98
+      // GEMMs the decoder's logits sat 1.3e-5 from the exact result where the CPU path sits at 4e-6.  Four K-tiles
+      // (128 k = 32 MFMAs) go into a block accumulator that is then added to the running sum: error ~ eps * n^(1/4)
+      // instead of eps * sqrt(n / 2).
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4_t fa[FM], fw[FN];
+#pragma unroll
+        for (int b = 0; b < FM; ++b) fa[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ (ks << 6)));
+#pragma unroll
+        for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ (ks << 6)));
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < FM; ++b) blk[a][b] = Mma<T>::step(fw[a], fa[b], blk[a][b]);
+      }
+      if (((kt - kt0) & 3) == 3 || kt + 1 == nk) {
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < FM; ++b) { acc[a][b] += blk[a][b]; blk[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+      }
+      continue;
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {

@@ -118,6 +118,24 @@ class Switches:
 # --------------------------------------------------------------------------------------
 # small helpers
 # --------------------------------------------------------------------------------------
+# The dtype of the places where the reference casts explicitly (HF: pixel_values.to(weight dtype); torchscale / HF: softmax in
+# fp32; torchscale FFN: activation in fp32).  float32 = the reference.  `working_dtype(torch.float64)` together with float64
+# weights evaluates the SAME algorithm in double precision: the yardstick that separates an fp32 implementation's
+# summation-order noise from an algorithmic difference (bench.py cpu_baseline.fp32_vs_float64, tests/test_model_gpu.py).
+_WORK = [torch.float32]
+
+
+class working_dtype:
+    def __init__(self, dt):
+        self.dt = dt
+
+    def __enter__(self):
+        self.prev, _WORK[0] = _WORK[0], self.dt
+
+    def __exit__(self, *a):
+        _WORK[0] = self.prev
+
+
 def _r(x: torch.Tensor, sw: Switches) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32) if sw.emulate_bf16 else x
 
@@ -147,7 +165,7 @@ def vit_forward(w: dict, pixels: torch.Tensor, cfg: VitCfg, sw: Switches, prefix
     """[B,3,H,W] any real dtype -> last_hidden_state [B, tokens, dim] (no post_layernorm on the
     sequence: HF CLIPVisionTransformer.forward)."""
     p = prefix
-    x = pixels.to(torch.float32)  # HF: pixel_values.to(dtype=target_dtype)
+    x = pixels.to(_WORK[0])  # HF: pixel_values.to(dtype=target_dtype)
     B = x.shape[0]
     pw = w[p + "embeddings.patch_embedding.weight"]
     if sw.emulate_bf16:
@@ -171,7 +189,7 @@ def vit_forward(w: dict, pixels: torch.Tensor, cfg: VitCfg, sw: Switches, prefix
         k = k.view(B, S, cfg.heads, hd).transpose(1, 2)
         v = v.view(B, S, cfg.heads, hd).transpose(1, 2)
         a = (_r(q, sw) @ _r(k, sw).transpose(-1, -2)) * (hd ** -0.5)
-        a = F.softmax(a, dim=-1, dtype=torch.float32)
+        a = F.softmax(a, dim=-1, dtype=_WORK[0])
         o = (_r(a, sw) @ _r(v, sw)).transpose(1, 2).reshape(B, S, cfg.dim)
         o = linear(o, w[q_ + "self_attn.out_proj.weight"], w[q_ + "self_attn.out_proj.bias"], sw)
         h = r + o
@@ -297,9 +315,9 @@ def decoder_layer(w: dict, x: torch.Tensor, i: int, cfg: DecoderCfg, sw: Switche
         k = apply_xpos(k, kc, ks)
         q = apply_xpos(q, qc, qs)
     a = torch.bmm(_r(q, sw), _r(k, sw).transpose(1, 2))
-    mask = torch.triu(torch.zeros([T, T]).float().fill_(float("-inf")), 1)
+    mask = torch.triu(torch.zeros([T, T]).to(_WORK[0]).fill_(float("-inf")), 1)
     a = torch.nan_to_num(a) + mask[None]
-    a = F.softmax(a, dim=-1, dtype=torch.float32)
+    a = F.softmax(a, dim=-1, dtype=_WORK[0])
     if drop is not None and (1 + 3 * i) in drop:
         a = a * drop[1 + 3 * i]
     o = torch.bmm(_r(a, sw), _r(v, sw))
@@ -314,7 +332,7 @@ def decoder_layer(w: dict, x: torch.Tensor, i: int, cfg: DecoderCfg, sw: Switche
     y = layer_norm(x, w[p + f"final_layer_norm{mw}.weight"], w[p + f"final_layer_norm{mw}.bias"], cfg.eps)
     y = y.reshape(-1, D)
     y = linear(y, w[p + f"ffn{mw}.fc1.weight"], w[p + f"ffn{mw}.fc1.bias"], sw)
-    y = act_fn(y.float(), cfg.act)
+    y = act_fn(y.to(_WORK[0]), cfg.act)
     if cfg.subln:
         y = layer_norm(y, w[p + f"ffn{mw}.ffn_layernorm.weight"], w[p + f"ffn{mw}.ffn_layernorm.bias"], cfg.eps)
     y = linear(y, w[p + f"ffn{mw}.fc2.weight"], w[p + f"ffn{mw}.fc2.bias"], sw).view(B, T, D)
@@ -374,7 +392,7 @@ def decoder_incremental(w: dict, x: torch.Tensor, cfg: DecoderCfg, sw: Switches,
             a = torch.bmm(_r(q, sw), _r(k, sw).transpose(1, 2))
             if lo == 0:
                 a = torch.nan_to_num(a) + torch.triu(torch.zeros([n, n]).fill_(float("-inf")), 1)[None]
-            a = F.softmax(a, dim=-1, dtype=torch.float32)
+            a = F.softmax(a, dim=-1, dtype=_WORK[0])
             o = torch.bmm(_r(a, sw), _r(v, sw)).transpose(0, 1).reshape(n, B, D).transpose(0, 1)
             if cfg.subln:
                 o = layer_norm(o, w[p + f"self_attn.inner_attn_ln{mw}.weight"], w[p + f"self_attn.inner_attn_ln{mw}.bias"], cfg.eps)
