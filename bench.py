@@ -417,6 +417,41 @@ def main():
             c3 = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
 
+    # ---- incremental decoding, one token per step against the KV cache (B = 1, bf16): streams the decoder's
+    # live bf16 weights once per token ----
+    decode = None
+    if rank == 0 and world == 1 and not force_dist and not args.no_extra:
+        try:
+            from kosmosx.model import KosmosLanguage
+            d = cfg.decoder
+            lm = KosmosLanguage(vocab_size=cfg.vocab, dim=d.decoder_embed_dim, _seed=0).eval().to(dev)
+            lm.precision = "bf16"
+            prefix, nstep = 114, 48
+            dtok = torch.randint(0, cfg.vocab, (1, prefix + nstep + 8), generator=torch.Generator().manual_seed(0)).to(dev)
+            with torch.no_grad():
+                for rep in range(2):                          # rep 0 = warm-up
+                    state = {"max_len": 512}
+                    lm(dtok[:, :prefix], incremental_state=state)
+                    for t in range(prefix, prefix + 4):
+                        lm(dtok[:, :t + 1], incremental_state=state)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for t in range(prefix + 4, prefix + 4 + nstep):
+                        lm(dtok[:, :t + 1], incremental_state=state)
+                    torch.cuda.synchronize()
+                    dts = (time.perf_counter() - t1) / nstep
+            L, D, F, V = d.decoder_layers, d.decoder_embed_dim, d.decoder_ffn_embed_dim, cfg.vocab
+            wb = 2.0 * (L * (4 * D * D + 2 * D * F) + D * V) + 2.0 * L * (prefix + 4 + nstep / 2) * D * 2
+            decode = {"workload": f"KosmosLanguage decode step, batch 1, context {prefix + 4}..{prefix + 4 + nstep} tokens, bf16",
+                      "ms_per_token": round(dts * 1e3, 3), "tokens_per_s": round(1.0 / dts, 1),
+                      "roofline": {"bound": "hbm", "achieved": round(wb / dts / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(wb / dts / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": wb,
+                                   "note": "decoder weights + KV cache streamed once per token"}}
+            del lm, state
+            torch.cuda.empty_cache()
+        except Exception as e:
+            decode = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- BASELINE.json configs[1]: batch 1 (one 224x224 image + 50 tokens), one request at a time: weight-streaming bound ----
     batch1 = None
     if rank == 0 and world == 1 and not force_dist and not args.no_extra:
@@ -526,7 +561,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "precision_modes": modes_block(args.precision, round(total / elapsed, 3), elapsed / args.steps, other_modes,
                                            parity_all, fl["total"], B),
-            "c3": c3, "batch1": batch1, "training_step": training,
+            "c3": c3, "batch1": batch1, "decode": decode, "training_step": training,
             "kernel_breakdown": breakdown,
             "gemm_shapes": gemm_shapes,
             "build_seconds": round(t_build, 1),

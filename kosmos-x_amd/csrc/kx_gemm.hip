@@ -17,11 +17,16 @@
 
 
 // K slices for a 64x64-tile launch: ~512 workgroups streaming the weights, at most 16 slices, at least two K-tiles per
-// slice, partials [slices, M, N] fp32 within the scratch.  `forced` > 0 overrides the count (tests).
-static long long splitk_slices(int64_t M, int64_t N, int64_t K, int bk, size_t ws_bytes, int forced) {
+// slice, partials [slices, M, N] fp32 within the scratch.  `forced` > 0 overrides the count (tests), < 0 is a minimum.
+static long long splitk_slices(int64_t M, int64_t N, int64_t K, int bk, size_t ws_bytes, int forced, bool f16c_rows = false) {
   const long long tiles = ((M + 63) / 64) * ((N + 63) / 64);
   const long long nk_all = K / bk;
-  long long sp = forced > 0 ? forced : (tiles >= 384 ? 1 : (512 + tiles - 1) / tiles);
+  // the ring kernel keeps 64 KB of LDS per workgroup = two workgroups per CU = 512 resident: never more slices than fit in
+  // ONE round (a 640-workgroup grid ran 1.25 rounds = twice the time); A/B: tuning key 4 = 6 restores the r1 rule
+  // (KX_F16C rows keep the r1 rule and the two-stage kernel: twice the K-tiles per slice, measured 7 % slower on the ring)
+  const bool ring = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 6 && !f16c_rows;
+  long long sp = forced > 0 ? forced : ring ? (tiles >= 256 ? 1 : 512 / tiles) : (tiles >= 384 ? 1 : (512 + tiles - 1) / tiles);
+  if (forced < 0 && sp < -forced) sp = -forced;   // callers whose epilogue lives in the reduce kernel (statistics producer)
   if (sp > 16) sp = 16;
   if (sp > nk_all / 2) sp = nk_all / 2;
   while (sp > 1 && (size_t)sp * M * N * 4 > ws_bytes) --sp;
@@ -35,7 +40,7 @@ static long long splitk_slices(int64_t M, int64_t N, int64_t K, int bk, size_t w
 int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_bytes) {
   auto cdiv = [](long long x, long long y) { return (x + y - 1) / y; };
   if (!ws_bytes || cdiv(M, 128) * cdiv(N, 128) >= 192) return 1;       // the automatic tile choice is not 64x64
-  if (prec == KX_PREC_F16C) return (int)splitk_slices(M, N, 2 * K, 64, ws_bytes, 0);   // 4K-byte rows = 2K 2-byte units
+  if (prec == KX_PREC_F16C) return (int)splitk_slices(M, N, 2 * K, 64, ws_bytes, 0, true);   // 4K-byte rows = 2K 2-byte units
   return (int)splitk_slices(M, N, K, (prec == KX_PREC_BF16 || prec == KX_PREC_F16) ? 64 : 32, ws_bytes, 0);
 }
 
@@ -129,6 +134,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     p.lean_xpos = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) == 3 && a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && p.vec8_ok &&
                   a->xpos_dim > 0 && !a->residual && !a->row_stats && !a->stats_out && a->act == KX_ACT_NONE &&
                   a->qcols % 256 == 0 && a->xpos_dim % 256 == 0;
+    p.ring = mode != 6 && !f16c;
     // A/B: tuning key 4 = 4 keeps the A&S erf in the lean epilogues
     p.gelu_poly = mode != 4 && a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && a->act == KX_ACT_GELU;
     p.fast_epilogue = mode == 2 || (mode != 1 && (a->residual || a->row_stats || a->xpos_dim > 0));
@@ -182,7 +188,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   // 64-column segments) — when the call will not actually be split, take 128x128 instead (its waves own 64 columns).
   if (tile == 64 && a->ln_operand_out) tile = 128;        // the producer lives in the 64-column store loops
   if (tile == 64 && a->stats_out &&
-      !(a->splitk_ws && splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk) > 1))
+      !(a->splitk_ws && splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk ? a->splitk : (a->stats_out && !f16c ? -2 : 0), f16c) > 1))
     tile = 128;
   if (tile == 16) {
     KX_REQUIRE(a->prec == KX_PREC_BF16 && a->M <= 16, "kx_gemm: tile 16 (weight streaming) is bf16, M <= 16 only");
@@ -211,7 +217,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     // Skinny problems (batch-1 shapes: M = 114 / 257 / 64) are weight-streaming bound and a 64x64 grid of N/64 x 2
     // workgroups leaves most CUs idle while each one walks all of K serially.  Slice K so that ~512 workgroups
     // stream the weights concurrently; partials are small ([splits][M][N] fp32, L2/MALL resident).
-    const long long sp = splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk);
+    const long long sp = splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk ? a->splitk : (a->stats_out && !f16c ? -2 : 0), f16c);
     if (sp > 1) {
       p.splitk = (int)sp;
       p.partial = (float*)a->splitk_ws;

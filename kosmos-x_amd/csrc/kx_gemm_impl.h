@@ -41,6 +41,7 @@ struct GemmParams {
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
   int lean_epilogue;    // 256-column kernel: accumulator-level epilogue + pure data movement (see lean_store_*)
   int lean_xpos;        // 256-column kernel, bf16 output: q-scale + XPos at accumulator level too (lean_bias_qscale_xpos)
+  int ring;             // 64x64 launches: 4-stage LDS ring, three K-tiles in flight (A/B: tuning key 4 = 6 turns it off)
   int gelu_poly;        // 256-column kernel, lean epilogues: KX_ACT_GELU_FAST may run as KX_ACT_GELU_POLY (plain bf16 in / out)
   int persistent;       // 256x256 kernel: > 0 = launch this many workgroups, each walking its tiles itself
   int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
@@ -599,14 +600,19 @@ __device__ __forceinline__ void lean_store_bf16(const GemmParams& p, const f32x4
   }
 }
 
-template <typename T, int BM, int BN, int ACT, int EPI = 0>   // EPI 1: lean bf16 epilogue (see above)
+// NST = LDS stages.  2: tile kt+1 is requested when tile kt's multiplication starts (the large-M kernels: MFMA time per
+// tile covers the latency).  4 (the skinny 64x64 launches): a ring with THREE K-tiles in flight and a counted s_waitcnt —
+// a 64x64x64 tile is 16 MFMAs per wave, so with one tile in flight every K-tile costs a full memory latency (measured
+// ~1.5 us per K-tile on the batch-1 shapes: 12 us for the 8 K-tiles of a ViT fc1 slice).
+template <typename T, int BM, int BN, int ACT, int EPI = 0, int NST = 2>   // EPI 1: lean bf16 epilogue (see above)
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int ROWB = 128;                 // bytes per staged tile row = one BK slice
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
   constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave (2x2 waves)
   constexpr int IA = BM / 32, IW = BN / 32;  // glds instructions per wave per stage (8 rows each)
   constexpr int EPI_BYTES = BM * BN * 4;     // the epilogue parks the whole fp32 tile in LDS
-  constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  constexpr int SMEM = NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES;
+  static_assert(NST == 2 || (NST == 4 && IA + IW == 4), "the counted waits below assume 4 DMA instructions per tile");
   static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU must fit the 160 KB LDS");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
@@ -694,13 +700,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int kchunk = (nk_all + p.splitk - 1) / p.splitk;
   const int kt0 = (int)blockIdx.y * kchunk;
   const int nk = min(nk_all, kt0 + kchunk);   // this block multiplies K-tiles [kt0, nk)
-  if (kt0 < nk) stage(kt0 & 1, kt0);
+  if constexpr (NST == 2) {
+    if (kt0 < nk) stage(kt0 & 1, kt0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NST - 1; ++j)
+      if (kt0 + j < nk) stage(j, kt0 + j);
+  }
   for (int kt = kt0; kt < nk; ++kt) {
-    // stage kt has landed (this wave's DMA) and every wave is done reading the other buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* base = smem + (kt & 1) * STAGE;
+    // stage kt has landed (this wave's DMA) and every wave is done reading the buffer that is refilled next
+    if constexpr (NST == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    } else {
+      const int ahead = nk - 1 - kt;                       // tiles requested after kt that may still be in flight
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // a RAW barrier: __syncthreads() carries a fence that drains vmcnt to 0 — the DMA of the next tiles would be waited for
+      // at every K-tile and the ring would be a two-stage pipeline again.  Every wave has consumed its fragments of tile
+      // kt-1 (its MFMAs waited for them) before it arrives here, so the slot refilled below is free.
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + NST - 1 < nk) stage((kt - kt0 + NST - 1) % NST, kt + NST - 1);
+    }
+    const char* base = smem + (NST == 2 ? (kt & 1) : ((kt - kt0) % NST)) * STAGE;
     if constexpr (kIsF16c<T>) {
       if (kt >= p.nk_main) {   // fp8 correction tile: one scaled MFMA per fragment pair over the whole 128-byte row
         u32x4_t fa0[FM], fa1[FM], fw0[FN], fw1[FN];
@@ -852,6 +878,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
   };
   GemmParams q = p;
   q.splitk = 1;
+  // The K-slice partials first: their loads depend on nothing, so they are in flight while the row statistics below go
+  // through their two block reductions (the kernel is a chain of dependent round trips: 12 us per launch at 114 rows).
+  // Slices are summed in slice order (deterministic), four loads in flight per 16-byte column group.
+  f32x4_t accs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = 4 * (tid + 256 * j);
+    accs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) {
+      const float* src = p.partial + (long long)m * p.N + n;
+      const long long zs = (long long)p.M * p.N;
+      int z = 0;
+      for (; z + 4 <= p.splitk; z += 4) {
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src + (z + 0) * zs), v1 = *reinterpret_cast<const f32x4_t*>(src + (z + 1) * zs);
+        const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(src + (z + 2) * zs), v3 = *reinterpret_cast<const f32x4_t*>(src + (z + 3) * zs);
+        accs[j] += v0; accs[j] += v1; accs[j] += v2; accs[j] += v3;
+      }
+      for (; z < p.splitk; ++z) accs[j] += *reinterpret_cast<const f32x4_t*>(src + z * zs);
+    }
+  }
   if (p.stats_partials) {
     const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
     float sm = 0.f;
@@ -875,9 +921,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
     const int n = 4 * (tid + 256 * j);
     x[j][0] = x[j][1] = x[j][2] = x[j][3] = 0.f;
     if (n < p.N) {
-      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      for (int z = 0; z < p.splitk; ++z)
-        acc += *reinterpret_cast<const f32x4_t*>(p.partial + ((long long)z * p.M + m) * p.N + n);
+      f32x4_t acc = accs[j];
       if (p.stats_partials) {                          // rstd * (acc - mean * colsum): first step of the epilogue
         const float4 c = *reinterpret_cast<const float4*>(p.colsum + n);
         const float mu = st[0], rs = st[1];
@@ -1790,7 +1834,12 @@ int launch(GemmParams& p, hipStream_t s) {
   const dim3 grid(p.tiles_m * p.tiles_n, p.splitk), block(256);
   if (p.splitk > 1) {
     // skinny problem: the tile kernels only produce partials (activation-free), the reduce kernel owns the epilogue
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p);
+    if constexpr (BM == 64 && BN == 64) {
+      if (p.ring) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE, 0, 4>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p);
+    } else {
+      hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p);
+    }
     KX_CHECK_LAUNCH("kx_gemm(split-K)");
     return launch_splitk_reduce(p, s);
   }
@@ -1799,6 +1848,19 @@ int launch(GemmParams& p, hipStream_t s) {
       if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
       if (p.act == KX_ACT_QUICK_GELU) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
       if (p.act == KX_ACT_GELU_FAST) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU_FAST, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
+    }
+  }
+  if constexpr (BM == 64 && BN == 64) {
+    if (p.ring) {
+      switch (p.act) {
+        case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE, 0, 4>), grid, block, 0, s, p); break;
+        case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU, 0, 4>), grid, block, 0, s, p); break;
+        case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU_FAST, 0, 4>), grid, block, 0, s, p); break;
+        case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU, 0, 4>), grid, block, 0, s, p); break;
+        default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+      }
+      KX_CHECK_LAUNCH("kx_gemm");
+      return KX_OK;
     }
   }
   // the activation is a compile-time property of the kernel: a runtime switch costs ~4 scalar branches per value

@@ -14,12 +14,15 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--prefix", type=int, default=114)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--max-len", type=int, default=512)
+ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "f16c", "mixed"],
+                help="bf16 streams the weights through the tile-16 kernels; the f16c / fp32 paths run the generic per-op step")
 ap.add_argument("--tune", default="", help="A/B: kx_set_tuning key=value pairs, e.g. 1=64 (tile kernels instead of tile 16)")
 a = ap.parse_args()
 for kv in filter(None, a.tune.split(",")):
     _hip.load().kx_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 dev = torch.device("cuda", 0)
 m = KosmosLanguage(vocab_size=32002, dim=2048, _seed=0).eval().to(dev)
+m.precision = a.precision
 tok = torch.randint(0, 32002, (a.batch, a.prefix + a.steps + 8), generator=torch.Generator().manual_seed(0)).to(dev)
 with torch.no_grad():
     for rep in range(2):                                    # rep 0 = warm-up
@@ -46,7 +49,7 @@ kvbytes = 2 * L * a.batch * tavg * d * 2
 agg = {}
 for kind, x, y, z, ms in recs:
     e = agg.setdefault(kind, [0, 0.0]); e[0] += 1; e[1] += ms
-print(json.dumps({"workload": f"KosmosLanguage decode step, B={a.batch}, context ~{int(tavg)} tokens, bf16",
+print(json.dumps({"workload": f"KosmosLanguage decode step, B={a.batch}, context ~{int(tavg)} tokens, {a.precision}",
                   "ms_per_token_step": round(dt * 1e3, 3), "host_issue_ms": round(host_dt * 1e3, 3), "tokens_per_s": round(a.batch / dt, 1),
                   "bytes_per_step_GB": round((wbytes + kvbytes) / 1e9, 3),
                   "achieved_GBs": round((wbytes + kvbytes) / dt / 1e9, 1),
