@@ -74,7 +74,7 @@ _PMC_KEYS = {"gemm_bf16_160x128": "gemm_kernel<{T},160,128", "gemm_bf16_128x128"
              "gemm_bf16_64x64": "gemm_kernel<{T},64,64", "gemm_bf16_256x128_phased": "gemm_kernel_p3<{T}",
              "gemm_bf16_256x256_phased": "gemm_kernel_p5<{T}", "attn_bf16": "attn_"}
 _PMC_FILES = {"bf16": ("profiles/r01_v_pmc.json", "bf16", "profiles/r01_v_pmc_summary.md"),
-              "mixed": ("profiles/r02_a_pmc.json", "f16c_t", "profiles/r02_a_pmc_summary.md")}
+              "mixed": ("profiles/r02_b_pmc.json", "f16c_t", "profiles/r02_b_pmc_summary.md")}
 
 
 def pmc_traffic(kernel, args):

@@ -154,7 +154,9 @@ def test_full_size_gradient_families_match_autograd():
         g, r = tr.grads[name].cpu(), w[name].grad
         if name == "embed.weight":                        # sparse: the rows of the batch's tokens (the rest is exactly zero)
             rows = tok.unique()
-            assert float(g.abs().sum()) == float(g[rows].abs().sum())
+            other = g.clone()
+            other[rows] = 0
+            assert float(other.abs().max()) == 0.0
             g, r = g[rows], r[rows]
         elif name == "embed_positions.weight":
             g, r = g[2:26], r[2:26]
