@@ -345,7 +345,8 @@ def main():
                                        f"measured with {P} steps in flight on {P} streams",
                         **({"note": "f16c kernels (Perceiver, decoder; every kernel in --precision f16c) issue one fp16 MFMA "
                             "pass plus two fp8 correction passes at twice the rate = 2x the bf16 MFMA time per ALGORITHMIC "
-                            "flop, which is what `achieved` counts; the CLIP tower's kernels in mixed mode are plain fp16 (1x)"}
+                            "flop, which is what `achieved` counts; the CLIP tower's kernels in mixed mode are plain fp16 (1x)",
+                            "matrix_pipe_frac": round(2.0 * ach / peak, 4)}   # MFMA issue time of this kernel / its peak issue rate
                            if args.precision in ("f16c", "mixed") else {}),
                         "launches_per_step": e["launches"], "avg_launch_ms": round(e["ms"] / e["launches"], 5),
                         "algorithmic_flops_per_step": e["flops"]}
