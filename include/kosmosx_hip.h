@@ -163,6 +163,10 @@ typedef struct {
    * gamma-folded weights, `colsum` and bias' = W·beta + b — torchscale's self_attn_layer_norm / final_layer_norm /
    * decoder.layer_norm and CLIP's layer_norm1/2 then cost no pass over the residual stream. */
   void* ln_operand_out; int32_t ln_operand_dt; float* ln_operand_stats;
+  /* tile 16 (weight streaming) only: W is stored [ceil(N/16)][K/32][64][8] bf16 — block (p, c) holds rows 16p..16p+15,
+   * columns 32c..32c+31 as 64 pieces of 16 bytes, piece l = row 16p + (l & 15), columns 32c + 8(l >> 4) .. +7 (the MFMA
+   * fragment a lane loads), rows past N zero.  K % 32 == 0; ldw is ignored. */
+  int32_t w_tiled;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 
@@ -304,6 +308,10 @@ typedef struct {
   /* Optional (all NULL = off): self_attn_layer_norm folded into qkv, final_layer_norm into fc1 (same packing rule) */
   const void* wqkv_f; const float* bqkv_f; const float* wqkv_colsum;
   const void* w1_f;   const float* b1_f;   const float* w1_colsum;
+  /* Optional (NULL = off), bf16 decode step only: wqkv / wo / w1 / w2 once more in the STREAMING layout of
+   * kx_gemm_args.w_tiled — the weight-streaming kernels then read one contiguous 1 KB block per wave instruction instead of
+   * 16 row segments of 64 B (4.2-5.0 vs 3.2-3.7 TB/s, profiles/r02_gemv_stream_probe.log). */
+  const void *wqkv_t, *wo_t, *w1_t, *w2_t;
 } kx_decoder_layer;
 
 typedef struct {
@@ -313,6 +321,7 @@ typedef struct {
   const void* wout;                           /* output_projection.weight [vocab, dim] */
   /* Optional: decoder.layer_norm folded into the output projection (bout_f = Wout·beta, [vocab]) */
   const void* wout_f; const float* bout_f; const float* wout_colsum;
+  const void* wout_t;                         /* optional: wout in the streaming layout (vocab padded to a multiple of 16 rows) */
 } kx_decoder_weights;
 
 /* Decoder.forward(x, passed_x=x)[0] (/root/reference/kosmosx/model.py:250, :320; torchscale

@@ -193,11 +193,13 @@ struct Gemv16 {
   const float *ln_g = nullptr, *ln_b = nullptr; float eps = 0.f;
   const float* partials_in = nullptr; int64_t nseg_in = 0, seg_in = 0; const float* colsum = nullptr;
   float* stats_out = nullptr;
+  const void* W_tiled = nullptr;          // the same matrix in the streaming layout (kx_gemm_args.w_tiled), or null
 };
 int gemv16(const Gemv16& v, hipStream_t s) {
   kx_gemm_args g;
   memset(&g, 0, sizeof(g));
-  g.A = v.A; g.lda = v.lda; g.W = v.W; g.ldw = v.K; g.C = v.C; g.ldc = v.ldc; g.cdt = v.cdt;
+  g.A = v.A; g.lda = v.lda; g.W = v.W_tiled ? v.W_tiled : v.W; g.w_tiled = v.W_tiled != nullptr; g.ldw = v.K;
+  g.C = v.C; g.ldc = v.ldc; g.cdt = v.cdt;
   g.bias = v.bias; g.residual = v.residual; g.ldr = v.ldc; g.M = v.M; g.N = v.N; g.K = v.K;
   g.act = v.act; g.qscale = v.qscale; g.qcols = v.qcols;
   g.xq_cs = v.xq_cs; g.xq_ss = v.xq_ss; g.xk_cs = v.xk_cs; g.xk_ss = v.xk_ss; g.xpos_T = v.xT; g.xpos_dim = v.xdim;
@@ -577,24 +579,29 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
       Gemv16 q{x, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D};
       q.bias = L.bqkv; q.qscale = 0.125f; q.qcols = D; q.ln_g = L.sa_g; q.ln_b = L.sa_b; q.eps = w->eps;
       if (w->xpos) { q.xq_cs = xq_cs; q.xq_ss = xq_ss; q.xk_cs = xk_cs; q.xk_ss = xk_ss; q.xT = 1; q.xdim = D; }
+      q.W_tiled = L.wqkv_t;
       KX_TRY(gemv16(q, s));
       KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, ct,
                                  w->subln ? d.partials : nullptr, B, w->heads, t, Tmax, prec, stream));
       Gemv16 o{d.att, D, L.wo, D, x, D, KX_F32, M, D};
       o.bias = L.bo; o.residual = x; o.eps = w->eps;
       if (w->subln) { o.partials_in = d.partials; o.nseg_in = w->heads; o.seg_in = 64; o.colsum = L.wo_colsum; }
+      o.W_tiled = L.wo_t;
       KX_TRY(gemv16(o, s));
       Gemv16 f1{x, D, L.w1, D, d.g, F, ct, M, F};
       f1.bias = L.b1; f1.act = w->act; f1.ln_g = L.fl_g; f1.ln_b = L.fl_b; f1.eps = w->eps;
       if (w->subln) f1.stats_out = d.partials;
+      f1.W_tiled = L.w1_t;
       KX_TRY(gemv16(f1, s));
       Gemv16 f2{d.g, F, L.w2, F, x, D, KX_F32, M, D};
       f2.bias = L.b2; f2.residual = x; f2.eps = w->eps;
       if (w->subln) { f2.partials_in = d.partials; f2.nseg_in = F / 16; f2.seg_in = 16; f2.colsum = L.w2_colsum; }
+      f2.W_tiled = L.w2_t;
       KX_TRY(gemv16(f2, s));
     }
     Gemv16 lo{x, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab};
     lo.ln_g = w->ln_g; lo.ln_b = w->ln_b; lo.eps = w->eps;
+    lo.W_tiled = w->wout_t;
     return gemv16(lo, s);
   }
   for (int i = 0; i < w->layers; ++i) {

@@ -109,7 +109,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
                   ((uintptr_t)a->ln_operand_out & 15) == 0 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1),
              "kx_gemm: ln_operand_out needs an fp32 output with residual, N %% 64 == 0, aligned rows, a 2-byte / KX_F16C "
              "operand dtype and the prefetching store loop");
-  p.stagger_ticks = 0;
+  p.stagger_ticks = 0; p.w_tiled = 0;
   p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
   p.stats_partials = nullptr; p.stats_in_nseg = 0; p.stats_in_seg = p.stats_eps = 0.f;
   p.ln_out = nullptr; p.ln_out_dt = 0; p.ln_out_g = p.ln_out_b = nullptr; p.ln_out_eps = 0.f;
@@ -192,6 +192,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     tile = 128;
   if (tile == 16) {
     KX_REQUIRE(a->prec == KX_PREC_BF16 && a->M <= 16, "kx_gemm: tile 16 (weight streaming) is bf16, M <= 16 only");
+    KX_REQUIRE(!a->w_tiled || a->K % 32 == 0, "kx_gemm: the streaming weight layout needs K %% 32 == 0");
+    p.w_tiled = a->w_tiled != 0;
     KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * 2 + 16) <= 128 * 1024 && a->K % 4 == 0),
                "kx_gemm: LayerNorm prologue needs beta and M*(2K+16) <= 128 KB");
     KX_REQUIRE(!a->stats_partials || (a->colsum && !a->row_stats && a->stats_in_nseg > 0 && a->stats_in_seg > 0),

@@ -41,6 +41,7 @@ struct GemmParams {
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
   int lean_epilogue;    // 256-column kernel: accumulator-level epilogue + pure data movement (see lean_store_*)
   int lean_xpos;        // 256-column kernel, bf16 output: q-scale + XPos at accumulator level too (lean_bias_qscale_xpos)
+  int w_tiled;          // tile 16: W in the streaming layout [N/16][K/32][1 KB] (kx_gemm_args.w_tiled)
   int ring;             // 64x64 launches: 4-stage LDS ring, three K-tiles in flight (A/B: tuning key 4 = 6 turns it off)
   int gelu_poly;        // 256-column kernel, lean epilogues: KX_ACT_GELU_FAST may run as KX_ACT_GELU_POLY (plain bf16 in / out)
   int persistent;       // 256x256 kernel: > 0 = launch this many workgroups, each walking its tiles itself
@@ -1699,11 +1700,16 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel(const GemmParams p, in
   const int n0 = blockIdx.x * 16;
   const int k0 = wave * kw, klen = min(kw, p.K - k0);           // may be <= 0 for trailing waves of a short K
   const int nrow = min(n0 + i, p.N - 1);                         // columns past N re-read the last row; never stored
-  const char* wp = p.W + (long long)nrow * p.ldw_b + ((long long)(k0 + 8 * g) << 1);
+  // streaming layout: a wave instruction reads ONE contiguous 1 KB block (lane l = piece l); row-major: 16 rows x 64 B
+  const char* wp = p.w_tiled ? p.W + (((long long)blockIdx.x * (p.K >> 5) + (k0 >> 5)) << 10) + (lane << 4)
+                             : p.W + (long long)nrow * p.ldw_b + ((long long)(k0 + 8 * g) << 1);
+  const int wstep = p.w_tiled ? 1024 : 64;                       // bytes from one 32-column k-step to the next
+  // (non-temporal loads on this stream: no difference in situ, 1.527 vs 1.532 ms per token)
+  auto ldw = [&](const char* q) { return *reinterpret_cast<const u32x4_t*>(q); };
   u32x4_t wf[U];
 #pragma unroll
   for (int u = 0; u < U; ++u)
-    if (32 * u < klen) wf[u] = *reinterpret_cast<const u32x4_t*>(wp + ((32 * u) << 1));
+    if (32 * u < klen) wf[u] = ldw(wp + u * wstep);
   if (p.stats_partials) {
     for (int m = wave; m < p.M; m += S) {
       const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
@@ -1758,7 +1764,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel(const GemmParams p, in
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (kk + 32 * u < klen) {
-        if (kk > 0) wf[u] = *reinterpret_cast<const u32x4_t*>(wp + ((kk + 32 * u) << 1));   // first batch: in flight
+        if (kk > 0) wf[u] = ldw(wp + ((kk >> 5) + u) * wstep);   // first batch: in flight
         xf[u] = *reinterpret_cast<const u32x4_t*>(xg + ((kk + 32 * u) << 1));
       }
 #pragma unroll

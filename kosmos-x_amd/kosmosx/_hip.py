@@ -46,7 +46,8 @@ class GemmArgs(C.Structure):
                 ("stats_partials", vp), ("stats_in_nseg", i64), ("stats_in_seg", i64), ("stats_eps", f32),
                 ("stats_out_seg", i32),
                 ("ln_out", vp), ("ln_out_dt", i32), ("ln_out_gamma", vp), ("ln_out_beta", vp), ("ln_out_eps", f32),
-                ("w_scale", vp), ("ln_operand_out", vp), ("ln_operand_dt", i32), ("ln_operand_stats", vp)]
+                ("w_scale", vp), ("ln_operand_out", vp), ("ln_operand_dt", i32), ("ln_operand_stats", vp),
+                ("w_tiled", i32)]
 
 
 class AttnArgs(C.Structure):
@@ -82,13 +83,14 @@ class PerceiverWeights(C.Structure):
 class DecoderLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("sa_g", "sa_b", "wqkv", "bqkv", "wo", "bo", "wo_colsum", "fl_g", "fl_b",
                                   "w1", "b1", "w2", "b2", "w2_colsum", "wqkv_f", "bqkv_f", "wqkv_colsum",
-                                  "w1_f", "b1_f", "w1_colsum")]
+                                  "w1_f", "b1_f", "w1_colsum", "wqkv_t", "wo_t", "w1_t", "w2_t")]
 
 
 class DecoderWeights(C.Structure):
     _fields_ = [("layers", i32), ("dim", i32), ("heads", i32), ("ffn", i32), ("vocab", i32), ("act", i32),
                 ("subln", i32), ("xpos", i32), ("eps", f32), ("layer", C.POINTER(DecoderLayer)),
-                ("ln_g", vp), ("ln_b", vp), ("wout", vp), ("wout_f", vp), ("bout_f", vp), ("wout_colsum", vp)]
+                ("ln_g", vp), ("ln_b", vp), ("wout", vp), ("wout_f", vp), ("bout_f", vp), ("wout_colsum", vp),
+                ("wout_t", vp)]
 
 
 class ProfRecord(C.Structure):

@@ -151,11 +151,13 @@ class _PackedMixin:
     ``invalidate_packed()`` after mutating parameters in place."""
 
     def _packed_init(self):
+        self._stream_src = {}
         self._packed = {}
         self._pack_gen = 0      # bumped on every invalidation: captured hipGraphs (raw pointers into `_packed`) check it
 
     def _drop_packed(self):
         self._packed = {}
+        self._stream_src = {}
         self._pack_gen = getattr(self, "_pack_gen", 0) + 1
 
     def invalidate_packed(self):
@@ -580,6 +582,8 @@ class Decoder(_PackedMixin, nn.Module):
         def v(t):
             t = _f32(t); keep.append(t); return t.data_ptr()
 
+        stream_src = []     # (layer index or -1, field, packed operand): what _pack_decode_tiles re-tiles for the decode step
+
         def fold(ln, lin):
             """Fold a sub-LayerNorm into the Linear that consumes it (see kx_decoder_layer in the header):
             W' = γ ⊙ W cast to the operand dtype, b' = W·β + b, colsum = Σ_k W'[n,k] of the cast values."""
@@ -589,6 +593,10 @@ class Decoder(_PackedMixin, nn.Module):
             keep.append(wp)
             return wp.data_ptr(), v(wf @ b_ + lin.bias.detach().float()), v(_operand_colsum(wp, prec, shp))
 
+        def src(i, field, ptr):   # remember the packed operand behind `ptr` (bf16 only: the decode step's precision)
+            if prec == "bf16":
+                stream_src.append((i, field, next(t for t in reversed(keep) if t.data_ptr() == ptr)))
+
         layers = (H.DecoderLayer * self.num_layers)()
         for i, L in enumerate(self.layers):
             sa, ffn = L.self_attn, _a(L.ffn)
@@ -596,6 +604,7 @@ class Decoder(_PackedMixin, nn.Module):
             e = layers[i]
             e.sa_g, e.sa_b = v(_a(L.self_attn_layer_norm).weight), v(_a(L.self_attn_layer_norm).bias)
             e.wqkv = op(torch.cat([q.weight, k.weight, vv.weight], 0))
+            src(i, "wqkv_t", e.wqkv)
             e.bqkv = v(torch.cat([q.bias, k.bias, vv.bias], 0))
             if a.subln:
                 e.wo, e.bo, e.wo_colsum = fold(_a(sa.inner_attn_ln), o)
@@ -605,6 +614,7 @@ class Decoder(_PackedMixin, nn.Module):
                 e.w2, e.b2 = op(ffn.fc2.weight), v(ffn.fc2.bias)
             e.fl_g, e.fl_b = v(_a(L.final_layer_norm).weight), v(_a(L.final_layer_norm).bias)
             e.w1, e.b1 = op(ffn.fc1.weight), v(ffn.fc1.bias)
+            src(i, "wo_t", e.wo); src(i, "w2_t", e.w2); src(i, "w1_t", e.w1)
             if prec in FOLD_PRECS and _fold_pre_ln():      # self_attn_layer_norm -> qkv, final_layer_norm -> fc1
                 sl, fl = _a(L.self_attn_layer_norm), _a(L.final_layer_norm)
                 t3 = _fold_ln_linear(sl.weight, sl.bias, torch.cat([q.weight, k.weight, vv.weight], 0),
@@ -621,6 +631,7 @@ class Decoder(_PackedMixin, nn.Module):
         w.layer = C.cast(layers, C.POINTER(H.DecoderLayer))
         w.ln_g, w.ln_b = v(self.layer_norm.weight), v(self.layer_norm.bias)
         w.wout = op(self.output_projection.weight)
+        src(-1, "wout_t", w.wout)
         if prec in FOLD_PRECS and _fold_pre_ln():          # decoder.layer_norm -> output_projection
             t3 = _fold_ln_linear(self.layer_norm.weight, self.layer_norm.bias, self.output_projection.weight, None, prec)
             keep.extend(t3)
@@ -628,7 +639,26 @@ class Decoder(_PackedMixin, nn.Module):
         emb, pos = _f32(self.embed_tokens.weight), _f32(self.embed_positions.weight)
         keep += [emb, pos]
         self._packed[key] = (w, layers, keep, emb, pos)
+        self._stream_src[key] = stream_src
         return self._packed[key]
+
+    def _pack_decode_tiles(self, prec: str):
+        """The decode step streams every weight once: a second copy of the bf16 operands in the STREAMING layout
+        (kx_gemm_args.w_tiled: one contiguous 1 KB block per wave instruction instead of 16 row segments of 64 B; 4.2-5.0 vs
+        3.2-3.7 TB/s) is made on the first decode step and hung into the packed weight structs (+2.6 GB at full size).
+        KOSMOSX_DECODE_TILED=0 keeps the row-major operands."""
+        key = (self.layer_norm.weight.device, prec)
+        todo = self._stream_src.pop(key, None)
+        if not todo or os.environ.get("KOSMOSX_DECODE_TILED", "1") == "0":
+            return
+        from .ops import tile_weight_rows
+        w, layers, keep, _, _ = self._packed[key]
+        for i, field, t in todo:
+            if t.shape[1] % 32:
+                continue
+            tt = tile_weight_rows(t)
+            keep.append(tt)
+            setattr(w if i < 0 else layers[i], field, tt.data_ptr())
 
     def _xpos_tables(self, T: int, device):
         key = (T, device)
@@ -729,6 +759,8 @@ class Decoder(_PackedMixin, nn.Module):
             raise RuntimeError("precision changed between incremental steps")
         if t >= Tmax or t + 2 >= pos.shape[0]:
             raise IndexError(f"index out of range in self: position {t + 2} exceeds the table / cache")
+        if prec == "bf16" and B <= 16:
+            self._pack_decode_tiles(prec)                  # first decode step: the streaming copy of the weights
         if passed_x is not None:
             _require_cuda(passed_x, "passed_x")
             x = passed_x[:, -1:].to(torch.float32).clone(memory_format=torch.contiguous_format)

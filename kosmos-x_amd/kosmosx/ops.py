@@ -71,7 +71,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, o
 def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
          xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None, splitk_ws=None,
          splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0, out_x3=False,
-         ln_out=None, ln_operand=None):
+         ln_out=None, ln_operand=None, w_tiled_rows=0):
     """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32].
     tile=16 (weight streaming, bf16, M <= 16) extras: ln = (gamma, beta, eps) with `a` the raw fp32 rows;
     stats_partials [M,nseg,2] instead of row_stats; stats_out_seg=16.
@@ -79,14 +79,15 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
     row-owning reduce kernel); the call then returns (out, ln)."""
     _need_cuda(a, w, bias, residual, out)
     M, K = a.shape
-    N = w.shape[0]
+    N = w_tiled_rows or w.shape[0]                 # w_tiled_rows = N: `w` is tile_weight_rows(W) (tile 16 only)
     prec = H.KX_PREC_BF16 if w.dtype == torch.bfloat16 else H.KX_PREC_F16 if w.dtype == torch.float16 else H.KX_PREC_F32
     if a.dtype != w.dtype and ln is None:
         raise TypeError("gemm operands must share a dtype")
     if out is None:
         out = torch.empty((M, 3 * N if out_x3 else N), dtype=torch.bfloat16 if out_x3 else out_dtype, device=a.device)
     g = H.GemmArgs()
-    g.A, g.lda, g.W, g.ldw = H.ptr(a), a.stride(0), H.ptr(w), w.stride(0)
+    g.A, g.lda, g.W, g.ldw = H.ptr(a), a.stride(0), H.ptr(w), (K if w_tiled_rows else w.stride(0))
+    g.w_tiled = 1 if w_tiled_rows else 0
     g.C, g.ldc, g.cdt = H.ptr(out), out.stride(0), (H.KX_BF16X3 if out_x3 else _cdt(out.dtype))
     g.bias, g.residual, g.ldr = H.ptr(bias), H.ptr(residual), (residual.stride(0) if residual is not None else 0)
     g.M, g.N, g.K = M, N, K
@@ -127,6 +128,18 @@ def _ln_operand_buffers(g, dt, M, N, device):
     st = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=device)
     g.ln_operand_out, g.ln_operand_stats = H.ptr(cp), H.ptr(st)
     return cp, st
+
+
+def tile_weight_rows(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] bf16 (K % 32 == 0) -> the streaming layout of kx_gemm_args.w_tiled: [ceil(N/16), K/32, 64, 8], piece l of block
+    (p, c) = row 16p + (l & 15), columns 32c + 8(l >> 4) .. +7; rows past N are zero.  A copy (torch data movement)."""
+    N, K = w.shape
+    assert K % 32 == 0 and w.dtype == torch.bfloat16
+    Np = (N + 15) // 16 * 16
+    if Np != N:
+        w = torch.cat([w, torch.zeros((Np - N, K), dtype=w.dtype, device=w.device)], 0)
+    # [p, i, c, g, 8] -> [p, c, g, i, 8]: piece index l = g * 16 + i
+    return w.view(Np // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(Np // 16, K // 32, 64, 8)
 
 
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,

@@ -57,3 +57,23 @@ def test_hip_prefill_and_decode_steps_match_full_forward(prec, tol):
         lm(tokd[:, :13], incremental_state=state2)
     with pytest.raises(IndexError):
         lm(tokd[:, :13], incremental_state={"max_len": 12})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 5])
+def test_decode_step_on_streaming_layout_weights_is_bitwise_the_row_major_step(B, monkeypatch):
+    """bf16 decode steps (up to 16 sequences) stream a second, re-tiled copy of the weights made on the first step
+    (Decoder._pack_decode_tiles); KOSMOSX_DECODE_TILED=0 keeps the row-major operands.  Same fragments, same order of products:
+    every step's logits are bit-identical."""
+    tok = torch.randint(0, 502, (B, 30), generator=torch.Generator().manual_seed(3)).cuda()
+    outs = {}
+    for tiled in ("0", "1"):
+        monkeypatch.setenv("KOSMOSX_DECODE_TILED", tiled)
+        lm = _lm(seed=7).to("cuda")
+        lm.precision = "bf16"
+        st = {}
+        lm(tok[:, :9], incremental_state=st)
+        outs[tiled] = [lm(tok[:, : t + 1], incremental_state=st).clone() for t in range(9, 30)]
+        w = lm.decoder._pack("bf16")[0]
+        assert bool(w.wout_t) == (tiled == "1") and bool(w.layer[0].w1_t) == (tiled == "1")
+    assert all(torch.equal(a, b) for a, b in zip(outs["0"], outs["1"]))

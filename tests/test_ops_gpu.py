@@ -422,6 +422,14 @@ def test_gemm_weight_streaming_decode_shapes(M, N, K):
     again = res.to(DEV).clone()
     ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), again, "gelu", out=again, tile=16)
     assert torch.equal(out, again)
+    # the same weights in the streaming layout (kx_gemm_args.w_tiled: one contiguous 1 KB block per wave instruction): same
+    # fragments, same order of products => the same bits
+    if K % 32 == 0:
+        wt = ops.tile_weight_rows(w.to(DEV))
+        assert wt.shape == ((N + 15) // 16, K // 32, 64, 8)
+        tiled = res.to(DEV).clone()
+        ops.gemm(a.to(DEV), wt, bias.to(DEV), tiled, "gelu", out=tiled, tile=16, w_tiled_rows=N)
+        assert torch.equal(tiled, out)
     ob = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), act="gelu", tile=16, out_dtype=torch.bfloat16)   # bf16 store
     refb = _gemm_ref(a.float(), w.float(), bias, None, "gelu")
     assert ((ob.float().cpu() - refb).abs() <= refb.abs() * 2 ** -8 + 1e-6).all()
