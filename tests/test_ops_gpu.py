@@ -447,11 +447,14 @@ def test_gemm_weight_streaming_prologues(M):
     gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
     w = (torch.randn(N, K, generator=g) / 40).to(torch.bfloat16)
     bias = torch.randn(N, generator=g)
-    # (a) LN prologue == separate kx_layernorm + tile 16, bit for bit
+    # (a) LN prologue == separate kx_layernorm + tile 16: the same two-pass statistics; the prologue sums a row across the
+    # workgroup's waves (one L2 round trip) where kx_layernorm walks it with one wave, so the fp32 statistics differ by
+    # rounding and a bf16 operand element may land on the neighbouring value once in a few thousand
     h = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out_dtype=torch.bfloat16)
     two = ops.gemm(h, w.to(DEV), bias.to(DEV), act="gelu", tile=16)
     one = ops.gemm(x.to(DEV), w.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5))
-    assert torch.equal(one, two)
+    assert rel_err(one, two.cpu()) < 1e-3
+    assert torch.equal(one, ops.gemm(x.to(DEV), w.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5)))
     # (b) producer statistics per 16 columns -> finalize == statistics of the stored values
     part = torch.zeros(M, N // 16, 2, device=DEV)
     y = ops.gemm(h, w.to(DEV), bias.to(DEV), act="gelu", tile=16, stats_out=part, stats_out_seg=16)
