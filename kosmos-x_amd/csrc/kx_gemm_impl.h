@@ -1867,11 +1867,283 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel(const GemmParams p, in
   }
 }
 
+// Second form of the same kernel (default; tuning key 8 = 1 runs the first one for A/B).  The arithmetic is the first form's,
+// operation for operation; what changes is WHEN the loads are issued.  A launch of this kernel is a chain of dependent
+// round trips around one 8 KB-per-wave stream — the activation row, the producer's statistics, gamma / beta, then (wave 0,
+// after the cross-wave sum) colsum, bias, XPos rows and the residual — and a CU's memory pipeline serves its requests in
+// order, so anything asked for AFTER the 64-128 KB of weight requests waits behind them.  Here every small load the
+// workgroup will need is issued first, in the order it is consumed, then the weights; the prologues and the epilogue
+// find their operands in registers.  LNP = LayerNorm prologue (A = raw fp32 rows) — a template parameter so that the two
+// operand paths do not add their registers (1024-thread workgroups: 128 VGPRs).
+struct GemvEpiOps { float4 c, b, r; float2 xc, xs; };
+
+template <int ACT, bool LNP>
+__global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, int S, int kw, int x_pitch) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  float* red = reinterpret_cast<float*>(lds);                    // [S][64] float4
+  float* st = reinterpret_cast<float*>(lds + S * 1024);          // [16][2] (mean, rstd)
+  char* xn = lds + S * 1024 + 128;                               // [M][x_pitch] bf16 (LayerNorm prologue)
+  constexpr int U = 8;
+  const int n0 = blockIdx.x * 16;
+  const int k0 = wave * kw, klen = min(kw, p.K - k0);           // may be <= 0 for trailing waves of a short K
+  const int nrow = min(n0 + i, p.N - 1);
+  const int xrow = min(i, p.M - 1);
+  const int k0w = klen > 0 ? k0 : 0;                             // (a wave without a K slice streams a valid address and drops it)
+  const char* wp = p.w_tiled ? p.W + (((long long)blockIdx.x * (p.K >> 5) + (k0w >> 5)) << 10) + (lane << 4)
+                             : p.W + (long long)nrow * p.ldw_b + ((long long)(k0w + 8 * g) << 1);
+  const int wstep = p.w_tiled ? 1024 : 64;
+  const int ulast = max(klen - 1, 0) >> 5;
+  auto ldw = [&](const char* q) { return *reinterpret_cast<const u32x4_t*>(q); };
+
+  // ---- (1) the small loads, in consumption order ----
+  const bool coop = LNP && (p.K >> 2) <= 64 * S && p.M <= 4;
+  const bool has = tid < (p.K >> 2);
+  float4 v[4], gm, bt;                                           // LNP, cooperative: this thread's float4 of rows 0..3
+  u32x4_t xf[U];                                                 // !LNP: the first batch of operand fragments
+  // statistics prologue: the producer's partials [M][nseg] float2 go through registers (requested first) into LDS, where
+  // the row-owning waves then find them — the same walk and arithmetic as from global memory
+  float2 ps[2];
+  const int np = p.M * p.stats_in_nseg;
+  const bool stat_stage = !LNP && p.stats_partials && np <= 128 * S;
+  float2* sp = reinterpret_cast<float2*>(xn);                    // (!LNP: the operand area is free)
+  if constexpr (LNP) {
+    if (coop) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = min(r, p.M - 1);
+        v[r] = has ? reinterpret_cast<const float4*>(p.A + (long long)m * p.lda_b)[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (has) { gm = reinterpret_cast<const float4*>(p.ln_g)[tid]; bt = reinterpret_cast<const float4*>(p.ln_b)[tid]; }
+    }
+  } else {
+    if (stat_stage) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (tid + 64 * S * t < np) ps[t] = reinterpret_cast<const float2*>(p.stats_partials)[tid + 64 * S * t];
+    }
+    const char* xg0 = p.A + (long long)xrow * p.lda_b + ((long long)(k0 + 8 * g) << 1);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (32 * u < klen) xf[u] = *reinterpret_cast<const u32x4_t*>(xg0 + (32 * u << 1));
+  }
+  const int em = i, en = n0 + 4 * g;                             // epilogue: lane = row em, columns en..en+3 (wave 0)
+  const bool live = em < p.M && en < p.N;
+  const bool pre = wave == 0 && live && en + 3 < p.N && p.vec_ok && !(p.row_stats && !p.stats_partials) &&
+                   (LNP || !p.xpos_dim);                         // (the XPos rows ride with the LayerNorm variant: the qkv GEMM)
+  GemvEpiOps eo;
+  if (pre) {
+    if (p.stats_partials) eo.c = *reinterpret_cast<const float4*>(p.colsum + en);
+    if (p.bias) eo.b = *reinterpret_cast<const float4*>(p.bias + en);
+    if constexpr (LNP) {
+      if (p.xpos_dim && en < 2 * p.xpos_dim) {
+        const bool isq = en < p.xpos_dim;
+        const int off = (em % p.xpos_T) * 32 + ((en & 63) >> 1);
+        eo.xc = *reinterpret_cast<const float2*>((isq ? p.xq_cs : p.xk_cs) + off);
+        eo.xs = *reinterpret_cast<const float2*>((isq ? p.xq_ss : p.xk_ss) + off);
+      }
+    }
+    if (p.residual) eo.r = *reinterpret_cast<const float4*>(p.residual + (long long)em * p.ldr + en);
+  }
+  // ---- (2) the stream: this wave's first 8 KB.  UNCONDITIONAL loads (k-steps past the slice re-read its last one): only
+  // then can the waits below be counted — "all but the last eight" — instead of draining the stream
+  u32x4_t wf[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) wf[u] = ldw(wp + min(u, ulast) * wstep);
+
+  // ---- (3) prologues ----
+  if (p.stats_partials) {
+    if (stat_stage) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (tid + 64 * S * t < np) sp[tid + 64 * S * t] = ps[t];
+      __syncthreads();
+    }
+    for (int m = wave; m < p.M; m += S) {
+      float sm = 0.f, m2 = 0.f;
+      float mean;
+      if (stat_stage) {
+        const float2* pr = sp + m * p.stats_in_nseg;
+        for (int j = lane; j < p.stats_in_nseg; j += 64) sm += pr[j].x;
+        mean = wave_sum(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
+        for (int j = lane; j < p.stats_in_nseg; j += 64) {
+          const float2 q = pr[j];
+          const float d = q.x / p.stats_in_seg - mean;
+          m2 += q.y + p.stats_in_seg * d * d;
+        }
+      } else {
+        const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
+        for (int j = lane; j < p.stats_in_nseg; j += 64) sm += pr[j].x;
+        mean = wave_sum(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
+        for (int j = lane; j < p.stats_in_nseg; j += 64) {
+          const float2 q = pr[j];
+          const float d = q.x / p.stats_in_seg - mean;
+          m2 += q.y + p.stats_in_seg * d * d;
+        }
+      }
+      const float var = wave_sum(m2) / (p.stats_in_seg * (float)p.stats_in_nseg);
+      if (lane == 0) { st[2 * m] = mean; st[2 * m + 1] = rsqrtf(var + p.stats_eps); }
+    }
+  }
+  if constexpr (LNP) {
+    if (coop) {
+      float* sc = red;                                           // [S][4] partial sums (the accumulator area, free until the MFMAs)
+      float mean[4], rstd[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sm = wave_sum((v[r].x + v[r].y) + (v[r].z + v[r].w));
+        if (lane == 0) sc[wave * 4 + r] = sm;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
+        for (int w = 0; w < S; ++w) t += sc[w * 4 + r];
+        mean[r] = t / (float)p.K;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = v[r].x - mean[r], b = v[r].y - mean[r], c = v[r].z - mean[r], d = v[r].w - mean[r];
+        const float q = wave_sum(has ? (a * a + b * b) + (c * c + d * d) : 0.f);
+        if (lane == 0) sc[wave * 4 + r] = q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
+        for (int w = 0; w < S; ++w) t += sc[w * 4 + r];
+        rstd[r] = rsqrtf(t / (float)p.K + p.ln_eps);
+      }
+      __syncthreads();                                           // sc (= red) is the accumulator area again
+      if (has) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r < p.M) {
+            uint2 o;
+            o.x = pack_bf16x2((v[r].x - mean[r]) * rstd[r] * gm.x + bt.x, (v[r].y - mean[r]) * rstd[r] * gm.y + bt.y);
+            o.y = pack_bf16x2((v[r].z - mean[r]) * rstd[r] * gm.z + bt.z, (v[r].w - mean[r]) * rstd[r] * gm.w + bt.w);
+            *reinterpret_cast<uint2*>(xn + r * x_pitch + tid * 8) = o;
+          }
+        }
+      }
+    } else {
+      const int nv = p.K >> 2;                                   // more rows: one wave per row, kx_layernorm's walk
+      for (int m = wave; m < p.M; m += S) {
+        const float4* xr = reinterpret_cast<const float4*>(p.A + (long long)m * p.lda_b);
+        float sm = 0.f;
+        for (int c = lane; c < nv; c += 64) { const float4 q = xr[c]; sm += (q.x + q.y) + (q.z + q.w); }
+        const float mean = wave_sum(sm) / (float)p.K;
+        float q2 = 0.f;
+        for (int c = lane; c < nv; c += 64) {
+          const float4 q = xr[c];
+          const float a = q.x - mean, b = q.y - mean, cc = q.z - mean, d = q.w - mean;
+          q2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+        const float rstd = rsqrtf(wave_sum(q2) / (float)p.K + p.ln_eps);
+        for (int c = lane; c < nv; c += 64) {
+          const float4 q = xr[c];
+          const float4 gq = reinterpret_cast<const float4*>(p.ln_g)[c];
+          const float4 bq = reinterpret_cast<const float4*>(p.ln_b)[c];
+          uint2 o;
+          o.x = pack_bf16x2((q.x - mean) * rstd * gq.x + bq.x, (q.y - mean) * rstd * gq.y + bq.y);
+          o.y = pack_bf16x2((q.z - mean) * rstd * gq.z + bq.z, (q.w - mean) * rstd * gq.w + bq.w);
+          *reinterpret_cast<uint2*>(xn + m * x_pitch + c * 8) = o;
+        }
+      }
+    }
+  }
+  if (LNP || p.stats_partials) __syncthreads();
+
+  // ---- (4) the products ----
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const char* xl = xn + xrow * x_pitch + ((k0 + 8 * g) << 1);   // LNP: the normalised rows in LDS
+  const char* xg = p.A + (long long)xrow * p.lda_b + ((long long)(k0 + 8 * g) << 1);
+  for (int kk = 0; kk < klen; kk += 32 * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kk + 32 * u < klen) {
+        if (kk > 0) wf[u] = ldw(wp + ((kk >> 5) + u) * wstep);   // first batch: in flight
+        if constexpr (LNP) xf[u] = *reinterpret_cast<const u32x4_t*>(xl + ((kk + 32 * u) << 1));
+        else if (kk > 0) xf[u] = *reinterpret_cast<const u32x4_t*>(xg + ((kk + 32 * u) << 1));
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kk + 32 * u < klen) acc = Mma<bf16_t>::step(wf[u], xf[u], acc);
+  }
+  *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < S; ++w) acc += *reinterpret_cast<const f32x4_t*>(red + (w * 64 + lane) * 4);
+
+  // ---- (5) epilogue (epilogue_compute4's arithmetic on the preloaded operands) ----
+  const int m = em, n = en;
+  float x[4] = {acc[0], acc[1], acc[2], acc[3]};
+  if (live && pre) {
+    if (p.stats_partials) {
+      const float2 ms = make_float2(st[2 * m], st[2 * m + 1]);
+      x[0] = ms.y * (x[0] - ms.x * eo.c.x); x[1] = ms.y * (x[1] - ms.x * eo.c.y);
+      x[2] = ms.y * (x[2] - ms.x * eo.c.z); x[3] = ms.y * (x[3] - ms.x * eo.c.w);
+    }
+    if (p.bias) { x[0] += eo.b.x; x[1] += eo.b.y; x[2] += eo.b.z; x[3] += eo.b.w; }
+    if (n < p.qcols) { x[0] *= p.qscale; x[1] *= p.qscale; x[2] *= p.qscale; x[3] *= p.qscale; }
+    if (p.xpos_dim && n < 2 * p.xpos_dim) {
+      const float y0 = x[0] * eo.xc.x + (-x[1]) * eo.xs.x;
+      const float y1 = x[1] * eo.xc.x + x[0] * eo.xs.x;
+      const float y2 = x[2] * eo.xc.y + (-x[3]) * eo.xs.y;
+      const float y3 = x[3] * eo.xc.y + x[2] * eo.xs.y;
+      x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;
+    }
+    if constexpr (ACT != KX_ACT_NONE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = apply_act<ACT>(x[j]);
+    }
+    if (p.residual) { x[0] += eo.r.x; x[1] += eo.r.y; x[2] += eo.r.z; x[3] += eo.r.w; }
+  } else if (live) {
+    GemmParams q = p;
+    q.stats_out = nullptr;
+    if (p.stats_partials) q.row_stats = st;                      // LDS through a generic pointer
+    x[0] = x[1] = x[2] = x[3] = 0.f;
+    epilogue_compute4<ACT>(q, m, n, acc, x);
+  }
+  if (p.stats_out) {
+    float sm = (x[0] + x[1]) + (x[2] + x[3]);
+    sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+    const float mu = sm * (1.0f / 16.0f);
+    const float d0 = x[0] - mu, d1 = x[1] - mu, d2 = x[2] - mu, d3 = x[3] - mu;
+    float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    m2 += __shfl_xor(m2, 16, 64); m2 += __shfl_xor(m2, 32, 64);
+    if (live && g == 0)
+      *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)m * p.stats_nseg + (n0 >> 4))) = make_float2(sm, m2);
+  }
+  if (!live) return;
+  const bool full = n + 3 < p.N && p.vec_ok;
+  const long long off = (long long)m * p.ldc + n;
+  if (p.c_bf16) {
+    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
+    if (full) { uint2 o; o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); *reinterpret_cast<uint2*>(c) = o; }
+    else for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = f32_to_bf16(x[j]);
+  } else {
+    float* c = reinterpret_cast<float*>(p.C) + off;
+    if (full) *reinterpret_cast<float4*>(c) = make_float4(x[0], x[1], x[2], x[3]);
+    else for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = x[j];
+  }
+}
+
+template <int ACT>
+void launch_gemv2(const GemmParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, int S, int kw, int x_pitch) {
+  if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<ACT, true>), grid, block, lds, s, p, S, kw, x_pitch);
+  else hipLaunchKernelGGL((gemv_fused_kernel2<ACT, false>), grid, block, lds, s, p, S, kw, x_pitch);
+}
+
 int launch_gemv_fused(GemmParams& p, hipStream_t s) {
   const int S = p.K <= 4096 ? 8 : 16;
   const int kw = ((p.K + S - 1) / S + 31) / 32 * 32;
   const int x_pitch = p.ln_g ? p.K * 2 + 16 : 0;
-  const size_t lds = (size_t)S * 1024 + 128 + (size_t)(p.ln_g ? p.M : 0) * x_pitch;
+  const size_t lds = (size_t)S * 1024 + 128 +
+                     (p.ln_g ? (size_t)p.M * x_pitch : p.stats_partials ? (size_t)128 * S * 8 : (size_t)0);   // operand rows | staged partials
   const dim3 grid((unsigned)((p.N + 15) / 16)), block(64 * S);
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
@@ -1879,7 +2151,22 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_QUICK_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<KX_ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<KX_ACT_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<KX_ACT_GELU_FAST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<KX_ACT_QUICK_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
+  if (kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 1) {
+    switch (p.act) {
+      case KX_ACT_NONE: launch_gemv2<KX_ACT_NONE>(p, grid, block, lds, s, S, kw, x_pitch); break;
+      case KX_ACT_GELU: launch_gemv2<KX_ACT_GELU>(p, grid, block, lds, s, S, kw, x_pitch); break;
+      case KX_ACT_GELU_FAST: launch_gemv2<KX_ACT_GELU_FAST>(p, grid, block, lds, s, S, kw, x_pitch); break;
+      case KX_ACT_QUICK_GELU: launch_gemv2<KX_ACT_QUICK_GELU>(p, grid, block, lds, s, S, kw, x_pitch); break;
+      default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+    }
+    KX_CHECK_LAUNCH("kx_gemm(weight streaming)");
+    return KX_OK;
+  }
   switch (p.act) {
     case KX_ACT_NONE: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_NONE>, grid, block, lds, s, p, S, kw, x_pitch); break;
     case KX_ACT_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;
