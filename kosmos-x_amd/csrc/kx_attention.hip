@@ -975,70 +975,82 @@ struct DecodeParams {
 
 template <typename T> struct Ld4;
 template <> struct Ld4<bf16_t> {
-  static __device__ __forceinline__ void load(const char* p, float (&x)[4]) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
+  typedef uint2 raw;
+  static constexpr int UK = 16;                            // keys per slot in flight (x 16 slots = 256 keys per round)
+  static __device__ __forceinline__ void unpack(const raw v, float (&x)[4]) {
     x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xffff0000u);
     x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
   }
 };
 template <> struct Ld4<float> {
-  static __device__ __forceinline__ void load(const char* p, float (&x)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-  }
+  typedef float4 raw;
+  static constexpr int UK = 8;
+  static __device__ __forceinline__ void unpack(const raw v, float (&x)[4]) { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
 };
 
+// One query per (head, sequence) against the cache.  At batch 1 this is 32 workgroups and pure latency, so the kernel is
+// ONE round trip: q, the first 256 (bf16) cached keys / values of the 16 slots and the new token's k / v — read from the
+// qkv row itself, not back through the cache — are all requested before anything is waited for; the cache append is a
+// side store nobody in this launch reads.  (First version: append, barrier, q, then the keys in rounds of 128 — four to
+// five dependent round trips, 9.9 us per launch for 150 keys.)  Same slots, same key order per slot, same arithmetic.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) {
   __shared__ float sm_m[16], sm_l[16], sm_o[16][64];
+  typedef typename Ld4<T>::raw raw;
+  constexpr int UK = Ld4<T>::UK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, li = lane & 15;              // 16-lane group = one key at a time; lane = dims 4li..4li+3
   const int h = blockIdx.x, b = blockIdx.y;
   const long long es = sizeof(T);
-  const char* qrow = p.qkv + ((long long)b * p.qkv_row + (long long)h * 64) * es;
-  char* kc = p.kcache + ((long long)b * p.cache_batch + (long long)h * 64) * es;
-  char* vc = p.vcache + ((long long)b * p.cache_batch + (long long)h * 64) * es;
-  // append the new token (row t): 64 k + 64 v elements per head, 16 lanes x 4 elements each
-  if (wave == 0 && grp < 2) {
-    const char* src = qrow + ((long long)(grp + 1) * p.D + 4 * li) * es;
-    char* dst = (grp == 0 ? kc : vc) + ((long long)p.t * p.cache_row + 4 * li) * es;
-    if (sizeof(T) == 2) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
-    else *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
-  }
-  __syncthreads();
-  float q[4];
-  Ld4<T>::load(qrow + 4 * li * es, q);
-  float m = -INFINITY, l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+  const char* qrow = p.qkv + ((long long)b * p.qkv_row + (long long)h * 64 + 4 * li) * es;
+  char* kc = p.kcache + ((long long)b * p.cache_batch + (long long)h * 64 + 4 * li) * es;
+  char* vc = p.vcache + ((long long)b * p.cache_batch + (long long)h * 64 + 4 * li) * es;
+  const char* knew = qrow + (long long)p.D * es;          // the new token (key t): k | v of the qkv row
+  const char* vnew = qrow + 2ll * p.D * es;
   const int nkeys = p.t + 1;
-  // eight keys of this slot in flight per round: the loop is a chain of dependent cache reads (~1 us each at
-  // batch 1 — ten of them for a 150-token context when issued one key at a time)
-  constexpr int UK = 8;
-  for (int j0 = wave * 4 + grp; j0 < nkeys; j0 += 16 * UK) {
-    float k[UK][4], v[UK][4];
+  const int slot = wave * 4 + grp;
+  const raw qr = *reinterpret_cast<const raw*>(qrow);
+  raw kr[UK], vr[UK];
 #pragma unroll
-    for (int u = 0; u < UK; ++u) {
-      const int j = j0 + 16 * u;
-      if (j < nkeys) {
-        Ld4<T>::load(kc + ((long long)j * p.cache_row + 4 * li) * es, k[u]);
-        Ld4<T>::load(vc + ((long long)j * p.cache_row + 4 * li) * es, v[u]);
+  for (int u = 0; u < UK; ++u) {                           // (slots past the end re-read the last key and drop it)
+    const int j = min(slot + 16 * u, p.t);
+    kr[u] = *reinterpret_cast<const raw*>(j == p.t ? knew : kc + (long long)j * p.cache_row * es);
+    vr[u] = *reinterpret_cast<const raw*>(j == p.t ? vnew : vc + (long long)j * p.cache_row * es);
+  }
+  if (wave == 0 && grp < 2) {                              // append row t: 64 k + 64 v elements per head
+    const raw nv = *reinterpret_cast<const raw*>(grp == 0 ? knew : vnew);
+    *reinterpret_cast<raw*>((grp == 0 ? kc : vc) + (long long)p.t * p.cache_row * es) = nv;
+  }
+  float q[4];
+  Ld4<T>::unpack(qr, q);
+  float m = -INFINITY, l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j0 = slot; j0 < nkeys; j0 += 16 * UK) {
+    if (j0 != slot) {                                      // contexts beyond the first round: one more round trip each
+#pragma unroll
+      for (int u = 0; u < UK; ++u) {
+        const int j = min(j0 + 16 * u, p.t);
+        kr[u] = *reinterpret_cast<const raw*>(j == p.t ? knew : kc + (long long)j * p.cache_row * es);
+        vr[u] = *reinterpret_cast<const raw*>(j == p.t ? vnew : vc + (long long)j * p.cache_row * es);
       }
     }
 #pragma unroll
     for (int u = 0; u < UK; ++u) {
       if (j0 + 16 * u < nkeys) {
-        float s = (q[0] * k[u][0] + q[1] * k[u][1]) + (q[2] * k[u][2] + q[3] * k[u][3]);
+        float k[4], v[4];
+        Ld4<T>::unpack(kr[u], k);
+        Ld4<T>::unpack(vr[u], v);
+        float s = (q[0] * k[0] + q[1] * k[1]) + (q[2] * k[2] + q[3] * k[3]);
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
         const float mn = fmaxf(m, s);
         const float a = __expf(m - mn), pj = __expf(s - mn);
         l = l * a + pj;
-        o[0] = o[0] * a + pj * v[u][0]; o[1] = o[1] * a + pj * v[u][1];
-        o[2] = o[2] * a + pj * v[u][2]; o[3] = o[3] * a + pj * v[u][3];
+        o[0] = o[0] * a + pj * v[0]; o[1] = o[1] * a + pj * v[1];
+        o[2] = o[2] * a + pj * v[2]; o[3] = o[3] * a + pj * v[3];
         m = mn;
       }
     }
   }
   // merge the 16 (wave, group) partial states
-  const int slot = wave * 4 + grp;
   if (li == 0) { sm_m[slot] = m; sm_l[slot] = l; }
   sm_o[slot][4 * li + 0] = o[0]; sm_o[slot][4 * li + 1] = o[1];
   sm_o[slot][4 * li + 2] = o[2]; sm_o[slot][4 * li + 3] = o[3];
