@@ -1911,12 +1911,13 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   float2* sp = reinterpret_cast<float2*>(xn);                    // (!LNP: the operand area is free)
   if constexpr (LNP) {
     if (coop) {
+      // (unconditional loads at a clamped index, masked where they are summed: a load under `has ? … : 0` makes the
+      // compiler wait for it at the join — a full round trip before the remaining loads and the stream are even issued)
+      const int vt = min(tid, (p.K >> 2) - 1);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = min(r, p.M - 1);
-        v[r] = has ? reinterpret_cast<const float4*>(p.A + (long long)m * p.lda_b)[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      if (has) { gm = reinterpret_cast<const float4*>(p.ln_g)[tid]; bt = reinterpret_cast<const float4*>(p.ln_b)[tid]; }
+      for (int r = 0; r < 4; ++r) v[r] = reinterpret_cast<const float4*>(p.A + (long long)min(r, p.M - 1) * p.lda_b)[vt];
+      gm = reinterpret_cast<const float4*>(p.ln_g)[vt];
+      bt = reinterpret_cast<const float4*>(p.ln_b)[vt];
     }
   } else {
     if (stat_stage) {
@@ -1993,7 +1994,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       float mean[4], rstd[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float sm = wave_sum((v[r].x + v[r].y) + (v[r].z + v[r].w));
+        const float sm = wave_sum(has ? (v[r].x + v[r].y) + (v[r].z + v[r].w) : 0.f);
         if (lane == 0) sc[wave * 4 + r] = sm;
       }
       __syncthreads();

@@ -176,19 +176,41 @@ class _PackedMixin:
         return super()._load_from_state_dict(*a, **k)
 
 
-def _validate_token_ids(tokens: torch.Tensor, vocab: int):
+_PINNED_RANGE = {}
+
+
+def _begin_token_id_check(tokens: torch.Tensor, vocab: int):
     """IndexError for ids outside [0, vocab) — what F.embedding raises on the reference's CPU path; the kernels only
-    clamp (memory safety).  One tiny reduction kernel + a 16-byte read-back; skipped while a hipGraph is being captured
-    (the graphed forward validates the live inputs before it replays)."""
+    clamp (memory safety).  One tiny reduction kernel + a 16-byte copy to pinned host memory are ENQUEUED here; the
+    returned callable waits for that copy (an event, not the stream) and raises.  The caller enqueues its own launches
+    in between, so the read-back does not leave the GPU idle: in the decode step the host stays one step ahead of the
+    device instead of draining the stream every token.  Skipped while a hipGraph is being captured (the graphed forward
+    validates the live inputs before it replays)."""
     if torch.cuda.is_current_stream_capturing():
-        return
-    mm = torch.empty(2, dtype=torch.int64, device=tokens.device)
+        return lambda: None
+    dev = tokens.device
+    mm = torch.empty(2, dtype=torch.int64, device=dev)
     H.check(H.load().kx_token_range(tokens.data_ptr(), tokens.numel(), mm.data_ptr(), _stream()), "kx_token_range")
-    lo, hi = mm.tolist()
-    if lo < 0 or hi >= vocab:
-        msg = f"index out of range in self: token id {hi if hi >= vocab else lo} outside the {vocab}-row embedding table"
-        logging.error(msg)
-        raise IndexError(msg)
+    slot = _PINNED_RANGE.get(dev)
+    if slot is None:
+        slot = _PINNED_RANGE[dev] = (torch.empty(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+    host, ev = slot
+    host.copy_(mm, non_blocking=True)
+    ev.record(torch.cuda.current_stream(dev))
+
+    def finish():
+        ev.synchronize()
+        lo, hi = host.tolist()
+        if lo < 0 or hi >= vocab:
+            msg = f"index out of range in self: token id {hi if hi >= vocab else lo} outside the {vocab}-row embedding table"
+            logging.error(msg)
+            raise IndexError(msg)
+    return finish
+
+
+def _validate_token_ids(tokens: torch.Tensor, vocab: int):
+    """The check above, finished at once."""
+    _begin_token_id_check(tokens, vocab)()
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -671,12 +693,14 @@ class Decoder(_PackedMixin, nn.Module):
 
     # -- stages -----------------------------------------------------------------------------------
     def embed(self, tokens: torch.Tensor | None, prec: str, img: torch.Tensor | None = None, splice_at: int = 2,
-              alias: bool | None = None, pos_offset: int = 0) -> torch.Tensor:
+              alias: bool | None = None, pos_offset: int = 0, defer_check: bool = False) -> torch.Tensor:
         """Fused forward_embedding/cat/forward_embedding of /root/reference/kosmosx/model.py:238-244
-        (img given) or the single forward_embedding of :319 (img None)."""
+        (img given) or the single forward_embedding of :319 (img None).  The token-id range check is read back after the
+        embedding launch; with ``defer_check`` the caller finishes it (``self._finish_check()``) after enqueuing more."""
         prec = H.stage_precision(prec, "decoder")
         _, _, _, emb, pos = self._pack(prec)
         lib = H.load()
+        check = None
         if tokens is not None:
             _require_cuda(tokens, "text_tokens")
             if tokens.dtype != torch.int64:
@@ -684,7 +708,7 @@ class Decoder(_PackedMixin, nn.Module):
             tokens = tokens.contiguous()
             B, Tt = tokens.shape
             if getattr(self, "validate_token_ids", True) and tokens.numel():
-                _validate_token_ids(tokens, emb.shape[0])
+                check = _begin_token_id_check(tokens, emb.shape[0])
         else:
             B, Tt = img.shape[0], 0
         n_img = 0 if img is None else img.shape[1]
@@ -698,7 +722,15 @@ class Decoder(_PackedMixin, nn.Module):
             logging.error(msg)
             raise IndexError("index out of range in self: " + msg)  # what F.embedding raises upstream
         H.check(rc, "kx_embed_splice")
+        self._pending_check = check
+        if not defer_check:
+            self._finish_check()
         return out
+
+    def _finish_check(self):
+        check, self._pending_check = getattr(self, "_pending_check", None), None
+        if check is not None:
+            check()
 
     def run(self, x: torch.Tensor, prec: str, logits_dtype=torch.float32) -> torch.Tensor:
         """x [B,T,dim] fp32 residual stream (CONSUMED) -> logits [B,T,vocab]."""
@@ -765,7 +797,7 @@ class Decoder(_PackedMixin, nn.Module):
             _require_cuda(passed_x, "passed_x")
             x = passed_x[:, -1:].to(torch.float32).clone(memory_format=torch.contiguous_format)
         else:
-            x = self.embed(tokens[:, -1:], prec, pos_offset=t)
+            x = self.embed(tokens[:, -1:], prec, pos_offset=t, defer_check=True)
         if x.shape[0] != B:
             raise ValueError("batch size changed between incremental steps")
         rows = tuple(None if tb is None else tb[t] for tb in state["xpos"])   # views: row t of each [Tmax, 32] table
@@ -776,6 +808,7 @@ class Decoder(_PackedMixin, nn.Module):
                                            state["kcache"].data_ptr(), state["vcache"].data_ptr(), Tmax,
                                            logits.data_ptr(), H.KX_F32, buf.data_ptr(), buf.numel(), H.PRECS[prec],
                                            _stream()), "kx_decoder_decode_step")
+        self._finish_check()                               # an IndexError leaves the state where it was (row t is rewritten)
         state["len"] = t + 1
         return logits
 
