@@ -16,6 +16,7 @@ ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--max-len", type=int, default=512)
 ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "f16c", "mixed"],
                 help="bf16 streams the weights through the tile-16 kernels; the f16c / fp32 paths run the generic per-op step")
+ap.add_argument("--by-shape", action="store_true", help="also print the per-launch time of each kernel shape (in-process events)")
 ap.add_argument("--tune", default="", help="A/B: kx_set_tuning key=value pairs, e.g. 1=64 (tile kernels instead of tile 16)")
 a = ap.parse_args()
 for kv in filter(None, a.tune.split(",")):
@@ -47,8 +48,13 @@ wbytes = 2 * (L * (4 * d * d + 2 * d * F) + d * V)
 tavg = a.prefix + 4 + a.steps / 2
 kvbytes = 2 * L * a.batch * tavg * d * 2
 agg = {}
+shapes = {}
 for kind, x, y, z, ms in recs:
     e = agg.setdefault(kind, [0, 0.0]); e[0] += 1; e[1] += ms
+    e = shapes.setdefault(f"{kind} {x}x{y}x{z}", [0, 0.0]); e[0] += 1; e[1] += ms
+if a.by_shape:
+    for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {k:40s} {v[0]:3d} launches  {v[1] / v[0] * 1e3:7.2f} us each", file=sys.stderr)
 print(json.dumps({"workload": f"KosmosLanguage decode step, B={a.batch}, context ~{int(tavg)} tokens, {a.precision}",
                   "ms_per_token_step": round(dt * 1e3, 3), "host_issue_ms": round(host_dt * 1e3, 3), "tokens_per_s": round(a.batch / dt, 1),
                   "bytes_per_step_GB": round((wbytes + kvbytes) / 1e9, 3),
