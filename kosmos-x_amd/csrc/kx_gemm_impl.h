@@ -1877,7 +1877,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel(const GemmParams p, in
 // operand paths do not add their registers (1024-thread workgroups: 128 VGPRs).
 struct GemvEpiOps { float4 c, b, r; float2 xc, xs; };
 
-template <int ACT, bool LNP>
+template <int ACT, bool LNP, int UW>
 __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, int S, int kw, int x_pitch) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1886,7 +1886,8 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   float* red = reinterpret_cast<float*>(lds);                    // [S][64] float4
   float* st = reinterpret_cast<float*>(lds + S * 1024);          // [16][2] (mean, rstd)
   char* xn = lds + S * 1024 + 128;                               // [M][x_pitch] bf16 (LayerNorm prologue)
-  constexpr int U = 8;
+  constexpr int U = UW;                                          // k-steps (1 KB each) a wave keeps in flight: 8, or 16 where a
+  constexpr bool XS = !LNP && UW == 16;                          //   wave's K slice is 512 (fc2) — then the operand rows are staged in LDS
   const int n0 = blockIdx.x * 16;
   const int k0 = wave * kw, klen = min(kw, p.K - k0);           // may be <= 0 for trailing waves of a short K
   const int nrow = min(n0 + i, p.N - 1);
@@ -1902,7 +1903,8 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   const bool coop = LNP && (p.K >> 2) <= 64 * S && p.M <= 4;
   const bool has = tid < (p.K >> 2);
   float4 v[4], gm, bt;                                           // LNP, cooperative: this thread's float4 of rows 0..3
-  u32x4_t xf[U];                                                 // !LNP: the first batch of operand fragments
+  u32x4_t xf[8];                                                 // !LNP: the first batch of operand fragments
+  u32x4_t xs[4];                                                 // XS: this thread's 16 bytes of operand rows 0..3
   // statistics prologue: the producer's partials [M][nseg] float2 go through registers (requested first) into LDS, where
   // the row-owning waves then find them — the same walk and arithmetic as from global memory
   float2 ps[2];
@@ -1915,7 +1917,8 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       // compiler wait for it at the join — a full round trip before the remaining loads and the stream are even issued)
       const int vt = min(tid, (p.K >> 2) - 1);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = reinterpret_cast<const float4*>(p.A + (long long)min(r, p.M - 1) * p.lda_b)[vt];
+      for (int r = 0; r < 4; ++r)                                // (1, 2 or 4 rows are reduced: M = 3 repeats its last row)
+        if (r < p.M || (r == 3 && p.M == 3)) v[r] = reinterpret_cast<const float4*>(p.A + (long long)min(r, p.M - 1) * p.lda_b)[vt];
       gm = reinterpret_cast<const float4*>(p.ln_g)[vt];
       bt = reinterpret_cast<const float4*>(p.ln_b)[vt];
     }
@@ -1925,10 +1928,16 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       for (int t = 0; t < 2; ++t)
         if (tid + 64 * S * t < np) ps[t] = reinterpret_cast<const float2*>(p.stats_partials)[tid + 64 * S * t];
     }
-    const char* xg0 = p.A + (long long)xrow * p.lda_b + ((long long)(k0 + 8 * g) << 1);
+    if constexpr (XS) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (32 * u < klen) xf[u] = *reinterpret_cast<const u32x4_t*>(xg0 + (32 * u << 1));
+      for (int r = 0; r < 4; ++r)
+        if (r < p.M && tid < (p.K >> 3)) xs[r] = *reinterpret_cast<const u32x4_t*>(p.A + (long long)r * p.lda_b + (tid << 4));
+    } else {
+      const char* xg0 = p.A + (long long)xrow * p.lda_b + ((long long)(k0 + 8 * g) << 1);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (32 * u < klen) xf[u] = *reinterpret_cast<const u32x4_t*>(xg0 + (32 * u << 1));
+    }
   }
   const int em = i, en = n0 + 4 * g;                             // epilogue: lane = row em, columns en..en+3 (wave 0)
   const bool live = em < p.M && en < p.N;
@@ -1955,6 +1964,12 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   for (int u = 0; u < U; ++u) wf[u] = ldw(wp + min(u, ulast) * wstep);
 
   // ---- (3) prologues ----
+  char* xsb = xn + (p.stats_partials ? 128 * S * 8 : 0);         // XS: operand rows [M][x_pitch] behind the staged partials
+  if constexpr (XS) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < p.M && tid < (p.K >> 3)) *reinterpret_cast<u32x4_t*>(xsb + r * x_pitch + (tid << 4)) = xs[r];
+  }
   if (p.stats_partials) {
     if (stat_stage) {
 #pragma unroll
@@ -1990,46 +2005,53 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   }
   if constexpr (LNP) {
     if (coop) {
-      float* sc = red;                                           // [S][4] partial sums (the accumulator area, free until the MFMAs)
-      float mean[4], rstd[4];
+      // Each wave reduces its own 256 columns to (sum, M2 about its own mean) — two shuffle trees per row — and the S pairs
+      // are combined with Chan's formula after ONE barrier (the kx_row_stats_finalize arithmetic).  The first version
+      // (sum, barrier, mean, barrier, squares, barrier, rstd, barrier, for four rows whatever M) put 2.4 us of shuffles
+      // and barriers between the arrival of x and the first product (profiles/r02_d_gemv_phase_trace.log).
+      float* sc = red;                                           // [S][4][4] (the accumulator area, free until the MFMAs)
+      const int cw = 4 * max(0, min(64, (p.K >> 2) - wave * 64)); // columns this wave holds
+      auto rows = [&](auto rc) {                                 // R rows at a time: their shuffle trees interleave
+        constexpr int R = decltype(rc)::value;
+        float sm[R], mw[R], q[R];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float sm = wave_sum(has ? (v[r].x + v[r].y) + (v[r].z + v[r].w) : 0.f);
-        if (lane == 0) sc[wave * 4 + r] = sm;
-      }
-      __syncthreads();
+        for (int r = 0; r < R; ++r) sm[r] = wave_sum(has ? (v[r].x + v[r].y) + (v[r].z + v[r].w) : 0.f);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = 0.f;
-        for (int w = 0; w < S; ++w) t += sc[w * 4 + r];
-        mean[r] = t / (float)p.K;
-      }
-      __syncthreads();
+        for (int r = 0; r < R; ++r) {
+          mw[r] = cw ? sm[r] / (float)cw : 0.f;
+          const float a = v[r].x - mw[r], b = v[r].y - mw[r], c = v[r].z - mw[r], d = v[r].w - mw[r];
+          q[r] = wave_sum(has ? (a * a + b * b) + (c * c + d * d) : 0.f);
+        }
+        if (lane == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a = v[r].x - mean[r], b = v[r].y - mean[r], c = v[r].z - mean[r], d = v[r].w - mean[r];
-        const float q = wave_sum(has ? (a * a + b * b) + (c * c + d * d) : 0.f);
-        if (lane == 0) sc[wave * 4 + r] = q;
-      }
-      __syncthreads();
+          for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(sc + (wave * 4 + r) * 4) = make_float4(sm[r], q[r], mw[r], (float)cw);
+        }
+        __syncthreads();
+        if (has) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = 0.f;
-        for (int w = 0; w < S; ++w) t += sc[w * 4 + r];
-        rstd[r] = rsqrtf(t / (float)p.K + p.ln_eps);
-      }
-      __syncthreads();                                           // sc (= red) is the accumulator area again
-      if (has) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (r < p.M) {
-            uint2 o;
-            o.x = pack_bf16x2((v[r].x - mean[r]) * rstd[r] * gm.x + bt.x, (v[r].y - mean[r]) * rstd[r] * gm.y + bt.y);
-            o.y = pack_bf16x2((v[r].z - mean[r]) * rstd[r] * gm.z + bt.z, (v[r].w - mean[r]) * rstd[r] * gm.w + bt.w);
-            *reinterpret_cast<uint2*>(xn + r * x_pitch + tid * 8) = o;
+          for (int r = 0; r < R; ++r) {
+            if (r < p.M) {
+              float t = 0.f;
+              for (int w = 0; w < S; ++w) t += sc[(w * 4 + r) * 4];
+              const float mean = t / (float)p.K;
+              float m2 = 0.f;
+              for (int w = 0; w < S; ++w) {
+                const float4 e = *reinterpret_cast<const float4*>(sc + (w * 4 + r) * 4);
+                const float dm = e.z - mean;
+                m2 += e.y + e.w * dm * dm;                         // (an empty wave: 0 + 0 * mean^2)
+              }
+              const float rstd = rsqrtf(m2 / (float)p.K + p.ln_eps);
+              uint2 o;
+              o.x = pack_bf16x2((v[r].x - mean) * rstd * gm.x + bt.x, (v[r].y - mean) * rstd * gm.y + bt.y);
+              o.y = pack_bf16x2((v[r].z - mean) * rstd * gm.z + bt.z, (v[r].w - mean) * rstd * gm.w + bt.w);
+              *reinterpret_cast<uint2*>(xn + r * x_pitch + tid * 8) = o;
+            }
           }
         }
-      }
+      };
+      if (p.M == 1) rows(std::integral_constant<int, 1>{});
+      else if (p.M == 2) rows(std::integral_constant<int, 2>{});
+      else rows(std::integral_constant<int, 4>{});
     } else {
       const int nv = p.K >> 2;                                   // more rows: one wave per row, kx_layernorm's walk
       for (int m = wave; m < p.M; m += S) {
@@ -2056,23 +2078,31 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       }
     }
   }
-  if (LNP || p.stats_partials) __syncthreads();
+  if (LNP || XS || p.stats_partials) __syncthreads();
 
   // ---- (4) the products ----
   f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const char* xl = xn + xrow * x_pitch + ((k0 + 8 * g) << 1);   // LNP: the normalised rows in LDS
+  const char* xl = (LNP ? xn : xsb) + xrow * x_pitch + ((k0 + 8 * g) << 1);   // LNP / XS: the operand rows in LDS
   const char* xg = p.A + (long long)xrow * p.lda_b + ((long long)(k0 + 8 * g) << 1);
   for (int kk = 0; kk < klen; kk += 32 * U) {
+    if (kk > 0) {                                                // (first batch: in flight)
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (kk + 32 * u < klen) {
-        if (kk > 0) wf[u] = ldw(wp + ((kk >> 5) + u) * wstep);   // first batch: in flight
-        if constexpr (LNP) xf[u] = *reinterpret_cast<const u32x4_t*>(xl + ((kk + 32 * u) << 1));
-        else if (kk > 0) xf[u] = *reinterpret_cast<const u32x4_t*>(xg + ((kk + 32 * u) << 1));
-      }
+      for (int u = 0; u < U; ++u)
+        if (kk + 32 * u < klen) wf[u] = ldw(wp + ((kk >> 5) + u) * wstep);
+    }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (kk + 32 * u < klen) acc = Mma<bf16_t>::step(wf[u], xf[u], acc);
+    for (int h = 0; h < U; h += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (kk + 32 * (h + u) < klen) {
+          if constexpr (LNP || XS) xf[u] = *reinterpret_cast<const u32x4_t*>(xl + ((kk + 32 * (h + u)) << 1));
+          else if (kk > 0) xf[u] = *reinterpret_cast<const u32x4_t*>(xg + ((kk + 32 * (h + u)) << 1));
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (kk + 32 * (h + u) < klen) acc = Mma<bf16_t>::step(wf[h + u], xf[u], acc);
+      if constexpr (U > 8) __builtin_amdgcn_sched_barrier(0);    // (keeps the second half's eight LDS reads out of the first half's registers)
+    }
   }
   *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
   __syncthreads();
@@ -2134,17 +2164,27 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
 }
 
 template <int ACT>
-void launch_gemv2(const GemmParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, int S, int kw, int x_pitch) {
-  if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<ACT, true>), grid, block, lds, s, p, S, kw, x_pitch);
-  else hipLaunchKernelGGL((gemv_fused_kernel2<ACT, false>), grid, block, lds, s, p, S, kw, x_pitch);
+void launch_gemv2(const GemmParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, int S, int kw, int x_pitch, bool deep) {
+  if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<ACT, true, 8>), grid, block, lds, s, p, S, kw, x_pitch);
+  else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<ACT, false, 16>), grid, block, lds, s, p, S, kw, x_pitch);
+  else hipLaunchKernelGGL((gemv_fused_kernel2<ACT, false, 8>), grid, block, lds, s, p, S, kw, x_pitch);
+}
+
+template <int ACT>
+void gemv2_lds_attr() {
+  (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<ACT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<ACT, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 int launch_gemv_fused(GemmParams& p, hipStream_t s) {
   const int S = p.K <= 4096 ? 8 : 16;
   const int kw = ((p.K + S - 1) / S + 31) / 32 * 32;
-  const int x_pitch = p.ln_g ? p.K * 2 + 16 : 0;
-  const size_t lds = (size_t)S * 1024 + 128 +
-                     (p.ln_g ? (size_t)p.M * x_pitch : p.stats_partials ? (size_t)128 * S * 8 : (size_t)0);   // operand rows | staged partials
+  const bool v2 = kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 1;
+  // second form, a wave's K slice longer than 8 k-steps (fc2: 512): 16 KB per wave in flight, operand rows through LDS
+  const bool deep = v2 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 2 && !p.ln_g && kw > 256 && p.M <= 4 && p.K <= 512 * S;
+  const int x_pitch = (p.ln_g || deep) ? p.K * 2 + 16 : 0;
+  const size_t lds = (size_t)S * 1024 + 128 +                   // accumulators | statistics | operand rows or staged partials (+ rows)
+                     (p.ln_g ? (size_t)p.M * x_pitch : (p.stats_partials ? (size_t)128 * S * 8 : (size_t)0) + (deep ? (size_t)p.M * x_pitch : (size_t)0));
   const dim3 grid((unsigned)((p.N + 15) / 16)), block(64 * S);
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
@@ -2152,17 +2192,14 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_QUICK_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<KX_ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<KX_ACT_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<KX_ACT_GELU_FAST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<KX_ACT_QUICK_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    gemv2_lds_attr<KX_ACT_NONE>(); gemv2_lds_attr<KX_ACT_GELU>(); gemv2_lds_attr<KX_ACT_GELU_FAST>(); gemv2_lds_attr<KX_ACT_QUICK_GELU>();
   });
-  if (kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 1) {
+  if (v2) {
     switch (p.act) {
-      case KX_ACT_NONE: launch_gemv2<KX_ACT_NONE>(p, grid, block, lds, s, S, kw, x_pitch); break;
-      case KX_ACT_GELU: launch_gemv2<KX_ACT_GELU>(p, grid, block, lds, s, S, kw, x_pitch); break;
-      case KX_ACT_GELU_FAST: launch_gemv2<KX_ACT_GELU_FAST>(p, grid, block, lds, s, S, kw, x_pitch); break;
-      case KX_ACT_QUICK_GELU: launch_gemv2<KX_ACT_QUICK_GELU>(p, grid, block, lds, s, S, kw, x_pitch); break;
+      case KX_ACT_NONE: launch_gemv2<KX_ACT_NONE>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
+      case KX_ACT_GELU: launch_gemv2<KX_ACT_GELU>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
+      case KX_ACT_GELU_FAST: launch_gemv2<KX_ACT_GELU_FAST>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
+      case KX_ACT_QUICK_GELU: launch_gemv2<KX_ACT_QUICK_GELU>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
       default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
     }
     KX_CHECK_LAUNCH("kx_gemm(weight streaming)");
