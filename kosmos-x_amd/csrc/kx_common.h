@@ -1,5 +1,6 @@
 // Shared device/host helpers for libkosmosx_hip.so (gfx950 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -198,6 +199,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// The same total through the data-parallel-primitive path: four DPP adds give every lane its 16-lane row's sum, four
+// v_readlane the rest — ~60 cycles where the ds_bpermute butterfly above takes ~500 (six dependent LDS-crossbar round trips).
+// A different summation tree: use it where a result is compared at a tolerance, not bit for bit.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});      // row_mirror
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -1983,7 +1983,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       if (stat_stage) {
         const float2* pr = sp + m * p.stats_in_nseg;
         for (int j = lane; j < p.stats_in_nseg; j += 64) sm += pr[j].x;
-        mean = wave_sum(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
+        mean = wave_sum_dpp(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
         for (int j = lane; j < p.stats_in_nseg; j += 64) {
           const float2 q = pr[j];
           const float d = q.x / p.stats_in_seg - mean;
@@ -1992,14 +1992,14 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       } else {
         const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
         for (int j = lane; j < p.stats_in_nseg; j += 64) sm += pr[j].x;
-        mean = wave_sum(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
+        mean = wave_sum_dpp(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
         for (int j = lane; j < p.stats_in_nseg; j += 64) {
           const float2 q = pr[j];
           const float d = q.x / p.stats_in_seg - mean;
           m2 += q.y + p.stats_in_seg * d * d;
         }
       }
-      const float var = wave_sum(m2) / (p.stats_in_seg * (float)p.stats_in_nseg);
+      const float var = wave_sum_dpp(m2) / (p.stats_in_seg * (float)p.stats_in_nseg);
       if (lane == 0) { st[2 * m] = mean; st[2 * m + 1] = rsqrtf(var + p.stats_eps); }
     }
   }
@@ -2015,12 +2015,12 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
         constexpr int R = decltype(rc)::value;
         float sm[R], mw[R], q[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) sm[r] = wave_sum(has ? (v[r].x + v[r].y) + (v[r].z + v[r].w) : 0.f);
+        for (int r = 0; r < R; ++r) sm[r] = wave_sum_dpp(has ? (v[r].x + v[r].y) + (v[r].z + v[r].w) : 0.f);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           mw[r] = cw ? sm[r] / (float)cw : 0.f;
           const float a = v[r].x - mw[r], b = v[r].y - mw[r], c = v[r].z - mw[r], d = v[r].w - mw[r];
-          q[r] = wave_sum(has ? (a * a + b * b) + (c * c + d * d) : 0.f);
+          q[r] = wave_sum_dpp(has ? (a * a + b * b) + (c * c + d * d) : 0.f);
         }
         if (lane == 0) {
 #pragma unroll
@@ -2058,14 +2058,14 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
         const float4* xr = reinterpret_cast<const float4*>(p.A + (long long)m * p.lda_b);
         float sm = 0.f;
         for (int c = lane; c < nv; c += 64) { const float4 q = xr[c]; sm += (q.x + q.y) + (q.z + q.w); }
-        const float mean = wave_sum(sm) / (float)p.K;
+        const float mean = wave_sum_dpp(sm) / (float)p.K;
         float q2 = 0.f;
         for (int c = lane; c < nv; c += 64) {
           const float4 q = xr[c];
           const float a = q.x - mean, b = q.y - mean, cc = q.z - mean, d = q.w - mean;
           q2 += (a * a + b * b) + (cc * cc + d * d);
         }
-        const float rstd = rsqrtf(wave_sum(q2) / (float)p.K + p.ln_eps);
+        const float rstd = rsqrtf(wave_sum_dpp(q2) / (float)p.K + p.ln_eps);
         for (int c = lane; c < nv; c += 64) {
           const float4 q = xr[c];
           const float4 gq = reinterpret_cast<const float4*>(p.ln_g)[c];

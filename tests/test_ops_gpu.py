@@ -472,7 +472,7 @@ def test_gemm_weight_streaming_prologues(M):
                          colsum=cs)
     via_part = ops.gemm(yb, w2, bias[:256].to(DEV).contiguous(), res.clone(), tile=16, stats_partials=part, stats_in_seg=16,
                         colsum=cs)
-    assert torch.equal(via_stats, via_part)
+    assert rel_err(via_part, via_stats.cpu()) < 1e-5     # the same Chan combination; the prologue sums with a different tree
     lnref = torch.nn.functional.layer_norm(yb.float().cpu(), (N,), eps=1e-5)
     ref = lnref @ w2.float().cpu().T + bias[:256] + res.cpu()
     assert rel_err(via_part, ref) < 2e-3          # statistics are of the fp32 values, the operand is their bf16 rounding
