@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
         Ld4<T>::unpack(kr[u], k);
         Ld4<T>::unpack(vr[u], v);
         float s = (q[0] * k[0] + q[1] * k[1]) + (q[2] * k[2] + q[3] * k[3]);
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        s = row16_sum_dpp(s);                               // (= the xor butterfly 1, 2, 4, 8, bit for bit)
         const float mn = fmaxf(m, s);
         const float a = __expf(m - mn), pj = __expf(s - mn);
         l = l * a + pj;
@@ -1066,9 +1066,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
     }
     const float ov = acc / L;                                  // lane = head dim
     if (p.stats_out) {
-      const float sm = wave_sum(ov);
+      const float sm = wave_sum_dpp(ov);
       const float dv = ov - sm * (1.0f / 64.0f);
-      const float m2 = wave_sum(dv * dv);
+      const float m2 = wave_sum_dpp(dv * dv);
       if (lane == 0) *reinterpret_cast<float2*>(p.stats_out + 2 * ((long long)b * p.H + h)) = make_float2(sm, m2);
     }
     const long long ooff = (long long)b * p.out_row + (long long)h * 64 + lane;
