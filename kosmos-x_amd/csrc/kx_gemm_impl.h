@@ -850,6 +850,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
   f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const bool vec = (n + 3 < p.N) && (p.N & 3) == 0;
+  // plain fp32 / 2-byte outputs without output statistics: the epilogue operands are requested with the slices (one round
+  // trip instead of two)
+  const bool pre = vec && p.vec_ok && p.splitk <= 8 && !p.stats_out && !p.c_x3 && !p.c_f16c && !p.lnop_out;
+  float4 ec, eb, er; float2 ems, exc, exs;
+  if (pre) {
+    if (p.row_stats) { ems = *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)m); ec = *reinterpret_cast<const float4*>(p.colsum + n); }
+    if (p.bias) eb = *reinterpret_cast<const float4*>(p.bias + n);
+    if (p.xpos_dim && n < 2 * p.xpos_dim) {
+      const bool isq = n < p.xpos_dim;
+      const int o = (m % p.xpos_T) * 32 + ((n & 63) >> 1);
+      exc = *reinterpret_cast<const float2*>((isq ? p.xq_cs : p.xk_cs) + o);
+      exs = *reinterpret_cast<const float2*>((isq ? p.xq_ss : p.xk_ss) + o);
+    }
+    if (p.residual) er = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n);
+  }
   if (vec && p.splitk <= 8) {                                     // all slices in flight at once, summed in slice order
     f32x4_t v[8];
     const float* src = p.partial + (long long)m * p.N + n;
@@ -869,7 +884,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   }
   GemmParams q = p;
   q.splitk = 1;
-  epilogue4<ACT>(q, m, n, acc);
+  if (!pre) { epilogue4<ACT>(q, m, n, acc); return; }
+  // epilogue_compute4's steps on the operands requested above
+  float x[4] = {acc[0], acc[1], acc[2], acc[3]};
+  if (p.row_stats) {
+    x[0] = ems.y * (x[0] - ems.x * ec.x); x[1] = ems.y * (x[1] - ems.x * ec.y);
+    x[2] = ems.y * (x[2] - ems.x * ec.z); x[3] = ems.y * (x[3] - ems.x * ec.w);
+  }
+  if (p.bias) { x[0] += eb.x; x[1] += eb.y; x[2] += eb.z; x[3] += eb.w; }
+  if (n < p.qcols) { x[0] *= p.qscale; x[1] *= p.qscale; x[2] *= p.qscale; x[3] *= p.qscale; }
+  if (p.xpos_dim && n < 2 * p.xpos_dim) {
+    const float y0 = x[0] * exc.x + (-x[1]) * exs.x;
+    const float y1 = x[1] * exc.x + x[0] * exs.x;
+    const float y2 = x[2] * exc.y + (-x[3]) * exs.y;
+    const float y3 = x[3] * exc.y + x[2] * exs.y;
+    x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;
+  }
+  if constexpr (ACT != KX_ACT_NONE) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = apply_act<ACT>(x[j]);
+  }
+  if (p.residual) { x[0] += er.x; x[1] += er.y; x[2] += er.z; x[3] += er.w; }
+  const long long off = (long long)m * p.ldc + n;
+  if (p.c_bf16) {
+    uint2 o; o.x = pack16(p, x[0], x[1]); o.y = pack16(p, x[2], x[3]);
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off) = make_float4(x[0], x[1], x[2], x[3]);
+  }
 }
 
 // Row-owning variant of the reduce kernel: one workgroup per output row (N <= 8192: 8 float4 per thread).  Besides the
