@@ -850,68 +850,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
   f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const bool vec = (n + 3 < p.N) && (p.N & 3) == 0;
-  // plain fp32 / 2-byte outputs without output statistics: the epilogue operands are requested with the slices (one round
-  // trip instead of two)
-  const bool pre = vec && p.vec_ok && p.splitk <= 8 && !p.stats_out && !p.c_x3 && !p.c_f16c && !p.lnop_out;
-  float4 ec, eb, er; float2 ems, exc, exs;
-  if (pre) {
-    if (p.row_stats) { ems = *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)m); ec = *reinterpret_cast<const float4*>(p.colsum + n); }
-    if (p.bias) eb = *reinterpret_cast<const float4*>(p.bias + n);
-    if (p.xpos_dim && n < 2 * p.xpos_dim) {
-      const bool isq = n < p.xpos_dim;
-      const int o = (m % p.xpos_T) * 32 + ((n & 63) >> 1);
-      exc = *reinterpret_cast<const float2*>((isq ? p.xq_cs : p.xk_cs) + o);
-      exs = *reinterpret_cast<const float2*>((isq ? p.xq_ss : p.xk_ss) + o);
-    }
-    if (p.residual) er = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n);
-  }
-  if (vec && p.splitk <= 8) {                                     // all slices in flight at once, summed in slice order
-    f32x4_t v[8];
-    const float* src = p.partial + (long long)m * p.N + n;
-    const long long zs = (long long)p.M * p.N;
-#pragma unroll
-    for (int z = 0; z < 8; ++z)
-      if (z < p.splitk) v[z] = *reinterpret_cast<const f32x4_t*>(src + z * zs);
-#pragma unroll
-    for (int z = 0; z < 8; ++z)
-      if (z < p.splitk) acc += v[z];
-  } else {
-    for (int z = 0; z < p.splitk; ++z) {
-      const float* src = p.partial + ((long long)z * p.M + m) * p.N + n;
-      if (vec) acc += *reinterpret_cast<const f32x4_t*>(src);
-      else for (int j = 0; j < 4; ++j) if (n + j < p.N) acc[j] += src[j];
-    }
+  for (int z = 0; z < p.splitk; ++z) {
+    const float* src = p.partial + ((long long)z * p.M + m) * p.N + n;
+    if (vec) acc += *reinterpret_cast<const f32x4_t*>(src);
+    else for (int j = 0; j < 4; ++j) if (n + j < p.N) acc[j] += src[j];
   }
   GemmParams q = p;
   q.splitk = 1;
-  if (!pre) { epilogue4<ACT>(q, m, n, acc); return; }
-  // epilogue_compute4's steps on the operands requested above
-  float x[4] = {acc[0], acc[1], acc[2], acc[3]};
-  if (p.row_stats) {
-    x[0] = ems.y * (x[0] - ems.x * ec.x); x[1] = ems.y * (x[1] - ems.x * ec.y);
-    x[2] = ems.y * (x[2] - ems.x * ec.z); x[3] = ems.y * (x[3] - ems.x * ec.w);
-  }
-  if (p.bias) { x[0] += eb.x; x[1] += eb.y; x[2] += eb.z; x[3] += eb.w; }
-  if (n < p.qcols) { x[0] *= p.qscale; x[1] *= p.qscale; x[2] *= p.qscale; x[3] *= p.qscale; }
-  if (p.xpos_dim && n < 2 * p.xpos_dim) {
-    const float y0 = x[0] * exc.x + (-x[1]) * exs.x;
-    const float y1 = x[1] * exc.x + x[0] * exs.x;
-    const float y2 = x[2] * exc.y + (-x[3]) * exs.y;
-    const float y3 = x[3] * exc.y + x[2] * exs.y;
-    x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;
-  }
-  if constexpr (ACT != KX_ACT_NONE) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = apply_act<ACT>(x[j]);
-  }
-  if (p.residual) { x[0] += er.x; x[1] += er.y; x[2] += er.z; x[3] += er.w; }
-  const long long off = (long long)m * p.ldc + n;
-  if (p.c_bf16) {
-    uint2 o; o.x = pack16(p, x[0], x[1]); o.y = pack16(p, x[2], x[3]);
-    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
-  } else {
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off) = make_float4(x[0], x[1], x[2], x[3]);
-  }
+  epilogue4<ACT>(q, m, n, acc);
 }
 
 // Row-owning variant of the reduce kernel: one workgroup per output row (N <= 8192: 8 float4 per thread).  Besides the
@@ -925,7 +871,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
   __shared__ float st[2];
   const int m = blockIdx.x, tid = threadIdx.x;
   auto bsum = [&](float v) {
-    v = wave_sum_dpp(v);
+    v = wave_sum(v);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
@@ -936,53 +882,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
   // The K-slice partials first: their loads depend on nothing, so they are in flight while the row statistics below go
   // through their two block reductions (the kernel is a chain of dependent round trips: 12 us per launch at 114 rows).
   // Slices are summed in slice order (deterministic), four loads in flight per 16-byte column group.
-  // Rows of <= 2048 columns in <= 8 slices (the decoder's and the tower's residual GEMMs at batch 1) go through ONE round
-  // trip: all 16 slice loads of a thread, the producer's statistics, colsum / bias / residual and gamma / beta of the
-  // LayerNorm that follows are requested before anything is waited for (the general path below waits four times for the
-  // slices alone, then once each for the epilogue operands and for gamma / beta: 9.5 us per launch, 22 % of the batch-1
-  // forward, profiles/r02_b_kernel_stats_b1_bf16.csv).
-  const bool fast = p.N <= 2048 && p.splitk <= 8 && (p.N & 3) == 0 && p.vec_ok && !p.xpos_dim && !(p.row_stats && !p.stats_partials);
   f32x4_t accs[8];
-  float4 ec[2], eb[2], er[2], lg[2], lb[2];
-  float2 sp0 = make_float2(0.f, 0.f);
-  if (fast) {
-    f32x4_t v[2][8];
-    const long long zs = (long long)p.M * p.N;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = 4 * (tid + 256 * j);
-      if (n < p.N) {
-        const float* src = p.partial + (long long)m * p.N + n;
-#pragma unroll
-        for (int z = 0; z < 8; ++z)
-          if (z < p.splitk) v[j][z] = *reinterpret_cast<const f32x4_t*>(src + z * zs);
-      }
-    }
-    if (p.stats_partials && tid < p.stats_in_nseg) sp0 = (reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg)[tid];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = 4 * (tid + 256 * j);
-      if (n < p.N) {
-        if (p.stats_partials) ec[j] = *reinterpret_cast<const float4*>(p.colsum + n);
-        if (p.bias) eb[j] = *reinterpret_cast<const float4*>(p.bias + n);
-        if (p.residual) er[j] = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n);
-        if (p.ln_out) { lg[j] = *reinterpret_cast<const float4*>(p.ln_out_g + n); lb[j] = *reinterpret_cast<const float4*>(p.ln_out_b + n); }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) accs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (4 * (tid + 256 * j) < p.N) {
-#pragma unroll
-        for (int z = 0; z < 8; ++z)
-          if (z < p.splitk) accs[j] += v[j][z];                  // slice order, as the general path
-      }
-    }
-  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (fast) break;
     const int n = 4 * (tid + 256 * j);
     accs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (n < p.N) {
@@ -999,23 +901,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
   }
   if (p.stats_partials) {
     const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
-    const bool one = fast && p.stats_in_nseg <= 256;            // this thread's partial is in sp0
     float sm = 0.f;
-    if (one) sm = sp0.x;
-    else for (int j = tid; j < p.stats_in_nseg; j += 256) sm += pr[j].x;
+    for (int j = tid; j < p.stats_in_nseg; j += 256) sm += pr[j].x;
     const float mean = bsum(sm) / (p.stats_in_seg * (float)p.stats_in_nseg);
     float m2 = 0.f;
-    if (one) {
-      if (tid < p.stats_in_nseg) {
-        const float d = sp0.x / p.stats_in_seg - mean;
-        m2 = sp0.y + p.stats_in_seg * d * d;
-      }
-    } else {
-      for (int j = tid; j < p.stats_in_nseg; j += 256) {
-        const float2 v = pr[j];
-        const float d = v.x / p.stats_in_seg - mean;
-        m2 += v.y + p.stats_in_seg * d * d;
-      }
+    for (int j = tid; j < p.stats_in_nseg; j += 256) {
+      const float2 v = pr[j];
+      const float d = v.x / p.stats_in_seg - mean;
+      m2 += v.y + p.stats_in_seg * d * d;
     }
     const float var = bsum(m2) / (p.stats_in_seg * (float)p.stats_in_nseg);
     if (tid == 0) { st[0] = mean; st[1] = rsqrtf(var + p.stats_eps); }
@@ -1031,23 +924,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
     if (n < p.N) {
       f32x4_t acc = accs[j];
       if (p.stats_partials) {                          // rstd * (acc - mean * colsum): first step of the epilogue
-        const float4 c = (fast && j < 2) ? ec[j & 1] : *reinterpret_cast<const float4*>(p.colsum + n);
+        const float4 c = *reinterpret_cast<const float4*>(p.colsum + n);
         const float mu = st[0], rs = st[1];
         acc[0] = rs * (acc[0] - mu * c.x); acc[1] = rs * (acc[1] - mu * c.y);
         acc[2] = rs * (acc[2] - mu * c.z); acc[3] = rs * (acc[3] - mu * c.w);
       }
-      if (fast && j < 2) {                             // epilogue_compute4's steps on the preloaded operands
-        x[j][0] = acc[0]; x[j][1] = acc[1]; x[j][2] = acc[2]; x[j][3] = acc[3];
-        if (p.bias) { x[j][0] += eb[j & 1].x; x[j][1] += eb[j & 1].y; x[j][2] += eb[j & 1].z; x[j][3] += eb[j & 1].w; }
-        if (n < p.qcols) { x[j][0] *= p.qscale; x[j][1] *= p.qscale; x[j][2] *= p.qscale; x[j][3] *= p.qscale; }
-        if constexpr (ACT != KX_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[j][e] = apply_act<ACT>(x[j][e]);
-        }
-        if (p.residual) { x[j][0] += er[j & 1].x; x[j][1] += er[j & 1].y; x[j][2] += er[j & 1].z; x[j][3] += er[j & 1].w; }
-      } else {
-        epilogue_compute4<ACT>(q, m, n, acc, x[j]);
-      }
+      epilogue_compute4<ACT>(q, m, n, acc, x[j]);
       const long long off = (long long)m * p.ldc + n;
       if (p.c_f16c) {
         f16c_store4(reinterpret_cast<char*>(p.C) + (long long)m * p.ldc * 2, n, p.N, x[j]);
@@ -1080,8 +962,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
   for (int j = 0; j < 8; ++j) {
     const int n = 4 * (tid + 256 * j);
     if (n >= p.N) continue;
-    const float4 gm = (fast && j < 2) ? lg[j & 1] : *reinterpret_cast<const float4*>(p.ln_out_g + n);
-    const float4 bt = (fast && j < 2) ? lb[j & 1] : *reinterpret_cast<const float4*>(p.ln_out_b + n);
+    const float4 gm = *reinterpret_cast<const float4*>(p.ln_out_g + n), bt = *reinterpret_cast<const float4*>(p.ln_out_b + n);
     const float o0 = (x[j][0] - mean) * rstd * gm.x + bt.x, o1 = (x[j][1] - mean) * rstd * gm.y + bt.y;
     const float o2 = (x[j][2] - mean) * rstd * gm.z + bt.z, o3 = (x[j][3] - mean) * rstd * gm.w + bt.w;
     if (p.ln_out_dt == KX_F16C) {
