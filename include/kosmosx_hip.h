@@ -501,7 +501,10 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  * key 5: phased GEMM kernels skip the MFMAs of waves whose rows are all beyond M (0 on, 1 off);
  * key 6: kx_clip_preprocess reads its taps from global memory instead of the LDS-staged row (0 auto, 1 force);
  * key 7: the 256-column GEMM kernel is launched persistently, each workgroup walking its own tiles (0 = one workgroup
- *        per CU, n > 0 = n workgroups, -1 = one workgroup per tile). */
+ *        per CU, n > 0 = n workgroups, -1 = one workgroup per tile);
+ * key 8: tile-16 weight-streaming kernel (0 = second form: small loads first, counted waits, one-barrier LayerNorm
+ *        prologue, 16 KB per wave in flight for K slices of 512; 1 = the first form; 2 = second form without the
+ *        16 KB variant). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------
