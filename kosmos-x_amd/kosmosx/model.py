@@ -192,15 +192,18 @@ def _begin_token_id_check(tokens: torch.Tensor, vocab: int):
     mm = torch.empty(2, dtype=torch.int64, device=dev)
     H.check(H.load().kx_token_range(tokens.data_ptr(), tokens.numel(), mm.data_ptr(), _stream()), "kx_token_range")
     slot = _PINNED_RANGE.get(dev)
-    if slot is None:
-        slot = _PINNED_RANGE[dev] = (torch.empty(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
-    host, ev = slot
+    if slot is None or slot[2]:                      # (a check still open on this device, e.g. another thread: its own buffer)
+        slot = [torch.empty(2, dtype=torch.int64).pin_memory(), torch.cuda.Event(), False]
+        _PINNED_RANGE.setdefault(dev, slot)
+    host, ev = slot[0], slot[1]
+    slot[2] = True
     host.copy_(mm, non_blocking=True)
     ev.record(torch.cuda.current_stream(dev))
 
     def finish():
         ev.synchronize()
         lo, hi = host.tolist()
+        slot[2] = False
         if lo < 0 or hi >= vocab:
             msg = f"index out of range in self: token id {hi if hi >= vocab else lo} outside the {vocab}-row embedding table"
             logging.error(msg)
