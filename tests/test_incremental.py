@@ -77,3 +77,60 @@ def test_decode_step_on_streaming_layout_weights_is_bitwise_the_row_major_step(B
         w = lm.decoder._pack("bf16")[0]
         assert bool(w.wout_t) == (tiled == "1") and bool(w.layer[0].w1_t) == (tiled == "1")
     assert all(torch.equal(a, b) for a, b in zip(outs["0"], outs["1"]))
+
+
+@pytest.mark.gpu
+def test_decode_step_with_an_out_of_range_token_raises_and_leaves_the_state_usable():
+    """The token-id check of a decode step is read back AFTER the step has been enqueued (the host stays one step ahead of
+    the device).  An id outside the table must still surface as the reference's IndexError from that very call, the
+    position must not advance, and the next valid call must rewrite the cache row and continue as if nothing happened."""
+    lm = _lm(seed=8).to("cuda")
+    lm.precision = "fp32"
+    tok = torch.randint(0, 502, (2, 20), generator=torch.Generator().manual_seed(4)).cuda()
+    ref_state, state = {}, {}
+    lm(tok[:, :9], incremental_state=ref_state)
+    lm(tok[:, :9], incremental_state=state)
+    want = [lm(tok[:, : t + 1], incremental_state=ref_state).clone() for t in range(9, 14)]
+    got = [lm(tok[:, : t + 1], incremental_state=state).clone() for t in range(9, 11)]
+    bad = tok[:, :12].clone()
+    bad[1, -1] = 502                                           # one past the last row
+    with pytest.raises(IndexError, match="index out of range"):
+        lm(bad, incremental_state=state)
+    assert state["len"] == 11
+    bad[1, -1] = -1
+    with pytest.raises(IndexError, match="index out of range"):
+        lm(bad, incremental_state=state)
+    assert state["len"] == 11
+    got += [lm(tok[:, : t + 1], incremental_state=state).clone() for t in range(11, 14)]
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 7])
+def test_decode_step_second_form_of_the_streaming_kernel_matches_the_first(B):
+    """kx_set_tuning(8, 1) runs the first form of the tile-16 kernel (loads in program order, two-pass LayerNorm prologue
+    with xor-butterfly sums); the default second form issues the small loads first and reduces with Chan's formula and
+    DPP sums.  Same products in the same order: only the fp32 statistics differ, by rounding — logits agree to 1e-5 of
+    their rms in fp32-accumulated bf16 arithmetic, and the first token (no statistics involved beyond them) bit for bit
+    when no LayerNorm prologue runs is covered by test_ops_gpu."""
+    from kosmosx import _hip
+    tok = torch.randint(0, 502, (B, 26), generator=torch.Generator().manual_seed(5)).cuda()
+    outs = {}
+    try:
+        for form in (1, 0, 2):
+            _hip.load().kx_set_tuning(8, form)
+            lm = _lm(seed=9).to("cuda")
+            lm.precision = "bf16"
+            st = {}
+            lm(tok[:, :9], incremental_state=st)
+            outs[form] = torch.cat([lm(tok[:, : t + 1], incremental_state=st) for t in range(9, 26)], 1)
+    finally:
+        _hip.load().kx_set_tuning(8, 0)
+    # bf16 operands: a statistic that moves by one fp32 ulp can flip the bf16 rounding of an operand element, and the flip
+    # travels through the layers and the KV cache — the two forms sit as far from each other as each sits from the oracle's
+    # fp32 forward, well inside the bf16 mode's bound
+    ref = O.kosmos_language_forward(oracle_weights(_lm(seed=9)), tok.cpu(), CFG)[:, 9:26]
+    for form in (0, 1):
+        assert rel_err(outs[form], ref) < 6e-2, form
+    assert rel_err(outs[0], outs[1].cpu()) < 3e-2
+    assert torch.equal(outs[0], outs[2])                      # (the 16 KB variant only applies to K slices of 512: not at this size)
