@@ -447,6 +447,9 @@ def main():
                       "ms_per_token": round(dts * 1e3, 3), "tokens_per_s": round(1.0 / dts, 1),
                       "roofline": {"bound": "hbm", "achieved": round(wb / dts / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(wb / dts / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": wb,
+                                   "traffic": 2.612e9, "traffic_unit": "bytes/step",
+                                   "traffic_source": "profiles/r02_d_decode_pmc_summary.md (committed FETCH_SIZE pass of "
+                                                     "tools/bench_decode.py, x2 gfx950 correction; not this run)",
                                    "note": "decoder weights + KV cache streamed once per token"}}
             del lm, state
             torch.cuda.empty_cache()

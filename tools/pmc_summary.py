@@ -7,7 +7,7 @@ from pathlib import Path
 root = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc")
 
 def short(name):
-    m = re.search(r"(gemm_kernel_p\d|gemm_kernel|attn_bf16_v2_kernel|attn_\w+_kernel|layernorm\w*_kernel|splitk_reduce_kernel|gemv_fused_kernel|"
+    m = re.search(r"(gemm_kernel_p\d|gemm_kernel|attn_bf16_v2_kernel|attn_\w+_kernel|layernorm\w*_kernel|splitk_reduce_rows_kernel|splitk_reduce_kernel|gemv_fused_kernel2|gemv_fused_kernel|"
                   r"row_stats_finalize_kernel|embed_splice_kernel|patchify_kernel|vit_assemble_kernel)(<[^>]*>)?", name)
     if not m:
         return None
