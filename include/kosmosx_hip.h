@@ -340,7 +340,9 @@ int kx_decoder_forward(const kx_decoder_weights* w, float* x, int64_t B, int64_t
  * MultiheadAttention's prev_key / prev_value path).  Not exercised by the reference's own call
  * (/root/reference/kosmosx/model.py:250 passes no incremental_state); built as the next row after the forward.
  *
- * Caches: kcache / vcache [layers, B, Tmax, dim] in the operand dtype of `prec`.  Keys are stored AFTER the XPos
+ * Caches: kcache / vcache, layers x B x Tmax x dim values in the operand dtype of `prec`, opaque to the caller (written
+ * by the prefill and the steps, read by the steps; per layer and sequence [heads][Tmax][64]: a head's keys are contiguous).
+ * Keys are stored AFTER the XPos
  * rotation/scale (torchscale stores them before and re-rotates the whole cache every step; the score only depends
  * on i − m and the centring constant cancels), so the tables passed to the prefill and to every
  * decode step must share ONE centring: build [Tmax, 32] tables once with min_pos of the prefill length.
@@ -504,7 +506,9 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  *        per CU, n > 0 = n workgroups, -1 = one workgroup per tile);
  * key 8: tile-16 weight-streaming kernel (0 = second form: small loads first, counted waits, one-barrier LayerNorm
  *        prologue, 16 KB per wave in flight for K slices of 512; 1 = the first form; 2 = second form without the
- *        16 KB variant). */
+ *        16 KB variant);
+ * key 9: KV-cache layout per layer and sequence (0 = [heads][Tmax][64]; 1 = the first layout [Tmax][heads*64]; set it
+ *        before a prefill and keep it for that cache's steps). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

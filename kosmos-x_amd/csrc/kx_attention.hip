@@ -967,7 +967,7 @@ namespace {
 struct DecodeParams {
   const char* qkv; long long qkv_row;        // [B, 3*D] rows: q | k | v of the new token (elements)
   char* kcache; char* vcache;                // [B, Tmax, D]
-  long long cache_batch, cache_row;          // element strides
+  long long cache_batch, cache_head, cache_row;   // element strides (head-major cache: head = Tmax*64, row = 64)
   void* out; long long out_row; int o_bf16, o_f16c;  // [B, D] (o_f16c: KX_F16C rows of D values, out_row in 2-byte units)
   float* stats_out;                          // [B, H, 2] or null
   int H, D, t;                               // t = number of tokens already cached (the new one goes to row t)
@@ -1003,8 +1003,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
   const int h = blockIdx.x, b = blockIdx.y;
   const long long es = sizeof(T);
   const char* qrow = p.qkv + ((long long)b * p.qkv_row + (long long)h * 64 + 4 * li) * es;
-  char* kc = p.kcache + ((long long)b * p.cache_batch + (long long)h * 64 + 4 * li) * es;
-  char* vc = p.vcache + ((long long)b * p.cache_batch + (long long)h * 64 + 4 * li) * es;
+  char* kc = p.kcache + ((long long)b * p.cache_batch + (long long)h * p.cache_head + 4 * li) * es;
+  char* vc = p.vcache + ((long long)b * p.cache_batch + (long long)h * p.cache_head + 4 * li) * es;
   const char* knew = qrow + (long long)p.D * es;          // the new token (key t): k | v of the qkv row
   const char* vnew = qrow + 2ll * p.D * es;
   const int nkeys = p.t + 1;
@@ -1087,15 +1087,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
 // prefill: copy the k and v column blocks of the fused qkv rows [B*T, 3D] into the caches [B, Tmax, D]
 template <typename T>
 __global__ __launch_bounds__(256) void kv_prefill_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
-                                                         int Tlen, int D, long long cache_batch) {
+                                                         int Tlen, int D, long long cache_batch, long long cache_head,
+                                                         long long cache_row) {
   const long long row = blockIdx.x;                       // b*T + t
   const long long b = row / Tlen, t = row % Tlen;
   const uint4* src = reinterpret_cast<const uint4*>(qkv + row * 3 * D);
   constexpr int EPV = 16 / sizeof(T);
   const int nv = D / EPV;
-  uint4* dk = reinterpret_cast<uint4*>(kc + b * cache_batch + t * D);
-  uint4* dv = reinterpret_cast<uint4*>(vc + b * cache_batch + t * D);
-  for (int c = threadIdx.x; c < nv; c += 256) { dk[c] = src[nv + c]; dv[c] = src[2 * nv + c]; }
+  for (int c = threadIdx.x; c < nv; c += 256) {           // 16-byte chunk c = head (c*EPV)/64, dims (c*EPV)%64 ...
+    const long long col = (long long)c * EPV;
+    const long long off = b * cache_batch + (col >> 6) * cache_head + t * cache_row + (col & 63);
+    *reinterpret_cast<uint4*>(kc + off) = src[nv + c];
+    *reinterpret_cast<uint4*>(vc + off) = src[2 * nv + c];
+  }
 }
 
 }  // namespace
@@ -1103,12 +1107,14 @@ __global__ __launch_bounds__(256) void kv_prefill_kernel(const T* __restrict__ q
 int kx_launch_kv_prefill(const void* qkv, void* kc, void* vc, int64_t B, int64_t T, int64_t D, int64_t Tmax, int prec,
                          hipStream_t s) {
   KxProfScope prof(KX_K_MISC, B * T, D, 4, s);
+  const bool head_major = kx_tuning_get(KX_TUNE_CACHE_LAYOUT) != 1;
+  const long long ch = head_major ? Tmax * 64 : 64, cr = head_major ? 64 : D;
   if (prec == KX_PREC_BF16)
     hipLaunchKernelGGL(kv_prefill_kernel<bf16_t>, dim3((unsigned)(B * T)), dim3(256), 0, s, (const bf16_t*)qkv,
-                       (bf16_t*)kc, (bf16_t*)vc, (int)T, (int)D, (long long)(Tmax * D));
+                       (bf16_t*)kc, (bf16_t*)vc, (int)T, (int)D, (long long)(Tmax * D), ch, cr);
   else
     hipLaunchKernelGGL(kv_prefill_kernel<float>, dim3((unsigned)(B * T)), dim3(256), 0, s, (const float*)qkv, (float*)kc,
-                       (float*)vc, (int)T, (int)D, (long long)(Tmax * D));
+                       (float*)vc, (int)T, (int)D, (long long)(Tmax * D), ch, cr);
   KX_CHECK_LAUNCH("kv_prefill");
   return KX_OK;
 }
@@ -1125,7 +1131,11 @@ extern "C" int kx_attention_decode(const void* qkv, void* kcache, void* vcache, 
   DecodeParams p;
   const int64_t D = H * 64;
   p.qkv = (const char*)qkv; p.qkv_row = 3 * D;
-  p.kcache = (char*)kcache; p.vcache = (char*)vcache; p.cache_batch = Tmax * D; p.cache_row = D;
+  // per sequence [H][Tmax][64] (a head's keys contiguous: one 128-byte line after the other) — tuning key 9 = 1 keeps the
+  // first layout [Tmax][H*64], whose keys of one head sit 4 KB apart
+  const bool head_major = kx_tuning_get(KX_TUNE_CACHE_LAYOUT) != 1;
+  p.kcache = (char*)kcache; p.vcache = (char*)vcache; p.cache_batch = Tmax * D;
+  p.cache_head = head_major ? Tmax * 64 : 64; p.cache_row = head_major ? 64 : D;
   p.out = out; p.out_row = odt == KX_F16C ? 2 * D : D; p.o_bf16 = odt == KX_BF16; p.o_f16c = odt == KX_F16C; p.stats_out = stats_out;
   p.H = (int)H; p.D = (int)D; p.t = (int)t;
   hipStream_t s = (hipStream_t)stream;

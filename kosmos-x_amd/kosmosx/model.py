@@ -771,8 +771,9 @@ class Decoder(_PackedMixin, nn.Module):
             if T > Tmax:
                 raise IndexError(f"index out of range in self: {T} tokens exceed the {Tmax}-row cache")
             dt = torch.float32 if prec in ("fp32", "f16c") else _prec_dtype(prec)   # q/k/v-typed cache
-            state["kcache"] = torch.empty((L, B, Tmax, D), dtype=dt, device=x.device)
-            state["vcache"] = torch.empty((L, B, Tmax, D), dtype=dt, device=x.device)
+            nh = D // 64                                       # opaque to the caller; the kernels keep [heads][Tmax][64] per sequence
+            state["kcache"] = torch.empty((L, B, nh, Tmax, 64), dtype=dt, device=x.device)
+            state["vcache"] = torch.empty((L, B, nh, Tmax, 64), dtype=dt, device=x.device)
             xp = self.layers[0].self_attn.xpos
             if xp is not None:
                 q = xp.tables_centred(Tmax, T, False)
