@@ -290,10 +290,10 @@ def main():
                 st.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(st):
                     logits = forward_shard()
-                    return gatherer.gather(logits) if gatherer is not None else logits
+                    return gatherer.gather(logits, total=B * world) if gatherer is not None else logits
             logits = forward_shard()
             if gatherer is not None:
-                return gatherer.gather(logits)
+                return gatherer.gather(logits, total=B * world)
             return logits
 
     def fence():
@@ -541,9 +541,8 @@ def main():
                                   f"batch 1, {t_cpu:.1f} s"}
 
     if rank == 0:
-        from oracle.kosmos_oracle import flops_per_sample
-        from helpers import oracle_cfg
-        fl = flops_per_sample(oracle_cfg(cfg), Tt)
+        from kosmosx.accounting import flops_per_sample
+        fl = flops_per_sample(cfg, Tt)
         total = world * B * args.steps
         line = {
             "metric": "multimodal forward samples/sec (224x224 img + 50 tok) @ 24L/2048d",
@@ -555,7 +554,7 @@ def main():
                                    "24L/2048d sub-LN XPos decoder, random-init weights (BASELINE.json configs[3] per-GPU share)",
                        "batch_per_gpu": B, "global_batch": world * B, "seq_len": Tt + cfg.perceiver.latents,
                        "text_len": Tt, "parallelism": f"dp{world}",
-                       "logits_gather": (None if gatherer is None else f"RCCL {args.gather_algo}, bf16 logits straight from the GEMM epilogue, "
+                       "logits_gather": (None if gatherer is None else f"RCCL {gatherer.last_algo} (requested: {args.gather_algo}), bf16 logits straight from the GEMM epilogue, "
                                                                "issued on a side stream (overlaps the next step)"),
                        "micro_batch_streams": S, "pipelined_steps": P, "hip_graph": bool(args.graph)},
             "algorithmic_gflop_per_sample": round(fl["total"] / 1e9, 2),

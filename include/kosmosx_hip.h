@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KX_ABI_VERSION 4
+#define KX_ABI_VERSION 5
 
 typedef enum {
   KX_OK = 0,
@@ -232,7 +232,22 @@ int kx_token_range(const int64_t* tokens, int64_t n, int64_t* out2, void* stream
  * Stage-level entry points (what kosmosx.model calls).  Weight structs hold device pointers
  * to tensors packed by the Python side from the reference's state_dict key namespace
  * (SURVEY.md §8b); `w*` GEMM operands are in the dtype of `prec`, everything else fp32.
+ *
+ * Binding safety (ABI 5).  The structs below grow at the end from one ABI version to the next, and the per-layer structs
+ * are walked as ARRAYS: a binding written against an older header would make the library index `layer[i]` with the wrong
+ * stride and read pointers out of the neighbouring element (round 2's INTEGRATION.md example did exactly that).  Every
+ * weights struct therefore starts with the two sizes the CALLER's declaration has — struct_bytes = sizeof(kx_*_weights),
+ * layer_bytes = sizeof(kx_*_layer) — and every stage entry point returns KX_ERR_INVALID_ARG ("stale binding") before
+ * touching anything else when they differ from the library's own.  kx_struct_bytes() reports the library's sizes so a
+ * binding can assert its mirrors at import time.
  * ---------------------------------------------------------------------------------------- */
+typedef enum {
+  KX_STRUCT_GEMM_ARGS = 0, KX_STRUCT_ATTN_ARGS = 1, KX_STRUCT_VIT_LAYER = 2, KX_STRUCT_VIT_WEIGHTS = 3,
+  KX_STRUCT_PERCEIVER_LAYER = 4, KX_STRUCT_PERCEIVER_WEIGHTS = 5, KX_STRUCT_DECODER_LAYER = 6,
+  KX_STRUCT_DECODER_WEIGHTS = 7, KX_STRUCT_RESAMPLE_PLAN = 8, KX_STRUCT_PROF_RECORD = 9, KX_STRUCT_COUNT = 10
+} kx_struct_id;
+/* sizeof() of the struct as this library was compiled; 0 for an unknown id.  Pure host arithmetic. */
+size_t kx_struct_bytes(int32_t id);
 typedef struct {
   const float *ln1_g, *ln1_b;                 /* layer_norm1 */
   const void* wqkv; const float* bqkv;        /* cat(q_proj,k_proj,v_proj) [3d,d] */
@@ -249,6 +264,7 @@ typedef struct {
 } kx_vit_layer;
 
 typedef struct {
+  uint32_t struct_bytes, layer_bytes;         /* = sizeof(kx_vit_weights), sizeof(kx_vit_layer) AS THE CALLER DECLARES THEM (below) */
   int32_t image, patch, dim, heads, ffn, layers, act; float eps;
   int32_t kpad;                               /* padded im2col K (multiple of 64) */
   const void* wpatch;                         /* [dim, kpad]  (conv weight flattened c,ky,kx, zero padded) */
@@ -273,6 +289,7 @@ typedef struct {
 } kx_perceiver_layer;
 
 typedef struct {
+  uint32_t struct_bytes, layer_bytes;         /* = sizeof(kx_perceiver_weights), sizeof(kx_perceiver_layer) of the caller */
   int32_t dim, depth, heads, latents, ff_mult, out_dim; float eps;
   const float* latents_p;                     /* perceive.latents [latents, dim] */
   const float* media_pos;                     /* perceive.media_pos_emb[0,0,:] [dim] */
@@ -315,6 +332,7 @@ typedef struct {
 } kx_decoder_layer;
 
 typedef struct {
+  uint32_t struct_bytes, layer_bytes;         /* = sizeof(kx_decoder_weights), sizeof(kx_decoder_layer) of the caller */
   int32_t layers, dim, heads, ffn, vocab, act, subln, xpos; float eps;
   const kx_decoder_layer* layer;              /* host array [layers] */
   const float *ln_g, *ln_b;                   /* decoder.layer_norm */

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
 __device__ __forceinline__ void split_f16x8(const float (&x)[8], u32x4_t& hi, u32x4_t& lo) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const kx_f16x2_t h = __builtin_convertvector((kx_f32x2_t){x[2 * j], x[2 * j + 1]}, kx_f16x2_t);
+    const kx_f16x2_t h = __builtin_convertvector((kx_f32x2_t){clamp_f16(x[2 * j]), clamp_f16(x[2 * j + 1])}, kx_f16x2_t);
     hi[j] = __builtin_bit_cast(unsigned, h);
     lo[j] = pack_f16x2(x[2 * j] - (float)h[0], x[2 * j + 1] - (float)h[1]);
   }
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
     if (p.o_f16c) {                                   // [fp16 | fp8 | fp8 residual] planes of the row, one value per lane
       char* row = reinterpret_cast<char*>(p.out) + (long long)b * p.out_row * 2;
       const long long n = (long long)h * 64 + lane, D = p.D;
-      const _Float16 hv = (_Float16)ov;
+      const _Float16 hv = (_Float16)clamp_f16(ov);
       reinterpret_cast<_Float16*>(row)[n] = hv;
       reinterpret_cast<unsigned char*>(row + 2 * D)[n] = (unsigned char)(pack_fp8x4(ov, 0.f, 0.f, 0.f) & 0xffu);
       reinterpret_cast<unsigned char*>(row + 3 * D)[n] = (unsigned char)(pack_fp8x4((ov - (float)hv) * 2048.0f, 0.f, 0.f, 0.f) & 0xffu);

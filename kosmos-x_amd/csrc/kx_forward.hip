@@ -165,7 +165,8 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   if (f16c) g.w_scale = (const uint8_t*)W + (size_t)N * (size_t)K * 4;
   g.act = act; g.qscale = qscale; g.qcols = qcols;
   g.xq_cs = xq_cs; g.xq_ss = xq_ss; g.xk_cs = xk_cs; g.xk_ss = xk_ss; g.xpos_T = xT; g.xpos_dim = xdim;
-  g.prec = km == 3 ? KX_PREC_BF16 : prec;   // bf16x3 runs the bf16 kernels over 3K g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
+  g.prec = km == 3 ? KX_PREC_BF16 : prec;   // bf16x3 runs the bf16 kernels over 3K
+  g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
   g.row_stats = row_stats; g.colsum = colsum; g.stats_out = stats_out;
   g.splitk_ws = g_splitk_ws; g.splitk_ws_bytes = g_splitk_ws_bytes; g.splitk = 0;
   if (rf) {
@@ -214,6 +215,32 @@ int gemv16(const Gemv16& v, hipStream_t s) {
 int ln(const float* x, const float* pre, const float* g, const float* b, void* y, int ydt, int64_t rows, int64_t cols,
        float eps, hipStream_t s, int64_t rpg = 0, int64_t ogs = 0, int64_t oro = 0) {
   return kx_layernorm(x, pre, g, b, y, (kx_dtype)ydt, rows, cols, eps, rpg ? rpg : rows, ogs, oro, (void*)s);
+}
+
+// Binding guard (header, "Binding safety"): the caller's sizeof() of the weights struct and of its per-layer struct
+#define KX_CHECK_BINDING(w, WT, LT, fn)                                                                                   \
+  KX_REQUIRE((w)->struct_bytes == sizeof(WT) && (w)->layer_bytes == sizeof(LT),                                           \
+             fn ": stale binding — caller declares " #WT " as %u bytes with %u-byte " #LT " elements, this library (ABI %d) " \
+             "has %zu / %zu; regenerate the binding from include/kosmosx_hip.h",                                          \
+             (unsigned)(w)->struct_bytes, (unsigned)(w)->layer_bytes, KX_ABI_VERSION, sizeof(WT), sizeof(LT))
+template <class WT, class LT> static bool binding_ok(const WT* w) {
+  return w && w->struct_bytes == sizeof(WT) && w->layer_bytes == sizeof(LT);
+}
+
+extern "C" size_t kx_struct_bytes(int32_t id) {
+  switch (id) {
+    case KX_STRUCT_GEMM_ARGS: return sizeof(kx_gemm_args);
+    case KX_STRUCT_ATTN_ARGS: return sizeof(kx_attn_args);
+    case KX_STRUCT_VIT_LAYER: return sizeof(kx_vit_layer);
+    case KX_STRUCT_VIT_WEIGHTS: return sizeof(kx_vit_weights);
+    case KX_STRUCT_PERCEIVER_LAYER: return sizeof(kx_perceiver_layer);
+    case KX_STRUCT_PERCEIVER_WEIGHTS: return sizeof(kx_perceiver_weights);
+    case KX_STRUCT_DECODER_LAYER: return sizeof(kx_decoder_layer);
+    case KX_STRUCT_DECODER_WEIGHTS: return sizeof(kx_decoder_weights);
+    case KX_STRUCT_RESAMPLE_PLAN: return sizeof(kx_resample_plan);
+    case KX_STRUCT_PROF_RECORD: return sizeof(kx_prof_record);
+    default: return 0;
+  }
 }
 
 // ---------------- ViT ----------------
@@ -283,12 +310,14 @@ DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, ch
 }  // namespace
 
 extern "C" size_t kx_vit_workspace_bytes(const kx_vit_weights* w, int64_t B, int32_t prec) {
-  return w ? vit_plan(w, B, prec, nullptr).total : 0;
+  if (!binding_ok<kx_vit_weights, kx_vit_layer>(w)) { kx_set_error("kx_vit_workspace_bytes: null or stale binding (struct_bytes / layer_bytes)"); return 0; }
+  return vit_plan(w, B, prec, nullptr).total;
 }
 
 extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int64_t B, float* out, void* workspace,
                               size_t workspace_bytes, int32_t prec, void* stream) {
   KX_REQUIRE(w && pixels && out && workspace, "kx_vit_forward: null pointer");
+  KX_CHECK_BINDING(w, kx_vit_weights, kx_vit_layer, "kx_vit_forward");
   KX_REQUIRE(B > 0, "kx_vit_forward: empty batch");
   KX_REQUIRE(w->dim == w->heads * 64, "kx_vit_forward: head_dim must be 64 (dim=%d heads=%d)", w->dim, w->heads);
   KX_REQUIRE(w->image % w->patch == 0 && w->kpad >= 3 * w->patch * w->patch && w->kpad % 64 == 0,
@@ -354,13 +383,15 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
 }
 
 extern "C" size_t kx_perceiver_workspace_bytes(const kx_perceiver_weights* w, int64_t B, int64_t m, int32_t prec) {
-  return w ? per_plan(w, B, m, prec, nullptr).total : 0;
+  if (!binding_ok<kx_perceiver_weights, kx_perceiver_layer>(w)) { kx_set_error("kx_perceiver_workspace_bytes: null or stale binding (struct_bytes / layer_bytes)"); return 0; }
+  return per_plan(w, B, m, prec, nullptr).total;
 }
 
 extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* x, int64_t B, int64_t m, float* out,
                                     float* lat_out, void* workspace, size_t workspace_bytes, int32_t prec,
                                     void* stream) {
   KX_REQUIRE(w && x && workspace, "kx_perceiver_forward: null pointer");
+  KX_CHECK_BINDING(w, kx_perceiver_weights, kx_perceiver_layer, "kx_perceiver_forward");
   KX_REQUIRE((out && w->wproj && w->out_dim > 0) || lat_out, "kx_perceiver_forward: nothing to produce");
   KX_REQUIRE(B > 0 && m > 0, "kx_perceiver_forward: empty input");
   KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_perceiver_forward: workspace must be 256-byte aligned");
@@ -406,7 +437,8 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
 }
 
 extern "C" size_t kx_decoder_workspace_bytes(const kx_decoder_weights* w, int64_t B, int64_t T, int32_t prec) {
-  return w ? dec_plan(w, B, T, prec, nullptr).total : 0;
+  if (!binding_ok<kx_decoder_weights, kx_decoder_layer>(w)) { kx_set_error("kx_decoder_workspace_bytes: null or stale binding (struct_bytes / layer_bytes)"); return 0; }
+  return dec_plan(w, B, T, prec, nullptr).total;
 }
 
 static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B, int64_t T, const float* xq_cs,
@@ -414,6 +446,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
                                 void* workspace, size_t workspace_bytes, int32_t prec, void* stream, void* kcache,
                                 void* vcache, int64_t Tmax) {
   KX_REQUIRE(w && x && logits && workspace, "kx_decoder_forward: null pointer");
+  KX_CHECK_BINDING(w, kx_decoder_weights, kx_decoder_layer, "kx_decoder_forward");
   KX_REQUIRE(!kcache == !vcache, "kx_decoder_prefill: kcache and vcache must be given together");
   KX_REQUIRE(!kcache || (prec != KX_PREC_BF16X3 && prec != KX_PREC_F16),
              "kx_decoder_prefill: incremental decoding is offered in bf16, fp32 and f16c (fp32 cache)");
@@ -551,6 +584,7 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
                                       void* vcache, int64_t Tmax, void* logits, int32_t ldt, void* workspace,
                                       size_t workspace_bytes, int32_t prec, void* stream) {
   KX_REQUIRE(w && x && logits && workspace && kcache && vcache, "kx_decoder_decode_step: null pointer");
+  KX_CHECK_BINDING(w, kx_decoder_weights, kx_decoder_layer, "kx_decoder_decode_step");
   KX_REQUIRE(prec != KX_PREC_BF16X3 && prec != KX_PREC_F16,
              "kx_decoder_decode_step: incremental decoding is offered in bf16, fp32 and f16c (fp32 cache)");
   KX_REQUIRE(B > 0 && t >= 0 && t < Tmax, "kx_decoder_decode_step: position %lld outside the cache of %lld rows",

@@ -65,7 +65,7 @@ __device__ __forceinline__ unsigned pack16(const GemmParams& p, float lo, float 
   return p.c_f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi);
 }
 __device__ __forceinline__ bf16_t cvt16(const GemmParams& p, float x) {
-  return p.c_f16 ? __builtin_bit_cast(bf16_t, (_Float16)x) : f32_to_bf16(x);
+  return p.c_f16 ? __builtin_bit_cast(bf16_t, (_Float16)clamp_f16(x)) : f32_to_bf16(x);
 }
 
 // Everything of the fused epilogue except the store: x[0..3] = columns n..n+3 of row m (in range: m < M, n < N).

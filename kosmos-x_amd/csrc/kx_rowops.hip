@@ -242,13 +242,13 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     if constexpr (sizeof(T) == 2) {
       if (fmt == 2) {                             // KX_F16C row: [fp16(kpad) | fp8(kpad) | fp8 residual(kpad)]
         char* pr = reinterpret_cast<char*>(patches) + prow * 4ll * kpad;
-        const _Float16 h = (_Float16)v;
+        const _Float16 h = (_Float16)clamp_f16(v);
         reinterpret_cast<_Float16*>(pr)[k] = h;
         const unsigned e = pack_fp8x4(v, 0.f, 0.f, 0.f), r = pack_fp8x4((v - (float)h) * 2048.0f, 0.f, 0.f, 0.f);
         reinterpret_cast<unsigned char*>(pr + 2ll * kpad)[k] = (unsigned char)(e & 0xffu);
         reinterpret_cast<unsigned char*>(pr + 3ll * kpad)[k] = (unsigned char)(r & 0xffu);
       } else if (fmt == 3) {                      // KX_F16
-        patches[prow * kpad + k] = __builtin_bit_cast(bf16_t, (_Float16)v);
+        patches[prow * kpad + k] = __builtin_bit_cast(bf16_t, (_Float16)clamp_f16(v));
       } else if (fmt == 1) {                      // KX_BF16X3 row: [hi(kpad) | hi(kpad) | lo(kpad)]
         const bf16_t hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
         T* pr = patches + prow * 3ll * kpad;

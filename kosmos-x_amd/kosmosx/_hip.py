@@ -13,7 +13,7 @@ from pathlib import Path
 
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
-ABI_VERSION = 4   # KX_ABI_VERSION of include/kosmosx_hip.h
+ABI_VERSION = 5   # KX_ABI_VERSION of include/kosmosx_hip.h
 
 KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16 = 0, 1, 2, 3, 4
 KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16 = 0, 1, 2, 3, 4
@@ -26,10 +26,16 @@ PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32, "bf16x3": KX_PREC_BF16X3, "f
 MODEL_PRECS = list(PRECS) + ["mixed"]
 
 
-def stage_precision(prec: str, stage: str) -> str:
-    """The arithmetic a stage ("vit", "perceiver", "decoder") runs in under the model-level mode `prec`."""
+def stage_precision(prec: str, stage: str, widths=()) -> str:
+    """The arithmetic a stage ("vit", "perceiver", "decoder") runs in under the model-level mode `prec`.
+    `widths`: the K extents of the stage's GEMMs.  f16c operand rows are built from 128-element fp8 blocks, so a stage
+    whose widths are multiples of 64 but not of 128 (dim = 192, 320, ...) cannot run it; under the DEFAULT mode ("mixed")
+    such a stage runs bf16x3 — the other arithmetic inside the 1e-3 bound — instead of failing at the first forward
+    (ADVICE r2).  An explicit "f16c" still raises (model._operand_f16c names the remedy)."""
     if prec == "mixed":
-        return "f16" if stage == "vit" else "f16c"
+        if stage == "vit":
+            return "f16"
+        return "bf16x3" if any(int(k) % 128 for k in widths) else "f16c"
     return prec
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -63,8 +69,20 @@ class VitLayer(C.Structure):
                                   "w1", "b1", "w2", "b2", "wqkv_f", "bqkv_f", "wqkv_colsum", "w1_f", "b1_f", "w1_colsum")]
 
 
-class VitWeights(C.Structure):
-    _fields_ = [("image", i32), ("patch", i32), ("dim", i32), ("heads", i32), ("ffn", i32), ("layers", i32),
+class _SizedWeights(C.Structure):
+    """Weights structs open with the caller's sizeof() of the struct and of its per-layer element (header: "Binding
+    safety"); the mirrors fill them in at construction so a mirror that falls behind the header fails with
+    KX_ERR_INVALID_ARG instead of being walked with the wrong stride."""
+    _layer_cls = None
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_bytes, self.layer_bytes = C.sizeof(type(self)), C.sizeof(self._layer_cls)
+
+
+class VitWeights(_SizedWeights):
+    _layer_cls = VitLayer
+    _fields_ = [("struct_bytes", C.c_uint32), ("layer_bytes", C.c_uint32), ("image", i32), ("patch", i32), ("dim", i32), ("heads", i32), ("ffn", i32), ("layers", i32),
                 ("act", i32), ("eps", f32), ("kpad", i32),
                 ("wpatch", vp), ("cls", vp), ("pos", vp), ("pre_g", vp), ("pre_b", vp),
                 ("layer", C.POINTER(VitLayer))]
@@ -74,8 +92,9 @@ class PerceiverLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("nm_g", "nm_b", "nl_g", "nl_b", "wq", "wkv", "wout", "ff_g", "ff_b", "w1", "w2")]
 
 
-class PerceiverWeights(C.Structure):
-    _fields_ = [("dim", i32), ("depth", i32), ("heads", i32), ("latents", i32), ("ff_mult", i32), ("out_dim", i32),
+class PerceiverWeights(_SizedWeights):
+    _layer_cls = PerceiverLayer
+    _fields_ = [("struct_bytes", C.c_uint32), ("layer_bytes", C.c_uint32), ("dim", i32), ("depth", i32), ("heads", i32), ("latents", i32), ("ff_mult", i32), ("out_dim", i32),
                 ("eps", f32), ("latents_p", vp), ("media_pos", vp), ("layer", C.POINTER(PerceiverLayer)),
                 ("norm_g", vp), ("norm_b", vp), ("wproj", vp)]
 
@@ -86,8 +105,9 @@ class DecoderLayer(C.Structure):
                                   "w1_f", "b1_f", "w1_colsum", "wqkv_t", "wo_t", "w1_t", "w2_t")]
 
 
-class DecoderWeights(C.Structure):
-    _fields_ = [("layers", i32), ("dim", i32), ("heads", i32), ("ffn", i32), ("vocab", i32), ("act", i32),
+class DecoderWeights(_SizedWeights):
+    _layer_cls = DecoderLayer
+    _fields_ = [("struct_bytes", C.c_uint32), ("layer_bytes", C.c_uint32), ("layers", i32), ("dim", i32), ("heads", i32), ("ffn", i32), ("vocab", i32), ("act", i32),
                 ("subln", i32), ("xpos", i32), ("eps", f32), ("layer", C.POINTER(DecoderLayer)),
                 ("ln_g", vp), ("ln_b", vp), ("wout", vp), ("wout_f", vp), ("bout_f", vp), ("wout_colsum", vp),
                 ("wout_t", vp)]
@@ -112,6 +132,7 @@ KERNEL_KINDS = ["gemm_bf16_128x128", "gemm_bf16_64x64", "gemm_f32_128x128", "gem
 SYMBOLS = {
     "kx_version": (C.c_int, []),
     "kx_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "kx_struct_bytes": (C.c_size_t, [i32]),
     "kx_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, i64, i64, f32, i64, i64, i64, vp]),
     "kx_gemm": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "kx_attention": (C.c_int, [C.POINTER(AttnArgs), vp]),
@@ -165,6 +186,10 @@ SYMBOLS = {
 }
 
 
+STRUCT_IDS = [GemmArgs, AttnArgs, VitLayer, VitWeights, PerceiverLayer, PerceiverWeights, DecoderLayer, DecoderWeights,
+              ResamplePlan, ProfRecord]            # index = kx_struct_id
+
+
 def lib_path() -> Path:
     return Path(os.environ.get("KOSMOSX_HIP_LIB", str(_LIB_PATH)))
 
@@ -190,6 +215,10 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.kx_version() != ABI_VERSION:
         raise RuntimeError(f"libkosmosx_hip.so ABI version {lib.kx_version()} != {ABI_VERSION}")
+    for sid, cls in enumerate(STRUCT_IDS):             # kx_struct_id order
+        if lib.kx_struct_bytes(sid) != C.sizeof(cls):
+            raise RuntimeError(f"ctypes mirror {cls.__name__} is {C.sizeof(cls)} bytes, the library's struct "
+                               f"{lib.kx_struct_bytes(sid)}: _hip.py is out of date with include/kosmosx_hip.h")
     _lib = lib
     return lib
 

@@ -65,7 +65,8 @@ def _operand_f16c(f: torch.Tensor) -> torch.Tensor:
     is the row's exponent (max|w| * 2^s in (64, 128]).  Returned as a flat uint8 tensor."""
     N, K = f.shape
     if K % 128:
-        raise ValueError(f"f16c operands need K % 128 == 0 (K={K})")
+        raise ValueError(f"f16c operands need K % 128 == 0 (K={K}); precision 'mixed' / 'f16c' fall back to bf16x3 per stage "
+                         f"for such widths (_stage_prec), or set KOSMOSX_PRECISION / model.precision explicitly")
     amax = f.abs().amax(dim=1).clamp_min(2.0 ** -100)
     sexp = (7 - torch.ceil(torch.log2(amax))).clamp(-100, 100)          # integer-valued
     sc = torch.exp2(sexp)[:, None]
@@ -191,19 +192,17 @@ def _begin_token_id_check(tokens: torch.Tensor, vocab: int):
     dev = tokens.device
     mm = torch.empty(2, dtype=torch.int64, device=dev)
     H.check(H.load().kx_token_range(tokens.data_ptr(), tokens.numel(), mm.data_ptr(), _stream()), "kx_token_range")
-    slot = _PINNED_RANGE.get(dev)
-    if slot is None or slot[2]:                      # (a check still open on this device, e.g. another thread: its own buffer)
-        slot = [torch.empty(2, dtype=torch.int64).pin_memory(), torch.cuda.Event(), False]
-        _PINNED_RANGE.setdefault(dev, slot)
-    host, ev = slot[0], slot[1]
-    slot[2] = True
+    pool = _PINNED_RANGE.setdefault(dev, [])         # free list of (pinned buffer, event); a check that is never finished
+    slot = pool.pop() if pool else (torch.empty(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())   # (an exception
+    host, ev = slot                                  # between begin and finish) just drops its pair: nothing stays "busy"
     host.copy_(mm, non_blocking=True)
     ev.record(torch.cuda.current_stream(dev))
 
     def finish():
         ev.synchronize()
         lo, hi = host.tolist()
-        slot[2] = False
+        if len(pool) < 8:
+            pool.append(slot)
         if lo < 0 or hi >= vocab:
             msg = f"index out of range in self: token id {hi if hi >= vocab else lo} outside the {vocab}-row embedding table"
             logging.error(msg)
@@ -382,6 +381,10 @@ class PerceiverResampler(_PackedMixin, nn.Module):
             for _ in range(depth)])
         self.norm = nn.LayerNorm(dim, eps=eps)
 
+    def _gemm_widths(self):
+        c = self.cfg
+        return (c.dim, c.dim_head * c.heads, c.dim * c.ff_mult)
+
     def _pack(self, prec: str, image_proj: torch.Tensor | None):
         dev = self.latents.device
         key = (dev, prec, None if image_proj is None else image_proj.data_ptr())
@@ -424,7 +427,7 @@ class PerceiverResampler(_PackedMixin, nn.Module):
             want_latents: bool = False):
         """x [B,m,dim] fp32 -> (projected [B,latents,out_dim] or None, latents [B,latents,dim] or None)."""
         _require_cuda(x, "media")
-        prec = H.stage_precision(prec, "perceiver")
+        prec = H.stage_precision(prec, "perceiver", self._gemm_widths())
         w, _, _ = self._pack(prec, image_proj)
         lib = H.load()
         x = x.to(torch.float32).contiguous()
@@ -592,6 +595,9 @@ class Decoder(_PackedMixin, nn.Module):
         self._xpos_cache = {}
         self._ws = _Workspace()
 
+    def _gemm_widths(self):
+        return (self.args.decoder_embed_dim, self.args.decoder_ffn_embed_dim)
+
     # -- weights ----------------------------------------------------------------------------------
     def _pack(self, prec: str):
         dev = self.layer_norm.weight.device
@@ -700,7 +706,7 @@ class Decoder(_PackedMixin, nn.Module):
         """Fused forward_embedding/cat/forward_embedding of /root/reference/kosmosx/model.py:238-244
         (img given) or the single forward_embedding of :319 (img None).  The token-id range check is read back after the
         embedding launch; with ``defer_check`` the caller finishes it (``self._finish_check()``) after enqueuing more."""
-        prec = H.stage_precision(prec, "decoder")
+        prec = H.stage_precision(prec, "decoder", self._gemm_widths())
         _, _, _, emb, pos = self._pack(prec)
         lib = H.load()
         check = None
@@ -737,7 +743,7 @@ class Decoder(_PackedMixin, nn.Module):
 
     def run(self, x: torch.Tensor, prec: str, logits_dtype=torch.float32) -> torch.Tensor:
         """x [B,T,dim] fp32 residual stream (CONSUMED) -> logits [B,T,vocab]."""
-        prec = H.stage_precision(prec, "decoder")
+        prec = H.stage_precision(prec, "decoder", self._gemm_widths())
         w, _, _, _, _ = self._pack(prec)
         lib = H.load()
         B, T, _ = x.shape
@@ -756,7 +762,7 @@ class Decoder(_PackedMixin, nn.Module):
         """torchscale's incremental_state protocol: the first call runs the whole prefix and fills the KV cache,
         every later call is given the token history (only its last token and its length are used, as upstream's
         `tokens[:, -1:]`) and appends one position.  ``state`` is an opaque dict owned by the caller."""
-        prec = H.stage_precision(prec, "decoder")
+        prec = H.stage_precision(prec, "decoder", self._gemm_widths())
         w, _, _, emb, pos = self._pack(prec)
         lib = H.load()
         D, L = self.args.decoder_embed_dim, self.num_layers

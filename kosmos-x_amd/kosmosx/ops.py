@@ -36,7 +36,7 @@ def pack_f16c_rows(x: torch.Tensor) -> torch.Tensor:
     """[rows, K] fp32 -> KX_F16C activation rows [rows, 4K] uint8: [fp16(x) | fp8(x) | fp8((x - fp16(x)) * 2^11)]
     (torch conversions; the device producers write the same bytes — kx_precision in include/kosmosx_hip.h)."""
     x = x.float()
-    h = x.to(torch.float16)
+    h = x.clamp(-65504.0, 65504.0).to(torch.float16)     # the fp16 piece saturates (csrc/kx_common.h: clamp_f16)
     e = x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
     r = ((x - h.float()) * 2048.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
     return torch.cat([h.view(torch.uint8).reshape(x.shape[0], -1), e.view(torch.uint8), r.view(torch.uint8)], dim=1).contiguous()

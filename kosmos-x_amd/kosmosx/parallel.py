@@ -34,7 +34,11 @@ class LogitsGatherer:
       grouped send / recv pairs, every peer over its own xGMI link at once — the fully-connected schedule SURVEY 8e
       computes at ~1/7 of a ring's time for this message (233 MB per rank in bf16 at 32 samples per GPU).
     * Ragged shards (global batch not divisible by world): rows are padded to the largest shard for ``all_gather`` and
-      the padding is dropped; ``direct`` sends exact sizes.  Shard sizes are exchanged once per distinct local size.
+      the padding is dropped; ``direct`` sends exact sizes.  The per-rank row counts come from the caller whenever it
+      knows them — ``gather(local, total=global_batch)`` (the ``shard_range`` split: no collective, no host sync) or
+      ``gather(local, sizes=[...])`` — and are otherwise exchanged on EVERY call (a 1-element all_gather): a cache keyed
+      on this rank's own row count let ranks disagree about whether to enter that collective on a ragged tail batch
+      (world 2, batches of 10 then 9 — rank 0 keeps 5 rows and skipped it, rank 1 entered it alone).
     """
 
     def __init__(self, group=None, wire_dtype: torch.dtype | None = torch.bfloat16, overlap: bool = True,
@@ -52,18 +56,38 @@ class LogitsGatherer:
         self._pending = []   # (event, send buffer) kept alive until wait()
         self._slot = 0
         self._out = [None] * max(2, int(slots))
-        self._sizes = {}     # local rows -> [rows of every rank]
+        self.last_algo = None                                   # what the last gather() actually ran (bench line)
 
-    def _shard_sizes(self, rows: int, device) -> list:
-        sizes = self._sizes.get(rows)
-        if sizes is None:
-            t = torch.tensor([rows], dtype=torch.int64, device=device)
-            allr = [torch.zeros_like(t) for _ in range(self.world)]
-            dist.all_gather(allr, t, group=self.group)
-            sizes = self._sizes[rows] = [int(x.item()) for x in allr]
-        return sizes
+    def _shard_sizes(self, rows: int, device, total=None, sizes=None) -> list:
+        """Rows of every rank.  Every rank must take the same branch: `total` / `sizes` are collective-free, the
+        fallback is a collective that all ranks enter on every call."""
+        if sizes is not None:
+            sizes = [int(n) for n in sizes]
+            if len(sizes) != self.world or sizes[self.rank] != rows:
+                raise ValueError(f"sizes {sizes} do not describe rank {self.rank}'s {rows} rows in a world of {self.world}")
+            return sizes
+        if total is not None:
+            sizes = [hi - lo for lo, hi in (shard_range(int(total), r, self.world) for r in range(self.world))]
+            if sizes[self.rank] != rows:
+                raise ValueError(f"rank {self.rank} holds {rows} rows; shard_range({total}, {self.rank}, {self.world}) "
+                                 f"gives {sizes[self.rank]}")
+            return sizes
+        t = torch.tensor([rows], dtype=torch.int64, device=device)
+        allr = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(allr, t, group=self.group)
+        return [int(x.item()) for x in allr]
+
+    def _peer(self, r: int) -> int:
+        """P2POp peers are GLOBAL ranks; self.rank / the staggered schedule are group-local."""
+        return r if self.group is None else dist.get_global_rank(self.group, r)
 
     def _exchange(self, out, wire, sizes):
+        if self.algo == "direct" and self.world == 1:           # force=True on one rank: the P2P machinery against itself
+            ops = [dist.P2POp(dist.isend, wire, self._peer(0), self.group),
+                   dist.P2POp(dist.irecv, out, self._peer(0), self.group)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            return out
         if self.algo == "direct" and self.world > 1:
             offs = [0]
             for n in sizes:
@@ -72,8 +96,8 @@ class LogitsGatherer:
             ops = []
             for d in range(1, self.world):                      # peer order staggered by rank: every link busy at once
                 dst, src = (self.rank + d) % self.world, (self.rank - d) % self.world
-                ops.append(dist.P2POp(dist.isend, wire, dst, self.group))
-                ops.append(dist.P2POp(dist.irecv, out[offs[src]:offs[src + 1]], src, self.group))
+                ops.append(dist.P2POp(dist.isend, wire, self._peer(dst), self.group))
+                ops.append(dist.P2POp(dist.irecv, out[offs[src]:offs[src + 1]], self._peer(src), self.group))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
             return out
@@ -90,12 +114,15 @@ class LogitsGatherer:
             lo += n
         return out
 
-    def gather(self, local: torch.Tensor) -> torch.Tensor:
+    def gather(self, local: torch.Tensor, total: int | None = None, sizes=None) -> torch.Tensor:
+        """total: the global batch that was split with shard_range (preferred); sizes: explicit rows per rank."""
         if self.world == 1 and not self.force:
+            self.last_algo = "none (one rank)"
             return local
         wire = local if (self.wire_dtype is None or local.dtype == self.wire_dtype) else local.to(self.wire_dtype)
         wire = wire.contiguous()
-        sizes = self._shard_sizes(wire.shape[0], wire.device) if self.world > 1 else [wire.shape[0]]
+        sizes = self._shard_sizes(wire.shape[0], wire.device, total, sizes) if self.world > 1 else [wire.shape[0]]
+        self.last_algo = self.algo if self.world > 1 else f"{self.algo} (forced on one rank)"
         shape = (sum(sizes),) + tuple(wire.shape[1:])
         slot = self._slot
         self._slot = (self._slot + 1) % len(self._out)
@@ -213,9 +240,11 @@ class Zero3Layout:
     scatter of its gradient) — DeepSpeed stage 3's traffic — and the optimizer needs no collective but the norm.
     The collectives are injected like ZeroShardedOptimizer's (device tensors on RCCL, host copies on gloo)."""
 
-    def __init__(self, groups, group=None):
-        """groups: list of lists of (name, numel, decayed) in buffer order (decayed entries first within a group)."""
+    def __init__(self, groups, group=None, force: bool = False):
+        """groups: list of lists of (name, numel, decayed) in buffer order (decayed entries first within a group).
+        force: run the collectives even with a single rank (exercises the RCCL path on a one-GPU box)."""
         self.group = group
+        self.force = bool(force) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.offset, self.gof = {}, {}            # name -> offset inside its group's full buffer / group index
@@ -257,12 +286,12 @@ class Zero3Layout:
         return out
 
     def _staged(self, t):
-        return self.world > 1 and t.is_cuda and dist.get_backend(self.group) == "gloo"
+        return (self.world > 1 or self.force) and t.is_cuda and dist.get_backend(self.group) == "gloo"
 
     def gather(self, gi, shard_p):
         """-> the group's full parameter buffer [padded] from every rank's slice."""
         mine = shard_p[self.shard_slice(gi)]
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return mine.clone()
         if self._staged(mine):
             full = torch.empty(self.padded[gi], dtype=mine.dtype)
@@ -275,7 +304,7 @@ class Zero3Layout:
     def scatter_grad(self, gi, full_g, shard_g):
         """reduce-scatter(SUM) of the group's full gradient buffer into this rank's gradient slice."""
         dst = shard_g[self.shard_slice(gi)]
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             dst.copy_(full_g)
         elif self._staged(full_g):
             out = torch.empty(self.shard[gi], dtype=full_g.dtype)
@@ -285,7 +314,7 @@ class Zero3Layout:
             dist.reduce_scatter_tensor(dst, full_g, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce_scalar(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return t
         if self._staged(t):
             h = t.cpu()

@@ -134,7 +134,7 @@ class LanguageModelTrainer:
             groups[gi_of(n)].append((n, params[n].numel(), True))
         for n in nodecay:
             groups[gi_of(n)].append((n, params[n].numel(), False))
-        z = self.zero = Zero3Layout(groups, self.group)
+        z = self.zero = Zero3Layout(groups, self.group, force=self._force_collectives)
         dev = next(self.model.parameters()).device
         self.shard_p = torch.zeros(z.shard_total, dtype=torch.float32, device=dev)
         self.shard_g = torch.zeros(z.shard_total, dtype=torch.float32, device=dev)

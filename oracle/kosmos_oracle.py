@@ -458,27 +458,3 @@ def kosmos_language_forward(w: dict, tokens: torch.Tensor, cfg: DecoderCfg, sw: 
     with torch.no_grad():
         x, _ = forward_embedding_tokens(w, tokens, cfg)
         return decoder_forward(w, x, cfg, sw)
-
-
-# --------------------------------------------------------------------------------------
-# work accounting — shared by bench.py so the roofline numerators are one formula
-# --------------------------------------------------------------------------------------
-def flops_per_sample(cfg: KosmosCfg, text_len: int) -> dict:
-    v, pc, d = cfg.vit, cfg.perceiver, cfg.decoder
-    S = v.tokens
-    P = S - 1
-    vit_lin = v.layers * S * (8 * v.dim * v.dim + 4 * v.dim * v.ffn)
-    vit_attn = v.layers * 4 * S * S * v.dim
-    vit_patch = 2 * P * (3 * v.patch * v.patch) * v.dim
-    inner = pc.heads * pc.dim_head
-    n, m = pc.latents, S
-    per = pc.depth * (2 * n * pc.dim * inner + 2 * (n + m) * pc.dim * 2 * inner + 4 * n * (n + m) * inner
-                      + 2 * n * inner * pc.dim + 4 * n * pc.dim * pc.dim * pc.ff_mult)
-    proj = 2 * n * pc.dim * d.dim
-    T = text_len + n
-    dec_lin = T * d.layers * (8 * d.dim * d.dim + 4 * d.dim * d.ffn)
-    dec_attn = d.layers * 2 * d.dim * T * (T + 1)      # causal-algorithmic
-    logits = T * 2 * d.dim * d.vocab
-    tot = vit_lin + vit_attn + vit_patch + per + proj + dec_lin + dec_attn + logits
-    return dict(vit=vit_lin + vit_attn + vit_patch, perceiver=per, image_proj=proj,
-                decoder_linear=dec_lin, decoder_attn=dec_attn, logits=logits, total=tot)

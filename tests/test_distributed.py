@@ -199,6 +199,89 @@ def test_logits_gatherer_algorithms_and_ragged_shards(algo, world, total):
         assert torch.equal(o, full + k), (algo, world, total, k)
 
 
+def _gather_tail_worker(rank, world, port, algo, mode, q):
+    """ONE gatherer fed a full batch and then a ragged tail batch (totals 8 then 7, then 8 again).  With the
+    old per-local-size cache rank 0 (4 rows both times at world 2: 4+4, 4+3) skipped the size exchange that rank 1 entered."""
+    for p in (str(ROOT), str(ROOT / "kosmos-x_amd"), str(ROOT / "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KOSMOSX_NO_LOGGING_CONFIG="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kosmosx.parallel import LogitsGatherer, shard_range
+    ga = LogitsGatherer(wire_dtype=None, algo=algo, slots=2)
+    outs = []
+    for k, total in enumerate((8, 7, 8, 5)):
+        full = torch.arange(total * 2 * 3, dtype=torch.float32).reshape(total, 2, 3) + 100 * k
+        lo, hi = shard_range(total, rank, world)
+        kw = {"total": total} if mode == "total" else ({"sizes": [b - a for a, b in (shard_range(total, r, world) for r in range(world))]}
+                                                       if mode == "sizes" else {})
+        outs.append(ga.gather(full[lo:hi], **kw).clone())
+    ga.wait()
+    bad = None
+    try:
+        ga.gather(torch.zeros(3, 2, 3), total=8)                       # 3 rows is not this rank's share of 8: loud, no collective
+    except ValueError as e:
+        bad = str(e)
+    if rank == 0:
+        q.put((outs, bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo", ["all_gather", "direct"])
+@pytest.mark.parametrize("mode", ["total", "sizes", "exchange"])
+def test_logits_gatherer_ragged_tail_batch_through_one_gatherer(algo, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_tail_worker, args=(r, 2, port, algo, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs, bad = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k, (total, o) in enumerate(zip((8, 7, 8, 5), outs)):
+        assert torch.equal(o, torch.arange(total * 2 * 3, dtype=torch.float32).reshape(total, 2, 3) + 100 * k), (algo, mode, k)
+    assert bad is not None and "shard_range" in bad
+
+
+def _subgroup_worker(rank, world, port, q):
+    """direct schedule inside a NON-default process group: P2P peers must be global ranks."""
+    for p in (str(ROOT), str(ROOT / "kosmos-x_amd"), str(ROOT / "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KOSMOSX_NO_LOGGING_CONFIG="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kosmosx.parallel import LogitsGatherer, shard_range
+    grp = dist.new_group([1, 2])                                        # group-local ranks 0, 1 = global ranks 1, 2
+    out = None
+    if rank in (1, 2):
+        ga = LogitsGatherer(group=grp, wire_dtype=None, algo="direct", slots=2)
+        full = torch.arange(5 * 4, dtype=torch.float32).reshape(5, 4)
+        lo, hi = shard_range(5, ga.rank, 2)
+        out = ga.gather(full[lo:hi], total=5).clone()
+        ga.wait()
+    if rank == 1:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_logits_gatherer_direct_in_a_subgroup():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert torch.equal(out, torch.arange(20, dtype=torch.float32).reshape(5, 4))
+
+
 def _zero3_worker(rank, world, port, q):
     for p in (str(ROOT), str(ROOT / "kosmos-x_amd")):
         sys.path.insert(0, p)

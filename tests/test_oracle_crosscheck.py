@@ -240,7 +240,9 @@ def test_oracle_position_table_overflow_raises_like_the_reference():
 
 def test_flops_accounting_matches_survey():
     """457.8 GFLOP per multimodal sample (T=114), 166.14 G per image."""
-    fl = O.flops_per_sample(O.KosmosCfg(), 50)
+    from kosmosx.accounting import flops_per_sample
+    from kosmosx.config import DecoderConfig, KosmosConfig
+    fl = flops_per_sample(KosmosConfig(decoder=DecoderConfig()), 50)
     assert abs(fl["total"] / 1e9 - 457.8) < 0.5
     assert abs((fl["vit"] + fl["perceiver"] + fl["image_proj"]) / 1e9 - 166.14) < 0.3
     assert abs(fl["decoder_attn"] / 1e9 - 1.29) < 0.01
