@@ -133,12 +133,14 @@ typedef struct {
    * [splits, M, N] fp32 are combined in slice order (deterministic) by a reduce kernel that owns the epilogue.
    * splitk: 0 = automatic, 1 = off, n = force n slices (tests). */
   void* splitk_ws; size_t splitk_ws_bytes; int32_t splitk;
-  /* Weight-streaming variant, tile = 16 (bf16, M <= 16: incremental decoding, one token per sequence).  One launch
+  /* Weight-streaming variant, tile = 16 (bf16 or fp32 operands, M <= 16: incremental decoding, one token per sequence;
+   * the fp32 form — exact-f32 MFMA, 4 bytes per weight — is the decode step of every precision that holds the north
+   * star's tolerance: fp32 itself, and f16c / mixed, whose caches are fp32 already).  One launch
    * per GEMM: a workgroup owns 16 output columns, its waves split K and stream their weight rows straight into
    * MFMA fragments, the partial sums meet in LDS (fixed order) and wave 0 runs the epilogue above.  It takes three
    * extra inputs that remove the small kernels around a decode-step GEMM (all optional, this variant only):
    *   ln_gamma/ln_beta/ln_eps : A is then the raw fp32 rows [M,K] (lda in floats) and LayerNorm(A)*gamma+beta, rounded
-   *       to bf16 exactly as kx_layernorm does, is the operand (M*(2K+16) <= 128 KB);
+   *       to bf16 exactly as kx_layernorm does (kept in fp32 for fp32 operands), is the operand (M*(K*es+16) <= 128 KB);
    *   stats_partials [M, stats_in_nseg, 2] + stats_in_seg + stats_eps : the consumer side of the folded sub-LayerNorm
    *       takes the producer's partial statistics directly (what kx_row_stats_finalize would turn into row_stats);
    *   stats_out_seg : the producer side emits its statistics per 16-column segment ([M, N/16, 2]; must be 16 here,
@@ -165,7 +167,8 @@ typedef struct {
   void* ln_operand_out; int32_t ln_operand_dt; float* ln_operand_stats;
   /* tile 16 (weight streaming) only: W is stored [ceil(N/16)][K/32][64][8] bf16 — block (p, c) holds rows 16p..16p+15,
    * columns 32c..32c+31 as 64 pieces of 16 bytes, piece l = row 16p + (l & 15), columns 32c + 8(l >> 4) .. +7 (the MFMA
-   * fragment a lane loads), rows past N zero.  K % 32 == 0; ldw is ignored. */
+   * fragment a lane loads), rows past N zero.  fp32 operands: [ceil(N/16)][K/16][64][4], piece l = row 16p + (l & 15),
+   * columns 16c + 4(l >> 4) .. +3.  K % 32 == 0; ldw is ignored. */
   int32_t w_tiled;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
@@ -325,7 +328,7 @@ typedef struct {
   /* Optional (all NULL = off): self_attn_layer_norm folded into qkv, final_layer_norm into fc1 (same packing rule) */
   const void* wqkv_f; const float* bqkv_f; const float* wqkv_colsum;
   const void* w1_f;   const float* b1_f;   const float* w1_colsum;
-  /* Optional (NULL = off), bf16 decode step only: wqkv / wo / w1 / w2 once more in the STREAMING layout of
+  /* Optional (NULL = off), decode step only (bf16 and fp32 operands): wqkv / wo / w1 / w2 once more in the STREAMING layout of
    * kx_gemm_args.w_tiled — the weight-streaming kernels then read one contiguous 1 KB block per wave instruction instead of
    * 16 row segments of 64 B (4.2-5.0 vs 3.2-3.7 TB/s, profiles/r02_gemv_stream_probe.log). */
   const void *wqkv_t, *wo_t, *w1_t, *w2_t;
@@ -526,7 +529,8 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  *        prologue, 16 KB per wave in flight for K slices of 512; 1 = the first form; 2 = second form without the
  *        16 KB variant);
  * key 9: KV-cache layout per layer and sequence (0 = [heads][Tmax][64]; 1 = the first layout [Tmax][heads*64]; set it
- *        before a prefill and keep it for that cache's steps). */
+ *        before a prefill and keep it for that cache's steps).
+ * key 10: 1 = the fp32 decode step keeps the split-K tile kernels instead of the fp32 weight-streaming kernel (A/B). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -195,6 +195,7 @@ struct Gemv16 {
   const float* partials_in = nullptr; int64_t nseg_in = 0, seg_in = 0; const float* colsum = nullptr;
   float* stats_out = nullptr;
   const void* W_tiled = nullptr;          // the same matrix in the streaming layout (kx_gemm_args.w_tiled), or null
+  int prec = KX_PREC_BF16;                // KX_PREC_BF16 or KX_PREC_F32 (operand dtype of A, unless ln_g, and of W)
 };
 int gemv16(const Gemv16& v, hipStream_t s) {
   kx_gemm_args g;
@@ -204,7 +205,7 @@ int gemv16(const Gemv16& v, hipStream_t s) {
   g.bias = v.bias; g.residual = v.residual; g.ldr = v.ldc; g.M = v.M; g.N = v.N; g.K = v.K;
   g.act = v.act; g.qscale = v.qscale; g.qcols = v.qcols;
   g.xq_cs = v.xq_cs; g.xq_ss = v.xq_ss; g.xk_cs = v.xk_cs; g.xk_ss = v.xk_ss; g.xpos_T = v.xT; g.xpos_dim = v.xdim;
-  g.prec = KX_PREC_BF16; g.tile = 16;
+  g.prec = v.prec; g.tile = 16;
   g.ln_gamma = v.ln_g; g.ln_beta = v.ln_b; g.ln_eps = v.eps;
   g.stats_partials = v.partials_in; g.stats_in_nseg = v.nseg_in; g.stats_in_seg = v.seg_in; g.stats_eps = v.eps;
   g.colsum = v.colsum;
@@ -603,39 +604,40 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
   const int ct = cdt(prec);
   const size_t es = esz(prec);
   const size_t layer_bytes = (size_t)B * Tmax * D * qes(prec);   // the cache holds q/k/v-typed values (fp32 for f16c)
-  // One token per sequence in bf16, up to 16 sequences: the step is 120 dependent launches of weight-streaming work,
-  // and launches are what it costs (~6 us each) — tile 16 does each GEMM in one launch and takes the LayerNorm and
-  // statistics-finalize kernels in as prologues: 5 launches per layer instead of 13.
-  if (prec == KX_PREC_BF16 && M <= 16 && kx_tuning_get(KX_TUNE_GEMM_TILE) == 0 && D % 16 == 0 && F % 16 == 0 &&
-      (size_t)M * (2 * D + 16) <= 128 * 1024) {
+  // One token per sequence, up to 16 sequences: the step is 120 dependent launches of weight-streaming work, and launches
+  // are what it costs (~6 us each) — tile 16 does each GEMM in one launch and takes the LayerNorm and
+  // statistics-finalize kernels in as prologues: 5 launches per layer instead of 13.  bf16 operands, or fp32 operands on the
+  // exact-f32 MFMA (KX_PREC_F32: what the Python side asks for in every precision that holds the north star's tolerance).
+  if ((prec == KX_PREC_BF16 || prec == KX_PREC_F32) && M <= 16 && kx_tuning_get(KX_TUNE_GEMM_TILE) == 0 && D % 32 == 0 &&
+      F % 32 == 0 && (size_t)M * (es * D + 16) <= 128 * 1024 && !(prec == KX_PREC_F32 && kx_tuning_get(KX_TUNE_DECODE_STREAM_F32) == 1)) {
     for (int i = 0; i < w->layers; ++i) {
       const kx_decoder_layer& L = w->layer[i];
       Gemv16 q{x, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D};
       q.bias = L.bqkv; q.qscale = 0.125f; q.qcols = D; q.ln_g = L.sa_g; q.ln_b = L.sa_b; q.eps = w->eps;
       if (w->xpos) { q.xq_cs = xq_cs; q.xq_ss = xq_ss; q.xk_cs = xk_cs; q.xk_ss = xk_ss; q.xT = 1; q.xdim = D; }
-      q.W_tiled = L.wqkv_t;
+      q.W_tiled = L.wqkv_t; q.prec = prec;
       KX_TRY(gemv16(q, s));
       KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, ct,
                                  w->subln ? d.partials : nullptr, B, w->heads, t, Tmax, prec, stream));
       Gemv16 o{d.att, D, L.wo, D, x, D, KX_F32, M, D};
       o.bias = L.bo; o.residual = x; o.eps = w->eps;
       if (w->subln) { o.partials_in = d.partials; o.nseg_in = w->heads; o.seg_in = 64; o.colsum = L.wo_colsum; }
-      o.W_tiled = L.wo_t;
+      o.W_tiled = L.wo_t; o.prec = prec;
       KX_TRY(gemv16(o, s));
       Gemv16 f1{x, D, L.w1, D, d.g, F, ct, M, F};
       f1.bias = L.b1; f1.act = w->act; f1.ln_g = L.fl_g; f1.ln_b = L.fl_b; f1.eps = w->eps;
       if (w->subln) f1.stats_out = d.partials;
-      f1.W_tiled = L.w1_t;
+      f1.W_tiled = L.w1_t; f1.prec = prec;
       KX_TRY(gemv16(f1, s));
       Gemv16 f2{d.g, F, L.w2, F, x, D, KX_F32, M, D};
       f2.bias = L.b2; f2.residual = x; f2.eps = w->eps;
       if (w->subln) { f2.partials_in = d.partials; f2.nseg_in = F / 16; f2.seg_in = 16; f2.colsum = L.w2_colsum; }
-      f2.W_tiled = L.w2_t;
+      f2.W_tiled = L.w2_t; f2.prec = prec;
       KX_TRY(gemv16(f2, s));
     }
     Gemv16 lo{x, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab};
     lo.ln_g = w->ln_g; lo.ln_b = w->ln_b; lo.eps = w->eps;
-    lo.W_tiled = w->wout_t;
+    lo.W_tiled = w->wout_t; lo.prec = prec;
     return gemv16(lo, s);
   }
   for (int i = 0; i < w->layers; ++i) {

@@ -191,11 +191,13 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       !(a->splitk_ws && splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk ? a->splitk : (a->stats_out && !f16c ? -2 : 0), f16c) > 1))
     tile = 128;
   if (tile == 16) {
-    KX_REQUIRE(a->prec == KX_PREC_BF16 && a->M <= 16, "kx_gemm: tile 16 (weight streaming) is bf16, M <= 16 only");
+    KX_REQUIRE((a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32) && a->M <= 16,
+               "kx_gemm: tile 16 (weight streaming) takes bf16 or fp32 operands, M <= 16 only");
     KX_REQUIRE(!a->w_tiled || a->K % 32 == 0, "kx_gemm: the streaming weight layout needs K %% 32 == 0");
     p.w_tiled = a->w_tiled != 0;
-    KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * 2 + 16) <= 128 * 1024 && a->K % 4 == 0),
-               "kx_gemm: LayerNorm prologue needs beta and M*(2K+16) <= 128 KB");
+    KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * es + 16) <= 128 * 1024 && a->K % 4 == 0),
+               "kx_gemm: LayerNorm prologue needs beta and M*(K*%d+16) <= 128 KB", es);
+    KX_REQUIRE(!a->ln_operand_out, "kx_gemm: tile 16 does not produce ln_operand_out");
     KX_REQUIRE(!a->stats_partials || (a->colsum && !a->row_stats && a->stats_in_nseg > 0 && a->stats_in_seg > 0),
                "kx_gemm: stats_partials needs colsum, nseg, seg size and excludes row_stats");
     KX_REQUIRE(!a->stats_out || (a->stats_out_seg == 16 && a->N % 16 == 0 && !a->residual),
@@ -238,7 +240,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
                "kx_gemm: ln_out needs 16-byte aligned gamma / beta / output");
     KX_REQUIRE(!a->stats_out, "kx_gemm: the row reduce does not produce statistics");
   }
-  const int kind = a->prec == KX_PREC_F32 ? (tile == 64 ? KX_K_GEMM_F32_64 : KX_K_GEMM_F32_128)
+  const int kind = a->prec == KX_PREC_F32 ? (tile == 64 || tile == 16 ? KX_K_GEMM_F32_64 : KX_K_GEMM_F32_128)
                    : (tile == 64 || tile == 16) ? KX_K_GEMM_BF16_64
                    : tile == 160 ? KX_K_GEMM_BF16_160
                    : (tile == 256 || tile == 257) ? KX_K_GEMM_BF16_256X128

@@ -1877,7 +1877,11 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel(const GemmParams p, in
 // operand paths do not add their registers (1024-thread workgroups: 128 VGPRs).
 struct GemvEpiOps { float4 c, b, r; float2 xc, xs; };
 
-template <int ACT, bool LNP, int UW>
+// T = bf16_t (16x16x32 bf16 MFMA; a 1 KB wave load is 16 rows x 32 k) or float (exact-f32 16x16x4 MFMA, four per 16-byte
+// chunk; a 1 KB wave load is 16 rows x 16 k): the fp32 instantiation is the decode step of the precisions that hold the
+// north star's tolerance (fp32, and f16c / mixed, whose KV cache is fp32 already) — 4 bytes per weight, the same bytes an
+// f16c row would stream, with exact products instead of compensated ones.
+template <typename T, int ACT, bool LNP, int UW>
 __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, int S, int kw, int x_pitch) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1886,24 +1890,31 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   float* red = reinterpret_cast<float*>(lds);                    // [S][64] float4
   float* st = reinterpret_cast<float*>(lds + S * 1024);          // [16][2] (mean, rstd)
   char* xn = lds + S * 1024 + 128;                               // [M][x_pitch] bf16 (LayerNorm prologue)
+  constexpr int ES = (int)sizeof(T);                               // operand bytes per value
+  constexpr int EPL = 16 / ES;                                     // values per lane chunk (16 B)
+  constexpr int KS = 4 * EPL;                                      // k-step: 32 (bf16) / 16 (fp32) values = 64 B per row
+  constexpr int KSH = ES == 2 ? 5 : 4;
+  constexpr int XG = (ES == 4 && UW == 16 && !LNP) ? 4 : 8;        // operand fragments held at a time (fp32, 16 KB in flight: the
+                                                                 //   64 stream registers leave room for four)
   constexpr int U = UW;                                          // k-steps (1 KB each) a wave keeps in flight: 8, or 16 where a
-  constexpr bool XS = !LNP && UW == 16;                          //   wave's K slice is 512 (fc2) — then the operand rows are staged in LDS
+  constexpr bool XS = !LNP && UW == 16 && sizeof(T) == 2;        //   wave's K slice is 512 (fc2) — then the bf16 operand rows are staged in LDS
+                                                                 //   (fp32 rows are read through the L2: four 32 KB rows do not fit beside the rest)
   const int n0 = blockIdx.x * 16;
   const int k0 = wave * kw, klen = min(kw, p.K - k0);           // may be <= 0 for trailing waves of a short K
   const int nrow = min(n0 + i, p.N - 1);
   const int xrow = min(i, p.M - 1);
   const int k0w = klen > 0 ? k0 : 0;                             // (a wave without a K slice streams a valid address and drops it)
-  const char* wp = p.w_tiled ? p.W + (((long long)blockIdx.x * (p.K >> 5) + (k0w >> 5)) << 10) + (lane << 4)
-                             : p.W + (long long)nrow * p.ldw_b + ((long long)(k0w + 8 * g) << 1);
+  const char* wp = p.w_tiled ? p.W + (((long long)blockIdx.x * (p.K >> KSH) + (k0w >> KSH)) << 10) + (lane << 4)
+                             : p.W + (long long)nrow * p.ldw_b + (long long)(k0w + EPL * g) * ES;
   const int wstep = p.w_tiled ? 1024 : 64;
-  const int ulast = max(klen - 1, 0) >> 5;
+  const int ulast = max(klen - 1, 0) >> KSH;
   auto ldw = [&](const char* q) { return *reinterpret_cast<const u32x4_t*>(q); };
 
   // ---- (1) the small loads, in consumption order ----
   const bool coop = LNP && (p.K >> 2) <= 64 * S && p.M <= 4;
   const bool has = tid < (p.K >> 2);
   float4 v[4], gm, bt;                                           // LNP, cooperative: this thread's float4 of rows 0..3
-  u32x4_t xf[8];                                                 // !LNP: the first batch of operand fragments
+  u32x4_t xf[XG];                                                // !LNP: the first batch of operand fragments
   u32x4_t xs[4];                                                 // XS: this thread's 16 bytes of operand rows 0..3
   // statistics prologue: the producer's partials [M][nseg] float2 go through registers (requested first) into LDS, where
   // the row-owning waves then find them — the same walk and arithmetic as from global memory
@@ -1931,12 +1942,12 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
     if constexpr (XS) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (r < p.M && tid < (p.K >> 3)) xs[r] = *reinterpret_cast<const u32x4_t*>(p.A + (long long)r * p.lda_b + (tid << 4));
+        if (r < p.M && tid < (p.K * ES >> 4)) xs[r] = *reinterpret_cast<const u32x4_t*>(p.A + (long long)r * p.lda_b + (tid << 4));
     } else {
-      const char* xg0 = p.A + (long long)xrow * p.lda_b + ((long long)(k0 + 8 * g) << 1);
+      const char* xg0 = p.A + (long long)xrow * p.lda_b + (long long)(k0 + EPL * g) * ES;
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (32 * u < klen) xf[u] = *reinterpret_cast<const u32x4_t*>(xg0 + (32 * u << 1));
+      for (int u = 0; u < XG; ++u)
+        if (KS * u < klen) xf[u] = *reinterpret_cast<const u32x4_t*>(xg0 + KS * u * ES);
     }
   }
   const int em = i, en = n0 + 4 * g;                             // epilogue: lane = row em, columns en..en+3 (wave 0)
@@ -1968,7 +1979,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   if constexpr (XS) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (r < p.M && tid < (p.K >> 3)) *reinterpret_cast<u32x4_t*>(xsb + r * x_pitch + (tid << 4)) = xs[r];
+      if (r < p.M && tid < (p.K * ES >> 4)) *reinterpret_cast<u32x4_t*>(xsb + r * x_pitch + (tid << 4)) = xs[r];
   }
   if (p.stats_partials) {
     if (stat_stage) {
@@ -2041,10 +2052,16 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
                 m2 += e.y + e.w * dm * dm;                         // (an empty wave: 0 + 0 * mean^2)
               }
               const float rstd = rsqrtf(m2 / (float)p.K + p.ln_eps);
-              uint2 o;
-              o.x = pack_bf16x2((v[r].x - mean) * rstd * gm.x + bt.x, (v[r].y - mean) * rstd * gm.y + bt.y);
-              o.y = pack_bf16x2((v[r].z - mean) * rstd * gm.z + bt.z, (v[r].w - mean) * rstd * gm.w + bt.w);
-              *reinterpret_cast<uint2*>(xn + r * x_pitch + tid * 8) = o;
+              const float y0 = (v[r].x - mean) * rstd * gm.x + bt.x, y1 = (v[r].y - mean) * rstd * gm.y + bt.y;
+              const float y2 = (v[r].z - mean) * rstd * gm.z + bt.z, y3 = (v[r].w - mean) * rstd * gm.w + bt.w;
+              if constexpr (ES == 2) {
+                uint2 o;
+                o.x = pack_bf16x2(y0, y1);
+                o.y = pack_bf16x2(y2, y3);
+                *reinterpret_cast<uint2*>(xn + r * x_pitch + tid * 8) = o;
+              } else {
+                *reinterpret_cast<float4*>(xn + r * x_pitch + tid * 16) = make_float4(y0, y1, y2, y3);
+              }
             }
           }
         }
@@ -2070,10 +2087,16 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
           const float4 q = xr[c];
           const float4 gq = reinterpret_cast<const float4*>(p.ln_g)[c];
           const float4 bq = reinterpret_cast<const float4*>(p.ln_b)[c];
-          uint2 o;
-          o.x = pack_bf16x2((q.x - mean) * rstd * gq.x + bq.x, (q.y - mean) * rstd * gq.y + bq.y);
-          o.y = pack_bf16x2((q.z - mean) * rstd * gq.z + bq.z, (q.w - mean) * rstd * gq.w + bq.w);
-          *reinterpret_cast<uint2*>(xn + m * x_pitch + c * 8) = o;
+          const float y0 = (q.x - mean) * rstd * gq.x + bq.x, y1 = (q.y - mean) * rstd * gq.y + bq.y;
+          const float y2 = (q.z - mean) * rstd * gq.z + bq.z, y3 = (q.w - mean) * rstd * gq.w + bq.w;
+          if constexpr (ES == 2) {
+            uint2 o;
+            o.x = pack_bf16x2(y0, y1);
+            o.y = pack_bf16x2(y2, y3);
+            *reinterpret_cast<uint2*>(xn + m * x_pitch + c * 8) = o;
+          } else {
+            *reinterpret_cast<float4*>(xn + m * x_pitch + c * 16) = make_float4(y0, y1, y2, y3);
+          }
         }
       }
     }
@@ -2082,26 +2105,26 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
 
   // ---- (4) the products ----
   f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const char* xl = (LNP ? xn : xsb) + xrow * x_pitch + ((k0 + 8 * g) << 1);   // LNP / XS: the operand rows in LDS
-  const char* xg = p.A + (long long)xrow * p.lda_b + ((long long)(k0 + 8 * g) << 1);
-  for (int kk = 0; kk < klen; kk += 32 * U) {
+  const char* xl = (LNP ? xn : xsb) + xrow * x_pitch + (k0 + EPL * g) * ES;   // LNP / XS: the operand rows in LDS
+  const char* xg = p.A + (long long)xrow * p.lda_b + (long long)(k0 + EPL * g) * ES;
+  for (int kk = 0; kk < klen; kk += KS * U) {
     if (kk > 0) {                                                // (first batch: in flight)
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (kk + 32 * u < klen) wf[u] = ldw(wp + ((kk >> 5) + u) * wstep);
+        if (kk + KS * u < klen) wf[u] = ldw(wp + ((kk >> KSH) + u) * wstep);
     }
 #pragma unroll
-    for (int h = 0; h < U; h += 8) {
+    for (int h = 0; h < U; h += XG) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (kk + 32 * (h + u) < klen) {
-          if constexpr (LNP || XS) xf[u] = *reinterpret_cast<const u32x4_t*>(xl + ((kk + 32 * (h + u)) << 1));
-          else if (kk > 0) xf[u] = *reinterpret_cast<const u32x4_t*>(xg + ((kk + 32 * (h + u)) << 1));
+      for (int u = 0; u < XG; ++u)
+        if (kk + KS * (h + u) < klen) {
+          if constexpr (LNP || XS) xf[u] = *reinterpret_cast<const u32x4_t*>(xl + (kk + KS * (h + u)) * ES);
+          else if (kk > 0 || h > 0) xf[u] = *reinterpret_cast<const u32x4_t*>(xg + (long long)(kk + KS * (h + u)) * ES);
         }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (kk + 32 * (h + u) < klen) acc = Mma<bf16_t>::step(wf[h + u], xf[u], acc);
-      if constexpr (U > 8) __builtin_amdgcn_sched_barrier(0);    // (keeps the second half's eight LDS reads out of the first half's registers)
+      for (int u = 0; u < XG; ++u)
+        if (kk + KS * (h + u) < klen) acc = Mma<T>::step(wf[h + u], xf[u], acc);
+      if constexpr (U > XG) __builtin_amdgcn_sched_barrier(0);    // (keeps the second half's eight LDS reads out of the first half's registers)
     }
   }
   *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
@@ -2163,56 +2186,76 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   }
 }
 
-template <int ACT>
+template <typename T, int ACT>
 void launch_gemv2(const GemmParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, int S, int kw, int x_pitch, bool deep) {
-  if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<ACT, true, 8>), grid, block, lds, s, p, S, kw, x_pitch);
-  else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<ACT, false, 16>), grid, block, lds, s, p, S, kw, x_pitch);
-  else hipLaunchKernelGGL((gemv_fused_kernel2<ACT, false, 8>), grid, block, lds, s, p, S, kw, x_pitch);
+  if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8>), grid, block, lds, s, p, S, kw, x_pitch);
+  else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16>), grid, block, lds, s, p, S, kw, x_pitch);
+  else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8>), grid, block, lds, s, p, S, kw, x_pitch);
 }
 
-template <int ACT>
+template <typename T, int ACT>
 void gemv2_lds_attr() {
-  (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<ACT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<ACT, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+// LDS the weight-streaming launch needs (kx_gemm checks it against the 160 KB of a CU before choosing tile 16)
+inline size_t gemv_lds_bytes(int M, int K, int es, bool ln, bool partials, bool deep, int S, int* x_pitch_out) {
+  const int x_pitch = (ln || deep) ? K * es + 16 : 0;
+  if (x_pitch_out) *x_pitch_out = x_pitch;
+  return (size_t)S * 1024 + 128 +                               // accumulators | statistics | operand rows or staged partials (+ rows)
+         (ln ? (size_t)M * x_pitch : (partials ? (size_t)128 * S * 8 : (size_t)0) + (deep ? (size_t)M * x_pitch : (size_t)0));
+}
+
+template <typename T>
 int launch_gemv_fused(GemmParams& p, hipStream_t s) {
-  const int S = p.K <= 4096 ? 8 : 16;
+  constexpr int ES = (int)sizeof(T);
+  const int S = (long long)p.K * ES <= 8192 ? 8 : 16;           // a wave's K slice: at most 1 KB of a row where 16 waves allow it
   const int kw = ((p.K + S - 1) / S + 31) / 32 * 32;
-  const bool v2 = kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 1;
+  const bool v2 = ES == 4 || kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 1;     // (the first form exists in bf16 only)
   // second form, a wave's K slice longer than 8 k-steps (fc2: 512): 16 KB per wave in flight, operand rows through LDS
-  const bool deep = v2 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 2 && !p.ln_g && kw > 256 && p.M <= 4 && p.K <= 512 * S;
-  const int x_pitch = (p.ln_g || deep) ? p.K * 2 + 16 : 0;
-  const size_t lds = (size_t)S * 1024 + 128 +                   // accumulators | statistics | operand rows or staged partials (+ rows)
-                     (p.ln_g ? (size_t)p.M * x_pitch : (p.stats_partials ? (size_t)128 * S * 8 : (size_t)0) + (deep ? (size_t)p.M * x_pitch : (size_t)0));
+  // (bf16: 8 k-steps = 256 values; fp32 rows are twice as long — four of them at K = 8192 do not fit beside the rest)
+  const bool deep = ES == 2 ? (v2 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 2 && !p.ln_g && kw > 256 && p.M <= 4 && p.K <= 512 * S)
+                            : (!p.ln_g && kw > 128 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 2);   // fp32: 16 KB per wave in flight, rows via L2
+  int x_pitch = 0;
+  const size_t lds = gemv_lds_bytes(p.M, p.K, ES, p.ln_g != nullptr, p.stats_partials != nullptr, deep && ES == 2, S, &x_pitch);
+  if (lds > 160 * 1024) {
+    kx_set_error("kx_gemm(weight streaming): %zu bytes of LDS needed (M=%d K=%d), 160 KB available", lds, p.M, p.K);
+    return KX_ERR_INVALID_ARG;
+  }
   const dim3 grid((unsigned)((p.N + 15) / 16)), block(64 * S);
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_QUICK_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    gemv2_lds_attr<KX_ACT_NONE>(); gemv2_lds_attr<KX_ACT_GELU>(); gemv2_lds_attr<KX_ACT_GELU_FAST>(); gemv2_lds_attr<KX_ACT_QUICK_GELU>();
+    if constexpr (ES == 2) {
+      (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_QUICK_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    gemv2_lds_attr<T, KX_ACT_NONE>(); gemv2_lds_attr<T, KX_ACT_GELU>(); gemv2_lds_attr<T, KX_ACT_GELU_FAST>(); gemv2_lds_attr<T, KX_ACT_QUICK_GELU>();
   });
   if (v2) {
     switch (p.act) {
-      case KX_ACT_NONE: launch_gemv2<KX_ACT_NONE>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
-      case KX_ACT_GELU: launch_gemv2<KX_ACT_GELU>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
-      case KX_ACT_GELU_FAST: launch_gemv2<KX_ACT_GELU_FAST>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
-      case KX_ACT_QUICK_GELU: launch_gemv2<KX_ACT_QUICK_GELU>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
+      case KX_ACT_NONE: launch_gemv2<T, KX_ACT_NONE>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
+      case KX_ACT_GELU: launch_gemv2<T, KX_ACT_GELU>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
+      case KX_ACT_GELU_FAST: launch_gemv2<T, KX_ACT_GELU_FAST>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
+      case KX_ACT_QUICK_GELU: launch_gemv2<T, KX_ACT_QUICK_GELU>(p, grid, block, lds, s, S, kw, x_pitch, deep); break;
       default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
     }
     KX_CHECK_LAUNCH("kx_gemm(weight streaming)");
     return KX_OK;
   }
-  switch (p.act) {
-    case KX_ACT_NONE: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_NONE>, grid, block, lds, s, p, S, kw, x_pitch); break;
-    case KX_ACT_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;
-    case KX_ACT_GELU_FAST: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU_FAST>, grid, block, lds, s, p, S, kw, x_pitch); break;
-    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_QUICK_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;
-    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+  if constexpr (ES == 2) {
+    switch (p.act) {
+      case KX_ACT_NONE: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_NONE>, grid, block, lds, s, p, S, kw, x_pitch); break;
+      case KX_ACT_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;
+      case KX_ACT_GELU_FAST: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_GELU_FAST>, grid, block, lds, s, p, S, kw, x_pitch); break;
+      case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(gemv_fused_kernel<KX_ACT_QUICK_GELU>, grid, block, lds, s, p, S, kw, x_pitch); break;
+      default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+    }
+    KX_CHECK_LAUNCH("kx_gemm(weight streaming)");
   }
-  KX_CHECK_LAUNCH("kx_gemm(weight streaming)");
   return KX_OK;
 }
 
@@ -2270,4 +2313,5 @@ int launch(GemmParams& p, hipStream_t s) {
 int kx_gemm_launch_tiles_bf16(GemmParams& p, int tile, hipStream_t s);
 int kx_gemm_launch_phased_bf16(GemmParams& p, int tile, hipStream_t s);
 int kx_gemm_launch_f32(GemmParams& p, int tile, hipStream_t s);
+int kx_gemm_launch_gemv_f32(GemmParams& p, hipStream_t s);   // tile 16 on fp32 operands (kx_gemm_gemv32.hip)
 int kx_gemm_launch_f16c(GemmParams& p, int tile, hipStream_t s);

@@ -624,8 +624,8 @@ class Decoder(_PackedMixin, nn.Module):
             keep.append(wp)
             return wp.data_ptr(), v(wf @ b_ + lin.bias.detach().float()), v(_operand_colsum(wp, prec, shp))
 
-        def src(i, field, ptr):   # remember the packed operand behind `ptr` (bf16 only: the decode step's precision)
-            if prec == "bf16":
+        def src(i, field, ptr):   # remember the packed operand behind `ptr` (bf16 / fp32: the decode step's precisions)
+            if prec in ("bf16", "fp32"):
                 stream_src.append((i, field, next(t for t in reversed(keep) if t.data_ptr() == ptr)))
 
         layers = (H.DecoderLayer * self.num_layers)()
@@ -801,8 +801,15 @@ class Decoder(_PackedMixin, nn.Module):
             raise RuntimeError("precision changed between incremental steps")
         if t >= Tmax or t + 2 >= pos.shape[0]:
             raise IndexError(f"index out of range in self: position {t + 2} exceeds the table / cache")
-        if prec == "bf16" and B <= 16:
-            self._pack_decode_tiles(prec)                  # first decode step: the streaming copy of the weights
+        # The arithmetic of a decode step.  A step is weight streaming — what it costs is bytes — and an f16c weight row is
+        # 4 bytes per value, exactly what the fp32 weight is: the f16c step therefore runs on the fp32 operands with the
+        # exact-f32 MFMA (same bytes, no compensation needed; its q/k/v cache is fp32 already), i.e. every precision that
+        # holds the north star's tolerance decodes with fp32 products.  KOSMOSX_DECODE_EXACT=0 keeps the f16c tile GEMMs (A/B).
+        sprec = "fp32" if (prec == "f16c" and os.environ.get("KOSMOSX_DECODE_EXACT", "1") != "0") else prec
+        if sprec != prec:
+            w = self._pack(sprec)[0]
+        if sprec in ("bf16", "fp32") and B <= 16:
+            self._pack_decode_tiles(sprec)                 # first decode step: the streaming copy of the weights
         if passed_x is not None:
             _require_cuda(passed_x, "passed_x")
             x = passed_x[:, -1:].to(torch.float32).clone(memory_format=torch.contiguous_format)
@@ -812,11 +819,11 @@ class Decoder(_PackedMixin, nn.Module):
             raise ValueError("batch size changed between incremental steps")
         rows = tuple(None if tb is None else tb[t] for tb in state["xpos"])   # views: row t of each [Tmax, 32] table
         logits = torch.empty((B, 1, w.vocab), dtype=torch.float32, device=x.device)
-        need = lib.kx_decoder_workspace_bytes(C.byref(w), B, 1, H.PRECS[prec])
+        need = lib.kx_decoder_workspace_bytes(C.byref(w), B, 1, H.PRECS[sprec])
         buf = self._ws.get(need, x.device)
         H.check(lib.kx_decoder_decode_step(C.byref(w), x.data_ptr(), B, t, *(H.ptr(r) for r in rows),
                                            state["kcache"].data_ptr(), state["vcache"].data_ptr(), Tmax,
-                                           logits.data_ptr(), H.KX_F32, buf.data_ptr(), buf.numel(), H.PRECS[prec],
+                                           logits.data_ptr(), H.KX_F32, buf.data_ptr(), buf.numel(), H.PRECS[sprec],
                                            _stream()), "kx_decoder_decode_step")
         self._finish_check()                               # an IndexError leaves the state where it was (row t is rewritten)
         state["len"] = t + 1

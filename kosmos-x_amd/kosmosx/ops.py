@@ -131,15 +131,18 @@ def _ln_operand_buffers(g, dt, M, N, device):
 
 
 def tile_weight_rows(w: torch.Tensor) -> torch.Tensor:
-    """[N, K] bf16 (K % 32 == 0) -> the streaming layout of kx_gemm_args.w_tiled: [ceil(N/16), K/32, 64, 8], piece l of block
-    (p, c) = row 16p + (l & 15), columns 32c + 8(l >> 4) .. +7; rows past N are zero.  A copy (torch data movement)."""
+    """[N, K] bf16 or fp32 (K % 32 == 0) -> the streaming layout of kx_gemm_args.w_tiled: [ceil(N/16), K/ks, 64, e] with
+    e = 16 bytes of values (8 bf16 / 4 fp32) and ks = 4e the k-step; piece l of block (p, c) = row 16p + (l & 15), columns
+    ks*c + e*(l >> 4) .. +e-1 — one contiguous 1 KB block per wave load; rows past N are zero.  A copy (torch data movement)."""
     N, K = w.shape
-    assert K % 32 == 0 and w.dtype == torch.bfloat16
+    assert K % 32 == 0 and w.dtype in (torch.bfloat16, torch.float32)
+    e = 16 // w.element_size()
+    ks = 4 * e
     Np = (N + 15) // 16 * 16
     if Np != N:
         w = torch.cat([w, torch.zeros((Np - N, K), dtype=w.dtype, device=w.device)], 0)
-    # [p, i, c, g, 8] -> [p, c, g, i, 8]: piece index l = g * 16 + i
-    return w.view(Np // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(Np // 16, K // 32, 64, 8)
+    # [p, i, c, g, e] -> [p, c, g, i, e]: piece index l = g * 16 + i
+    return w.view(Np // 16, 16, K // ks, 4, e).permute(0, 2, 3, 1, 4).contiguous().view(Np // 16, K // ks, 64, e)
 
 
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,

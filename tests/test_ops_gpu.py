@@ -437,6 +437,81 @@ def test_gemm_weight_streaming_decode_shapes(M, N, K):
         ops.gemm(torch.zeros(17, K, device=DEV, dtype=torch.bfloat16), w.to(DEV), tile=16)
 
 
+@pytest.mark.parametrize("M", [1, 4, 15])
+@pytest.mark.parametrize("N,K", [(264, 2048), (2048, 8192), (1002, 320), (6144, 2048)])
+def test_gemm_weight_streaming_fp32_operands(M, N, K):
+    """tile 16 on fp32 operands (exact-f32 MFMA, four 16x16x4 products per 16-byte chunk): the decode step of the
+    precisions that meet the north star's tolerance.  Against float64: fp32-GEMM accuracy (blocked by the waves' K slices),
+    deterministic, row-major and streaming layouts bit-identical, ragged N / K tails."""
+    g = _g(11 * M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 40
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = _gemm_ref(a.double(), w.double(), bias.double(), res.double(), "gelu")
+    out = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, "gelu", out=out, tile=16)
+    e = float((out.cpu().double() - ref).abs().max() / ref.pow(2).mean().sqrt())
+    assert e < 3e-6, e
+    again = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), again, "gelu", out=again, tile=16)
+    assert torch.equal(out, again)
+    if K % 32 == 0:
+        wt = ops.tile_weight_rows(w.to(DEV))
+        assert wt.shape == ((N + 15) // 16, K // 16, 64, 4)
+        tiled = res.to(DEV).clone()
+        ops.gemm(a.to(DEV), wt, bias.to(DEV), tiled, "gelu", out=tiled, tile=16, w_tiled_rows=N)
+        assert torch.equal(tiled, out)
+    # against the split-K tile kernel of the fp32 mode (the path this replaces in the decode step): same class of error
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device=DEV)
+    tiles = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), tiles, "gelu", out=tiles, tile=64, splitk_ws=ws)
+    assert float((tiles.cpu().double() - ref).abs().max() / ref.pow(2).mean().sqrt()) < 3e-6
+    with pytest.raises(RuntimeError, match="tile 16"):
+        ops.gemm(torch.zeros(17, K, device=DEV), w.to(DEV), tile=16)
+
+
+@pytest.mark.parametrize("M", [1, 3, 8, 15])
+def test_gemm_weight_streaming_fp32_prologues(M):
+    """The decode step's prologues on fp32 operands: LayerNorm of the raw rows (the operand stays fp32: no rounding at
+    all between the statistics and the product), folded-LN statistics from the producer's partials, XPos + q-scale."""
+    N, K = 512, 2048
+    g = _g(300 + M)
+    x = torch.randn(M, K, generator=g) * 3 + 0.5
+    gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    w = torch.randn(N, K, generator=g) / 40
+    bias = torch.randn(N, generator=g)
+    h64 = torch.nn.functional.layer_norm(x.double(), (K,), gam.double(), bet.double(), 1e-5)
+    ref = _gemm_ref(h64, w.double(), bias.double(), None, "gelu")
+    one = ops.gemm(x.to(DEV), w.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5))
+    assert float((one.cpu().double() - ref).abs().max() / ref.pow(2).mean().sqrt()) < 5e-6
+    assert torch.equal(one, ops.gemm(x.to(DEV), w.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5)))
+    h = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV))
+    two = ops.gemm(h, w.to(DEV), bias.to(DEV), act="gelu", tile=16)
+    assert rel_err(one, two.cpu()) < 5e-6
+    # producer statistics per 16 columns, consumer from partials == finalize + row_stats
+    part = torch.zeros(M, N // 16, 2, device=DEV)
+    y = ops.gemm(h, w.to(DEV), bias.to(DEV), act="gelu", tile=16, stats_out=part, stats_out_seg=16)
+    assert torch.equal(y, two)
+    st = ops.row_stats_finalize(part, 16).cpu()
+    assert (st[:, 0] - y.cpu().mean(1)).abs().max() < 2e-5
+    w2 = (torch.randn(256, N, generator=g) / 20).to(DEV)
+    cs = w2.sum(1)
+    res = torch.randn(M, 256, generator=g).to(DEV)
+    b2 = bias[:256].to(DEV).contiguous()
+    via_part = ops.gemm(y, w2, b2, res.clone(), tile=16, stats_partials=part, stats_in_seg=16, colsum=cs)
+    y64 = y.cpu().double()
+    ln64 = (y64 - y64.mean(1, keepdim=True)) / torch.sqrt(y64.var(1, unbiased=False, keepdim=True) + 1e-5)
+    ref2 = ln64 @ w2.cpu().double().t() + b2.cpu().double() + res.cpu().double()
+    assert float((via_part.cpu().double() - ref2).abs().max() / ref2.pow(2).mean().sqrt()) < 2e-5
+    # q-scale + XPos rows of one position (xpos_T = 1), as the qkv GEMM of a decode step
+    xq = [torch.randn(1, 32, generator=g).to(DEV) for _ in range(4)]
+    wq = (torch.randn(384, K, generator=g) / 40).to(DEV)
+    bq = torch.randn(384, generator=g).to(DEV)
+    got = ops.gemm(x.to(DEV), wq, bq, tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5), qscale=0.125, qcols=128, xpos=xq, xpos_dim=128)
+    want = ops.gemm(h, wq, bq, tile=64, qscale=0.125, qcols=128, xpos=xq, xpos_dim=128)
+    assert rel_err(got, want.cpu()) < 5e-6
+
+
 @pytest.mark.parametrize("M", [1, 7, 16])
 def test_gemm_weight_streaming_prologues(M):
     """The three things the decode step folds into tile 16: LayerNorm of the raw rows (bit-identical operand to

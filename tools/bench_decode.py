@@ -15,7 +15,8 @@ ap.add_argument("--prefix", type=int, default=114)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--max-len", type=int, default=512)
 ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "f16c", "mixed"],
-                help="bf16 streams the weights through the tile-16 kernels; the f16c / fp32 paths run the generic per-op step")
+                help="bf16 streams bf16 weights through the tile-16 kernels; fp32 / f16c / mixed stream fp32 weights through "
+                     "the same kernels on the exact-f32 MFMA (KOSMOSX_DECODE_EXACT=0: f16c keeps its tile GEMMs)")
 ap.add_argument("--by-shape", action="store_true", help="also print the per-launch time of each kernel shape (in-process events)")
 ap.add_argument("--tune", default="", help="A/B: kx_set_tuning key=value pairs, e.g. 1=64 (tile kernels instead of tile 16)")
 a = ap.parse_args()
@@ -44,9 +45,10 @@ with torch.no_grad():
     recs = _hip.prof_collect()
     _hip.prof_enable(False)
 L, d, F, V = 24, 2048, 8192, 32002
-wbytes = 2 * (L * (4 * d * d + 2 * d * F) + d * V)
+eb = 2 if a.precision in ('bf16', 'bf16x3') else 4                 # operand bytes per weight / cached value
+wbytes = eb * (L * (4 * d * d + 2 * d * F) + d * V)
 tavg = a.prefix + 4 + a.steps / 2
-kvbytes = 2 * L * a.batch * tavg * d * 2
+kvbytes = 2 * L * a.batch * tavg * d * eb
 agg = {}
 shapes = {}
 for kind, x, y, z, ms in recs:
