@@ -73,8 +73,19 @@ def parse():
 _PMC_KEYS = {"gemm_bf16_160x128": "gemm_kernel<{T},160,128", "gemm_bf16_128x128": "gemm_kernel<{T},128,128",
              "gemm_bf16_64x64": "gemm_kernel<{T},64,64", "gemm_bf16_256x128_phased": "gemm_kernel_p3<{T}",
              "gemm_bf16_256x256_phased": "gemm_kernel_p5<{T}", "attn_bf16": "attn_"}
-_PMC_FILES = {"bf16": ("profiles/r01_v_pmc.json", "bf16", "profiles/r01_v_pmc_summary.md"),
-              "mixed": ("profiles/r02_b_pmc.json", "f16c_t", "profiles/r02_b_pmc_summary.md")}
+_PMC_FILES = {"mixed": ("profiles/r03_pmc.json", "f16c_t", "profiles/r03_pmc_summary.md")}
+
+
+def gemm_sources_digest() -> str:
+    """sha256 over the sources of the GEMM kernel family (what roofline.traffic was measured on)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = Path(__file__).resolve().parent / "kosmos-x_amd" / "csrc"
+    for f in sorted(list(csrc.glob("kx_gemm*")) + [csrc / "kx_common.h"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
 
 
 def pmc_traffic(kernel, args):
@@ -90,7 +101,12 @@ def pmc_traffic(kernel, args):
     if not f.exists():
         return {"traffic": None}
     key = key.format(T=ent[1])
-    rows = [v for k, v in json.loads(f.read_text()).items() if k.startswith(key)]
+    data = json.loads(f.read_text())
+    meta = data.pop("_meta", {})
+    if meta.get("gemm_sources_digest") != gemm_sources_digest():          # counters of other code are not this code's traffic
+        return {"traffic": None, "traffic_source": f"{ent[0]} was collected on GEMM sources {meta.get('gemm_sources_digest')}, "
+                                                   f"this library is built from {gemm_sources_digest()}: refused (re-run tools/pmc_round.sh)"}
+    rows = [v for k, v in data.items() if k.startswith(key)]
     n = sum(v["launches"] for v in rows)
     if not n:
         return {"traffic": None}

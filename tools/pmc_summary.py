@@ -41,5 +41,9 @@ for r in rows:
 # machine-readable companion: per-launch HBM-side traffic (fetch x2 + write, bytes) per kernel, for bench.py's roofline.traffic
 import json
 out = {r[0]: {"launches": r[1], "fetch_bytes_x2": round(r[7] * 1048576), "write_bytes": round(r[8] * 1048576)} for r in rows}
+# which code these counters belong to: bench.py refuses the file when the GEMM-family sources have changed since
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import gemm_sources_digest
+out["_meta"] = {"gemm_sources_digest": gemm_sources_digest(), "kernels": sorted(r[0] for r in rows)}
 if len(sys.argv) > 2:
     Path(sys.argv[2]).write_text(json.dumps(out, indent=1))

@@ -46,6 +46,13 @@ def mm_format(a, w, fmt):
         a8, ar8 = f8(a * sa), f8((a - ah) * sa * c)
         w8, wr8 = f8(w * sw_), f8((w - wh) * sw_ * c)
         return ah @ wh.t() + (a8 @ wr8.t() + ar8 @ w8.t()) / (sa * sw_ * c)
+    if fmt in ("f16cw", "f16ca"):   # f16c with ONE of the two fp8 correction products: weight-side (a8 * dw8) or activation-side (da8 * w8)
+        ah, wh = a.half().float(), w.half().float()
+        sa, sw_ = p2(a), p2(w)
+        c = 2.0 ** 11
+        if fmt == "f16cw":
+            return ah @ wh.t() + (f8(a * sa) @ f8((w - wh) * sw_ * c).t()) / (sa * sw_ * c)
+        return ah @ wh.t() + (f8((a - ah) * sa * c) @ f8(w * sw_).t()) / (sa * sw_ * c)
     if fmt == "f16x2a":   # activation split in two fp16, weight single fp16
         ah, wh = a.half().float(), w.half().float()
         al = (a - ah).half().float()
