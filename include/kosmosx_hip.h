@@ -170,6 +170,14 @@ typedef struct {
    * fragment a lane loads), rows past N zero.  fp32 operands: [ceil(N/16)][K/16][64][4], piece l = row 16p + (l & 15),
    * columns 16c + 4(l >> 4) .. +3.  K % 32 == 0; ldw is ignored. */
   int32_t w_tiled;
+  /* tile 16 (weight streaming) only — the residual stream of a decode step as a PAIR (x = xa + xb, always summed in that
+   * order).  A residual GEMM with few columns (out_proj / fc2: N = 2048 -> 128 workgroups for 256 CUs) is launched with its
+   * K extent cut into `ksplit` (1 or 2) parts, one workgroup per (16 columns, part): part 0 writes
+   * C = (residual + residual2) + bias + its partial product, part 1 writes its partial product to C2 [M, N] fp32 (ldc) —
+   * no cross-workgroup reduction, no atomics, bit-reproducible.  Needs an fp32 C, no activation / statistics producer / XPos /
+   * ln_gamma, N % 16 == 0, K % (64 * ksplit) == 0.  residual2 (optional, with `residual`): second addend of the residual.
+   * a_add (optional, with ln_gamma): second addend of the raw rows, LayerNorm(A + a_add) is the operand. */
+  int32_t ksplit; void* C2; const float* residual2; const float* a_add;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 
@@ -530,7 +538,8 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  *        16 KB variant);
  * key 9: KV-cache layout per layer and sequence (0 = [heads][Tmax][64]; 1 = the first layout [Tmax][heads*64]; set it
  *        before a prefill and keep it for that cache's steps).
- * key 10: 1 = the fp32 decode step keeps the split-K tile kernels instead of the fp32 weight-streaming kernel (A/B). */
+ * key 10: 1 = the fp32 decode step keeps the split-K tile kernels instead of the fp32 weight-streaming kernel (A/B).
+ * key 11: 1 = the streamed decode step keeps ONE workgroup per 16 columns in its residual GEMMs (no kx_gemm_args.ksplit pair). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -186,6 +186,18 @@ bool row_reduce_available(int64_t M, int64_t N, int64_t K, int prec) {
   return kx_gemm_auto_splits(M, N, K * kmul(prec), gp, g_splitk_ws_bytes) > 1;
 }
 
+static int cu_count() {   // CUs of the current device (cached for device 0..63)
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 // tile 16 (weight streaming, bf16, M <= 16) with its prologues — see kx_gemm_args in the header
 struct Gemv16 {
   const void* A; int64_t lda; const void* W; int64_t K; void* C; int64_t ldc; int cdt; int64_t M, N;
@@ -196,6 +208,7 @@ struct Gemv16 {
   float* stats_out = nullptr;
   const void* W_tiled = nullptr;          // the same matrix in the streaming layout (kx_gemm_args.w_tiled), or null
   int prec = KX_PREC_BF16;                // KX_PREC_BF16 or KX_PREC_F32 (operand dtype of A, unless ln_g, and of W)
+  int ksplit = 0; void* C2 = nullptr; const float* residual2 = nullptr; const float* a_add = nullptr;   // kx_gemm_args: the pair form
 };
 int gemv16(const Gemv16& v, hipStream_t s) {
   kx_gemm_args g;
@@ -210,6 +223,7 @@ int gemv16(const Gemv16& v, hipStream_t s) {
   g.stats_partials = v.partials_in; g.stats_in_nseg = v.nseg_in; g.stats_in_seg = v.seg_in; g.stats_eps = v.eps;
   g.colsum = v.colsum;
   g.stats_out = v.stats_out; g.stats_out_seg = v.stats_out ? 16 : 0;
+  g.ksplit = v.ksplit; g.C2 = v.C2; g.residual2 = v.residual2; g.a_add = v.a_add;
   return kx_gemm(&g, (void*)s);
 }
 
@@ -286,7 +300,7 @@ PerBufs per_plan(const kx_perceiver_weights* w, int64_t B, int64_t m, int prec, 
 }
 
 // ---------------- Decoder ----------------
-struct DecBufs { void *h, *qkv, *att, *g, *splitk; float *partials, *stats, *partials2, *stats2; size_t total; };
+struct DecBufs { void *h, *qkv, *att, *g, *splitk; float *partials, *stats, *partials2, *stats2, *xb, *ya, *yb; size_t total; };
 DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, char* base) {
   const int64_t M = B * T;
   const size_t es = esz(prec);
@@ -303,6 +317,9 @@ DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, ch
   d.stats = (float*)c.take((size_t)M * 2 * 4);
   d.partials2 = (float*)c.take((size_t)M * ((w->dim + 63) / 64) * 2 * 4);   // folded pre-LayerNorms (residual-stream rows)
   d.stats2 = (float*)c.take((size_t)M * 2 * 4);
+  // decode step (T = 1): the residual stream as a pair — second addend of x, and the pair the attention block writes
+  d.xb = d.ya = d.yb = nullptr;
+  if (T == 1) { d.xb = (float*)c.take((size_t)M * w->dim * 4); d.ya = (float*)c.take((size_t)M * w->dim * 4); d.yb = (float*)c.take((size_t)M * w->dim * 4); }
   d.splitk = c.take(KX_SPLITK_WS);
   d.total = c.off;
   return d;
@@ -610,33 +627,47 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
   // exact-f32 MFMA (KX_PREC_F32: what the Python side asks for in every precision that holds the north star's tolerance).
   if ((prec == KX_PREC_BF16 || prec == KX_PREC_F32) && M <= 16 && kx_tuning_get(KX_TUNE_GEMM_TILE) == 0 && D % 32 == 0 &&
       F % 32 == 0 && (size_t)M * (es * D + 16) <= 128 * 1024 && !(prec == KX_PREC_F32 && kx_tuning_get(KX_TUNE_DECODE_STREAM_F32) == 1)) {
+    // The residual GEMMs have N = D columns = D / 16 workgroups (128 at full size: half the CUs stream).  Where that leaves
+    // CUs idle they run as TWO workgroups per column block, each over half of K, and the residual stream becomes a pair
+    // x = xa + xb (kx_gemm_args.ksplit): part 0 writes (xa' + xb') + bias + its product to the next pair's first member,
+    // part 1 its product to the second; the LayerNorm prologues and the next residual read sum the pair in that order.
+    // No cross-workgroup reduction, deterministic.  Tuning key 11 = 1 keeps one workgroup per block (in place: x += ...).
+    const bool pair = kx_tuning_get(KX_TUNE_DECODE_KSPLIT) != 1 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 1 &&
+                      D / 16 <= (cu_count() * 3) / 4 && D % 128 == 0 && F % 128 == 0 &&
+                      M <= 4;   // (five rows and more take the wave-per-row LayerNorm prologue, which walks each row three times: reading a
+                                //  pair there cost more than the idle CUs — B = 8: 1.43 -> 1.55 ms per step in bf16)
+    float *pa = x, *pb = nullptr;                                 // the stream as the next reader finds it
     for (int i = 0; i < w->layers; ++i) {
       const kx_decoder_layer& L = w->layer[i];
-      Gemv16 q{x, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D};
-      q.bias = L.bqkv; q.qscale = 0.125f; q.qcols = D; q.ln_g = L.sa_g; q.ln_b = L.sa_b; q.eps = w->eps;
+      Gemv16 q{pa, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D};
+      q.bias = L.bqkv; q.qscale = 0.125f; q.qcols = D; q.ln_g = L.sa_g; q.ln_b = L.sa_b; q.eps = w->eps; q.a_add = pb;
       if (w->xpos) { q.xq_cs = xq_cs; q.xq_ss = xq_ss; q.xk_cs = xk_cs; q.xk_ss = xk_ss; q.xT = 1; q.xdim = D; }
       q.W_tiled = L.wqkv_t; q.prec = prec;
       KX_TRY(gemv16(q, s));
       KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, ct,
                                  w->subln ? d.partials : nullptr, B, w->heads, t, Tmax, prec, stream));
-      Gemv16 o{d.att, D, L.wo, D, x, D, KX_F32, M, D};
-      o.bias = L.bo; o.residual = x; o.eps = w->eps;
+      float *qa = pair ? d.ya : pa, *qb = pair ? d.yb : nullptr;   // what out_proj writes
+      Gemv16 o{d.att, D, L.wo, D, qa, D, KX_F32, M, D};
+      o.bias = L.bo; o.residual = pa; o.residual2 = pb; o.eps = w->eps;
+      if (pair) { o.ksplit = 2; o.C2 = qb; }
       if (w->subln) { o.partials_in = d.partials; o.nseg_in = w->heads; o.seg_in = 64; o.colsum = L.wo_colsum; }
       o.W_tiled = L.wo_t; o.prec = prec;
       KX_TRY(gemv16(o, s));
-      Gemv16 f1{x, D, L.w1, D, d.g, F, ct, M, F};
-      f1.bias = L.b1; f1.act = w->act; f1.ln_g = L.fl_g; f1.ln_b = L.fl_b; f1.eps = w->eps;
+      Gemv16 f1{qa, D, L.w1, D, d.g, F, ct, M, F};
+      f1.bias = L.b1; f1.act = w->act; f1.ln_g = L.fl_g; f1.ln_b = L.fl_b; f1.eps = w->eps; f1.a_add = qb;
       if (w->subln) f1.stats_out = d.partials;
       f1.W_tiled = L.w1_t; f1.prec = prec;
       KX_TRY(gemv16(f1, s));
-      Gemv16 f2{d.g, F, L.w2, F, x, D, KX_F32, M, D};
-      f2.bias = L.b2; f2.residual = x; f2.eps = w->eps;
+      pa = x; pb = pair ? d.xb : nullptr;                         // what fc2 writes
+      Gemv16 f2{d.g, F, L.w2, F, pa, D, KX_F32, M, D};
+      f2.bias = L.b2; f2.residual = qa; f2.residual2 = qb; f2.eps = w->eps;
+      if (pair) { f2.ksplit = 2; f2.C2 = pb; }
       if (w->subln) { f2.partials_in = d.partials; f2.nseg_in = F / 16; f2.seg_in = 16; f2.colsum = L.w2_colsum; }
       f2.W_tiled = L.w2_t; f2.prec = prec;
       KX_TRY(gemv16(f2, s));
     }
-    Gemv16 lo{x, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab};
-    lo.ln_g = w->ln_g; lo.ln_b = w->ln_b; lo.eps = w->eps;
+    Gemv16 lo{pa, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab};
+    lo.ln_g = w->ln_g; lo.ln_b = w->ln_b; lo.eps = w->eps; lo.a_add = pb;
     lo.W_tiled = w->wout_t; lo.prec = prec;
     return gemv16(lo, s);
   }

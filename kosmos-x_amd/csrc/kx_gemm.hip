@@ -110,6 +110,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
              "kx_gemm: ln_operand_out needs an fp32 output with residual, N %% 64 == 0, aligned rows, a 2-byte / KX_F16C "
              "operand dtype and the prefetching store loop");
   p.stagger_ticks = 0; p.w_tiled = 0;
+  p.gsplit = 1; p.kfull = p.K; p.C2 = nullptr; p.residual2 = nullptr; p.a_add = nullptr;
   p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
   p.stats_partials = nullptr; p.stats_in_nseg = 0; p.stats_in_seg = p.stats_eps = 0.f;
   p.ln_out = nullptr; p.ln_out_dt = 0; p.ln_out_g = p.ln_out_b = nullptr; p.ln_out_eps = 0.f;
@@ -198,6 +199,19 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * es + 16) <= 128 * 1024 && a->K % 4 == 0),
                "kx_gemm: LayerNorm prologue needs beta and M*(K*%d+16) <= 128 KB", es);
     KX_REQUIRE(!a->ln_operand_out, "kx_gemm: tile 16 does not produce ln_operand_out");
+    KX_REQUIRE(!a->residual2 || a->residual, "kx_gemm: residual2 is the second addend of `residual`");
+    KX_REQUIRE(!a->a_add || a->ln_gamma, "kx_gemm: a_add is the second addend of the LayerNorm-prologue rows (ln_gamma)");
+    KX_REQUIRE(!(a->residual2 || a->ksplit > 1) || (p.vec_ok && a->N % 16 == 0 && !a->xpos_dim && !(a->row_stats && !a->stats_partials)),
+               "kx_gemm: residual2 / ksplit need N %% 16 == 0, 16-byte aligned rows, no XPos, statistics as partials");
+    KX_REQUIRE(kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 1 || !(a->residual2 || a->a_add || a->ksplit > 1),
+               "kx_gemm: the pair form of the residual stream needs the second form of the streaming kernel (tuning key 8 != 1)");
+    p.residual2 = a->residual2; p.a_add = a->a_add;
+    if (a->ksplit > 1) {
+      KX_REQUIRE(a->ksplit == 2 && a->C2 && a->cdt == KX_F32 && a->act == KX_ACT_NONE && !a->stats_out && !a->ln_gamma &&
+                     a->K % (64 * a->ksplit) == 0 && ((uintptr_t)a->C2 & 15) == 0,
+                 "kx_gemm: ksplit = 2 needs C2, an fp32 C, no activation / statistics producer / ln_gamma, K %% 128 == 0");
+      p.gsplit = a->ksplit; p.C2 = a->C2; p.kfull = p.K; p.K = p.K / a->ksplit;
+    }
     KX_REQUIRE(!a->stats_partials || (a->colsum && !a->row_stats && a->stats_in_nseg > 0 && a->stats_in_seg > 0),
                "kx_gemm: stats_partials needs colsum, nseg, seg size and excludes row_stats");
     KX_REQUIRE(!a->stats_out || (a->stats_out_seg == 16 && a->N % 16 == 0 && !a->residual),
@@ -210,6 +224,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   } else {
     KX_REQUIRE(!(a->ln_gamma || (a->stats_out_seg != 0 && a->stats_out_seg != 64)),
                "kx_gemm: ln_gamma / stats_out_seg = 16 belong to tile 16 (weight streaming)");
+    KX_REQUIRE(a->ksplit <= 1 && !a->C2 && !a->residual2 && !a->a_add, "kx_gemm: ksplit / C2 / residual2 / a_add belong to tile 16");
     if (a->stats_partials) {                            // consumed by the row-owning split-K reduce (checked below)
       KX_REQUIRE(a->colsum && !a->row_stats && a->stats_in_nseg > 0 && a->stats_in_seg > 0,
                  "kx_gemm: stats_partials needs colsum, nseg, seg size and excludes row_stats");

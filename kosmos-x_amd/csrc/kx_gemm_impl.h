@@ -49,6 +49,12 @@ struct GemmParams {
   // weight-streaming variant (gemv_fused_kernel) only
   const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
   const float* stats_partials; int stats_in_nseg; float stats_in_seg, stats_eps;
+  // weight streaming, the decode step's residual stream as a PAIR (x = xa + xb, summed in that order wherever it is read):
+  // a residual GEMM with few columns (N = 2048: 128 workgroups on 256 CUs) is launched with its K extent split over
+  // gsplit = 2 workgroups per column block (blockIdx.y); split 0 writes C = residual (+ residual2) + bias + its partial,
+  // split 1 writes its partial to C2 — no cross-workgroup reduction, no atomics, bit-reproducible.  K is the extent of ONE
+  // split, kfull the row length of W.  a_add: second addend of the LayerNorm-prologue rows (A + a_add is normalised).
+  int gsplit, kfull; void* C2; const float* residual2; const float* a_add;
   // row-owning split-K reduce: optional LayerNorm of the finished row as a second output
   void* ln_out; int ln_out_dt; const float *ln_out_g, *ln_out_b; float ln_out_eps;
 };
@@ -1875,7 +1881,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel(const GemmParams p, in
 // workgroup will need is issued first, in the order it is consumed, then the weights; the prologues and the epilogue
 // find their operands in registers.  LNP = LayerNorm prologue (A = raw fp32 rows) — a template parameter so that the two
 // operand paths do not add their registers (1024-thread workgroups: 128 VGPRs).
-struct GemvEpiOps { float4 c, b, r; float2 xc, xs; };
+struct GemvEpiOps { float4 c, b, r, r2; float2 xc, xs; };
 
 // T = bf16_t (16x16x32 bf16 MFMA; a 1 KB wave load is 16 rows x 32 k) or float (exact-f32 16x16x4 MFMA, four per 16-byte
 // chunk; a 1 KB wave load is 16 rows x 16 k): the fp32 instantiation is the decode step of the precisions that hold the
@@ -1900,12 +1906,14 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   constexpr bool XS = !LNP && UW == 16 && sizeof(T) == 2;        //   wave's K slice is 512 (fc2) — then the bf16 operand rows are staged in LDS
                                                                  //   (fp32 rows are read through the L2: four 32 KB rows do not fit beside the rest)
   const int n0 = blockIdx.x * 16;
+  const int ksp = blockIdx.y;                                    // K split of a residual GEMM (GemmParams.gsplit), else 0
+  const long long kbase = (long long)ksp * p.K;                  // p.K = this split's extent, p.kfull = the row length of W
   const int k0 = wave * kw, klen = min(kw, p.K - k0);           // may be <= 0 for trailing waves of a short K
   const int nrow = min(n0 + i, p.N - 1);
   const int xrow = min(i, p.M - 1);
   const int k0w = klen > 0 ? k0 : 0;                             // (a wave without a K slice streams a valid address and drops it)
-  const char* wp = p.w_tiled ? p.W + (((long long)blockIdx.x * (p.K >> KSH) + (k0w >> KSH)) << 10) + (lane << 4)
-                             : p.W + (long long)nrow * p.ldw_b + (long long)(k0w + EPL * g) * ES;
+  const char* wp = p.w_tiled ? p.W + (((long long)blockIdx.x * (p.kfull >> KSH) + ((kbase + k0w) >> KSH)) << 10) + (lane << 4)
+                             : p.W + (long long)nrow * p.ldw_b + (kbase + k0w + EPL * g) * ES;
   const int wstep = p.w_tiled ? 1024 : 64;
   const int ulast = max(klen - 1, 0) >> KSH;
   auto ldw = [&](const char* q) { return *reinterpret_cast<const u32x4_t*>(q); };
@@ -1913,7 +1921,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   // ---- (1) the small loads, in consumption order ----
   const bool coop = LNP && (p.K >> 2) <= 64 * S && p.M <= 4;
   const bool has = tid < (p.K >> 2);
-  float4 v[4], gm, bt;                                           // LNP, cooperative: this thread's float4 of rows 0..3
+  float4 v[4], v2[4], gm, bt;                                    // LNP, cooperative: this thread's float4 of rows 0..3 (v2: the pair's second addend)
   u32x4_t xf[XG];                                                // !LNP: the first batch of operand fragments
   u32x4_t xs[4];                                                 // XS: this thread's 16 bytes of operand rows 0..3
   // statistics prologue: the producer's partials [M][nseg] float2 go through registers (requested first) into LDS, where
@@ -1930,6 +1938,12 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
 #pragma unroll
       for (int r = 0; r < 4; ++r)                                // (1, 2 or 4 rows are reduced: M = 3 repeats its last row)
         if (r < p.M || (r == 3 && p.M == 3)) v[r] = reinterpret_cast<const float4*>(p.A + (long long)min(r, p.M - 1) * p.lda_b)[vt];
+      if (p.a_add) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < p.M || (r == 3 && p.M == 3))
+            v2[r] = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.a_add) + (long long)min(r, p.M - 1) * p.lda_b)[vt];
+      }
       gm = reinterpret_cast<const float4*>(p.ln_g)[vt];
       bt = reinterpret_cast<const float4*>(p.ln_b)[vt];
     }
@@ -1942,9 +1956,9 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
     if constexpr (XS) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (r < p.M && tid < (p.K * ES >> 4)) xs[r] = *reinterpret_cast<const u32x4_t*>(p.A + (long long)r * p.lda_b + (tid << 4));
+        if (r < p.M && tid < (p.K * ES >> 4)) xs[r] = *reinterpret_cast<const u32x4_t*>(p.A + (long long)r * p.lda_b + kbase * ES + (tid << 4));
     } else {
-      const char* xg0 = p.A + (long long)xrow * p.lda_b + (long long)(k0 + EPL * g) * ES;
+      const char* xg0 = p.A + (long long)xrow * p.lda_b + (kbase + k0 + EPL * g) * ES;
 #pragma unroll
       for (int u = 0; u < XG; ++u)
         if (KS * u < klen) xf[u] = *reinterpret_cast<const u32x4_t*>(xg0 + KS * u * ES);
@@ -1967,6 +1981,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       }
     }
     if (p.residual) eo.r = *reinterpret_cast<const float4*>(p.residual + (long long)em * p.ldr + en);
+    if (p.residual2) eo.r2 = *reinterpret_cast<const float4*>(p.residual2 + (long long)em * p.ldr + en);
   }
   // ---- (2) the stream: this wave's first 8 KB.  UNCONDITIONAL loads (k-steps past the slice re-read its last one): only
   // then can the waits below be counted — "all but the last eight" — instead of draining the stream
@@ -2015,6 +2030,11 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
     }
   }
   if constexpr (LNP) {
+    if (coop && p.a_add) {                                       // the pair's sum, in the order every reader uses: xa + xb
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < p.M || (r == 3 && p.M == 3)) { v[r].x += v2[r].x; v[r].y += v2[r].y; v[r].z += v2[r].z; v[r].w += v2[r].w; }
+    }
     if (coop) {
       // Each wave reduces its own 256 columns to (sum, M2 about its own mean) — two shuffle trees per row — and the S pairs
       // are combined with Chan's formula after ONE barrier (the kx_row_stats_finalize arithmetic).  The first version
@@ -2073,18 +2093,20 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       const int nv = p.K >> 2;                                   // more rows: one wave per row, kx_layernorm's walk
       for (int m = wave; m < p.M; m += S) {
         const float4* xr = reinterpret_cast<const float4*>(p.A + (long long)m * p.lda_b);
+        const float4* xr2 = p.a_add ? reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.a_add) + (long long)m * p.lda_b) : nullptr;
+        auto row4 = [&](int c) { float4 q = xr[c]; if (xr2) { const float4 q2 = xr2[c]; q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w; } return q; };
         float sm = 0.f;
-        for (int c = lane; c < nv; c += 64) { const float4 q = xr[c]; sm += (q.x + q.y) + (q.z + q.w); }
+        for (int c = lane; c < nv; c += 64) { const float4 q = row4(c); sm += (q.x + q.y) + (q.z + q.w); }
         const float mean = wave_sum_dpp(sm) / (float)p.K;
         float q2 = 0.f;
         for (int c = lane; c < nv; c += 64) {
-          const float4 q = xr[c];
+          const float4 q = row4(c);
           const float a = q.x - mean, b = q.y - mean, cc = q.z - mean, d = q.w - mean;
           q2 += (a * a + b * b) + (cc * cc + d * d);
         }
         const float rstd = rsqrtf(wave_sum_dpp(q2) / (float)p.K + p.ln_eps);
         for (int c = lane; c < nv; c += 64) {
-          const float4 q = xr[c];
+          const float4 q = row4(c);
           const float4 gq = reinterpret_cast<const float4*>(p.ln_g)[c];
           const float4 bq = reinterpret_cast<const float4*>(p.ln_b)[c];
           const float y0 = (q.x - mean) * rstd * gq.x + bq.x, y1 = (q.y - mean) * rstd * gq.y + bq.y;
@@ -2106,7 +2128,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   // ---- (4) the products ----
   f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const char* xl = (LNP ? xn : xsb) + xrow * x_pitch + (k0 + EPL * g) * ES;   // LNP / XS: the operand rows in LDS
-  const char* xg = p.A + (long long)xrow * p.lda_b + (long long)(k0 + EPL * g) * ES;
+  const char* xg = p.A + (long long)xrow * p.lda_b + (kbase + k0 + EPL * g) * ES;
   for (int kk = 0; kk < klen; kk += KS * U) {
     if (kk > 0) {                                                // (first batch: in flight)
 #pragma unroll
@@ -2137,11 +2159,11 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   float x[4] = {acc[0], acc[1], acc[2], acc[3]};
   if (live && pre) {
     if (p.stats_partials) {
-      const float2 ms = make_float2(st[2 * m], st[2 * m + 1]);
+      const float2 ms = make_float2(ksp ? 0.f : st[2 * m], st[2 * m + 1]);     // (the mean * colsum term belongs to split 0)
       x[0] = ms.y * (x[0] - ms.x * eo.c.x); x[1] = ms.y * (x[1] - ms.x * eo.c.y);
       x[2] = ms.y * (x[2] - ms.x * eo.c.z); x[3] = ms.y * (x[3] - ms.x * eo.c.w);
     }
-    if (p.bias) { x[0] += eo.b.x; x[1] += eo.b.y; x[2] += eo.b.z; x[3] += eo.b.w; }
+    if (p.bias && !ksp) { x[0] += eo.b.x; x[1] += eo.b.y; x[2] += eo.b.z; x[3] += eo.b.w; }
     if (n < p.qcols) { x[0] *= p.qscale; x[1] *= p.qscale; x[2] *= p.qscale; x[3] *= p.qscale; }
     if (p.xpos_dim && n < 2 * p.xpos_dim) {
       const float y0 = x[0] * eo.xc.x + (-x[1]) * eo.xs.x;
@@ -2154,7 +2176,10 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[j] = apply_act<ACT>(x[j]);
     }
-    if (p.residual) { x[0] += eo.r.x; x[1] += eo.r.y; x[2] += eo.r.z; x[3] += eo.r.w; }
+    if (p.residual && !ksp) {
+      if (p.residual2) { eo.r.x += eo.r2.x; eo.r.y += eo.r2.y; eo.r.z += eo.r2.z; eo.r.w += eo.r2.w; }   // xa + xb first
+      x[0] += eo.r.x; x[1] += eo.r.y; x[2] += eo.r.z; x[3] += eo.r.w;
+    }
   } else if (live) {
     GemmParams q = p;
     q.stats_out = nullptr;
@@ -2175,12 +2200,13 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   if (!live) return;
   const bool full = n + 3 < p.N && p.vec_ok;
   const long long off = (long long)m * p.ldc + n;
+  void* const Cout = ksp ? p.C2 : p.C;
   if (p.c_bf16) {
-    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
+    bf16_t* c = reinterpret_cast<bf16_t*>(Cout) + off;
     if (full) { uint2 o; o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); *reinterpret_cast<uint2*>(c) = o; }
     else for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = f32_to_bf16(x[j]);
   } else {
-    float* c = reinterpret_cast<float*>(p.C) + off;
+    float* c = reinterpret_cast<float*>(Cout) + off;
     if (full) *reinterpret_cast<float4*>(c) = make_float4(x[0], x[1], x[2], x[3]);
     else for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = x[j];
   }
@@ -2211,7 +2237,10 @@ inline size_t gemv_lds_bytes(int M, int K, int es, bool ln, bool partials, bool 
 template <typename T>
 int launch_gemv_fused(GemmParams& p, hipStream_t s) {
   constexpr int ES = (int)sizeof(T);
-  const int S = (long long)p.K * ES <= 8192 ? 8 : 16;           // a wave's K slice: at most 1 KB of a row where 16 waves allow it
+  // waves per workgroup: 8 while a wave's K slice is at most 512 values (bf16: 1 KB of row, fp32: 2 KB), else 16.  Two
+  // 512-thread workgroups share a CU and overlap their phases: fp32 rows of K = 2048 on 16 waves (every k-step of a slice
+  // in flight at once, one workgroup per CU) measured 20.7 / 23.0 us for the qkv / fc1 launches against 12.6 / 15.9.
+  const int S = p.K <= 4096 ? 8 : 16;
   const int kw = ((p.K + S - 1) / S + 31) / 32 * 32;
   const bool v2 = ES == 4 || kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 1;     // (the first form exists in bf16 only)
   // second form, a wave's K slice longer than 8 k-steps (fc2: 512): 16 KB per wave in flight, operand rows through LDS
@@ -2224,7 +2253,7 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
     kx_set_error("kx_gemm(weight streaming): %zu bytes of LDS needed (M=%d K=%d), 160 KB available", lds, p.M, p.K);
     return KX_ERR_INVALID_ARG;
   }
-  const dim3 grid((unsigned)((p.N + 15) / 16)), block(64 * S);
+  const dim3 grid((unsigned)((p.N + 15) / 16), (unsigned)(p.gsplit > 1 ? p.gsplit : 1)), block(64 * S);
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
     if constexpr (ES == 2) {

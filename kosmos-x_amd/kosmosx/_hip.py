@@ -53,7 +53,7 @@ class GemmArgs(C.Structure):
                 ("stats_out_seg", i32),
                 ("ln_out", vp), ("ln_out_dt", i32), ("ln_out_gamma", vp), ("ln_out_beta", vp), ("ln_out_eps", f32),
                 ("w_scale", vp), ("ln_operand_out", vp), ("ln_operand_dt", i32), ("ln_operand_stats", vp),
-                ("w_tiled", i32)]
+                ("w_tiled", i32), ("ksplit", i32), ("C2", vp), ("residual2", vp), ("a_add", vp)]
 
 
 class AttnArgs(C.Structure):

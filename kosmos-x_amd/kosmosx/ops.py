@@ -71,7 +71,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, o
 def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
          xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None, splitk_ws=None,
          splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0, out_x3=False,
-         ln_out=None, ln_operand=None, w_tiled_rows=0):
+         ln_out=None, ln_operand=None, w_tiled_rows=0, ksplit=0, out2=None, residual2=None, a_add=None):
     """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32].
     tile=16 (weight streaming, bf16, M <= 16) extras: ln = (gamma, beta, eps) with `a` the raw fp32 rows;
     stats_partials [M,nseg,2] instead of row_stats; stats_out_seg=16.
@@ -105,6 +105,8 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
         g.stats_partials, g.stats_in_nseg = H.ptr(stats_partials), stats_partials.shape[1]
         g.stats_in_seg, g.stats_eps = stats_in_seg, float(stats_eps)
     g.stats_out_seg = stats_out_seg
+    # tile 16, the residual stream as a pair (kx_gemm_args.ksplit): out2 receives part 1's product
+    g.ksplit, g.C2, g.residual2, g.a_add = ksplit, H.ptr(out2), H.ptr(residual2), H.ptr(a_add)
     lnt = None
     if ln_out is not None:
         lnt = torch.empty((M, N), dtype=ln_out[3], device=a.device)

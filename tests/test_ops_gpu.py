@@ -512,6 +512,58 @@ def test_gemm_weight_streaming_fp32_prologues(M):
     assert rel_err(got, want.cpu()) < 5e-6
 
 
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(1, 2048, 8192), (4, 2048, 2048), (8, 512, 1024), (15, 256, 4096)])
+def test_gemm_weight_streaming_pair_form(prec, M, N, K):
+    """kx_gemm_args.ksplit = 2: a residual GEMM of the decode step runs as two workgroups per 16 columns, each over half of
+    K; part 0 writes (residual + residual2) + bias + its product, part 1 its product to C2.  The pair sums to the
+    one-workgroup result up to fp32 rounding, repeats bit for bit, takes the folded-LN statistics from partials and both
+    weight layouts; a_add is the second addend of the LayerNorm-prologue rows."""
+    g = _g(17 * M + N + K)
+    a = torch.randn(M, K, generator=g).to(prec)
+    w = (torch.randn(N, K, generator=g) / 40).to(prec)
+    bias = torch.randn(N, generator=g)
+    ra, rb = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g) * 0.1
+    ref = a.double() @ w.double().t() + bias.double() + (ra + rb).double()
+    c1, c2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), ra.to(DEV), out=c1, tile=16, ksplit=2, out2=c2, residual2=rb.to(DEV))
+    got = (c1 + c2).cpu().double()
+    tol = 3e-6 if prec == torch.float32 else 3e-5
+    assert float((got - ref).abs().max() / ref.pow(2).mean().sqrt()) < tol
+    one = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), (ra + rb).to(DEV), tile=16)
+    assert rel_err(c1 + c2, one.cpu()) < 2e-6
+    d1, d2 = torch.empty_like(c1), torch.empty_like(c2)
+    ops.gemm(a.to(DEV), ops.tile_weight_rows(w.to(DEV)), bias.to(DEV), ra.to(DEV), out=d1, tile=16, ksplit=2, out2=d2,
+             residual2=rb.to(DEV), w_tiled_rows=N)
+    assert torch.equal(c1, d1) and torch.equal(c2, d2)                      # streaming layout: the same bits, and repeatable
+    # folded sub-LN consume from the producer's partials: rstd * (acc - mean * colsum) — the mean term rides with part 0
+    part = torch.zeros(M, K // 16, 2, device=DEV)
+    af = a.float().to(DEV)
+    for j in range(K // 16):
+        seg = af[:, 16 * j:16 * j + 16]
+        part[:, j, 0] = seg.sum(1)
+        part[:, j, 1] = ((seg - seg.mean(1, keepdim=True)) ** 2).sum(1)
+    cs = w.float().sum(1).to(DEV)
+    e1, e2 = torch.empty_like(c1), torch.empty_like(c2)
+    ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), ra.to(DEV), out=e1, tile=16, ksplit=2, out2=e2, residual2=rb.to(DEV),
+             stats_partials=part, stats_in_seg=16, colsum=cs)
+    a64 = a.double()
+    ln = (a64 - a64.mean(1, keepdim=True)) / torch.sqrt(a64.var(1, unbiased=False, keepdim=True) + 1e-5)
+    ref_ln = ln @ w.double().t() + bias.double() + (ra + rb).double()
+    assert float(((e1 + e2).cpu().double() - ref_ln).abs().max() / ref_ln.pow(2).mean().sqrt()) < (2e-5 if prec == torch.float32 else 2e-4)
+    # LayerNorm prologue over a pair of addends
+    if K <= 2048:
+        xa, xb = torch.randn(M, K, generator=g) * 2, torch.randn(M, K, generator=g) * 0.3
+        gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+        two = ops.gemm(xa.to(DEV), w.to(DEV), bias.to(DEV), tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5), a_add=xb.to(DEV))
+        pre = ops.gemm((xa + xb).to(DEV), w.to(DEV), bias.to(DEV), tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5))
+        assert torch.equal(two, pre)                                        # xa + xb is formed first, in fp32: the same operand
+    with pytest.raises(RuntimeError, match="ksplit"):
+        ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), ra.to(DEV), out=c1, tile=16, ksplit=2, out2=c2, act="gelu")
+    with pytest.raises(RuntimeError, match="tile 16"):
+        ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), ra.to(DEV), out=c1, tile=64, ksplit=2, out2=c2)
+
+
 @pytest.mark.parametrize("M", [1, 7, 16])
 def test_gemm_weight_streaming_prologues(M):
     """The three things the decode step folds into tile 16: LayerNorm of the raw rows (bit-identical operand to
