@@ -236,7 +236,16 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     // Skinny problems (batch-1 shapes: M = 114 / 257 / 64) are weight-streaming bound and a 64x64 grid of N/64 x 2
     // workgroups leaves most CUs idle while each one walks all of K serially.  Slice K so that ~512 workgroups
     // stream the weights concurrently; partials are small ([splits][M][N] fp32, L2/MALL resident).
-    const long long sp = splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk ? a->splitk : (a->stats_out && !f16c ? -2 : 0), f16c);
+    long long sp = splitk_slices(a->M, a->N, p.K, 128 / es, a->splitk_ws_bytes, a->splitk ? a->splitk : (a->stats_out && !f16c ? -2 : 0), f16c);
+    // ... unless the tiles alone nearly fill the chip (the batch-1 qkv GEMMs: 192 / 240 tiles) and nothing needs the reduce
+    // kernel: then ONE workgroup per tile walks all of K on the 8-stage ring (six K-tiles in flight instead of three) and
+    // the reduce launch with its dirty-L2 boundary disappears.  Tuning key 4 = 7 keeps the split.
+    const long long tiles64 = ((a->M + 63) / 64) * ((a->N + 63) / 64);
+    if (sp == 2 && !a->splitk && p.ring && es == 2 && !f16 && tiles64 >= 160 && tiles64 <= kx_cu_count() && !a->stats_out &&
+        !a->ln_out && !a->stats_partials && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 7 && p.K / 64 >= 8) {
+      sp = 1;
+      p.ring = 8;
+    }
     if (sp > 1) {
       p.splitk = (int)sp;
       p.partial = (float*)a->splitk_ws;

@@ -619,8 +619,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int IA = BM / 32, IW = BN / 32;  // glds instructions per wave per stage (8 rows each)
   constexpr int EPI_BYTES = BM * BN * 4;     // the epilogue parks the whole fp32 tile in LDS
   constexpr int SMEM = NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES;
-  static_assert(NST == 2 || (NST == 4 && IA + IW == 4), "the counted waits below assume 4 DMA instructions per tile");
-  static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU must fit the 160 KB LDS");
+  static_assert(NST == 2 || ((NST == 4 || NST == 8) && IA + IW == 4), "the counted waits below assume 4 DMA instructions per tile");
+  static_assert((NST == 8 ? 1 : 2) * SMEM <= 160 * 1024, "two workgroups per CU (one with the 8-stage ring) must fit the 160 KB LDS");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   // ---- XCD-aware, grouped tile mapping ----
@@ -721,8 +721,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       __syncthreads();
       if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     } else {
-      const int ahead = nk - 1 - kt;                       // tiles requested after kt that may still be in flight
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      const int ahead = min(nk - 1 - kt, NST - 2);         // tiles requested after kt that may still be in flight
+      if constexpr (NST == 8) {                            // (unsplit skinny launches: six K-tiles in flight per workgroup)
+        switch (ahead) {
+          case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+          case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+      } else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // a RAW barrier: __syncthreads() carries a fence that drains vmcnt to 0 — the DMA of the next tiles would be waited for
@@ -2309,6 +2319,20 @@ int launch(GemmParams& p, hipStream_t s) {
       if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
       if (p.act == KX_ACT_QUICK_GELU) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
       if (p.act == KX_ACT_GELU_FAST) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU_FAST, 1>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm"); return KX_OK; }
+    }
+  }
+  if constexpr (BM == 64 && BN == 64 && sizeof(T) == 2 && !kIsF16c<T>) {
+    // unsplit skinny launch whose tiles fit one per CU: the 8-stage ring (128 KB of LDS, six K-tiles in flight) walks all of
+    // K in one workgroup — no partials, no reduce launch (the batch-1 qkv GEMMs: 192 / 240 tiles)
+    if (p.ring == 8) {
+      switch (p.act) {
+        case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE, 0, 8>), grid, block, 0, s, p); break;
+        case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU_FAST, 0, 8>), grid, block, 0, s, p); break;
+        case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU, 0, 8>), grid, block, 0, s, p); break;
+        default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
+      }
+      KX_CHECK_LAUNCH("kx_gemm");
+      return KX_OK;
     }
   }
   if constexpr (BM == 64 && BN == 64) {

@@ -437,6 +437,40 @@ def test_gemm_weight_streaming_decode_shapes(M, N, K):
         ops.gemm(torch.zeros(17, K, device=DEV, dtype=torch.bfloat16), w.to(DEV), tile=16)
 
 
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(114, 6144, 2048), (257, 3072, 1024), (64, 12288, 512)])
+def test_gemm_skinny_unsplit_on_the_eight_stage_ring(prec, M, N, K):
+    """Batch-1 qkv shapes: 160..256 tiles of 64x64 nearly fill the chip on their own, so the automatic choice walks all of K
+    in ONE workgroup per tile on the 8-stage LDS ring (six K-tiles in flight) instead of two K slices + a reduce launch.
+    Same products, one accumulation order instead of two partial sums: equal to the split launch up to fp32 rounding;
+    the fused epilogue (bias, q-scale, XPos) is the tile kernel's own."""
+    from kosmosx import _hip
+    g = _g(M + N + K)
+    a = torch.randn(M, K, generator=g).to(prec)
+    w = (torch.randn(N, K, generator=g) / 40).to(prec)
+    bias = torch.randn(N, generator=g)
+    T_ = M // 2 if M % 2 == 0 else M
+    xp = [torch.randn(T_, 32, generator=g).to(DEV) for _ in range(4)]
+    xd = (N // 3) // 64 * 64
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    kw = dict(qscale=0.125, qcols=xd, xpos=xp, xpos_dim=xd, splitk_ws=ws)
+    one = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), **kw)
+    assert torch.equal(one, ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), **kw))
+    lib = _hip.load()
+    try:
+        lib.kx_set_tuning(4, 7)
+        split = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), **kw)
+    finally:
+        lib.kx_set_tuning(4, 0)
+    assert rel_err(one, split.cpu()) < 2e-5          # (fp32 accumulation order only; measured 3-5e-6 through the XPos rotation)
+    forced = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), tile=64, qscale=0.125, qcols=xd, xpos=xp, xpos_dim=xd)   # no scratch: two-stage kernel
+    assert rel_err(one, forced.cpu()) < 2e-5
+    y = a.double() @ w.double().t() + bias.double()
+    y[:, :xd] *= 0.125
+    ref_v = y[:, 2 * xd:]
+    assert float((one[:, 2 * xd:].cpu().double() - ref_v).abs().max() / ref_v.pow(2).mean().sqrt()) < 3e-5
+
+
 @pytest.mark.parametrize("M", [1, 4, 15])
 @pytest.mark.parametrize("N,K", [(264, 2048), (2048, 8192), (1002, 320), (6144, 2048)])
 def test_gemm_weight_streaming_fp32_operands(M, N, K):
