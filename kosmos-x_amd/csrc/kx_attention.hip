@@ -432,7 +432,12 @@ __device__ __forceinline__ f32x4_t mma_f16(u32x4_t a, u32x4_t b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
-template <bool CAUSAL>
+// PVS = true (default): P and V on split operands too.  PVS = false (tuning key 2 = 4, A/B only): P and V as plain fp16,
+// O^T += V^T P^T is one MFMA instead of three and P is not split on the VALU.  The CPU study said it would fit
+// (tools/precision_study.py --attn-list: q / k in plain fp16 leave 0.95 / 1.4e-3 on the logits on their own, p and v
+// together move 2.5e-4 to 3.5e-4); measured on the device at full size it does NOT: 1.5-1.7e-3 (B = 32 rows, T = 2046,
+// decode prefill — round 3, tests/test_fullsize_parity_gpu.py with key 2 = 4), for 0.5 % of the B = 32 step.  Kept off.
+template <bool CAUSAL, bool PVS>
 __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned short Kh[2][64 * 64], Kl[2][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned short Vh[2][64 * VSTR], Vl[2][64 * VSTR];
@@ -497,9 +502,14 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
       *reinterpret_cast<u32x4_t*>(&Kl[buf][row * 64 + ((part ^ (row & 7)) << 3)]) = lo;
       const float vx[8] = {vreg[j][0].x * SC, vreg[j][0].y * SC, vreg[j][0].z * SC, vreg[j][0].w * SC,
                            vreg[j][1].x * SC, vreg[j][1].y * SC, vreg[j][1].z * SC, vreg[j][1].w * SC};
-      split_f16x8(vx, hi, lo);
+      if constexpr (PVS) {
+        split_f16x8(vx, hi, lo);
+        *reinterpret_cast<u32x4_t*>(&Vl[buf][row * VSTR + part * 8]) = lo;
+      } else {
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) hi[j2] = pack_f16x2(vx[2 * j2], vx[2 * j2 + 1]);
+      }
       *reinterpret_cast<u32x4_t*>(&Vh[buf][row * VSTR + part * 8]) = hi;
-      *reinterpret_cast<u32x4_t*>(&Vl[buf][row * VSTR + part * 8]) = lo;
     }
   };
 
@@ -584,7 +594,11 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
         for (int c = 0; c < 2; ++c) {
           const float x[8] = {st[qb][2 * c][0], st[qb][2 * c][1], st[qb][2 * c][2], st[qb][2 * c][3],
                               st[qb][2 * c + 1][0], st[qb][2 * c + 1][1], st[qb][2 * c + 1][2], st[qb][2 * c + 1][3]};
-          split_f16x8(x, ph[qb][c], pl[qb][c]);
+          if constexpr (PVS) split_f16x8(x, ph[qb][c], pl[qb][c]);
+          else {
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) ph[qb][c][j2] = pack_f16x2(x[2 * j2], x[2 * j2 + 1]);
+          }
         }
       }
       // ---- O'^T += V'^T P'^T : V fragments by transpose-read from the hi and lo planes (k map as in v2) ----
@@ -595,14 +609,20 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
           const int vo = (32 * c + 4 * g + (li >> 2)) * VSTR + d * 16 + (li & 3) * 4;
           const u32x2_t h0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vh[buf][vo]));
           const u32x2_t h1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vh[buf][vo + 16 * VSTR]));
-          const u32x2_t l0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vl[buf][vo]));
-          const u32x2_t l1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vl[buf][vo + 16 * VSTR]));
-          const u32x4_t vh = (u32x4_t){h0[0], h0[1], h1[0], h1[1]}, vl = (u32x4_t){l0[0], l0[1], l1[0], l1[1]};
+          const u32x4_t vh = (u32x4_t){h0[0], h0[1], h1[0], h1[1]};
+          if constexpr (PVS) {
+            const u32x2_t l0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vl[buf][vo]));
+            const u32x2_t l1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vl[buf][vo + 16 * VSTR]));
+            const u32x4_t vl = (u32x4_t){l0[0], l0[1], l1[0], l1[1]};
 #pragma unroll
-          for (int qb = 0; qb < 2; ++qb) {
-            ot[qb][d] = mma_f16(vl, ph[qb][c], ot[qb][d]);
-            ot[qb][d] = mma_f16(vh, pl[qb][c], ot[qb][d]);
-            ot[qb][d] = mma_f16(vh, ph[qb][c], ot[qb][d]);
+            for (int qb = 0; qb < 2; ++qb) {
+              ot[qb][d] = mma_f16(vl, ph[qb][c], ot[qb][d]);
+              ot[qb][d] = mma_f16(vh, pl[qb][c], ot[qb][d]);
+              ot[qb][d] = mma_f16(vh, ph[qb][c], ot[qb][d]);
+            }
+          } else {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) ot[qb][d] = mma_f16(vh, ph[qb][c], ot[qb][d]);
           }
         }
     }
@@ -920,10 +940,15 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   KxProfScope prof(a->prec == KX_PREC_F32 ? KX_K_ATTN_F32 : KX_K_ATTN_BF16, a->B * a->H, a->Tq, a->Tk, s);
   if (a->prec == KX_PREC_F16C) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
-    if (a->mask == KX_ATTN_CAUSAL)
-      hipLaunchKernelGGL(attn_f16s_kernel<true>, dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
-    else
-      hipLaunchKernelGGL(attn_f16s_kernel<false>, dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+    const bool pvs = kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 4;       // 4 = A/B: P and V as plain fp16 (misses the tolerance)
+    const dim3 gc((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), gf(nx, (unsigned)a->H, (unsigned)a->B);
+    if (a->mask == KX_ATTN_CAUSAL) {
+      if (pvs) hipLaunchKernelGGL((attn_f16s_kernel<true, true>), gc, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_f16s_kernel<true, false>), gc, dim3(256), 0, s, p);
+    } else {
+      if (pvs) hipLaunchKernelGGL((attn_f16s_kernel<false, true>), gf, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_f16s_kernel<false, false>), gf, dim3(256), 0, s, p);
+    }
   } else if (f16) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     if (a->mask == KX_ATTN_CAUSAL)

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from kosmosx import ops  # noqa: E402
+from kosmosx import _hip, ops  # noqa: E402
 from kosmosx.model import Kosmos, KosmosLanguage, _operand_colsum, _operand_f16c  # noqa: E402
 from oracle import kosmos_oracle as O  # noqa: E402
 from helpers import max_abs, oracle_cfg, oracle_weights, rel_err, tiny_config  # noqa: E402
@@ -140,8 +140,23 @@ ATTN_CASES = [(2, 3, 114, 114, True), (1, 2, 115, 115, True), (2, 2, 257, 257, F
               (1, 1, 1, 1, True), (1, 2, 9, 9, True), (3, 1, 130, 130, True), (1, 2, 700, 700, True), (1, 1, 5, 77, False)]
 
 
+@pytest.fixture
+def split_pv():
+    """(the default) P and V on split operands as well: the three-product form of O += P V."""
+    yield
+
+
+@pytest.fixture
+def plain_pv():
+    """tuning key 2 = 4 (A/B only): P and V as plain fp16."""
+    lib = _hip.load()
+    lib.kx_set_tuning(2, 4)
+    yield
+    lib.kx_set_tuning(2, 0)
+
+
 @pytest.mark.parametrize("case", ATTN_CASES)
-def test_attention_f16c_split_products(case):
+def test_attention_f16c_split_products(case, split_pv):
     B, Hh, Tq, Tk, causal = case
     g = _g(Tq * 7 + Tk)
     q = (torch.randn(B, Tq, Hh, 64, generator=g) * 0.6).to(DEV)
@@ -160,7 +175,33 @@ def test_attention_f16c_split_products(case):
     assert e * 20 < e16 or e16 < 1e-6
 
 
-def test_attention_f16c_softmax_spike_and_strided_views():
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_f16c_ab_variant_split_scores_plain_pv(case, plain_pv):
+    """The A/B variant of the KX_PREC_F16C attention (off: it misses the logit tolerance at full size): scores from split q / k, P and V as plain fp16.  Against float64 the
+    output carries only P's and V's fp16 rounding — |err| <= ~2^-11 max|v|, far below what plain-fp16 q / k do to the scores
+    — and it equals the float64 attention evaluated on fp16-rounded V to within P's rounding."""
+    B, Hh, Tq, Tk, causal = case
+    g = _g(Tq * 7 + Tk)
+    q = (torch.randn(B, Tq, Hh, 64, generator=g) * 0.6).to(DEV)
+    k = (torch.randn(B, Tk, Hh, 64, generator=g) * 1.5).to(DEV)
+    v = torch.randn(B, Tk, Hh, 64, generator=g).to(DEV)
+    ref = _attn_ref(q, k, v, causal)
+    st = torch.zeros(B * Tq, Hh, 2, device=DEV)
+    out = ops.attention(q, k, v, causal, f16c=True, stats_out=st)
+    assert torch.equal(out, ops.attention(q, k, v, causal, f16c=True))
+    vmax = max(1.0, float(v.abs().max()))
+    e = float((out.cpu().double() - ref).abs().max())
+    assert e < 2.0 ** -10 * vmax, (case, e)
+    ev = float((out.cpu().double() - _attn_ref(q, k, v.half().float(), causal)).abs().max())
+    assert ev < 2.0 ** -10 * vmax
+    seg = out.cpu().double().view(B * Tq, Hh, 64)
+    assert float((st[:, :, 0].cpu().double() - seg.sum(-1)).abs().max()) < 1e-4       # statistics of the values it wrote
+    qh, kh = q.half().float(), k.half().float()
+    e16 = float((_attn_ref(qh, kh, v, causal) - ref).abs().max())
+    assert e < e16 or e16 < 2e-4                                                     # still better than plain-fp16 scores
+
+
+def test_attention_f16c_softmax_spike_and_strided_views(split_pv):
     g = _g(3)
     qkv = torch.randn(2, 200, 3 * 4 * 64, generator=g).to(DEV)
     qkv[:, 150, 256:512] *= 12.0                                              # a late key that moves every running max
@@ -168,6 +209,16 @@ def test_attention_f16c_softmax_spike_and_strided_views():
     ref = _attn_ref(q, k, v, True)
     out = ops.attention(q, k, v, True, f16c=True)
     assert float((out.cpu().double() - ref).abs().max()) < 5e-6 * max(1.0, float(ref.abs().max()))
+
+
+def test_attention_f16c_ab_variant_softmax_spike(plain_pv):
+    g = _g(3)
+    qkv = torch.randn(2, 200, 3 * 4 * 64, generator=g).to(DEV)
+    qkv[:, 150, 256:512] *= 12.0
+    q, k, v = (qkv[:, :, i * 256:(i + 1) * 256].unflatten(2, (4, 64)) for i in range(3))
+    ref = _attn_ref(q, k, v, True)
+    out = ops.attention(q, k, v, True, f16c=True)
+    assert float((out.cpu().double() - ref).abs().max()) < 2.0 ** -10 * max(1.0, float(v.abs().max()))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -98,8 +98,14 @@ class Study:
         y = mm_format(x.reshape(-1, x.shape[-1]), w, fmt).reshape(*x.shape[:-1], w.shape[0])
         return y if b is None else y + b
 
-    def r(self, x, sw):   # attention operands (q, k, p, v)
+    def r(self, x, sw):   # attention operands (q, k, p, v) — the oracle rounds them in exactly this order, attention by attention
         f = self.attn_fmt
+        if f.startswith("fp16:"):      # "fp16:qk" = only the named operands (of q, k, p, v) in plain fp16, the others exact
+            self._n = getattr(self, "_n", 0) + 1
+            which = "qkpv"[(self._n - 1) % 4]
+            if x.dim() == 4 and x.shape[1] == 16 and "vit.attn" in self.override:
+                return x.half().float()
+            return x.half().float() if which in f[5:] else x
         if x.dim() == 4 and x.shape[1] == 16 and "vit.attn" in self.override:   # the ViT's [B,16,257,*] operands
             f = self.override["vit.attn"]
         if f == "fp32":
@@ -120,6 +126,7 @@ def main():
     ap.add_argument("--formats", default="bf16,fp16,f16x2a,f16c,f16c_static,bf16x3")
     ap.add_argument("--attn", default="match")
     ap.add_argument("--text", type=int, default=50)
+    ap.add_argument("--attn-list", default="", help="mixed-mode runs over several attention operand settings, e.g. split,fp16:p,fp16:v,fp16:pv,fp16:qk,fp16")
     ap.add_argument("--mix", default="", help="one run with several families overridden: fam=fmt,fam=fmt (vit.attn too)")
     ap.add_argument("--budget", default="", help="error budget: run BASE with ONE GEMM family at a time in this cheaper "
                                                  "format, e.g. --budget fp16 (base format = first of --formats)")
@@ -166,6 +173,15 @@ def main():
         attn = a.attn
         if attn == "match":
             attn = {"bf16": "bf16", "fp16": "fp16", "f16x2a": "fp16"}.get(fmt, "split")
+        if a.attn_list:
+            for attn_ in a.attn_list.split(","):
+                st = Study(fmt, attn_, w, {"vit.qkv": "fp16", "vit.out": "fp16", "vit.fc1": "fp16", "vit.fc2": "fp16", "vit.attn": "fp16"})
+                O.linear, O._r = st.linear, st.r
+                out = O.kosmos_forward(w, tok, img, cfg, O.Switches(emulate_bf16=True))
+                O.linear, O._r = lin0, r0
+                d = out - ref
+                print(f"{fmt} (tower fp16) attn={attn_:10s}: max|d|/rms = {float(d.abs().max()) / rms:.3e}   rms(d)/rms = {float(d.pow(2).mean().sqrt()) / rms:.3e}", flush=True)
+            continue
         st = Study(fmt, attn)
         O.linear, O._r = st.linear, st.r
         sw = O.Switches(emulate_bf16=True)     # routes the conv through _r as well
