@@ -196,8 +196,14 @@ __device__ __forceinline__ f32x4_t mma16(u32x4_t a, u32x4_t b, f32x4_t c) {
 template <bool F16>
 __device__ __forceinline__ unsigned pack16x2(float lo, float hi) { return F16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
 
-template <bool CAUSAL, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p) {
+// FOLD (unmasked launches whose last query block holds at most 32 queries — the CLIP tower: T = 257 = 2 x 128 + 1): the
+// workgroups carry a FIFTH wave that is idle except in the last launched block, where it takes the tail queries
+// (nx - 1) * 128 ... — so the launch has nx - 1 blocks per (batch, head) instead of nx.  A workgroup's time is the K / V
+// stream it walks, whatever its queries: the third block of the tower's launches streamed all 257 keys for ONE query
+// (1536 workgroups = three rounds of the chip; folded: 1024 = two).  Bit-identical, and measured 0.8 % SLOWER in situ: off by default.
+template <bool CAUSAL, bool F16 = false, bool FOLD = false>
+__global__ __launch_bounds__(FOLD ? 320 : 256, 2) void attn_bf16_v2_kernel(const AttnParams p) {
+  static_assert(!(CAUSAL && FOLD), "the tail fold is for unmasked launches (causal blocks are paired instead)");
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * VSTR];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
   for (int pass = 0; pass < npass; ++pass) {
   const int qblk0 = (pass == 0 ? (int)blockIdx.x : qb_second) * 128;
   const int qw0 = qblk0 + wave * 32;                        // first query of this wave
-  const bool wave_live = qw0 < p.Tq;
+  const bool wave_live = qw0 < p.Tq && (!FOLD || wave < 4 || blockIdx.x + 1 == gridDim.x);   // (FOLD: wave 4 = the tail, last block only)
   const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + (long long)b * p.qbs + (long long)h * 64;
   const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + (long long)b * p.kbs + (long long)h * 64;
   const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + (long long)b * p.kbs + (long long)h * 64;
@@ -241,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
   // cooperative tile loads: thread owns chunks c = tid, tid+256 -> (row c>>3, 16-B part c&7)
   u32x4_t kreg[2], vreg[2];
   auto gload = [&](int t) {   // rows past Tk are clamped to the last key: finite data, masked to P = 0 by the softmax
+    if (FOLD && tid >= 256) return;                           // (the fifth wave does not stage)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = tid + 256 * j, row = c >> 3, part = c & 7;
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
     }
   };
   auto lstore = [&](int buf) {
+    if (FOLD && tid >= 256) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = tid + 256 * j, row = c >> 3, part = c & 7;
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const AttnParams p
   for (int qb = 0; qb < 2; ++qb) {
     const float l = lt[qb][0];           // sum over all keys of the bf16 P the PV product used
     const float inv = 1.0f / l;
-    const int qi = qw0 + qb * 16 + li;
+    const int qi = wave_live ? qw0 + qb * 16 + li : p.Tq;      // (a FOLD workgroup's idle fifth wave owns no query)
     if (p.lse_out && g == 0 && qi < p.Tq)            // log-sum-exp of the query's scores, for the backward pass
       p.lse_out[((long long)b * p.H + h) * p.Tq + qi] = m_run[qb] + logf(l);
     if (p.stats_out) {   // (sum, M2 about the mean) of this query's 64 outputs for head h: 16 local values x 4 lanes
@@ -938,6 +946,10 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
              "kx_attention: stats_out is not implemented by the v1 A/B kernel");
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(a->prec == KX_PREC_F32 ? KX_K_ATTN_F32 : KX_K_ATTN_BF16, a->B * a->H, a->Tq, a->Tk, s);
+  // unmasked launch whose last 128-query block would hold <= 32 queries, folded into a fifth wave: A/B only (tuning key
+  // 2 = 5).  Measured at B = 32 (same box, round 3): mixed 1096 -> 1088 samples/s, bf16 1728 -> 1712 — the tail block's
+  // workgroup has one live wave and retires quickly; 320-thread workgroups cost the other blocks more than it saves.
+  const bool fold = a->mask != KX_ATTN_CAUSAL && a->Tq > 128 && (a->Tq - 1) % 128 < 32 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 5;
   if (a->prec == KX_PREC_F16C) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     const bool pvs = kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 4;       // 4 = A/B: P and V as plain fp16 (misses the tolerance)
@@ -953,6 +965,8 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     if (a->mask == KX_ATTN_CAUSAL)
       hipLaunchKernelGGL((attn_bf16_v2_kernel<true, true>), dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+    else if (fold)
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, true, true>), dim3(nx - 1, (unsigned)a->H, (unsigned)a->B), dim3(320), 0, s, p);
     else
       hipLaunchKernelGGL((attn_bf16_v2_kernel<false, true>), dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
   } else if (a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1) {   // v1, kept for A/B
@@ -963,6 +977,8 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     if (a->mask == KX_ATTN_CAUSAL)   // causal workgroups take query-block pairs (x, nx-1-x)
       hipLaunchKernelGGL((attn_bf16_v2_kernel<true, false>), dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+    else if (fold)
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false, true>), dim3(nx - 1, (unsigned)a->H, (unsigned)a->B), dim3(320), 0, s, p);
     else
       hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false>), dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
   } else if (kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1 && !drop) {

@@ -223,6 +223,34 @@ def test_attention_bf16(case):
     assert float((out.cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < 3e-3, case
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Tq,Tk", [(257, 257), (129, 129), (160, 200), (161, 161), (385, 385), (416, 257), (130, 64)])
+def test_attention_tail_block_folded_into_a_fifth_wave(dt, Tq, Tk):
+    """A/B variant (tuning key 2 = 5; off by default: 0.8 % slower in situ): unmasked launches whose last 128-query block holds
+    <= 32 queries (the CLIP tower: 257 = 2 x 128 + 1) run with one block fewer, a fifth wave of the last launched workgroup
+    taking the tail queries.  Same per-wave arithmetic: bit-identical to the default launch, statistics and strided views
+    included; Tq = 161 (33 tail queries) is not folded."""
+    from kosmosx import _hip
+    g = _g(Tq * 5 + Tk)
+    qkv = torch.randn(2, max(Tq, Tk), 3 * 3 * 64, generator=g).to(dt).to(DEV)
+    q, k, v = (qkv[:, :, i * 192:(i + 1) * 192].unflatten(2, (3, 64)) for i in range(3))
+    q, k, v = q[:, :Tq], k[:, :Tk], v[:, :Tk]
+    ref = _attn_ref(q.float().cpu() , k.float().cpu(), v.float().cpu(), False)
+    st = torch.zeros(2 * Tq, 3, 2, device=DEV)
+    plain = ops.attention(q, k, v, False, out_dtype=torch.float32, stats_out=st)
+    assert rel_err(plain, ref) < 1.5e-2
+    lib = _hip.load()
+    try:
+        lib.kx_set_tuning(2, 5)
+        st2 = torch.zeros_like(st)
+        out = ops.attention(q, k, v, False, out_dtype=torch.float32, stats_out=st2)
+        o16 = ops.attention(q, k, v, False)                                  # 2-byte output
+    finally:
+        lib.kx_set_tuning(2, 0)
+    assert torch.equal(out, plain) and torch.equal(st, st2)
+    assert o16.dtype == dt and torch.equal(o16, ops.attention(q, k, v, False))
+
+
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_attention_f32(case):
     B, H, Tq, Tk, causal = case
