@@ -132,6 +132,11 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     // A/B only (tuning key 4 = 3): measured SLOWER than the row-major store loop it was meant to replace — C3 qkv 36.5 ms
     // (1084 TFLOP/s) on the generic loop, 49.3 ms with the tables read from global in accumulator layout, 44.5 ms with
     // them staged through LDS (the 256-row variant pushes half of its rotated accumulators through scratch).
+    // KX_F16C output (the decoder's fc1 in f16c / mixed) without residual / XPos / q-scale split inside a tile: the 256-column
+    // kernel's three-plane lean store (tuning key 4 = 8: generic loops, A/B)
+    p.lean_f16c = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 8 && p.c_f16c && f16c &&
+                  !a->residual && !a->xpos_dim && a->qcols % 64 == 0 && a->N % 16 == 0 && (a->ldc * 2) % 16 == 0 &&
+                  !a->ln_operand_out;
     p.lean_xpos = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) == 3 && a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && p.vec8_ok &&
                   a->xpos_dim > 0 && !a->residual && !a->row_stats && !a->stats_out && a->act == KX_ACT_NONE &&
                   a->qcols % 256 == 0 && a->xpos_dim % 256 == 0;

@@ -41,6 +41,7 @@ struct GemmParams {
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
   int lean_epilogue;    // 256-column kernel: accumulator-level epilogue + pure data movement (see lean_store_*)
   int lean_xpos;        // 256-column kernel, bf16 output: q-scale + XPos at accumulator level too (lean_bias_qscale_xpos)
+  int lean_f16c;        // 256-column kernel, KX_F16C output: accumulator-level epilogue + three-plane tile store (lean_store_f16c)
   int w_tiled;          // tile 16: W in the streaming layout [N/16][K/32][1 KB] (kx_gemm_args.w_tiled)
   int ring;             // 64x64 launches: 4-stage LDS ring, three K-tiles in flight (A/B: tuning key 4 = 6 turns it off)
   int gelu_poly;        // 256-column kernel, lean epilogues: KX_ACT_GELU_FAST may run as KX_ACT_GELU_POLY (plain bf16 in / out)
@@ -604,6 +605,67 @@ __device__ __forceinline__ void lean_store_bf16(const GemmParams& p, const f32x4
     const int rt = ps * RPP + wave * RPI + rl;
     const uint4 v = *reinterpret_cast<const uint4*>(smem + rt * RB + ((cl ^ (rt & 7)) << 4));
     if (m0 + rt < p.M) *reinterpret_cast<uint4*>(cbase + (long long)(m0 + rt) * p.ldc) = v;
+  }
+}
+
+// KX_F16C output of the 256-column kernel (the decoder's fc1 in f16c / mixed: 4 bytes per value, [fp16 | fp8 | fp8 residual]
+// planes per row).  Round 2 sent these through the generic store loops (fp32 parking in two halves, ~100 instructions per
+// 8 values: fc1 ran at 535 TF/s where fc2 ran at 638 at C3's rows).  Here the values are packed ONCE at accumulator level
+// (f16c_pack4) and parked as the three planes they become — a 256 x 256 tile is 256 KB of output, so in two halves of 128
+// tile rows (the b-fragments [h * FM/2, (h+1) * FM/2) of both wave rows): H plane 128 x 512 B, E and R planes 128 x 256 B
+// (128 KB, the staging LDS), 16-byte chunks XOR-swizzled by row (H: & 7 as the bf16 store, E / R: & 15 — sixteen rows of a
+// fragment write the same column block); after one barrier every wave instruction stores whole rows of one plane.
+template <int BM, int FM, int FN>
+__device__ __forceinline__ void lean_store_f16c(const GemmParams& p, const f32x4_t (&acc)[FN][FM], char* smem, int m0, int n0,
+                                                int wm, int wn, int wave, int lane, int g, int li) {
+  static_assert(BM == 256 && FM == 8 && FN == 4, "written for the 256 x 256 tile (8 waves of 128 x 64)");
+  char* const Hp = smem;                    // [128][512 B]
+  char* const Ep = smem + 128 * 512;        // [128][256 B]
+  char* const Rp = Ep + 128 * 256;          // [128][256 B]
+  char* const Cb = reinterpret_cast<char*>(p.C);
+  const long long pitch = 2ll * p.ldc;      // bytes per output row (ldc counts 2-byte units)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();                        // the K loop's last fragment reads / the previous half's row reads are done
+#pragma unroll
+    for (int bb = 0; bb < FM / 2; ++bb) {
+      const int b = half * (FM / 2) + bb;
+      const int hr = wm * 64 + bb * 16 + li;                       // row inside this half's 128
+#pragma unroll
+      for (int a = 0; a < FN; ++a) {
+        uint2 h; unsigned e, r;
+        f16c_pack4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3], h, e, r);
+        const int ch = (wn * 8 + a * 2 + (g >> 1)) ^ (hr & 7);
+        *reinterpret_cast<uint2*>(Hp + hr * 512 + ch * 16 + (g & 1) * 8) = h;
+        const int ce = (wn * 4 + a) ^ (hr & 15);
+        *reinterpret_cast<unsigned*>(Ep + hr * 256 + ce * 16 + g * 4) = e;
+        *reinterpret_cast<unsigned*>(Rp + hr * 256 + ce * 16 + g * 4) = r;
+      }
+    }
+    __syncthreads();
+    auto tile_row = [&](int hr) { return (hr >> 6) * 128 + half * 64 + (hr & 63); };
+    {                                        // H plane: two 512-byte rows per wave instruction, 16 rows per pass
+      const int cl = lane & 31, rl = lane >> 5;
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int hr = ps * 16 + wave * 2 + rl, m = m0 + tile_row(hr);
+        const uint4 v = *reinterpret_cast<const uint4*>(Hp + hr * 512 + ((cl ^ (hr & 7)) << 4));
+        if (m < p.M) *reinterpret_cast<uint4*>(Cb + m * pitch + 2ll * n0 + cl * 16) = v;
+      }
+    }
+    {                                        // E and R planes: four 256-byte rows per wave instruction, 32 rows per pass
+      const int cl = lane & 15, rl = lane >> 4;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int hr = ps * 32 + wave * 4 + rl, m = m0 + tile_row(hr);
+        const uint4 ve = *reinterpret_cast<const uint4*>(Ep + hr * 256 + ((cl ^ (hr & 15)) << 4));
+        const uint4 vr = *reinterpret_cast<const uint4*>(Rp + hr * 256 + ((cl ^ (hr & 15)) << 4));
+        if (m < p.M) {
+          *reinterpret_cast<uint4*>(Cb + m * pitch + 2ll * p.N + n0 + cl * 16) = ve;
+          *reinterpret_cast<uint4*>(Cb + m * pitch + 3ll * p.N + n0 + cl * 16) = vr;
+        }
+      }
+    }
   }
 }
 
@@ -1562,6 +1624,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const int lane = lane_e, g = lane_e >> 4, li = lane_e & 15;
   constexpr int WN = 64, CH = WN / 4;
   const bool pre = p.stats_out != nullptr;
+  if constexpr (EPI == 6 || EPI == 7) {               // KX_F16C output: accumulator-level arithmetic, three-plane tile store
+    if constexpr (EPI == 7) prepass_bias_act_stats<ACT, FM, FN>(p, acc, m0 + wm * (BM / 2), n0 + wn * WN, g, li);
+    else lean_bias_act<ACT, FM, FN>(p, acc, n0 + wn * WN, g, m0 + wm * (BM / 2), li);
+    KX_TL_STAMP(3);
+    lean_store_f16c<BM, FM, FN>(p, acc, smem, m0, n0, wm, wn, wave, lane, g, li);
+    KX_TL_STAMP(4);
+    KX_TL_STAMP(5);
+    KX_TL_COMMIT();
+  } else
   if constexpr (EPI == 1 || EPI == 4 || EPI == 5) {   // bias / activation (/ statistics, / XPos) on the accumulators, bf16 tile store
     if constexpr (EPI == 5) {
       const bool rot = n0 < 2 * p.xpos_dim;                 // tile-uniform: xpos_dim % 256 == 0 (kx_gemm checks)
@@ -1613,6 +1684,15 @@ int launch_p5e(GemmParams& p, hipStream_t s) {
   const int nwg = p.tiles_m * p.tiles_n;
   const dim3 grid(p.persistent > 0 ? (nwg < p.persistent ? nwg : p.persistent) : nwg), block(512);
   // the lean variants are instantiated for the activations the forward uses them with; anything else takes EPI 0
+  if constexpr (EPI == 6 || EPI == 7) {     // KX_F16C output (BM = 256): plain and GELU, with (7) or without (6) produced statistics
+    if constexpr (kIsF16c<T> && BM == 256) {
+      if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, EPI>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
+      if constexpr (EPI == 7) {             // (GELU without statistics spills 248 B / lane in this form: it keeps the generic loops)
+        if (p.act == KX_ACT_GELU_FAST) { hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, EPI>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
+      }
+    }
+    return launch_p5e<T, BM, 0>(p, s);
+  } else
   if (p.act == KX_ACT_NONE && EPI != 4) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, EPI>), grid, block, 0, s, p);
   else if (EPI == 5) return launch_p5e<T, BM, 0>(p, s);
   else if (p.act == KX_ACT_GELU_FAST && (EPI == 0 || EPI == 1 || EPI == 4)) {
@@ -1639,7 +1719,11 @@ template <typename T, int BM>
 int launch_p5(GemmParams& p, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + 255) / 256;
-  if constexpr (kIsF16c<T>) return launch_p5e<T, BM, 0>(p, s);   // KX_F16C outputs take the generic store loops
+  if constexpr (kIsF16c<T>) {
+    // KX_F16C output on whole 256-column tiles, no residual / XPos: the three-plane lean store (else the generic loops)
+    if (BM == 256 && p.lean_f16c && p.N % 256 == 0) return p.stats_out ? launch_p5e<T, BM, 7>(p, s) : launch_p5e<T, BM, 6>(p, s);
+    return launch_p5e<T, BM, 0>(p, s);
+  }
   else if (p.lean_xpos && p.N % 256 == 0) return launch_p5e<T, BM, 5>(p, s);
   else if (p.lean_epilogue && p.N % 256 == 0) return p.stats_out ? launch_p5e<T, BM, 4>(p, s) : launch_p5e<T, BM, 1>(p, s);
   return launch_p5e<T, BM, 0>(p, s);

@@ -67,6 +67,47 @@ def test_f16c_producers_write_the_format_bit_exactly():
     assert torch.equal(oc.view(-1, 4 * 192), ops.pack_f16c_rows(o32.view(-1, 192)))
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 512, 256), (456, 1024, 512), (3648, 768, 256), (130, 256, 1024)])
+def test_f16c_lean_three_plane_store_of_the_256_column_kernel(M, N, K):
+    """The decoder's fc1 in f16c / mixed writes KX_F16C rows from the 256-column kernel: round 3's lean store packs at
+    accumulator level and parks the tile as its three planes (two halves of 128 rows).  Bytes == packing the fp32 output
+    of the same kernel, == the generic store loops (tuning key 4 = 8), statistics identical; ragged M, plain and
+    GELU + statistics (the fc1 form), with and without the folded pre-LN consume."""
+    g = _g(M + N + K)
+    a = ops.pack_f16c_rows((torch.randn(M, K, generator=g) * 1.3).to(DEV))
+    wp = _operand_f16c((torch.randn(N, K, generator=g) * 0.05).to(DEV))
+    bias = torch.randn(N, generator=g).to(DEV)
+    rs = torch.stack([torch.randn(M, generator=g) * 0.1, 1 + 0.2 * torch.rand(M, generator=g)], 1).contiguous().to(DEV)
+    cs = torch.randn(N, generator=g).to(DEV)
+    lib = _hip.load()
+    for tile in (512, 0):
+        for kw in (dict(), dict(act="gelu", stats=True), dict(act="gelu", stats=True, fold=True), dict(fold=True)):
+            st1 = torch.zeros(M, N // 64, 2, device=DEV) if kw.get("stats") else None
+            st2 = torch.zeros(M, N // 64, 2, device=DEV) if kw.get("stats") else None
+            st3 = torch.zeros(M, N // 64, 2, device=DEV) if kw.get("stats") else None
+            extra = dict(row_stats=rs, colsum=cs) if kw.get("fold") else {}
+            act = kw.get("act", "none")
+            c32 = ops.gemm_f16c(a, wp, N, K, bias=bias, act=act, tile=tile, stats_out=st1, **extra)
+            cc = ops.gemm_f16c(a, wp, N, K, bias=bias, act=act, tile=tile, out_f16c=True, stats_out=st2, **extra)
+            exact = not (kw.get("fold") and not kw.get("stats"))
+            # (fold without statistics: the fp32 output applies rstd * (acc - mean * colsum) + bias in the store loop, the lean path
+            #  as two packed FMAs at accumulator level — the same value to an fp32 rounding, not the same bits)
+            if exact:
+                assert torch.equal(cc, ops.pack_f16c_rows(c32)), (tile, kw)
+            else:
+                h, _, _ = ops.unpack_f16c_rows(cc.cpu(), N)
+                assert float((h - c32.cpu()).abs().max()) <= float(c32.abs().max()) * 2.0 ** -10, (tile, kw)
+                continue
+            try:
+                lib.kx_set_tuning(4, 8)
+                gen = ops.gemm_f16c(a, wp, N, K, bias=bias, act=act, tile=tile, out_f16c=True, stats_out=st3, **extra)
+            finally:
+                lib.kx_set_tuning(4, 0)
+            assert torch.equal(cc, gen), (tile, kw)
+            if st1 is not None:
+                assert torch.equal(st2, st3) and torch.equal(st1, st2)
+
+
 SHAPES = [(1, 64, 128), (114, 2048, 2048), (257, 1024, 4096), (130, 264, 128), (300, 1002, 640), (64, 512, 1024),
           (513, 768, 256), (3648, 512, 2048)]
 

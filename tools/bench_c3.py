@@ -17,7 +17,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--gemm-tile", type=int, default=0)
 ap.add_argument("--tune", default="")
-ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
+ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32", "f16c", "mixed"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 m = KosmosLanguage(vocab_size=32002, dim=2048, _seed=0).eval().to(dev)     # /root/reference/example_lang.py:9-12
