@@ -22,3 +22,7 @@ if [[ "${2:-all}" == all || "${2:-all}" == bench ]]; then
   find $O/prof_dec -name "*kernel_trace.csv" -delete; find $O/prof_dec -name "*.db" -delete 2>/dev/null
 fi
 echo done
+if [[ "${2:-all}" == all || "${2:-all}" == pmc ]]; then
+  PMC_OUT=$O/pmc bash tools/pmc_round.sh > $O/pmc_round.log 2>&1; tail -3 $O/pmc_round.log
+fi
+echo done-pmc
