@@ -111,6 +111,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
              "operand dtype and the prefetching store loop");
   p.stagger_ticks = 0; p.w_tiled = 0;
   p.gsplit = 1; p.kfull = p.K; p.C2 = nullptr; p.residual2 = nullptr; p.a_add = nullptr;
+  p.no_rowreg = kx_tuning_get(KX_TUNE_GEMV_VARIANT) == 3;
   p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
   p.stats_partials = nullptr; p.stats_in_nseg = 0; p.stats_in_seg = p.stats_eps = 0.f;
   p.ln_out = nullptr; p.ln_out_dt = 0; p.ln_out_g = p.ln_out_b = nullptr; p.ln_out_eps = 0.f;

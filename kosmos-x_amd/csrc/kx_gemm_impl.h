@@ -56,6 +56,8 @@ struct GemmParams {
   // split 1 writes its partial to C2 — no cross-workgroup reduction, no atomics, bit-reproducible.  K is the extent of ONE
   // split, kfull the row length of W.  a_add: second addend of the LayerNorm-prologue rows (A + a_add is normalised).
   int gsplit, kfull; void* C2; const float* residual2; const float* a_add;
+  int no_rowreg;        // A/B (tuning key 8 = 3): the 5..8-row LayerNorm prologue keeps the three-walk form
+  int gb_staged;        // row-in-registers prologue: gamma | beta are passed through LDS (else read from global when needed)
   // row-owning split-K reduce: optional LayerNorm of the finished row as a second output
   void* ln_out; int ln_out_dt; const float *ln_out_g, *ln_out_b; float ln_out_eps;
 };
@@ -1976,6 +1978,11 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel(const GemmParams p, in
 // find their operands in registers.  LNP = LayerNorm prologue (A = raw fp32 rows) — a template parameter so that the two
 // operand paths do not add their registers (1024-thread workgroups: 128 VGPRs).
 struct GemvEpiOps { float4 c, b, r, r2; float2 xc, xs; };
+// LayerNorm prologue, 5..8 rows: one wave per row with the row in registers (gamma / beta through 8K bytes of LDS); tuning
+// key 8 = 3 keeps the three-walk form (A/B)
+__host__ __device__ inline bool gemv_rowreg(int M, int K, int S, bool pair) {
+  return M > 4 && M <= S && (K & 3) == 0 && (K >> 2) <= 512 && (K >> 2) <= 64 * S && !pair;
+}
 
 // T = bf16_t (16x16x32 bf16 MFMA; a 1 KB wave load is 16 rows x 32 k) or float (exact-f32 16x16x4 MFMA, four per 16-byte
 // chunk; a 1 KB wave load is 16 rows x 16 k): the fp32 instantiation is the decode step of the precisions that hold the
@@ -2015,7 +2022,9 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   // ---- (1) the small loads, in consumption order ----
   const bool coop = LNP && (p.K >> 2) <= 64 * S && p.M <= 4;
   const bool has = tid < (p.K >> 2);
-  float4 v[4], v2[4], gm, bt;                                    // LNP, cooperative: this thread's float4 of rows 0..3 (v2: the pair's second addend)
+  const bool rowreg = LNP && !coop && gemv_rowreg(p.M, p.K, S, p.a_add != nullptr) && !p.no_rowreg;   // 5..8 rows: one wave per row, the row in registers
+  float4 vv[8], gm, bt;                                          // LNP, cooperative: this thread's float4 of rows 0..3 in vv[0..3], the pair's second
+                                                                 // addend in vv[4..7]; row-in-registers form: this lane's eight float4 of the wave's row
   u32x4_t xf[XG];                                                // !LNP: the first batch of operand fragments
   u32x4_t xs[4];                                                 // XS: this thread's 16 bytes of operand rows 0..3
   // statistics prologue: the producer's partials [M][nseg] float2 go through registers (requested first) into LDS, where
@@ -2031,13 +2040,29 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       const int vt = min(tid, (p.K >> 2) - 1);
 #pragma unroll
       for (int r = 0; r < 4; ++r)                                // (1, 2 or 4 rows are reduced: M = 3 repeats its last row)
-        if (r < p.M || (r == 3 && p.M == 3)) v[r] = reinterpret_cast<const float4*>(p.A + (long long)min(r, p.M - 1) * p.lda_b)[vt];
+        if (r < p.M || (r == 3 && p.M == 3)) vv[r] = reinterpret_cast<const float4*>(p.A + (long long)min(r, p.M - 1) * p.lda_b)[vt];
       if (p.a_add) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (r < p.M || (r == 3 && p.M == 3))
-            v2[r] = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.a_add) + (long long)min(r, p.M - 1) * p.lda_b)[vt];
+            vv[4 + r] = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.a_add) + (long long)min(r, p.M - 1) * p.lda_b)[vt];
       }
+      gm = reinterpret_cast<const float4*>(p.ln_g)[vt];
+      bt = reinterpret_cast<const float4*>(p.ln_b)[vt];
+    } else if (rowreg) {
+      // Five to eight rows: the first form's wave-per-row prologue walked its row three times through the L2 (sum, squares,
+      // normalise: three dependent round trips, each queued behind the weight requests).  Here a wave's row is requested ONCE,
+      // up front — eight float4 per lane, the registers the cooperative form uses for four rows and their pair — and gamma /
+      // beta arrive one float4 per thread and are passed around through LDS (where that still leaves room for two workgroups
+      // per CU: fp32 rows of 7-8 sequences do not, they read gamma / beta from the L2 when they normalise).  kx_layernorm's
+      // arithmetic, statement for statement.
+      const int nvr = p.K >> 2;
+      if (wave < p.M) {
+        const float4* xr = reinterpret_cast<const float4*>(p.A + (long long)wave * p.lda_b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = xr[min(lane + 64 * j, nvr - 1)];
+      }
+      const int vt = min(tid, nvr - 1);
       gm = reinterpret_cast<const float4*>(p.ln_g)[vt];
       bt = reinterpret_cast<const float4*>(p.ln_b)[vt];
     }
@@ -2127,7 +2152,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
     if (coop && p.a_add) {                                       // the pair's sum, in the order every reader uses: xa + xb
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (r < p.M || (r == 3 && p.M == 3)) { v[r].x += v2[r].x; v[r].y += v2[r].y; v[r].z += v2[r].z; v[r].w += v2[r].w; }
+        if (r < p.M || (r == 3 && p.M == 3)) { vv[r].x += vv[4 + r].x; vv[r].y += vv[4 + r].y; vv[r].z += vv[4 + r].z; vv[r].w += vv[4 + r].w; }
     }
     if (coop) {
       // Each wave reduces its own 256 columns to (sum, M2 about its own mean) — two shuffle trees per row — and the S pairs
@@ -2140,11 +2165,11 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
         constexpr int R = decltype(rc)::value;
         float sm[R], mw[R], q[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) sm[r] = wave_sum_dpp(has ? (v[r].x + v[r].y) + (v[r].z + v[r].w) : 0.f);
+        for (int r = 0; r < R; ++r) sm[r] = wave_sum_dpp(has ? (vv[r].x + vv[r].y) + (vv[r].z + vv[r].w) : 0.f);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           mw[r] = cw ? sm[r] / (float)cw : 0.f;
-          const float a = v[r].x - mw[r], b = v[r].y - mw[r], c = v[r].z - mw[r], d = v[r].w - mw[r];
+          const float a = vv[r].x - mw[r], b = vv[r].y - mw[r], c = vv[r].z - mw[r], d = vv[r].w - mw[r];
           q[r] = wave_sum_dpp(has ? (a * a + b * b) + (c * c + d * d) : 0.f);
         }
         if (lane == 0) {
@@ -2166,8 +2191,8 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
                 m2 += e.y + e.w * dm * dm;                         // (an empty wave: 0 + 0 * mean^2)
               }
               const float rstd = rsqrtf(m2 / (float)p.K + p.ln_eps);
-              const float y0 = (v[r].x - mean) * rstd * gm.x + bt.x, y1 = (v[r].y - mean) * rstd * gm.y + bt.y;
-              const float y2 = (v[r].z - mean) * rstd * gm.z + bt.z, y3 = (v[r].w - mean) * rstd * gm.w + bt.w;
+              const float y0 = (vv[r].x - mean) * rstd * gm.x + bt.x, y1 = (vv[r].y - mean) * rstd * gm.y + bt.y;
+              const float y2 = (vv[r].z - mean) * rstd * gm.z + bt.z, y3 = (vv[r].w - mean) * rstd * gm.w + bt.w;
               if constexpr (ES == 2) {
                 uint2 o;
                 o.x = pack_bf16x2(y0, y1);
@@ -2183,6 +2208,46 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       if (p.M == 1) rows(std::integral_constant<int, 1>{});
       else if (p.M == 2) rows(std::integral_constant<int, 2>{});
       else rows(std::integral_constant<int, 4>{});
+    } else if (rowreg) {
+      const int nvr = p.K >> 2;
+      float* gb = reinterpret_cast<float*>(xn + p.M * x_pitch);  // [2][K]: gamma | beta
+      if (p.gb_staged) {
+        if (has) { reinterpret_cast<float4*>(gb)[tid] = gm; reinterpret_cast<float4*>(gb + p.K)[tid] = bt; }
+        __syncthreads();
+      }
+      if (wave < p.M) {
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (lane + 64 * j < nvr) sm += (vv[j].x + vv[j].y) + (vv[j].z + vv[j].w);
+        const float mean = wave_sum_dpp(sm) / (float)p.K;
+        float q2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (lane + 64 * j < nvr) {
+            const float a = vv[j].x - mean, b = vv[j].y - mean, cc = vv[j].z - mean, d = vv[j].w - mean;
+            q2 += (a * a + b * b) + (cc * cc + d * d);
+          }
+        const float rstd = rsqrtf(wave_sum_dpp(q2) / (float)p.K + p.ln_eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = lane + 64 * j;
+          if (c < nvr) {
+            const float4 gq = p.gb_staged ? reinterpret_cast<const float4*>(gb)[c] : reinterpret_cast<const float4*>(p.ln_g)[c];
+            const float4 bq = p.gb_staged ? reinterpret_cast<const float4*>(gb + p.K)[c] : reinterpret_cast<const float4*>(p.ln_b)[c];
+            const float y0 = (vv[j].x - mean) * rstd * gq.x + bq.x, y1 = (vv[j].y - mean) * rstd * gq.y + bq.y;
+            const float y2 = (vv[j].z - mean) * rstd * gq.z + bq.z, y3 = (vv[j].w - mean) * rstd * gq.w + bq.w;
+            if constexpr (ES == 2) {
+              uint2 o;
+              o.x = pack_bf16x2(y0, y1);
+              o.y = pack_bf16x2(y2, y3);
+              *reinterpret_cast<uint2*>(xn + wave * x_pitch + c * 8) = o;
+            } else {
+              *reinterpret_cast<float4*>(xn + wave * x_pitch + c * 16) = make_float4(y0, y1, y2, y3);
+            }
+          }
+        }
+      }
     } else {
       const int nv = p.K >> 2;                                   // more rows: one wave per row, kx_layernorm's walk
       for (int m = wave; m < p.M; m += S) {
@@ -2342,7 +2407,10 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
   const bool deep = ES == 2 ? (v2 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 2 && !p.ln_g && kw > 256 && p.M <= 4 && p.K <= 512 * S)
                             : (!p.ln_g && kw > 128 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 2);   // fp32: 16 KB per wave in flight, rows via L2
   int x_pitch = 0;
-  const size_t lds = gemv_lds_bytes(p.M, p.K, ES, p.ln_g != nullptr, p.stats_partials != nullptr, deep && ES == 2, S, &x_pitch);
+  size_t lds = gemv_lds_bytes(p.M, p.K, ES, p.ln_g != nullptr, p.stats_partials != nullptr, deep && ES == 2, S, &x_pitch);
+  // row-in-registers LayerNorm prologue (5..8 rows): gamma | beta go through 8K bytes of LDS when two workgroups still fit a CU
+  p.gb_staged = p.ln_g && !p.no_rowreg && gemv_rowreg(p.M, p.K, S, p.a_add != nullptr) && lds + 8 * (size_t)p.K <= 80 * 1024;
+  if (p.gb_staged) lds += 8 * (size_t)p.K;
   if (lds > 160 * 1024) {
     kx_set_error("kx_gemm(weight streaming): %zu bytes of LDS needed (M=%d K=%d), 160 KB available", lds, p.M, p.K);
     return KX_ERR_INVALID_ARG;

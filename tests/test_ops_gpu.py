@@ -532,6 +532,36 @@ def test_gemm_weight_streaming_fp32_operands(M, N, K):
         ops.gemm(torch.zeros(17, K, device=DEV), w.to(DEV), tile=16)
 
 
+@pytest.mark.parametrize("prec", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,K", [(5, 2048), (8, 2048), (7, 1024), (6, 320)])
+def test_gemm_weight_streaming_row_in_registers_prologue(prec, M, K):
+    """5..8 rows: the LayerNorm prologue keeps a wave's row in registers (one round trip instead of three walks through the
+    L2).  kx_layernorm's arithmetic, statement for statement — the compiler contracts the normalisation's multiply-adds
+    differently in the two loop shapes, so the forms agree to an fp32 rounding of the operand, not always to the bit
+    (a bf16 operand element may land on the neighbouring value once in a few thousand, as for the cooperative form)."""
+    from kosmosx import _hip
+    N = 512
+    g = _g(50 * M + K)
+    x = torch.randn(M, K, generator=g) * 3 + 0.5
+    gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    w = (torch.randn(N, K, generator=g) / 40).to(prec)
+    bias = torch.randn(N, generator=g)
+    args = (x.to(DEV), w.to(DEV), bias.to(DEV))
+    one = ops.gemm(*args, act="gelu", tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5))
+    lib = _hip.load()
+    try:
+        lib.kx_set_tuning(8, 3)
+        walk = ops.gemm(*args, act="gelu", tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5))
+    finally:
+        lib.kx_set_tuning(8, 0)
+    tol = 2e-6 if prec == torch.float32 else 1e-3
+    assert rel_err(one, walk.cpu()) < tol
+    assert torch.equal(one, ops.gemm(*args, act="gelu", tile=16, ln=(gam.to(DEV), bet.to(DEV), 1e-5)))      # repeatable
+    h = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out_dtype=prec)
+    two = ops.gemm(h, w.to(DEV), bias.to(DEV), act="gelu", tile=16)
+    assert rel_err(one, two.cpu()) < tol
+
+
 @pytest.mark.parametrize("M", [1, 3, 8, 15])
 def test_gemm_weight_streaming_fp32_prologues(M):
     """The decode step's prologues on fp32 operands: LayerNorm of the raw rows (the operand stays fp32: no rounding at
