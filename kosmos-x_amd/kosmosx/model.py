@@ -70,7 +70,7 @@ def _operand_f16c(f: torch.Tensor) -> torch.Tensor:
     amax = f.abs().amax(dim=1).clamp_min(2.0 ** -100)
     sexp = (7 - torch.ceil(torch.log2(amax))).clamp(-100, 100)          # integer-valued
     sc = torch.exp2(sexp)[:, None]
-    h = f.to(torch.float16)
+    h = f.clamp(-65504.0, 65504.0).to(torch.float16)         # saturates like every fp16 operand conversion (csrc: clamp_f16)
     r = ((f - h.float()) * sc * 2048.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
     e = (f * sc).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
     rows = torch.cat([h.view(torch.uint8).reshape(N, 2 * K), r.view(torch.uint8), e.view(torch.uint8)], dim=1)
