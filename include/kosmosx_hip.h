@@ -66,7 +66,10 @@ typedef enum {
  * (tools/precision_study.py --budget fp16): the whole CLIP tower in plain fp16 moves the logits by 2.5e-4, every decoder
  * GEMM family by 1.4-2.7e-3.  The model-level mode "mixed" therefore runs the tower in KX_PREC_F16 and the Perceiver and
  * decoder in KX_PREC_F16C.  Values must fit fp16 (|x| < 65504). */
-typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3, KX_PREC_F16 = 4 } kx_precision;
+/* KX_PREC_F32W24 (kx_decoder_decode_step / kx_decoder_workspace_bytes only): KX_PREC_F32 arithmetic whose STREAMING copies
+ * (kx_decoder_layer.w*_t, kx_decoder_weights.wout_t) are 24-bit weight planes (kx_gemm_args.w_tiled = 2); the row-major fp32
+ * operands beside them hold the same values (low mantissa byte zero).  The decode step of f16c / mixed: 3 bytes per weight. */
+typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3, KX_PREC_F16 = 4, KX_PREC_F32W24 = 5 } kx_precision;
 typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3, KX_F16 = 4 } kx_dtype;
 typedef enum { KX_ACT_NONE = 0, KX_ACT_GELU = 1, KX_ACT_QUICK_GELU = 2 } kx_act;
 typedef enum { KX_ATTN_FULL = 0, KX_ATTN_CAUSAL = 1 } kx_attn_mask;
@@ -168,7 +171,12 @@ typedef struct {
   /* tile 16 (weight streaming) only: W is stored [ceil(N/16)][K/32][64][8] bf16 — block (p, c) holds rows 16p..16p+15,
    * columns 32c..32c+31 as 64 pieces of 16 bytes, piece l = row 16p + (l & 15), columns 32c + 8(l >> 4) .. +7 (the MFMA
    * fragment a lane loads), rows past N zero.  fp32 operands: [ceil(N/16)][K/16][64][4], piece l = row 16p + (l & 15),
-   * columns 16c + 4(l >> 4) .. +3.  K % 32 == 0; ldw is ignored. */
+   * columns 16c + 4(l >> 4) .. +3.  K % 32 == 0; ldw is ignored.
+   * w_tiled = 2 (fp32 operands only): 24-BIT weights — each value is an fp32 number whose low mantissa byte is zero (round
+   * the weight to 16 significant bits), stored as its top three bytes: [ceil(N/16)][K/32][1536 B], a block = rows 16p..16p+15
+   * x columns 32c..32c+31 as 64 pieces of 16 B (piece l: the bf16 halves of row 16p + (l & 15), columns 32c + 4(l >> 4) .. +3
+   * then 32c + 16 + 4(l >> 4) .. +3) followed by 64 pieces of 8 B (the third bytes of the same eight values).  The kernel
+   * rebuilds the fp32 values in registers and multiplies on the exact-f32 MFMA: 3 bytes streamed per weight. */
   int32_t w_tiled;
   /* tile 16 (weight streaming) only — the residual stream of a decode step as a PAIR (x = xa + xb, always summed in that
    * order).  A residual GEMM with few columns (out_proj / fc2: N = 2048 -> 128 workgroups for 256 CUs) is launched with its

@@ -207,13 +207,14 @@ struct Gemv16 {
   const float* partials_in = nullptr; int64_t nseg_in = 0, seg_in = 0; const float* colsum = nullptr;
   float* stats_out = nullptr;
   const void* W_tiled = nullptr;          // the same matrix in the streaming layout (kx_gemm_args.w_tiled), or null
+  int tiled_fmt = 1;                      // kx_gemm_args.w_tiled of W_tiled: 1 = operand-dtype tiles, 2 = 24-bit planes
   int prec = KX_PREC_BF16;                // KX_PREC_BF16 or KX_PREC_F32 (operand dtype of A, unless ln_g, and of W)
   int ksplit = 0; void* C2 = nullptr; const float* residual2 = nullptr; const float* a_add = nullptr;   // kx_gemm_args: the pair form
 };
 int gemv16(const Gemv16& v, hipStream_t s) {
   kx_gemm_args g;
   memset(&g, 0, sizeof(g));
-  g.A = v.A; g.lda = v.lda; g.W = v.W_tiled ? v.W_tiled : v.W; g.w_tiled = v.W_tiled != nullptr; g.ldw = v.K;
+  g.A = v.A; g.lda = v.lda; g.W = v.W_tiled ? v.W_tiled : v.W; g.w_tiled = v.W_tiled ? v.tiled_fmt : 0; g.ldw = v.K;
   g.C = v.C; g.ldc = v.ldc; g.cdt = v.cdt;
   g.bias = v.bias; g.residual = v.residual; g.ldr = v.ldc; g.M = v.M; g.N = v.N; g.K = v.K;
   g.act = v.act; g.qscale = v.qscale; g.qcols = v.qcols;
@@ -336,6 +337,7 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
                               size_t workspace_bytes, int32_t prec, void* stream) {
   KX_REQUIRE(w && pixels && out && workspace, "kx_vit_forward: null pointer");
   KX_CHECK_BINDING(w, kx_vit_weights, kx_vit_layer, "kx_vit_forward");
+  KX_REQUIRE(prec >= KX_PREC_BF16 && prec <= KX_PREC_F16, "kx_vit_forward: bad precision %d (KX_PREC_F32W24 is a decode-step format)", prec);
   KX_REQUIRE(B > 0, "kx_vit_forward: empty batch");
   KX_REQUIRE(w->dim == w->heads * 64, "kx_vit_forward: head_dim must be 64 (dim=%d heads=%d)", w->dim, w->heads);
   KX_REQUIRE(w->image % w->patch == 0 && w->kpad >= 3 * w->patch * w->patch && w->kpad % 64 == 0,
@@ -410,6 +412,7 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
                                     void* stream) {
   KX_REQUIRE(w && x && workspace, "kx_perceiver_forward: null pointer");
   KX_CHECK_BINDING(w, kx_perceiver_weights, kx_perceiver_layer, "kx_perceiver_forward");
+  KX_REQUIRE(prec >= KX_PREC_BF16 && prec <= KX_PREC_F16, "kx_perceiver_forward: bad precision %d (KX_PREC_F32W24 is a decode-step format)", prec);
   KX_REQUIRE((out && w->wproj && w->out_dim > 0) || lat_out, "kx_perceiver_forward: nothing to produce");
   KX_REQUIRE(B > 0 && m > 0, "kx_perceiver_forward: empty input");
   KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_perceiver_forward: workspace must be 256-byte aligned");
@@ -456,7 +459,7 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
 
 extern "C" size_t kx_decoder_workspace_bytes(const kx_decoder_weights* w, int64_t B, int64_t T, int32_t prec) {
   if (!binding_ok<kx_decoder_weights, kx_decoder_layer>(w)) { kx_set_error("kx_decoder_workspace_bytes: null or stale binding (struct_bytes / layer_bytes)"); return 0; }
-  return dec_plan(w, B, T, prec, nullptr).total;
+  return dec_plan(w, B, T, prec == KX_PREC_F32W24 ? KX_PREC_F32 : prec, nullptr).total;
 }
 
 static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B, int64_t T, const float* xq_cs,
@@ -465,6 +468,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
                                 void* vcache, int64_t Tmax) {
   KX_REQUIRE(w && x && logits && workspace, "kx_decoder_forward: null pointer");
   KX_CHECK_BINDING(w, kx_decoder_weights, kx_decoder_layer, "kx_decoder_forward");
+  KX_REQUIRE(prec >= KX_PREC_BF16 && prec <= KX_PREC_F16, "kx_decoder_forward: bad precision %d (KX_PREC_F32W24 is a decode-step format)", prec);
   KX_REQUIRE(!kcache == !vcache, "kx_decoder_prefill: kcache and vcache must be given together");
   KX_REQUIRE(!kcache || (prec != KX_PREC_BF16X3 && prec != KX_PREC_F16),
              "kx_decoder_prefill: incremental decoding is offered in bf16, fp32 and f16c (fp32 cache)");
@@ -601,6 +605,8 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
                                       const float* xq_ss, const float* xk_cs, const float* xk_ss, void* kcache,
                                       void* vcache, int64_t Tmax, void* logits, int32_t ldt, void* workspace,
                                       size_t workspace_bytes, int32_t prec, void* stream) {
+  const int tfmt = prec == KX_PREC_F32W24 ? 2 : 1;             // what the streaming copies (w*_t) hold
+  if (prec == KX_PREC_F32W24) prec = KX_PREC_F32;
   KX_REQUIRE(w && x && logits && workspace && kcache && vcache, "kx_decoder_decode_step: null pointer");
   KX_CHECK_BINDING(w, kx_decoder_weights, kx_decoder_layer, "kx_decoder_decode_step");
   KX_REQUIRE(prec != KX_PREC_BF16X3 && prec != KX_PREC_F16,
@@ -642,7 +648,7 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
       Gemv16 q{pa, D, L.wqkv, D, d.qkv, 3 * D, ct, M, 3 * D};
       q.bias = L.bqkv; q.qscale = 0.125f; q.qcols = D; q.ln_g = L.sa_g; q.ln_b = L.sa_b; q.eps = w->eps; q.a_add = pb;
       if (w->xpos) { q.xq_cs = xq_cs; q.xq_ss = xq_ss; q.xk_cs = xk_cs; q.xk_ss = xk_ss; q.xT = 1; q.xdim = D; }
-      q.W_tiled = L.wqkv_t; q.prec = prec;
+      q.W_tiled = L.wqkv_t; q.tiled_fmt = tfmt; q.prec = prec;
       KX_TRY(gemv16(q, s));
       KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, ct,
                                  w->subln ? d.partials : nullptr, B, w->heads, t, Tmax, prec, stream));
@@ -651,24 +657,24 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
       o.bias = L.bo; o.residual = pa; o.residual2 = pb; o.eps = w->eps;
       if (pair) { o.ksplit = 2; o.C2 = qb; }
       if (w->subln) { o.partials_in = d.partials; o.nseg_in = w->heads; o.seg_in = 64; o.colsum = L.wo_colsum; }
-      o.W_tiled = L.wo_t; o.prec = prec;
+      o.W_tiled = L.wo_t; o.tiled_fmt = tfmt; o.prec = prec;
       KX_TRY(gemv16(o, s));
       Gemv16 f1{qa, D, L.w1, D, d.g, F, ct, M, F};
       f1.bias = L.b1; f1.act = w->act; f1.ln_g = L.fl_g; f1.ln_b = L.fl_b; f1.eps = w->eps; f1.a_add = qb;
       if (w->subln) f1.stats_out = d.partials;
-      f1.W_tiled = L.w1_t; f1.prec = prec;
+      f1.W_tiled = L.w1_t; f1.tiled_fmt = tfmt; f1.prec = prec;
       KX_TRY(gemv16(f1, s));
       pa = x; pb = pair ? d.xb : nullptr;                         // what fc2 writes
       Gemv16 f2{d.g, F, L.w2, F, pa, D, KX_F32, M, D};
       f2.bias = L.b2; f2.residual = qa; f2.residual2 = qb; f2.eps = w->eps;
       if (pair) { f2.ksplit = 2; f2.C2 = pb; }
       if (w->subln) { f2.partials_in = d.partials; f2.nseg_in = F / 16; f2.seg_in = 16; f2.colsum = L.w2_colsum; }
-      f2.W_tiled = L.w2_t; f2.prec = prec;
+      f2.W_tiled = L.w2_t; f2.tiled_fmt = tfmt; f2.prec = prec;
       KX_TRY(gemv16(f2, s));
     }
     Gemv16 lo{pa, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab};
     lo.ln_g = w->ln_g; lo.ln_b = w->ln_b; lo.eps = w->eps; lo.a_add = pb;
-    lo.W_tiled = w->wout_t; lo.prec = prec;
+    lo.W_tiled = w->wout_t; lo.tiled_fmt = tfmt; lo.prec = prec;
     return gemv16(lo, s);
   }
   for (int i = 0; i < w->layers; ++i) {

@@ -1988,7 +1988,13 @@ __host__ __device__ inline bool gemv_rowreg(int M, int K, int S, bool pair) {
 // chunk; a 1 KB wave load is 16 rows x 16 k): the fp32 instantiation is the decode step of the precisions that hold the
 // north star's tolerance (fp32, and f16c / mixed, whose KV cache is fp32 already) — 4 bytes per weight, the same bytes an
 // f16c row would stream, with exact products instead of compensated ones.
-template <typename T, int ACT, bool LNP, int UW>
+// W24 (fp32 operands only, kx_gemm_args.w_tiled = 2): the streamed weights are 24-BIT values — an fp32 weight rounded to 16
+// significant bits, stored as its top three bytes in two planes per block of 16 rows x 32 k (64 x 16 B of bf16 halves,
+// then 64 x 8 B of third bytes: 1.5 KB contiguous per pair of k-steps) — and are put back together in registers (one
+// v_perm_b32 per value) before the same exact-f32 MFMA.  3 bytes per weight instead of 4: the decode step of f16c / mixed,
+// whose own weights carry 15-16 bits.  Products, order and everything around them are the fp32 form's: on weights that are
+// exactly representable in 24 bits the two forms give the same bits.
+template <typename T, int ACT, bool LNP, int UW, bool W24 = false>
 __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, int S, int kw, int x_pitch) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2016,6 +2022,11 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   const char* wp = p.w_tiled ? p.W + (((long long)blockIdx.x * (p.kfull >> KSH) + ((kbase + k0w) >> KSH)) << 10) + (lane << 4)
                              : p.W + (long long)nrow * p.ldw_b + (kbase + k0w + EPL * g) * ES;
   const int wstep = p.w_tiled ? 1024 : 64;
+  static_assert(!W24 || sizeof(T) == 4, "24-bit weight planes reconstruct fp32 operands");
+  // W24: block of a k-step PAIR (32 k): [64 lanes x 16 B: bf16 halves of k-steps 2c, 2c+1][64 lanes x 8 B: their third bytes]
+  const char* wph = p.W + ((long long)blockIdx.x * (p.kfull >> 5) + ((kbase + k0w) >> 5)) * 1536 + (lane << 4);
+  const char* wpl = wph + 1024 - (lane << 3);
+  const int ulast2 = max(klen - 1, 0) >> 5;
   const int ulast = max(klen - 1, 0) >> KSH;
   auto ldw = [&](const char* q) { return *reinterpret_cast<const u32x4_t*>(q); };
 
@@ -2104,9 +2115,31 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   }
   // ---- (2) the stream: this wave's first 8 KB.  UNCONDITIONAL loads (k-steps past the slice re-read its last one): only
   // then can the waits below be counted — "all but the last eight" — instead of draining the stream
-  u32x4_t wf[U];
+  u32x4_t wf[W24 ? 1 : U];
+  u32x4_t rawh[W24 ? U / 2 : 1];
+  u32x2_t rawl[W24 ? U / 2 : 1];
+  if constexpr (W24) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) wf[u] = ldw(wp + min(u, ulast) * wstep);
+    for (int u2 = 0; u2 < U / 2; ++u2) {
+      rawh[u2] = *reinterpret_cast<const u32x4_t*>(wph + min(u2, ulast2) * 1536);
+      rawl[u2] = *reinterpret_cast<const u32x2_t*>(wpl + min(u2, ulast2) * 1536);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) wf[u] = ldw(wp + min(u, ulast) * wstep);
+  }
+  auto wfrag = [&](int u) -> u32x4_t {                           // the weight fragment of in-flight k-step u (u: compile-time)
+    if constexpr (W24) {
+      const u32x4_t hh = rawh[u >> 1];
+      const u32x2_t ll = rawl[u >> 1];
+      const unsigned h0 = (u & 1) ? hh[2] : hh[0], h1 = (u & 1) ? hh[3] : hh[1], l = (u & 1) ? ll[1] : ll[0];
+      // value j = bytes (0, third byte j, bf16 half j): src0 = the halves, src1 = the third bytes
+      return (u32x4_t){__builtin_amdgcn_perm(h0, l, 0x0504000cu), __builtin_amdgcn_perm(h0, l, 0x0706010cu),
+                       __builtin_amdgcn_perm(h1, l, 0x0504020cu), __builtin_amdgcn_perm(h1, l, 0x0706030cu)};
+    } else {
+      return wf[u];
+    }
+  };
 
   // ---- (3) prologues ----
   char* xsb = xn + (p.stats_partials ? 128 * S * 8 : 0);         // XS: operand rows [M][x_pitch] behind the staged partials
@@ -2290,9 +2323,18 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   const char* xg = p.A + (long long)xrow * p.lda_b + (kbase + k0 + EPL * g) * ES;
   for (int kk = 0; kk < klen; kk += KS * U) {
     if (kk > 0) {                                                // (first batch: in flight)
+      if constexpr (W24) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (kk + KS * u < klen) wf[u] = ldw(wp + ((kk >> KSH) + u) * wstep);
+        for (int u2 = 0; u2 < U / 2; ++u2)
+          if (kk + 32 * u2 < klen) {
+            rawh[u2] = *reinterpret_cast<const u32x4_t*>(wph + ((kk >> 5) + u2) * 1536);
+            rawl[u2] = *reinterpret_cast<const u32x2_t*>(wpl + ((kk >> 5) + u2) * 1536);
+          }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (kk + KS * u < klen) wf[u] = ldw(wp + ((kk >> KSH) + u) * wstep);
+      }
     }
 #pragma unroll
     for (int h = 0; h < U; h += XG) {
@@ -2304,7 +2346,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
         }
 #pragma unroll
       for (int u = 0; u < XG; ++u)
-        if (kk + KS * (h + u) < klen) acc = Mma<T>::step(wf[h + u], xf[u], acc);
+        if (kk + KS * (h + u) < klen) acc = Mma<T>::step(wfrag(h + u), xf[u], acc);
       if constexpr (U > XG) __builtin_amdgcn_sched_barrier(0);    // (keeps the second half's eight LDS reads out of the first half's registers)
     }
   }
@@ -2373,6 +2415,14 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
 
 template <typename T, int ACT>
 void launch_gemv2(const GemmParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, int S, int kw, int x_pitch, bool deep) {
+  if constexpr (sizeof(T) == 4) {
+    if (p.w_tiled == 2) {              // 24-bit weight planes
+      if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      return;
+    }
+  }
   if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8>), grid, block, lds, s, p, S, kw, x_pitch);
   else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16>), grid, block, lds, s, p, S, kw, x_pitch);
   else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8>), grid, block, lds, s, p, S, kw, x_pitch);
@@ -2383,6 +2433,11 @@ void gemv2_lds_attr() {
   (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if constexpr (sizeof(T) == 4) {
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
 }
 
 // LDS the weight-streaming launch needs (kx_gemm checks it against the 160 KB of a CU before choosing tile 16)

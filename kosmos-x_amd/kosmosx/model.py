@@ -41,7 +41,7 @@ def _stream() -> int:
 
 
 def _prec_dtype(prec: str):
-    return torch.float32 if prec == "fp32" else torch.float16 if prec == "f16" else torch.bfloat16
+    return torch.float32 if prec in ("fp32", "w24") else torch.float16 if prec == "f16" else torch.bfloat16
 
 
 def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
@@ -51,6 +51,9 @@ def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
     t = t.detach()
     if prec == "f16c":
         return _operand_f16c(t.float())
+    if prec == "w24":       # fp32 rounded to 16 significant bits (low mantissa byte zero): what the 24-bit streaming planes hold
+        from .ops import round_to_24_bits
+        return round_to_24_bits(t).contiguous()
     if prec != "bf16x3":
         return t.to(_prec_dtype(prec)).contiguous()
     f = t.float()
@@ -625,7 +628,7 @@ class Decoder(_PackedMixin, nn.Module):
             return wp.data_ptr(), v(wf @ b_ + lin.bias.detach().float()), v(_operand_colsum(wp, prec, shp))
 
         def src(i, field, ptr):   # remember the packed operand behind `ptr` (bf16 / fp32: the decode step's precisions)
-            if prec in ("bf16", "fp32"):
+            if prec in ("bf16", "fp32", "w24"):
                 stream_src.append((i, field, next(t for t in reversed(keep) if t.data_ptr() == ptr)))
 
         layers = (H.DecoderLayer * self.num_layers)()
@@ -682,12 +685,14 @@ class Decoder(_PackedMixin, nn.Module):
         todo = self._stream_src.pop(key, None)
         if not todo or os.environ.get("KOSMOSX_DECODE_TILED", "1") == "0":
             return
-        from .ops import tile_weight_rows
+        from .ops import tile_weight_rows, tile_weight_rows_w24
         w, layers, keep, _, _ = self._packed[key]
         for i, field, t in todo:
             if t.shape[1] % 32:
+                if prec == "w24":
+                    raise ValueError("the 24-bit streaming planes need K % 32 == 0")   # (decoder widths are multiples of 64)
                 continue
-            tt = tile_weight_rows(t)
+            tt = tile_weight_rows_w24(t) if prec == "w24" else tile_weight_rows(t)
             keep.append(tt)
             setattr(w if i < 0 else layers[i], field, tt.data_ptr())
 
@@ -805,10 +810,14 @@ class Decoder(_PackedMixin, nn.Module):
         # 4 bytes per value, exactly what the fp32 weight is: the f16c step therefore runs on the fp32 operands with the
         # exact-f32 MFMA (same bytes, no compensation needed; its q/k/v cache is fp32 already), i.e. every precision that
         # holds the north star's tolerance decodes with fp32 products.  KOSMOSX_DECODE_EXACT=0 keeps the f16c tile GEMMs (A/B).
-        sprec = "fp32" if (prec == "f16c" and os.environ.get("KOSMOSX_DECODE_EXACT", "1") != "0") else prec
+        # ... and since the f16c weights themselves carry 15-16 bits, the weights of that step are rounded to 16 significant
+        # bits and streamed as THREE bytes each ("w24": kx_gemm_args.w_tiled = 2; the activations and the products stay fp32).
+        # KOSMOSX_DECODE_EXACT=fp32 streams the full fp32 weights (4 bytes), =0 keeps the f16c tile GEMMs.
+        exact = os.environ.get("KOSMOSX_DECODE_EXACT", "1")
+        sprec = prec if (prec != "f16c" or exact == "0") else ("fp32" if exact == "fp32" else "w24")
         if sprec != prec:
             w = self._pack(sprec)[0]
-        if sprec in ("bf16", "fp32") and B <= 16:
+        if sprec in ("bf16", "fp32", "w24") and B <= 16:
             self._pack_decode_tiles(sprec)                 # first decode step: the streaming copy of the weights
         if passed_x is not None:
             _require_cuda(passed_x, "passed_x")
@@ -819,11 +828,13 @@ class Decoder(_PackedMixin, nn.Module):
             raise ValueError("batch size changed between incremental steps")
         rows = tuple(None if tb is None else tb[t] for tb in state["xpos"])   # views: row t of each [Tmax, 32] table
         logits = torch.empty((B, 1, w.vocab), dtype=torch.float32, device=x.device)
-        need = lib.kx_decoder_workspace_bytes(C.byref(w), B, 1, H.PRECS[sprec])
+        # (w24 without streaming copies — KOSMOSX_DECODE_TILED=0, more than 16 sequences — is plain fp32 on the rounded operands)
+        pid = H.KX_PREC_F32W24 if (sprec == "w24" and bool(w.wout_t)) else H.PACK_PRECS[sprec]
+        need = lib.kx_decoder_workspace_bytes(C.byref(w), B, 1, pid)
         buf = self._ws.get(need, x.device)
         H.check(lib.kx_decoder_decode_step(C.byref(w), x.data_ptr(), B, t, *(H.ptr(r) for r in rows),
                                            state["kcache"].data_ptr(), state["vcache"].data_ptr(), Tmax,
-                                           logits.data_ptr(), H.KX_F32, buf.data_ptr(), buf.numel(), H.PRECS[sprec],
+                                           logits.data_ptr(), H.KX_F32, buf.data_ptr(), buf.numel(), pid,
                                            _stream()), "kx_decoder_decode_step")
         self._finish_check()                               # an IndexError leaves the state where it was (row t is rewritten)
         state["len"] = t + 1

@@ -81,13 +81,13 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
     M, K = a.shape
     N = w_tiled_rows or w.shape[0]                 # w_tiled_rows = N: `w` is tile_weight_rows(W) (tile 16 only)
     prec = H.KX_PREC_BF16 if w.dtype == torch.bfloat16 else H.KX_PREC_F16 if w.dtype == torch.float16 else H.KX_PREC_F32
-    if a.dtype != w.dtype and ln is None:
+    if a.dtype != w.dtype and ln is None and w.dtype != torch.uint8:
         raise TypeError("gemm operands must share a dtype")
     if out is None:
         out = torch.empty((M, 3 * N if out_x3 else N), dtype=torch.bfloat16 if out_x3 else out_dtype, device=a.device)
     g = H.GemmArgs()
     g.A, g.lda, g.W, g.ldw = H.ptr(a), a.stride(0), H.ptr(w), (K if w_tiled_rows else w.stride(0))
-    g.w_tiled = 1 if w_tiled_rows else 0
+    g.w_tiled = (2 if w.dtype == torch.uint8 else 1) if w_tiled_rows else 0     # uint8 tiles = 24-bit planes (tile_weight_rows_w24)
     g.C, g.ldc, g.cdt = H.ptr(out), out.stride(0), (H.KX_BF16X3 if out_x3 else _cdt(out.dtype))
     g.bias, g.residual, g.ldr = H.ptr(bias), H.ptr(residual), (residual.stride(0) if residual is not None else 0)
     g.M, g.N, g.K = M, N, K
@@ -145,6 +145,32 @@ def tile_weight_rows(w: torch.Tensor) -> torch.Tensor:
         w = torch.cat([w, torch.zeros((Np - N, K), dtype=w.dtype, device=w.device)], 0)
     # [p, i, c, g, e] -> [p, c, g, i, e]: piece index l = g * 16 + i
     return w.view(Np // 16, 16, K // ks, 4, e).permute(0, 2, 3, 1, 4).contiguous().view(Np // 16, K // ks, 64, e)
+
+
+def round_to_24_bits(w: torch.Tensor) -> torch.Tensor:
+    """fp32 -> the nearest (ties to even) fp32 value whose low mantissa byte is zero: 16 significant bits, what the 24-bit
+    weight planes of kx_gemm_args.w_tiled = 2 can hold."""
+    b = w.detach().float().contiguous().view(torch.int32)
+    b = (b + 0x7F + ((b >> 8) & 1)) & ~0xFF
+    return b.view(torch.float32)
+
+
+def tile_weight_rows_w24(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] fp32 whose values fit 24 bits (round_to_24_bits), K % 32 == 0 -> kx_gemm_args.w_tiled = 2 planes, uint8
+    [ceil(N/16), K/32, 1536]: per block of 16 rows x 32 columns, 64 pieces of 16 B (piece l = row 16p + (l & 15): the bf16
+    halves of columns 32c + 4(l >> 4) .. +3, then 32c + 16 + 4(l >> 4) .. +3) followed by 64 pieces of 8 B (their third bytes)."""
+    N, K = w.shape
+    assert K % 32 == 0 and w.dtype == torch.float32
+    bits = w.contiguous().view(torch.int32)
+    assert int((bits & 0xFF).abs().max()) == 0, "values must be rounded to 24 bits first (round_to_24_bits)"
+    Np = (N + 15) // 16 * 16
+    if Np != N:
+        bits = torch.cat([bits, torch.zeros((Np - N, K), dtype=torch.int32, device=w.device)], 0)
+    # [p, i, c, half, g, j] -> [p, c, g, i, half, j]: piece l = g * 16 + i holds (half, j) = 8 values
+    v = bits.view(Np // 16, 16, K // 32, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).contiguous()
+    hi = ((v >> 16) & 0xFFFF).to(torch.int16).view(Np // 16, K // 32, 64 * 8).view(torch.uint8)      # little-endian halves
+    lo = ((v >> 8) & 0xFF).to(torch.uint8).view(Np // 16, K // 32, 64 * 8)
+    return torch.cat([hi.view(Np // 16, K // 32, 1024), lo], dim=2).contiguous()
 
 
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,

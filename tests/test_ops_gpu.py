@@ -562,6 +562,54 @@ def test_gemm_weight_streaming_row_in_registers_prologue(prec, M, K):
     assert rel_err(one, two.cpu()) < tol
 
 
+@pytest.mark.parametrize("M", [1, 4, 7, 15])
+@pytest.mark.parametrize("N,K", [(264, 2048), (2048, 8192), (1002, 320), (6144, 2048), (512, 64)])
+def test_gemm_weight_streaming_24_bit_weight_planes(M, N, K):
+    """kx_gemm_args.w_tiled = 2: the streamed weights are 3 bytes each (fp32 rounded to 16 significant bits, top three bytes
+    in two planes), rebuilt in registers and multiplied on the exact-f32 MFMA.  On those rounded values the fp32 kernel
+    computes the same products in the same order: bit-identical outputs (row-major and 16-byte tiles); against the
+    UN-rounded weights the result carries only the rounding, 2^-17 per weight.  With the LayerNorm prologue, the statistics
+    consumer and the pair form."""
+    g = _g(13 * M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 40
+    w[0, :8] = torch.tensor([0.0, -0.0, 1e-30, -3e-20, 6.5e4, -1.0, 2.0 ** -14, 1.0 + 2.0 ** -16])      # zeros, tiny, a tie
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    wr = ops.round_to_24_bits(w)
+    assert int((wr.view(torch.int32) & 0xFF).abs().max()) == 0
+    assert float(((wr - w).abs() / w.abs().clamp_min(1e-37)).max()) <= 2.0 ** -16
+    assert float(wr[0, 7]) == 1.0                                           # the tie 1 + 2^-16 rounds to even
+    if K % 32:
+        with pytest.raises(AssertionError):
+            ops.tile_weight_rows_w24(wr.to(DEV))
+        return
+    planes = ops.tile_weight_rows_w24(wr.to(DEV))
+    assert planes.dtype == torch.uint8 and planes.shape == ((N + 15) // 16, K // 32, 1536)
+    out = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), planes, bias.to(DEV), out, "gelu", out=out, tile=16, w_tiled_rows=N)
+    same = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), wr.to(DEV), bias.to(DEV), same, "gelu", out=same, tile=16)
+    assert torch.equal(out, same)
+    tiled = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), ops.tile_weight_rows(wr.to(DEV)), bias.to(DEV), tiled, "gelu", out=tiled, tile=16, w_tiled_rows=N)
+    assert torch.equal(out, tiled)
+    ref = _gemm_ref(a.double(), w.double(), bias.double(), res.double(), "gelu")
+    bound = 2.0 ** -16 * (a.abs().double() @ w.abs().double().t()) + 1e-5    # every weight moved by <= 2^-17 of itself; |gelu'| <= 1.13
+    assert bool(((out.cpu().double() - ref).abs() <= 1.2 * bound).all())
+    if K <= 2048:                                                           # LayerNorm prologue (qkv / fc1 / logits of a step)
+        gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+        ln = (gam.to(DEV), bet.to(DEV), 1e-5)
+        x = (a * 3 + 0.5).to(DEV)
+        assert torch.equal(ops.gemm(x, planes, bias.to(DEV), act="gelu", tile=16, ln=ln, w_tiled_rows=N),
+                           ops.gemm(x, wr.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=ln))
+    if N % 16 == 0 and K % 128 == 0:                                        # the residual GEMMs as workgroup pairs
+        c1, c2, d1, d2 = (torch.empty(M, N, device=DEV) for _ in range(4))
+        rb = (res * 0.1).to(DEV)
+        ops.gemm(a.to(DEV), planes, bias.to(DEV), res.to(DEV), out=c1, tile=16, ksplit=2, out2=c2, residual2=rb, w_tiled_rows=N)
+        ops.gemm(a.to(DEV), wr.to(DEV), bias.to(DEV), res.to(DEV), out=d1, tile=16, ksplit=2, out2=d2, residual2=rb)
+        assert torch.equal(c1, d1) and torch.equal(c2, d2)
+
+
 @pytest.mark.parametrize("M", [1, 3, 8, 15])
 def test_gemm_weight_streaming_fp32_prologues(M):
     """The decode step's prologues on fp32 operands: LayerNorm of the raw rows (the operand stays fp32: no rounding at
