@@ -437,8 +437,8 @@ def main():
     # ---- incremental decoding, one token per step against the KV cache (B = 1): a step streams the
     # decoder's live weights once.  Every mode is timed and its logits kept; the cpu_baseline leg below compares them with the
     # oracle, and the block's headline is the FASTEST MODE THAT MEETS THE TOLERANCE (round 2 headlined
-    # bf16, the mode the same line marks meets_tolerance: false).  "mixed" / "f16c" steps run fp32 products on weights rounded
-    # to 16 significant bits and streamed as 3 bytes each (Decoder._forward_incremental; an f16c row would stream 4).
+    # bf16, the mode the same line marks meets_tolerance: false).  "mixed" / "f16c" steps run fp32 products on block-scaled
+    # 16-bit weights streamed as 2.125 bytes each (Decoder._forward_incremental; an f16c row would stream 4).
     decode, decode_check = None, None
     if rank == 0 and world == 1 and not force_dist and not args.no_extra:
         try:
@@ -471,13 +471,13 @@ def main():
                         torch.cuda.synchronize()
                         dts = (time.perf_counter() - t1) / nstep
                 kept[mode] = torch.cat(outs, 1)[0].float().cpu()                   # [nstep, V]
-                wbytes = {"bf16": 2.0, "mixed": 3.0, "fp32": 4.0}[mode]            # bytes streamed per weight
+                wbytes = {"bf16": 2.0, "mixed": 2.125, "fp32": 4.0}[mode]          # bytes streamed per weight
                 cbytes = 2.0 if mode == "bf16" else 4.0                             # bytes per cached key / value
                 wb = wbytes * nw + 2.0 * L * (prefix + 4 + nstep / 2) * D * cbytes
                 modes[mode] = {"ms_per_token": round(dts * 1e3, 3), "tokens_per_s": round(1.0 / dts, 1),
                                "step_arithmetic": {"bf16": "bf16 operands, bf16 KV cache",
-                                                   "mixed": "fp32 products on the exact-f32 MFMA; weights rounded to 16 significant bits "
-                                                            "and streamed as 3 bytes each (24-bit planes, rebuilt in registers), fp32 KV cache",
+                                                   "mixed": "fp32 products on the exact-f32 MFMA; block-scaled 16-bit weights (int16 + one fp32 scale "
+                                                            "per row and 32 columns: 2.125 bytes streamed per weight, rebuilt in registers), fp32 KV cache",
                                                    "fp32": "fp32 operands on the exact-f32 MFMA (weight-streaming kernel, 4 bytes per "
                                                            "weight), fp32 KV cache"}[mode],
                                "roofline": {"bound": "hbm", "achieved": round(wb / dts / 1e9, 1), "peak": PEAK_HBM_GBS,

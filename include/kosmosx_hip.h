@@ -69,7 +69,9 @@ typedef enum {
 /* KX_PREC_F32W24 (kx_decoder_decode_step / kx_decoder_workspace_bytes only): KX_PREC_F32 arithmetic whose STREAMING copies
  * (kx_decoder_layer.w*_t, kx_decoder_weights.wout_t) are 24-bit weight planes (kx_gemm_args.w_tiled = 2); the row-major fp32
  * operands beside them hold the same values (low mantissa byte zero).  The decode step of f16c / mixed: 3 bytes per weight. */
-typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3, KX_PREC_F16 = 4, KX_PREC_F32W24 = 5 } kx_precision;
+/* KX_PREC_F32W16: the same with block-scaled 16-bit streaming copies (kx_gemm_args.w_tiled = 3): 2.125 bytes per weight. */
+typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3, KX_PREC_F16 = 4, KX_PREC_F32W24 = 5,
+               KX_PREC_F32W16 = 6 } kx_precision;
 typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3, KX_F16 = 4 } kx_dtype;
 typedef enum { KX_ACT_NONE = 0, KX_ACT_GELU = 1, KX_ACT_QUICK_GELU = 2 } kx_act;
 typedef enum { KX_ATTN_FULL = 0, KX_ATTN_CAUSAL = 1 } kx_attn_mask;
@@ -176,7 +178,11 @@ typedef struct {
    * the weight to 16 significant bits), stored as its top three bytes: [ceil(N/16)][K/32][1536 B], a block = rows 16p..16p+15
    * x columns 32c..32c+31 as 64 pieces of 16 B (piece l: the bf16 halves of row 16p + (l & 15), columns 32c + 4(l >> 4) .. +3
    * then 32c + 16 + 4(l >> 4) .. +3) followed by 64 pieces of 8 B (the third bytes of the same eight values).  The kernel
-   * rebuilds the fp32 values in registers and multiplies on the exact-f32 MFMA: 3 bytes streamed per weight. */
+   * rebuilds the fp32 values in registers and multiplies on the exact-f32 MFMA: 3 bytes streamed per weight.
+   * w_tiled = 3 (fp32 operands only): BLOCK-SCALED 16-BIT weights — [ceil(N/16)][K/32][1088 B]: 64 pieces of 16 B of int16
+   * values q (the piece order of w_tiled = 2's halves) followed by the fp32 scales of the block's 16 rows (64 B);
+   * w = (float)q * scale with scale = max|w| over the row's 32 columns / 32767 (1 for an all-zero run).  2.125 bytes per
+   * weight; the row-major fp32 operand beside it holds exactly (float)q * scale. */
   int32_t w_tiled;
   /* tile 16 (weight streaming) only — the residual stream of a decode step as a PAIR (x = xa + xb, always summed in that
    * order).  A residual GEMM with few columns (out_proj / fc2: N = 2048 -> 128 workgroups for 256 CUs) is launched with its

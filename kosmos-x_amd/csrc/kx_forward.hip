@@ -337,7 +337,7 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
                               size_t workspace_bytes, int32_t prec, void* stream) {
   KX_REQUIRE(w && pixels && out && workspace, "kx_vit_forward: null pointer");
   KX_CHECK_BINDING(w, kx_vit_weights, kx_vit_layer, "kx_vit_forward");
-  KX_REQUIRE(prec >= KX_PREC_BF16 && prec <= KX_PREC_F16, "kx_vit_forward: bad precision %d (KX_PREC_F32W24 is a decode-step format)", prec);
+  KX_REQUIRE(prec >= KX_PREC_BF16 && prec <= KX_PREC_F16, "kx_vit_forward: bad precision %d (KX_PREC_F32W24 / W16 are decode-step formats)", prec);
   KX_REQUIRE(B > 0, "kx_vit_forward: empty batch");
   KX_REQUIRE(w->dim == w->heads * 64, "kx_vit_forward: head_dim must be 64 (dim=%d heads=%d)", w->dim, w->heads);
   KX_REQUIRE(w->image % w->patch == 0 && w->kpad >= 3 * w->patch * w->patch && w->kpad % 64 == 0,
@@ -412,7 +412,7 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
                                     void* stream) {
   KX_REQUIRE(w && x && workspace, "kx_perceiver_forward: null pointer");
   KX_CHECK_BINDING(w, kx_perceiver_weights, kx_perceiver_layer, "kx_perceiver_forward");
-  KX_REQUIRE(prec >= KX_PREC_BF16 && prec <= KX_PREC_F16, "kx_perceiver_forward: bad precision %d (KX_PREC_F32W24 is a decode-step format)", prec);
+  KX_REQUIRE(prec >= KX_PREC_BF16 && prec <= KX_PREC_F16, "kx_perceiver_forward: bad precision %d (KX_PREC_F32W24 / W16 are decode-step formats)", prec);
   KX_REQUIRE((out && w->wproj && w->out_dim > 0) || lat_out, "kx_perceiver_forward: nothing to produce");
   KX_REQUIRE(B > 0 && m > 0, "kx_perceiver_forward: empty input");
   KX_REQUIRE(((uintptr_t)workspace & 255) == 0, "kx_perceiver_forward: workspace must be 256-byte aligned");
@@ -459,7 +459,7 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
 
 extern "C" size_t kx_decoder_workspace_bytes(const kx_decoder_weights* w, int64_t B, int64_t T, int32_t prec) {
   if (!binding_ok<kx_decoder_weights, kx_decoder_layer>(w)) { kx_set_error("kx_decoder_workspace_bytes: null or stale binding (struct_bytes / layer_bytes)"); return 0; }
-  return dec_plan(w, B, T, prec == KX_PREC_F32W24 ? KX_PREC_F32 : prec, nullptr).total;
+  return dec_plan(w, B, T, (prec == KX_PREC_F32W24 || prec == KX_PREC_F32W16) ? KX_PREC_F32 : prec, nullptr).total;
 }
 
 static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B, int64_t T, const float* xq_cs,
@@ -468,7 +468,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
                                 void* vcache, int64_t Tmax) {
   KX_REQUIRE(w && x && logits && workspace, "kx_decoder_forward: null pointer");
   KX_CHECK_BINDING(w, kx_decoder_weights, kx_decoder_layer, "kx_decoder_forward");
-  KX_REQUIRE(prec >= KX_PREC_BF16 && prec <= KX_PREC_F16, "kx_decoder_forward: bad precision %d (KX_PREC_F32W24 is a decode-step format)", prec);
+  KX_REQUIRE(prec >= KX_PREC_BF16 && prec <= KX_PREC_F16, "kx_decoder_forward: bad precision %d (KX_PREC_F32W24 / W16 are decode-step formats)", prec);
   KX_REQUIRE(!kcache == !vcache, "kx_decoder_prefill: kcache and vcache must be given together");
   KX_REQUIRE(!kcache || (prec != KX_PREC_BF16X3 && prec != KX_PREC_F16),
              "kx_decoder_prefill: incremental decoding is offered in bf16, fp32 and f16c (fp32 cache)");
@@ -605,8 +605,8 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
                                       const float* xq_ss, const float* xk_cs, const float* xk_ss, void* kcache,
                                       void* vcache, int64_t Tmax, void* logits, int32_t ldt, void* workspace,
                                       size_t workspace_bytes, int32_t prec, void* stream) {
-  const int tfmt = prec == KX_PREC_F32W24 ? 2 : 1;             // what the streaming copies (w*_t) hold
-  if (prec == KX_PREC_F32W24) prec = KX_PREC_F32;
+  const int tfmt = prec == KX_PREC_F32W24 ? 2 : prec == KX_PREC_F32W16 ? 3 : 1;   // what the streaming copies (w*_t) hold
+  if (prec == KX_PREC_F32W24 || prec == KX_PREC_F32W16) prec = KX_PREC_F32;
   KX_REQUIRE(w && x && logits && workspace && kcache && vcache, "kx_decoder_decode_step: null pointer");
   KX_CHECK_BINDING(w, kx_decoder_weights, kx_decoder_layer, "kx_decoder_decode_step");
   KX_REQUIRE(prec != KX_PREC_BF16X3 && prec != KX_PREC_F16,

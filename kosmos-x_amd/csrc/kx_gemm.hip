@@ -201,8 +201,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     KX_REQUIRE((a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32) && a->M <= 16,
                "kx_gemm: tile 16 (weight streaming) takes bf16 or fp32 operands, M <= 16 only");
     KX_REQUIRE(!a->w_tiled || a->K % 32 == 0, "kx_gemm: the streaming weight layout needs K %% 32 == 0");
-    KX_REQUIRE(a->w_tiled >= 0 && a->w_tiled <= 2 && (a->w_tiled != 2 || (a->prec == KX_PREC_F32 && a->K % 32 == 0)),
-               "kx_gemm: w_tiled is 0, 1 or (fp32 operands, K %% 32 == 0) 2 = 24-bit weight planes");
+    KX_REQUIRE(a->w_tiled >= 0 && a->w_tiled <= 3 && (a->w_tiled < 2 || (a->prec == KX_PREC_F32 && a->K % 32 == 0)),
+               "kx_gemm: w_tiled is 0, 1 or (fp32 operands, K %% 32 == 0) 2 = 24-bit planes / 3 = block-scaled 16-bit weights");
     p.w_tiled = a->w_tiled;
     KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * es + 16) <= 128 * 1024 && a->K % 4 == 0),
                "kx_gemm: LayerNorm prologue needs beta and M*(K*%d+16) <= 128 KB", es);

@@ -1994,7 +1994,12 @@ __host__ __device__ inline bool gemv_rowreg(int M, int K, int S, bool pair) {
 // v_perm_b32 per value) before the same exact-f32 MFMA.  3 bytes per weight instead of 4: the decode step of f16c / mixed,
 // whose own weights carry 15-16 bits.  Products, order and everything around them are the fp32 form's: on weights that are
 // exactly representable in 24 bits the two forms give the same bits.
-template <typename T, int ACT, bool LNP, int UW, bool W24 = false>
+// WF = 16 (kx_gemm_args.w_tiled = 3): block-scaled 16-BIT weights — per block of 16 rows x 32 k, 64 x 16 B of int16 values
+// (the same piece order as the 24-bit halves) followed by the 16 rows' fp32 scales (64 B): w = q * scale, scale = the
+// block's max|w| / 32767.  2.125 bytes per weight — bf16's bytes — rebuilt as fp32 (convert + one multiply per value) in front
+// of the exact-f32 MFMA.  With exact activations this leaves 2.5e-4 on the logits (tools/precision_study.py --formats
+// wbq16f_32; 16-significant-bit floats: 1.1e-4), inside the 1e-3 the f16c / mixed modes promise.
+template <typename T, int ACT, bool LNP, int UW, int WF = 0>
 __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, int S, int kw, int x_pitch) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2022,10 +2027,13 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   const char* wp = p.w_tiled ? p.W + (((long long)blockIdx.x * (p.kfull >> KSH) + ((kbase + k0w) >> KSH)) << 10) + (lane << 4)
                              : p.W + (long long)nrow * p.ldw_b + (kbase + k0w + EPL * g) * ES;
   const int wstep = p.w_tiled ? 1024 : 64;
-  static_assert(!W24 || sizeof(T) == 4, "24-bit weight planes reconstruct fp32 operands");
+  constexpr bool W24 = WF != 0;                                    // (compressed weight planes of either kind)
+  constexpr int WBLK = WF == 16 ? 1088 : 1536;                     // bytes per block of 16 rows x 32 k
+  static_assert(WF == 0 || ((WF == 24 || WF == 16) && sizeof(T) == 4), "weight planes reconstruct fp32 operands");
   // W24: block of a k-step PAIR (32 k): [64 lanes x 16 B: bf16 halves of k-steps 2c, 2c+1][64 lanes x 8 B: their third bytes]
-  const char* wph = p.W + ((long long)blockIdx.x * (p.kfull >> 5) + ((kbase + k0w) >> 5)) * 1536 + (lane << 4);
-  const char* wpl = wph + 1024 - (lane << 3);
+  const char* wph = p.W + ((long long)blockIdx.x * (p.kfull >> 5) + ((kbase + k0w) >> 5)) * WBLK + (lane << 4);
+  const char* wpl = WF == 16 ? wph + 1024 - (lane << 4) + (i << 2)      // this lane's row scale
+                             : wph + 1024 - (lane << 3);                // this lane's eight third bytes
   const int ulast2 = max(klen - 1, 0) >> 5;
   const int ulast = max(klen - 1, 0) >> KSH;
   auto ldw = [&](const char* q) { return *reinterpret_cast<const u32x4_t*>(q); };
@@ -2117,19 +2125,28 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   // then can the waits below be counted — "all but the last eight" — instead of draining the stream
   u32x4_t wf[W24 ? 1 : U];
   u32x4_t rawh[W24 ? U / 2 : 1];
-  u32x2_t rawl[W24 ? U / 2 : 1];
+  u32x2_t rawl[WF == 24 ? U / 2 : 1];
+  float rsc[WF == 16 ? U / 2 : 1];
   if constexpr (W24) {
 #pragma unroll
     for (int u2 = 0; u2 < U / 2; ++u2) {
-      rawh[u2] = *reinterpret_cast<const u32x4_t*>(wph + min(u2, ulast2) * 1536);
-      rawl[u2] = *reinterpret_cast<const u32x2_t*>(wpl + min(u2, ulast2) * 1536);
+      rawh[u2] = *reinterpret_cast<const u32x4_t*>(wph + min(u2, ulast2) * WBLK);
+      if constexpr (WF == 16) rsc[u2] = *reinterpret_cast<const float*>(wpl + min(u2, ulast2) * WBLK);
+      else rawl[u2] = *reinterpret_cast<const u32x2_t*>(wpl + min(u2, ulast2) * WBLK);
     }
   } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) wf[u] = ldw(wp + min(u, ulast) * wstep);
   }
   auto wfrag = [&](int u) -> u32x4_t {                           // the weight fragment of in-flight k-step u (u: compile-time)
-    if constexpr (W24) {
+    if constexpr (WF == 16) {
+      const u32x4_t hh = rawh[u >> 1];
+      const int q01 = (int)((u & 1) ? hh[2] : hh[0]), q23 = (int)((u & 1) ? hh[3] : hh[1]);
+      const float sc = rsc[u >> 1];
+      const float f0 = (float)(short)(q01 & 0xffff) * sc, f1 = (float)(q01 >> 16) * sc;
+      const float f2 = (float)(short)(q23 & 0xffff) * sc, f3 = (float)(q23 >> 16) * sc;
+      return (u32x4_t){__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2), __float_as_uint(f3)};
+    } else if constexpr (WF == 24) {
       const u32x4_t hh = rawh[u >> 1];
       const u32x2_t ll = rawl[u >> 1];
       const unsigned h0 = (u & 1) ? hh[2] : hh[0], h1 = (u & 1) ? hh[3] : hh[1], l = (u & 1) ? ll[1] : ll[0];
@@ -2327,8 +2344,9 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
 #pragma unroll
         for (int u2 = 0; u2 < U / 2; ++u2)
           if (kk + 32 * u2 < klen) {
-            rawh[u2] = *reinterpret_cast<const u32x4_t*>(wph + ((kk >> 5) + u2) * 1536);
-            rawl[u2] = *reinterpret_cast<const u32x2_t*>(wpl + ((kk >> 5) + u2) * 1536);
+            rawh[u2] = *reinterpret_cast<const u32x4_t*>(wph + ((kk >> 5) + u2) * WBLK);
+            if constexpr (WF == 16) rsc[u2] = *reinterpret_cast<const float*>(wpl + ((kk >> 5) + u2) * WBLK);
+            else rawl[u2] = *reinterpret_cast<const u32x2_t*>(wpl + ((kk >> 5) + u2) * WBLK);
           }
       } else {
 #pragma unroll
@@ -2417,9 +2435,15 @@ template <typename T, int ACT>
 void launch_gemv2(const GemmParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, int S, int kw, int x_pitch, bool deep) {
   if constexpr (sizeof(T) == 4) {
     if (p.w_tiled == 2) {              // 24-bit weight planes
-      if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, true>), grid, block, lds, s, p, S, kw, x_pitch);
-      else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, true>), grid, block, lds, s, p, S, kw, x_pitch);
-      else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, 24>), grid, block, lds, s, p, S, kw, x_pitch);
+      else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, 24>), grid, block, lds, s, p, S, kw, x_pitch);
+      else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8, 24>), grid, block, lds, s, p, S, kw, x_pitch);
+      return;
+    }
+    if (p.w_tiled == 3) {              // block-scaled 16-bit weights
+      if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, 16>), grid, block, lds, s, p, S, kw, x_pitch);
+      else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, 16>), grid, block, lds, s, p, S, kw, x_pitch);
+      else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8, 16>), grid, block, lds, s, p, S, kw, x_pitch);
       return;
     }
   }
@@ -2434,9 +2458,12 @@ void gemv2_lds_attr() {
   (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if constexpr (sizeof(T) == 4) {
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
 }
 

@@ -15,7 +15,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
 ABI_VERSION = 5   # KX_ABI_VERSION of include/kosmosx_hip.h
 
-KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16, KX_PREC_F32W24 = 0, 1, 2, 3, 4, 5
+KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16, KX_PREC_F32W24, KX_PREC_F32W16 = 0, 1, 2, 3, 4, 5, 6
 KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16 = 0, 1, 2, 3, 4
 KX_ACT_NONE, KX_ACT_GELU, KX_ACT_QUICK_GELU = 0, 1, 2
 KX_ATTN_FULL, KX_ATTN_CAUSAL = 0, 1
@@ -25,7 +25,7 @@ PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32, "bf16x3": KX_PREC_BF16X3, "f
 # and decoder in f16c; kx_precision in include/kosmosx_hip.h, tools/precision_study.py --budget)
 MODEL_PRECS = list(PRECS) + ["mixed"]
 # internal pack name -> kx_precision: "w24" = fp32 operands rounded to 24 bits + 3-byte streaming copies (the decode step of f16c / mixed)
-PACK_PRECS = dict(PRECS, w24=KX_PREC_F32)
+PACK_PRECS = dict(PRECS, w24=KX_PREC_F32, w16=KX_PREC_F32)     # w16: block-scaled int16 streaming copies (2.125 B / weight)
 
 
 def stage_precision(prec: str, stage: str, widths=()) -> str:

@@ -41,7 +41,10 @@ def _stream() -> int:
 
 
 def _prec_dtype(prec: str):
-    return torch.float32 if prec in ("fp32", "w24") else torch.float16 if prec == "f16" else torch.bfloat16
+    return torch.float32 if prec in ("fp32", "w24", "w16") else torch.float16 if prec == "f16" else torch.bfloat16
+
+
+_W16_PARTS = {}     # data_ptr of a "w16" operand -> (q int16, scale fp32) it was built from
 
 
 def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
@@ -54,6 +57,14 @@ def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
     if prec == "w24":       # fp32 rounded to 16 significant bits (low mantissa byte zero): what the 24-bit streaming planes hold
         from .ops import round_to_24_bits
         return round_to_24_bits(t).contiguous()
+    if prec == "w16":       # fp32 values (float)q * scale of the block-scaled int16 representation (the 16-bit streaming planes)
+        from .ops import quantize_block16
+        q, sc, wq = quantize_block16(t.float())
+        import weakref
+        for k_ in [k_ for k_, v_ in _W16_PARTS.items() if v_[2]() is None]:      # operands that were dropped before a decode step
+            del _W16_PARTS[k_]
+        _W16_PARTS[wq.data_ptr()] = (q, sc, weakref.ref(wq))     # the planes are built from these on the first decode step
+        return wq
     if prec != "bf16x3":
         return t.to(_prec_dtype(prec)).contiguous()
     f = t.float()
@@ -628,7 +639,7 @@ class Decoder(_PackedMixin, nn.Module):
             return wp.data_ptr(), v(wf @ b_ + lin.bias.detach().float()), v(_operand_colsum(wp, prec, shp))
 
         def src(i, field, ptr):   # remember the packed operand behind `ptr` (bf16 / fp32: the decode step's precisions)
-            if prec in ("bf16", "fp32", "w24"):
+            if prec in ("bf16", "fp32", "w24", "w16"):
                 stream_src.append((i, field, next(t for t in reversed(keep) if t.data_ptr() == ptr)))
 
         layers = (H.DecoderLayer * self.num_layers)()
@@ -685,14 +696,22 @@ class Decoder(_PackedMixin, nn.Module):
         todo = self._stream_src.pop(key, None)
         if not todo or os.environ.get("KOSMOSX_DECODE_TILED", "1") == "0":
             return
-        from .ops import tile_weight_rows, tile_weight_rows_w24
+        from .ops import quantize_block16, tile_weight_rows, tile_weight_rows_w16, tile_weight_rows_w24
         w, layers, keep, _, _ = self._packed[key]
         for i, field, t in todo:
             if t.shape[1] % 32:
-                if prec == "w24":
-                    raise ValueError("the 24-bit streaming planes need K % 32 == 0")   # (decoder widths are multiples of 64)
+                if prec in ("w24", "w16"):
+                    raise ValueError("the compressed streaming planes need K % 32 == 0")   # (decoder widths are multiples of 64)
                 continue
-            tt = tile_weight_rows_w24(t) if prec == "w24" else tile_weight_rows(t)
+            if prec == "w16":       # t holds (float)q * scale; q and scale were kept when it was packed
+                q, sc, ref = _W16_PARTS.pop(t.data_ptr(), (None, None, lambda: None))
+                if q is None or ref() is not t:
+                    q, sc, wq = quantize_block16(t)
+                    if not torch.equal(wq, t):
+                        raise RuntimeError("w16 operand without its (q, scale) parts")
+                tt = tile_weight_rows_w16(q, sc)
+            else:
+                tt = tile_weight_rows_w24(t) if prec == "w24" else tile_weight_rows(t)
             keep.append(tt)
             setattr(w if i < 0 else layers[i], field, tt.data_ptr())
 
@@ -814,10 +833,10 @@ class Decoder(_PackedMixin, nn.Module):
         # bits and streamed as THREE bytes each ("w24": kx_gemm_args.w_tiled = 2; the activations and the products stay fp32).
         # KOSMOSX_DECODE_EXACT=fp32 streams the full fp32 weights (4 bytes), =0 keeps the f16c tile GEMMs.
         exact = os.environ.get("KOSMOSX_DECODE_EXACT", "1")
-        sprec = prec if (prec != "f16c" or exact == "0") else ("fp32" if exact == "fp32" else "w24")
+        sprec = prec if (prec != "f16c" or exact == "0") else ({"fp32": "fp32", "w24": "w24"}.get(exact, "w16"))
         if sprec != prec:
             w = self._pack(sprec)[0]
-        if sprec in ("bf16", "fp32", "w24") and B <= 16:
+        if sprec in ("bf16", "fp32", "w24", "w16") and B <= 16:
             self._pack_decode_tiles(sprec)                 # first decode step: the streaming copy of the weights
         if passed_x is not None:
             _require_cuda(passed_x, "passed_x")
@@ -829,7 +848,8 @@ class Decoder(_PackedMixin, nn.Module):
         rows = tuple(None if tb is None else tb[t] for tb in state["xpos"])   # views: row t of each [Tmax, 32] table
         logits = torch.empty((B, 1, w.vocab), dtype=torch.float32, device=x.device)
         # (w24 without streaming copies — KOSMOSX_DECODE_TILED=0, more than 16 sequences — is plain fp32 on the rounded operands)
-        pid = H.KX_PREC_F32W24 if (sprec == "w24" and bool(w.wout_t)) else H.PACK_PRECS[sprec]
+        pid = ({"w24": H.KX_PREC_F32W24, "w16": H.KX_PREC_F32W16}[sprec] if (sprec in ("w24", "w16") and bool(w.wout_t))
+               else H.PACK_PRECS[sprec])
         need = lib.kx_decoder_workspace_bytes(C.byref(w), B, 1, pid)
         buf = self._ws.get(need, x.device)
         H.check(lib.kx_decoder_decode_step(C.byref(w), x.data_ptr(), B, t, *(H.ptr(r) for r in rows),

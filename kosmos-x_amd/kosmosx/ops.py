@@ -87,7 +87,8 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
         out = torch.empty((M, 3 * N if out_x3 else N), dtype=torch.bfloat16 if out_x3 else out_dtype, device=a.device)
     g = H.GemmArgs()
     g.A, g.lda, g.W, g.ldw = H.ptr(a), a.stride(0), H.ptr(w), (K if w_tiled_rows else w.stride(0))
-    g.w_tiled = (2 if w.dtype == torch.uint8 else 1) if w_tiled_rows else 0     # uint8 tiles = 24-bit planes (tile_weight_rows_w24)
+    # uint8 tiles: 24-bit planes (tile_weight_rows_w24, 1536-byte blocks) or block-scaled 16-bit weights (_w16, 1088-byte blocks)
+    g.w_tiled = ((3 if w.shape[-1] == 1088 else 2) if w.dtype == torch.uint8 else 1) if w_tiled_rows else 0
     g.C, g.ldc, g.cdt = H.ptr(out), out.stride(0), (H.KX_BF16X3 if out_x3 else _cdt(out.dtype))
     g.bias, g.residual, g.ldr = H.ptr(bias), H.ptr(residual), (residual.stride(0) if residual is not None else 0)
     g.M, g.N, g.K = M, N, K
@@ -171,6 +172,36 @@ def tile_weight_rows_w24(w: torch.Tensor) -> torch.Tensor:
     hi = ((v >> 16) & 0xFFFF).to(torch.int16).view(Np // 16, K // 32, 64 * 8).view(torch.uint8)      # little-endian halves
     lo = ((v >> 8) & 0xFF).to(torch.uint8).view(Np // 16, K // 32, 64 * 8)
     return torch.cat([hi.view(Np // 16, K // 32, 1024), lo], dim=2).contiguous()
+
+
+def quantize_block16(w: torch.Tensor):
+    """fp32 [N, K] (K % 32 == 0) -> (q int16 [N, K], scale fp32 [N, K/32], wq fp32 [N, K]): per row and block of 32 columns
+    scale = max|w| / 32767 (1 for an all-zero block), q = round(w / scale), wq = q * scale — the values the block-scaled 16-bit
+    planes of kx_gemm_args.w_tiled = 3 hold, as the kernel rebuilds them ((float)q * scale, one fp32 rounding)."""
+    N, K = w.shape
+    assert K % 32 == 0
+    wb = w.detach().float().reshape(N, K // 32, 32)
+    amax = wb.abs().amax(-1)
+    scale = torch.where(amax > 0, amax / 32767.0, torch.ones_like(amax))
+    q = torch.round(wb / scale[..., None]).clamp(-32767, 32767).to(torch.int16)
+    wq = (q.float() * scale[..., None]).reshape(N, K).contiguous()
+    return q.reshape(N, K).contiguous(), scale.contiguous(), wq
+
+
+def tile_weight_rows_w16(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """(q int16 [N, K], scale fp32 [N, K/32]) -> kx_gemm_args.w_tiled = 3 planes, uint8 [ceil(N/16), K/32, 1088]: per block
+    64 pieces of 16 B (piece l = row 16p + (l & 15): columns 32c + 4(l >> 4) .. +3, then 32c + 16 + 4(l >> 4) .. +3) followed
+    by the block's 16 row scales."""
+    N, K = q.shape
+    assert K % 32 == 0 and q.dtype == torch.int16 and scale.shape == (N, K // 32)
+    Np = (N + 15) // 16 * 16
+    if Np != N:
+        q = torch.cat([q, torch.zeros((Np - N, K), dtype=q.dtype, device=q.device)], 0)
+        scale = torch.cat([scale, torch.ones((Np - N, K // 32), dtype=scale.dtype, device=scale.device)], 0)
+    v = q.view(Np // 16, 16, K // 32, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).contiguous()          # [p, c, g, i, half, j]
+    qb = v.view(Np // 16, K // 32, 64 * 8).view(torch.uint8).view(Np // 16, K // 32, 1024)
+    sb = scale.float().view(Np // 16, 16, K // 32).permute(0, 2, 1).contiguous().view(torch.uint8).view(Np // 16, K // 32, 64)
+    return torch.cat([qb, sb], dim=2).contiguous()
 
 
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,

@@ -62,16 +62,18 @@ def test_hip_prefill_and_decode_steps_match_full_forward(prec, tol):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 3, 6])
 def test_f16c_decode_step_forms(B, monkeypatch):
-    """The decode step of f16c / mixed: default = fp32 products on weights rounded to 16 significant bits, streamed as 3
-    bytes each (KX_PREC_F32W24); KOSMOSX_DECODE_EXACT=fp32 streams the full fp32 weights; =0 keeps the f16c tile GEMMs;
-    KOSMOSX_DECODE_TILED=0 runs the 24-bit step on its row-major (rounded fp32) operands — bit-identical to the planes.
-    All inside the tolerance against the oracle; the two exact-product forms differ by the weight rounding only."""
+    """The decode step of f16c / mixed: default = fp32 products on block-scaled 16-bit weights, streamed as 2.125 bytes each
+    (KX_PREC_F32W16); KOSMOSX_DECODE_EXACT=w24 streams weights rounded to 16 significant bits as 3 bytes; =fp32 the full
+    fp32 weights; =0 keeps the f16c tile GEMMs; KOSMOSX_DECODE_TILED=0 runs the compressed steps on their row-major fp32
+    operands — bit-identical to the planes.  All inside the tolerance against the oracle; the exact-product forms differ by
+    the weight rounding only."""
     lm0 = _lm(seed=12)
     tok = torch.randint(0, 502, (B, 30), generator=torch.Generator().manual_seed(6))
     ref = O.kosmos_language_forward(oracle_weights(lm0), tok, CFG)[:, 9:30]
     outs = {}
-    for name, env in (("w24", {}), ("fp32", {"KOSMOSX_DECODE_EXACT": "fp32"}), ("tiles", {"KOSMOSX_DECODE_EXACT": "0"}),
-                      ("w24_rowmajor", {"KOSMOSX_DECODE_TILED": "0"})):
+    for name, env in (("w16", {}), ("w24", {"KOSMOSX_DECODE_EXACT": "w24"}), ("fp32", {"KOSMOSX_DECODE_EXACT": "fp32"}),
+                      ("tiles", {"KOSMOSX_DECODE_EXACT": "0"}), ("w16_rowmajor", {"KOSMOSX_DECODE_TILED": "0"}),
+                      ("w24_rowmajor", {"KOSMOSX_DECODE_EXACT": "w24", "KOSMOSX_DECODE_TILED": "0"})):
         for k in ("KOSMOSX_DECODE_EXACT", "KOSMOSX_DECODE_TILED"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -82,11 +84,11 @@ def test_f16c_decode_step_forms(B, monkeypatch):
         lm(tok[:, :9].cuda(), incremental_state=st)
         outs[name] = torch.cat([lm(tok[:, : t + 1].cuda(), incremental_state=st) for t in range(9, 30)], 1)
         assert rel_err(outs[name], ref) < 1e-3, name
-        if name == "w24":
-            w = lm.decoder._pack("w24")[0]
-            assert bool(w.wout_t) and bool(w.layer[0].wqkv_t)                      # the 24-bit planes were the ones streamed
-    assert torch.equal(outs["w24"], outs["w24_rowmajor"])
-    assert rel_err(outs["w24"], outs["fp32"].cpu()) < 2e-4
+        if name in ("w16", "w24"):
+            w = lm.decoder._pack(name)[0]
+            assert bool(w.wout_t) and bool(w.layer[0].wqkv_t)                      # the compressed planes were the ones streamed
+    assert torch.equal(outs["w24"], outs["w24_rowmajor"]) and torch.equal(outs["w16"], outs["w16_rowmajor"])
+    assert rel_err(outs["w24"], outs["fp32"].cpu()) < 2e-4 and rel_err(outs["w16"], outs["fp32"].cpu()) < 5e-4
 
 
 @pytest.mark.gpu

@@ -610,6 +610,47 @@ def test_gemm_weight_streaming_24_bit_weight_planes(M, N, K):
         assert torch.equal(c1, d1) and torch.equal(c2, d2)
 
 
+@pytest.mark.parametrize("M", [1, 4, 7, 15])
+@pytest.mark.parametrize("N,K", [(264, 2048), (2048, 8192), (1002, 320), (6144, 2048), (512, 64)])
+def test_gemm_weight_streaming_block_scaled_16_bit_weights(M, N, K):
+    """kx_gemm_args.w_tiled = 3: int16 weights with one fp32 scale per row and block of 32 columns (2.125 bytes per weight),
+    rebuilt as (float)q * scale and multiplied on the exact-f32 MFMA.  On those values the fp32 kernel computes the same
+    products in the same order: bit-identical outputs; against the un-quantised weights every weight moved by at most half
+    a step of its block (max|w| / 65534).  With the LayerNorm prologue and the pair form."""
+    g = _g(19 * M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 40
+    w[1, :32] = 0.0                                                         # an all-zero block
+    w[2, 32:64] *= 1e-6                                                     # a tiny block keeps its own scale
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    q, sc, wq = ops.quantize_block16(w)
+    assert float(sc[1, 0]) == 1.0 and int(q[1, :32].abs().max()) == 0 and int(q.abs().max()) == 32767
+    step = (w.reshape(N, K // 32, 32).abs().amax(-1) / 32767.0)[..., None].expand(N, K // 32, 32).reshape(N, K)
+    assert bool(((wq - w).abs() <= 0.51 * step + 1e-30).all())          # half a step (+ the fp32 roundings of w / scale and q * scale)
+    planes = ops.tile_weight_rows_w16(q.to(DEV), sc.to(DEV))
+    assert planes.dtype == torch.uint8 and planes.shape == ((N + 15) // 16, K // 32, 1088)
+    out = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), planes, bias.to(DEV), out, "gelu", out=out, tile=16, w_tiled_rows=N)
+    same = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), wq.to(DEV), bias.to(DEV), same, "gelu", out=same, tile=16)
+    assert torch.equal(out, same)
+    ref = _gemm_ref(a.double(), w.double(), bias.double(), res.double(), "gelu")
+    bound = 1.2 * (a.abs().double() @ (0.5 * step).double().t()) + 1e-5
+    assert bool(((out.cpu().double() - ref).abs() <= bound).all())
+    if K <= 2048:
+        gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+        ln = (gam.to(DEV), bet.to(DEV), 1e-5)
+        x = (a * 3 + 0.5).to(DEV)
+        assert torch.equal(ops.gemm(x, planes, bias.to(DEV), act="gelu", tile=16, ln=ln, w_tiled_rows=N),
+                           ops.gemm(x, wq.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=ln))
+    if N % 16 == 0 and K % 128 == 0:
+        c1, c2, d1, d2 = (torch.empty(M, N, device=DEV) for _ in range(4))
+        rb = (res * 0.1).to(DEV)
+        ops.gemm(a.to(DEV), planes, bias.to(DEV), res.to(DEV), out=c1, tile=16, ksplit=2, out2=c2, residual2=rb, w_tiled_rows=N)
+        ops.gemm(a.to(DEV), wq.to(DEV), bias.to(DEV), res.to(DEV), out=d1, tile=16, ksplit=2, out2=d2, residual2=rb)
+        assert torch.equal(c1, d1) and torch.equal(c2, d2)
+
+
 @pytest.mark.parametrize("M", [1, 3, 8, 15])
 def test_gemm_weight_streaming_fp32_prologues(M):
     """The decode step's prologues on fp32 operands: LayerNorm of the raw rows (the operand stays fp32: no rounding at

@@ -46,7 +46,7 @@ with torch.no_grad():
     _hip.prof_enable(False)
 L, d, F, V = 24, 2048, 8192, 32002
 eb = 2 if a.precision in ('bf16', 'bf16x3') else 4                 # bytes per cached key / value
-ewb = eb if a.precision not in ('f16c', 'mixed') else {'1': 3, 'fp32': 4, '0': 4}.get(os.environ.get('KOSMOSX_DECODE_EXACT', '1'), 3)   # streamed per weight
+ewb = eb if a.precision not in ('f16c', 'mixed') else {'1': 2.125, 'w24': 3, 'fp32': 4, '0': 4}.get(os.environ.get('KOSMOSX_DECODE_EXACT', '1'), 2.125)   # streamed per weight
 wbytes = ewb * (L * (4 * d * d + 2 * d * F) + d * V)
 tavg = a.prefix + 4 + a.steps / 2
 kvbytes = 2 * L * a.batch * tavg * d * eb

@@ -53,6 +53,23 @@ def mm_format(a, w, fmt):
         if fmt == "f16cw":
             return ah @ wh.t() + (f8(a * sa) @ f8((w - wh) * sw_ * c).t()) / (sa * sw_ * c)
         return ah @ wh.t() + (f8((a - ah) * sa * c) @ f8(w * sw_).t()) / (sa * sw_ * c)
+    if fmt.startswith("w") and fmt[1:3] in ("fl", "bq"):   # exact activations; weights: wfl16 = float rounded to 16 significant bits
+        if fmt.startswith("wfl"):                            # (the 24-bit planes of the decode step); wbq16_32 = int16 with one
+            n = int(fmt[3:])                                 # power-of-two scale per block of 32 along K; wbq16f_32: fp32 scale
+            b = w.contiguous().view(torch.int32)
+            sh = 24 - n
+            wr = ((b + (1 << (sh - 1)) - 1 + ((b >> sh) & 1)) & ~((1 << sh) - 1)).view(torch.float32)
+            return a @ wr.t()
+        spec, blk = fmt[3:].split("_")
+        blk = int(blk)
+        bits = int(spec.rstrip("f"))
+        N, K = w.shape
+        wb = w.reshape(N, K // blk, blk)
+        amax = wb.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+        qmax = float(2 ** (bits - 1) - 1)
+        sc = amax / qmax if spec.endswith("f") else torch.exp2(torch.ceil(torch.log2(amax / qmax)))
+        wr = (torch.round(wb / sc).clamp(-qmax, qmax) * sc).reshape(N, K)
+        return a @ wr.t()
     if fmt == "f16x2a":   # activation split in two fp16, weight single fp16
         ah, wh = a.half().float(), w.half().float()
         al = (a - ah).half().float()
