@@ -552,7 +552,7 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  * key 8: tile-16 weight-streaming kernel (0 = second form: small loads first, counted waits, one-barrier LayerNorm
  *        prologue, 16 KB per wave in flight for K slices of 512; 1 = the first form; 2 = second form without the
  *        16 KB variant; 3 = second form whose 5..8-row LayerNorm prologue walks its row three times instead of
- *        keeping it in registers);
+ *        keeping it in registers; 4 = fp32 operands with one or two rows multiply on the matrix pipe instead of the VALU);
  * key 9: KV-cache layout per layer and sequence (0 = [heads][Tmax][64]; 1 = the first layout [Tmax][heads*64]; set it
  *        before a prefill and keep it for that cache's steps).
  * key 10: 1 = the fp32 decode step keeps the split-K tile kernels instead of the fp32 weight-streaming kernel (A/B).

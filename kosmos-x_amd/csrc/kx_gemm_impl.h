@@ -57,6 +57,7 @@ struct GemmParams {
   // split, kfull the row length of W.  a_add: second addend of the LayerNorm-prologue rows (A + a_add is normalised).
   int gsplit, kfull; void* C2; const float* residual2; const float* a_add;
   int no_rowreg;        // A/B (tuning key 8 = 3): the 5..8-row LayerNorm prologue keeps the three-walk form
+  int valu;             // fp32 operands, M <= 4: multiply on the VALU (gemv_fused_kernel2<..., VAL>), set by launch_gemv_fused
   int gb_staged;        // row-in-registers prologue: gamma | beta are passed through LDS (else read from global when needed)
   // row-owning split-K reduce: optional LayerNorm of the finished row as a second output
   void* ln_out; int ln_out_dt; const float *ln_out_g, *ln_out_b; float ln_out_eps;
@@ -1999,7 +2000,14 @@ __host__ __device__ inline bool gemv_rowreg(int M, int K, int S, bool pair) {
 // block's max|w| / 32767.  2.125 bytes per weight — bf16's bytes — rebuilt as fp32 (convert + one multiply per value) in front
 // of the exact-f32 MFMA.  With exact activations this leaves 2.5e-4 on the logits (tools/precision_study.py --formats
 // wbq16f_32; 16-significant-bit floats: 1.1e-4), inside the 1e-3 the f16c / mixed modes promise.
-template <typename T, int ACT, bool LNP, int UW, int WF = 0>
+// VAL (fp32 operands, one or two rows; instantiated for up to four): the products on the VALU instead of the matrix pipe.  A 16x16x4 f32 MFMA multiplies 64 weights
+// by SIXTEEN activation rows in 32 cycles whatever M is — at one sequence 15 of them are padding, and the step's 1.34 G
+// weights cost 0.27 ms of matrix time (the fp32 launches measured 12 us before their bytes against 9 for bf16's).  Here a
+// lane multiplies its four weights of a k-step by the M rows' values (broadcast reads of the fp32 operand rows in LDS: the
+// LayerNorm prologue's, or staged for the residual GEMMs) with M x 4 FMAs: (3 + M) VALU operations per weight, ~40-70 us per
+// step over the whole chip.  Exact fp32 products in a fixed order (a lane's k-steps in sequence, then the four k-groups,
+// then the waves): deterministic, not bit-identical to the MFMA form's order.
+template <typename T, int ACT, bool LNP, int UW, int WF = 0, bool VAL = false>
 __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, int S, int kw, int x_pitch) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2030,6 +2038,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   constexpr bool W24 = WF != 0;                                    // (compressed weight planes of either kind)
   constexpr int WBLK = WF == 16 ? 1088 : 1536;                     // bytes per block of 16 rows x 32 k
   static_assert(WF == 0 || ((WF == 24 || WF == 16) && sizeof(T) == 4), "weight planes reconstruct fp32 operands");
+  static_assert(!VAL || sizeof(T) == 4, "the VALU form multiplies fp32 operands");
   // W24: block of a k-step PAIR (32 k): [64 lanes x 16 B: bf16 halves of k-steps 2c, 2c+1][64 lanes x 8 B: their third bytes]
   const char* wph = p.W + ((long long)blockIdx.x * (p.kfull >> 5) + ((kbase + k0w) >> 5)) * WBLK + (lane << 4);
   const char* wpl = WF == 16 ? wph + 1024 - (lane << 4) + (i << 2)      // this lane's row scale
@@ -2046,6 +2055,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
                                                                  // addend in vv[4..7]; row-in-registers form: this lane's eight float4 of the wave's row
   u32x4_t xf[XG];                                                // !LNP: the first batch of operand fragments
   u32x4_t xs[4];                                                 // XS: this thread's 16 bytes of operand rows 0..3
+  float4 xv4[VAL && !LNP ? 8 : 1];                               // VAL, residual GEMMs: this thread's two float4 of operand rows 0..3
   // statistics prologue: the producer's partials [M][nseg] float2 go through registers (requested first) into LDS, where
   // the row-owning waves then find them — the same walk and arithmetic as from global memory
   float2 ps[2];
@@ -2091,7 +2101,15 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       for (int t = 0; t < 2; ++t)
         if (tid + 64 * S * t < np) ps[t] = reinterpret_cast<const float2*>(p.stats_partials)[tid + 64 * S * t];
     }
-    if constexpr (XS) {
+    if constexpr (VAL) {                                       // the operand rows go through LDS: M x 2 float4 per thread
+      const int nch = p.K >> 2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                              // (rows past M re-read the last one: unconditional loads)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          xv4[r * 2 + j] = *reinterpret_cast<const float4*>(p.A + (long long)min(r, p.M - 1) * p.lda_b + kbase * ES + ((long long)min(tid + j * 64 * S, nch - 1) << 4));
+      }
+    } else if constexpr (XS) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (r < p.M && tid < (p.K * ES >> 4)) xs[r] = *reinterpret_cast<const u32x4_t*>(p.A + (long long)r * p.lda_b + kbase * ES + (tid << 4));
@@ -2164,6 +2182,15 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (r < p.M && tid < (p.K * ES >> 4)) *reinterpret_cast<u32x4_t*>(xsb + r * x_pitch + (tid << 4)) = xs[r];
+  }
+  if constexpr (VAL && !LNP) {
+    const int nch = p.K >> 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (r < p.M && tid + j * 64 * S < nch) *reinterpret_cast<float4*>(xsb + r * x_pitch + ((tid + j * 64 * S) << 4)) = xv4[r * 2 + j];
+    }
   }
   if (p.stats_partials) {
     if (stat_stage) {
@@ -2332,10 +2359,11 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
       }
     }
   }
-  if (LNP || XS || p.stats_partials) __syncthreads();
+  if (LNP || XS || VAL || p.stats_partials) __syncthreads();
 
   // ---- (4) the products ----
   f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float av[4] = {0.f, 0.f, 0.f, 0.f};            // VAL: this lane's column, rows 0..3
   const char* xl = (LNP ? xn : xsb) + xrow * x_pitch + (k0 + EPL * g) * ES;   // LNP / XS: the operand rows in LDS
   const char* xg = p.A + (long long)xrow * p.lda_b + (kbase + k0 + EPL * g) * ES;
   for (int kk = 0; kk < klen; kk += KS * U) {
@@ -2354,6 +2382,21 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
           if (kk + KS * u < klen) wf[u] = ldw(wp + ((kk >> KSH) + u) * wstep);
       }
     }
+    if constexpr (VAL) {
+      const char* xlv = (LNP ? xn : xsb) + (k0 + kk + EPL * g) * ES;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (kk + KS * u < klen) {
+          const u32x4_t wv = wfrag(u);
+          const float w0 = __uint_as_float(wv[0]), w1 = __uint_as_float(wv[1]), w2 = __uint_as_float(wv[2]), w3 = __uint_as_float(wv[3]);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            if (m < p.M) {
+              const float4 xq = *reinterpret_cast<const float4*>(xlv + m * x_pitch + KS * u * ES);
+              av[m] = fmaf(w3, xq.w, fmaf(w2, xq.z, fmaf(w1, xq.y, fmaf(w0, xq.x, av[m]))));
+            }
+        }
+    } else {
 #pragma unroll
     for (int h = 0; h < U; h += XG) {
 #pragma unroll
@@ -2367,11 +2410,29 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
         if (kk + KS * (h + u) < klen) acc = Mma<T>::step(wfrag(h + u), xf[u], acc);
       if constexpr (U > XG) __builtin_amdgcn_sched_barrier(0);    // (keeps the second half's eight LDS reads out of the first half's registers)
     }
+    }  // MFMA form
   }
-  *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
-  __syncthreads();
-  if (wave != 0) return;
-  for (int w = 1; w < S; ++w) acc += *reinterpret_cast<const f32x4_t*>(red + (w * 64 + lane) * 4);
+  if constexpr (VAL) {
+    // lane (g, i) holds column n0 + i, rows 0..3, over its k-group: meet the four groups, then the waves ([S][4 rows][16 columns])
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      av[m] += __shfl_xor(av[m], 16, 64);
+      av[m] += __shfl_xor(av[m], 32, 64);
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) red[(wave * 4 + m) * 16 + i] = av[m];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (i < 4)                                                     // epilogue layout: lane = row i, columns n0 + 4g .. +3
+      for (int w = 0; w < S; ++w) acc += *reinterpret_cast<const f32x4_t*>(red + (w * 4 + i) * 16 + 4 * g);
+  } else {
+    *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < S; ++w) acc += *reinterpret_cast<const f32x4_t*>(red + (w * 64 + lane) * 4);
+  }
 
   // ---- (5) epilogue (epilogue_compute4's arithmetic on the preloaded operands) ----
   const int m = em, n = en;
@@ -2434,6 +2495,22 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
 template <typename T, int ACT>
 void launch_gemv2(const GemmParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, int S, int kw, int x_pitch, bool deep) {
   if constexpr (sizeof(T) == 4) {
+    if (p.valu) {                      // M <= 4: the products on the VALU (fp32 rows, 24-bit or 16-bit planes)
+      if (p.w_tiled == 2) {
+        if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, 24, true>), grid, block, lds, s, p, S, kw, x_pitch);
+        else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, 24, true>), grid, block, lds, s, p, S, kw, x_pitch);
+        else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8, 24, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      } else if (p.w_tiled == 3) {
+        if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, 16, true>), grid, block, lds, s, p, S, kw, x_pitch);
+        else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, 16, true>), grid, block, lds, s, p, S, kw, x_pitch);
+        else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8, 16, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      } else {
+        if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, 0, true>), grid, block, lds, s, p, S, kw, x_pitch);
+        else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, 0, true>), grid, block, lds, s, p, S, kw, x_pitch);
+        else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8, 0, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      }
+      return;
+    }
     if (p.w_tiled == 2) {              // 24-bit weight planes
       if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, 24>), grid, block, lds, s, p, S, kw, x_pitch);
       else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, 24>), grid, block, lds, s, p, S, kw, x_pitch);
@@ -2464,6 +2541,15 @@ void gemv2_lds_attr() {
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, 24, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, 24, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, 24, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
 }
 
@@ -2474,6 +2560,11 @@ inline size_t gemv_lds_bytes(int M, int K, int es, bool ln, bool partials, bool 
   return (size_t)S * 1024 + 128 +                               // accumulators | statistics | operand rows or staged partials (+ rows)
          (ln ? (size_t)M * x_pitch : (partials ? (size_t)128 * S * 8 : (size_t)0) + (deep ? (size_t)M * x_pitch : (size_t)0));
 }
+
+// Up to how many rows the fp32 streaming kernel multiplies on the VALU: measured per decode step (same box, round 3; tuning key
+// 8 = 4 keeps the matrix pipe), B = 1: 1.29 -> 1.17 ms (mixed), 1.62 -> 1.53 (fp32); B = 2: 1.35 -> 1.30; B = 4: 1.55 -> 1.64 and
+// 1.86 -> 1.94 — four rows cost four times the FMAs and LDS reads, and the matrix pipe's padding is only 4x there.
+inline int kx_valu_rows() { return 2; }
 
 template <typename T>
 int launch_gemv_fused(GemmParams& p, hipStream_t s) {
@@ -2490,6 +2581,17 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
                             : (!p.ln_g && kw > 128 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 2);   // fp32: 16 KB per wave in flight, rows via L2
   int x_pitch = 0;
   size_t lds = gemv_lds_bytes(p.M, p.K, ES, p.ln_g != nullptr, p.stats_partials != nullptr, deep && ES == 2, S, &x_pitch);
+  // fp32 operands, up to four rows: the products on the VALU (see gemv_fused_kernel2, VAL).  The residual GEMMs' operand
+  // rows are staged in LDS for it (two float4 per thread and row: K <= 8 * 64 * S).  Tuning key 8 = 4 keeps the MFMA form.
+  p.valu = 0;
+  if (ES == 4 && p.M <= kx_valu_rows() && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 4) {
+    if (p.ln_g) p.valu = 1;
+    else if ((p.K >> 2) <= 2 * 64 * S && lds + (size_t)p.M * ((size_t)p.K * 4 + 16) <= 96 * 1024) {
+      p.valu = 1;
+      x_pitch = p.K * 4 + 16;
+      lds += (size_t)p.M * x_pitch;
+    }
+  }
   // row-in-registers LayerNorm prologue (5..8 rows): gamma | beta go through 8K bytes of LDS when two workgroups still fit a CU
   p.gb_staged = p.ln_g && !p.no_rowreg && gemv_rowreg(p.M, p.K, S, p.a_add != nullptr) && lds + 8 * (size_t)p.K <= 80 * 1024;
   if (p.gb_staged) lds += 8 * (size_t)p.K;

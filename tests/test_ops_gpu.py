@@ -651,6 +651,56 @@ def test_gemm_weight_streaming_block_scaled_16_bit_weights(M, N, K):
         assert torch.equal(c1, d1) and torch.equal(c2, d2)
 
 
+@pytest.mark.parametrize("M", [1, 2, 3])
+@pytest.mark.parametrize("N,K", [(2048, 8192), (6144, 2048), (1002, 320), (2048, 2048)])
+def test_gemm_weight_streaming_valu_form_for_one_or_two_rows(M, N, K):
+    """fp32 operands, M <= 2 (M = 3 runs the matrix pipe both ways): the products run on the VALU (a 16x16x4 f32 MFMA
+    multiplies by sixteen rows whatever M is).
+    Exact fp32 products in another fixed order: equal to the MFMA form (tuning key 8 = 4) to fp32 rounding, deterministic,
+    against float64 at fp32-GEMM accuracy; LayerNorm prologue, statistics consumer, pair form and the weight planes included."""
+    from kosmosx import _hip
+    g = _g(23 * M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 40
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    lib = _hip.load()
+
+    def both(fn):
+        v = fn()
+        assert torch.equal(v, fn())
+        try:
+            lib.kx_set_tuning(8, 4)
+            mf = fn()
+        finally:
+            lib.kx_set_tuning(8, 0)
+        return v, mf
+    ref = _gemm_ref(a.double(), w.double(), bias.double(), res.double(), "gelu")
+    v, mf = both(lambda: ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV).clone(), "gelu", tile=16))
+    assert float((v.cpu().double() - ref).abs().max() / ref.pow(2).mean().sqrt()) < 3e-6
+    assert rel_err(v, mf.cpu()) < 5e-6
+    if K % 32 == 0:
+        q, sc, wq = ops.quantize_block16(w)
+        planes = ops.tile_weight_rows_w16(q.to(DEV), sc.to(DEV))
+        v, mf = both(lambda: ops.gemm(a.to(DEV), planes, bias.to(DEV), res.to(DEV).clone(), "gelu", tile=16, w_tiled_rows=N))
+        assert rel_err(v, mf.cpu()) < 5e-6
+        assert torch.equal(v, ops.gemm(a.to(DEV), wq.to(DEV), bias.to(DEV), res.to(DEV).clone(), "gelu", tile=16))
+    if K <= 2048:
+        gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+        ln = (gam.to(DEV), bet.to(DEV), 1e-5)
+        x = (a * 3 + 0.5).to(DEV)
+        v, mf = both(lambda: ops.gemm(x, w.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=ln))
+        assert rel_err(v, mf.cpu()) < 5e-6
+    if N % 16 == 0 and K % 128 == 0:
+        rb = (res * 0.1).to(DEV)
+
+        def pair():
+            c1, c2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+            ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), out=c1, tile=16, ksplit=2, out2=c2, residual2=rb)
+            return c1 + c2
+        v, mf = both(pair)
+        assert rel_err(v, mf.cpu()) < 5e-6
+
+
 @pytest.mark.parametrize("M", [1, 3, 8, 15])
 def test_gemm_weight_streaming_fp32_prologues(M):
     """The decode step's prologues on fp32 operands: LayerNorm of the raw rows (the operand stays fp32: no rounding at
