@@ -2562,9 +2562,9 @@ inline size_t gemv_lds_bytes(int M, int K, int es, bool ln, bool partials, bool 
 }
 
 // Up to how many rows the fp32 streaming kernel multiplies on the VALU: measured per decode step (same box, round 3; tuning key
-// 8 = 4 keeps the matrix pipe), B = 1: 1.29 -> 1.17 ms (mixed), 1.62 -> 1.53 (fp32); B = 2: 1.35 -> 1.30; B = 4: 1.55 -> 1.64 and
-// 1.86 -> 1.94 — four rows cost four times the FMAs and LDS reads, and the matrix pipe's padding is only 4x there.
-inline int kx_valu_rows() { return 2; }
+// 8 = 4 keeps the matrix pipe), B = 1: 1.29 -> 1.17 ms (mixed), 1.62 -> 1.53 (fp32); B = 2: 1.35 -> 1.30; B = 3 / 4: 1.50 / 1.55 either
+// way once the residual GEMMs' staged rows are bounded to two workgroups per CU (unbounded, four rows of fc2 = 66 KB of LDS: 1.64).
+inline int kx_valu_rows() { const int t = kx_tuning_get(KX_TUNE_GEMV_VARIANT); return t >= 10 ? t - 10 : 2; }   // (key 8 = 10 + n: up to n rows, A/B)
 
 template <typename T>
 int launch_gemv_fused(GemmParams& p, hipStream_t s) {
@@ -2586,7 +2586,7 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
   p.valu = 0;
   if (ES == 4 && p.M <= kx_valu_rows() && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 4) {
     if (p.ln_g) p.valu = 1;
-    else if ((p.K >> 2) <= 2 * 64 * S && lds + (size_t)p.M * ((size_t)p.K * 4 + 16) <= 96 * 1024) {
+    else if ((p.K >> 2) <= 2 * 64 * S && lds + (size_t)p.M * ((size_t)p.K * 4 + 16) <= 80 * 1024) {   // (two workgroups per CU still fit)
       p.valu = 1;
       x_pitch = p.K * 4 + 16;
       lds += (size_t)p.M * x_pitch;
