@@ -182,7 +182,10 @@ typedef struct {
    * w_tiled = 3 (fp32 operands only): BLOCK-SCALED 16-BIT weights — [ceil(N/16)][K/32][1088 B]: 64 pieces of 16 B of int16
    * values q (the piece order of w_tiled = 2's halves) followed by the fp32 scales of the block's 16 rows (64 B);
    * w = (float)q * scale with scale = max|w| over the row's 32 columns / 32767 (1 for an all-zero run).  2.125 bytes per
-   * weight; the row-major fp32 operand beside it holds exactly (float)q * scale. */
+   * weight; the row-major fp32 operand beside it holds exactly (float)q * scale.  Launches the VALU form does not take
+   * (three rows and more; two rows of K = 8192) multiply fp16 PIECES on the fp16 MFMA: q = 1024 (q >> 10) + (q & 1023), the
+   * activation as fp16 hi + lo (21-22 significant bits, absolute floor 2^-25); exact products, the block's scale applied to
+   * each 32-k partial sum: within 2^-20 sum|a||w| of the exact-f32 form (tuning key 8 = 5). */
   int32_t w_tiled;
   /* tile 16 (weight streaming) only — the residual stream of a decode step as a PAIR (x = xa + xb, always summed in that
    * order).  A residual GEMM with few columns (out_proj / fc2: N = 2048 -> 128 workgroups for 256 CUs) is launched with its
@@ -552,7 +555,9 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  * key 8: tile-16 weight-streaming kernel (0 = second form: small loads first, counted waits, one-barrier LayerNorm
  *        prologue, 16 KB per wave in flight for K slices of 512; 1 = the first form; 2 = second form without the
  *        16 KB variant; 3 = second form whose 5..8-row LayerNorm prologue walks its row three times instead of
- *        keeping it in registers; 4 = fp32 operands with one or two rows multiply on the matrix pipe instead of the VALU);
+ *        keeping it in registers; 4 = fp32 operands with one or two rows multiply on the matrix pipe instead of the VALU;
+ *        5 = block-scaled 16-bit planes (w_tiled = 3) keep the exact-f32 MFMA where the default multiplies fp16 pieces;
+ *        10 + n = the VALU form takes up to n rows (default 2));
  * key 9: KV-cache layout per layer and sequence (0 = [heads][Tmax][64]; 1 = the first layout [Tmax][heads*64]; set it
  *        before a prefill and keep it for that cache's steps).
  * key 10: 1 = the fp32 decode step keeps the split-K tile kernels instead of the fp32 weight-streaming kernel (A/B).

@@ -62,16 +62,15 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
-def build_timeline(verbose: bool = True) -> Path:
-    """Side library with the 256-column GEMM kernel's timeline stamps compiled in (-DKX_TIMELINE), for
-    tools/gemm_timeline.py.  Never loaded by the product (KOSMOSX_HIP_LIB points the tool at it)."""
-    out = BUILD_DIR / "tl"
+def build_variant(define: str, tag: str, verbose: bool = True) -> Path:
+    """Side library with one extra -D (measurement builds; never loaded by the product: KOSMOSX_HIP_LIB points a tool at it)."""
+    out = BUILD_DIR / tag
     out.mkdir(parents=True, exist_ok=True)
     srcs = sorted(CSRC.glob("*.hip"))
 
     def cc(src: Path) -> Path:
         obj = out / (src.stem + ".o")
-        cmd = [HIPCC, *FLAGS, "-DKX_TIMELINE", "-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC, *FLAGS, "-D" + define, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -79,12 +78,20 @@ def build_timeline(verbose: bool = True) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(cc, srcs))
-    lib = out / "libkosmosx_hip_tl.so"
+    lib = out / f"libkosmosx_hip_{tag}.so"
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(lib)], check=True)
     return lib
+
+
+def build_timeline(verbose: bool = True) -> Path:
+    """Side library with the 256-column GEMM kernel's timeline stamps compiled in (-DKX_TIMELINE), for
+    tools/gemm_timeline.py."""
+    return build_variant("KX_TIMELINE", "tl", verbose)
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     if "--timeline" in sys.argv:
         print(build_timeline())
+    if "--fp6-rate-probe" in sys.argv:          # tools/fp6_rate_probe.sh: correction MFMAs issued as e2m3 (timing only)
+        print(build_variant("KX_FP6_RATE_PROBE", "fp6probe"))

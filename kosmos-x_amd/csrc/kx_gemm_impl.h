@@ -59,6 +59,7 @@ struct GemmParams {
   int no_rowreg;        // A/B (tuning key 8 = 3): the 5..8-row LayerNorm prologue keeps the three-walk form
   int valu;             // fp32 operands, M <= 4: multiply on the VALU (gemv_fused_kernel2<..., VAL>), set by launch_gemv_fused
   int gb_staged;        // row-in-registers prologue: gamma | beta are passed through LDS (else read from global when needed)
+  int hp;               // block-scaled 16-bit planes, 3..16 rows: fp16 pieces on the fp16 MFMA (gemv_fused_kernel2<..., HP>), set by launch_gemv_fused
   // row-owning split-K reduce: optional LayerNorm of the finished row as a second output
   void* ln_out; int ln_out_dt; const float *ln_out_g, *ln_out_b; float ln_out_eps;
 };
@@ -470,7 +471,11 @@ template <> struct Mma<f16c_t> {   // the fp16 segment of KX_F16C rows
 __device__ __forceinline__ f32x4_t mma_fp8(u32x4_t w0, u32x4_t w1, u32x4_t a0, u32x4_t a1, f32x4_t c, int wsc) {
   const i32x8_t W = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
   const i32x8_t A = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+#ifdef KX_FP6_RATE_PROBE   // TIMING PROBE ONLY (tools/fp6_rate_probe.sh): the same registers declared e2m3 — the matrix pipe's fp6 rate on
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(W, A, c, 2, 2, 0, wsc, 0, 116);   // this kernel's loop, wrong numbers
+#else
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(W, A, c, 0, 0, 0, wsc, 0, 116);
+#endif
 }
 template <typename T> constexpr bool kIsF16c = std::is_same<T, f16c_t>::value;
 template <> struct Mma<float> {
@@ -2007,7 +2012,42 @@ __host__ __device__ inline bool gemv_rowreg(int M, int K, int S, bool pair) {
 // LayerNorm prologue's, or staged for the residual GEMMs) with M x 4 FMAs: (3 + M) VALU operations per weight, ~40-70 us per
 // step over the whole chip.  Exact fp32 products in a fixed order (a lane's k-steps in sequence, then the four k-groups,
 // then the waves): deterministic, not bit-identical to the MFMA form's order.
-template <typename T, int ACT, bool LNP, int UW, int WF = 0, bool VAL = false>
+// HP (block-scaled 16-bit planes, 3..16 rows): fp16 PIECES on the fp16 MFMA instead of rebuilt fp32 values on the exact-f32 one
+// (eight 16x16x4 MFMAs = 256 cycles per block of 16 rows x 32 k, whatever M is).  A weight q (int16) = 1024 * (q >> 10) + (q & 1023):
+// the high piece is an integer in [-32, 31] (exact in fp16), the low piece's ten bits ARE an fp16 subnormal, (q & 1023) * 2^-24 (the
+// matrix pipe keeps subnormal inputs exactly: tools/probes/f16_pieces_probe.hip).  An activation x = hi + lo, hi = fp16(x) (toward zero), lo =
+// fp16(x - hi): 21-22 significant bits, down to an absolute 2^-25.  Four 16x16x32 fp16 MFMAs per block (the two activation pieces against each weight piece,
+// chained per weight piece) = 64 cycles, every product exact in the fp32 accumulator, and the block's scale applied to the 32-k partial sum
+// before it joins the running fp32 sum.  The operands swap roles (activation rows are the MFMA's rows) so that a lane's column is
+// the weight row whose scale it already holds; the accumulators are transposed once, on their way through LDS to wave 0.
+// Not bit-identical to the fp32 form: equal to ~2^-21 relative to sum |a||w| (tests/test_ops_gpu.py); tuning key 8 = 5 keeps the
+// exact-f32 MFMA.
+typedef _Float16 kx_h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_f16_pieces(float x0, float x1, unsigned& hi, unsigned& lo) {
+  // hi rounded toward zero (one instruction for the pair, saturating at 65504 instead of overflowing): the remainder is exact in fp32
+  const kx_h2_t h = __builtin_bit_cast(kx_h2_t, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  hi = __builtin_bit_cast(unsigned, h);
+  const kx_h2_t l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};      // (|x - hi| <= 2^-11 |x|: no clamp needed)
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// two int16 weights -> their high pieces (q >> 10, in [-32, 31]) as two fp16 values
+__device__ __forceinline__ unsigned f16_high_pieces(unsigned q2) {
+  const short h0 = (short)(((int)(q2 << 16)) >> 26), h1 = (short)(((int)q2) >> 26);
+  const kx_h2_t v = {(_Float16)h0, (_Float16)h1};
+  return __builtin_bit_cast(unsigned, v);
+}
+// one 16-byte chunk of fp16 pieces per k-group: [k-step 0: 4 halves][k-step 1: 4 halves]; hi pieces at +0, lo pieces at +64 of a
+// block's 128 bytes (c4 = the float4 index of the four values in their row)
+__device__ __forceinline__ void store_f16_pieces4(char* rowbase, int c4, float y0, float y1, float y2, float y3) {
+  uint2 h, l;
+  split_f16_pieces(y0, y1, h.x, l.x);
+  split_f16_pieces(y2, y3, h.y, l.y);
+  char* d = rowbase + (c4 >> 3) * 128 + ((c4 & 3) << 4) + ((c4 & 4) << 1);
+  *reinterpret_cast<uint2*>(d) = h;
+  *reinterpret_cast<uint2*>(d + 64) = l;
+}
+
+template <typename T, int ACT, bool LNP, int UW, int WF = 0, bool VAL = false, bool HP = false>
 __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, int S, int kw, int x_pitch) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2039,6 +2079,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   constexpr int WBLK = WF == 16 ? 1088 : 1536;                     // bytes per block of 16 rows x 32 k
   static_assert(WF == 0 || ((WF == 24 || WF == 16) && sizeof(T) == 4), "weight planes reconstruct fp32 operands");
   static_assert(!VAL || sizeof(T) == 4, "the VALU form multiplies fp32 operands");
+  static_assert(!HP || (WF == 16 && !VAL), "fp16 pieces are made from the block-scaled 16-bit planes");
   // W24: block of a k-step PAIR (32 k): [64 lanes x 16 B: bf16 halves of k-steps 2c, 2c+1][64 lanes x 8 B: their third bytes]
   const char* wph = p.W + ((long long)blockIdx.x * (p.kfull >> 5) + ((kbase + k0w) >> 5)) * WBLK + (lane << 4);
   const char* wpl = WF == 16 ? wph + 1024 - (lane << 4) + (i << 2)      // this lane's row scale
@@ -2275,6 +2316,8 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
                 o.x = pack_bf16x2(y0, y1);
                 o.y = pack_bf16x2(y2, y3);
                 *reinterpret_cast<uint2*>(xn + r * x_pitch + tid * 8) = o;
+              } else if constexpr (HP) {
+                store_f16_pieces4(xn + r * x_pitch, tid, y0, y1, y2, y3);
               } else {
                 *reinterpret_cast<float4*>(xn + r * x_pitch + tid * 16) = make_float4(y0, y1, y2, y3);
               }
@@ -2319,6 +2362,8 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
               o.x = pack_bf16x2(y0, y1);
               o.y = pack_bf16x2(y2, y3);
               *reinterpret_cast<uint2*>(xn + wave * x_pitch + c * 8) = o;
+            } else if constexpr (HP) {
+              store_f16_pieces4(xn + wave * x_pitch, c, y0, y1, y2, y3);
             } else {
               *reinterpret_cast<float4*>(xn + wave * x_pitch + c * 16) = make_float4(y0, y1, y2, y3);
             }
@@ -2352,6 +2397,8 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
             o.x = pack_bf16x2(y0, y1);
             o.y = pack_bf16x2(y2, y3);
             *reinterpret_cast<uint2*>(xn + m * x_pitch + c * 8) = o;
+          } else if constexpr (HP) {
+            store_f16_pieces4(xn + m * x_pitch, c, y0, y1, y2, y3);
           } else {
             *reinterpret_cast<float4*>(xn + m * x_pitch + c * 16) = make_float4(y0, y1, y2, y3);
           }
@@ -2396,6 +2443,53 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
               av[m] = fmaf(w3, xq.w, fmaf(w2, xq.z, fmaf(w1, xq.y, fmaf(w0, xq.x, av[m]))));
             }
         }
+    } else if constexpr (HP) {
+      const char* xlh = xn + xrow * x_pitch + ((k0 + kk) >> 5) * 128 + (g << 4);    // LNP: this lane's row of pieces in LDS
+#pragma unroll
+      for (int h = 0; h < U; h += XG) {
+        if constexpr (!LNP) {
+#pragma unroll
+          for (int u = 0; u < XG; ++u)
+            if (kk + KS * (h + u) < klen && (kk > 0 || h > 0)) xf[u] = *reinterpret_cast<const u32x4_t*>(xg + (long long)(kk + KS * (h + u)) * ES);
+        }
+#pragma unroll
+        for (int u2 = 0; u2 < XG / 2; ++u2) {
+          const int ub = (h >> 1) + u2;                          // block (k-step pair) of the in-flight batch
+          if (kk + 32 * ub < klen) {
+            u32x4_t ahi, alo;
+            if constexpr (LNP) {
+              ahi = *reinterpret_cast<const u32x4_t*>(xlh + ub * 128);
+              alo = *reinterpret_cast<const u32x4_t*>(xlh + ub * 128 + 64);
+            } else {
+              const u32x4_t x0 = xf[2 * u2], x1 = xf[2 * u2 + 1];
+              unsigned ph[4], pl[4];
+              split_f16_pieces(__uint_as_float(x0[0]), __uint_as_float(x0[1]), ph[0], pl[0]);
+              split_f16_pieces(__uint_as_float(x0[2]), __uint_as_float(x0[3]), ph[1], pl[1]);
+              split_f16_pieces(__uint_as_float(x1[0]), __uint_as_float(x1[1]), ph[2], pl[2]);
+              split_f16_pieces(__uint_as_float(x1[2]), __uint_as_float(x1[3]), ph[3], pl[3]);
+              ahi = (u32x4_t){ph[0], ph[1], ph[2], ph[3]};
+              alo = (u32x4_t){pl[0], pl[1], pl[2], pl[3]};
+            }
+            const u32x4_t hh = rawh[ub];
+            u32x4_t whi, wlo;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              wlo[d] = hh[d] & 0x03ff03ffu;
+              whi[d] = f16_high_pieces(hh[d]);
+            }
+            const f16x8_t AH = __builtin_bit_cast(f16x8_t, ahi), AL = __builtin_bit_cast(f16x8_t, alo);
+            const f16x8_t WH = __builtin_bit_cast(f16x8_t, whi), WL = __builtin_bit_cast(f16x8_t, wlo);
+            f32x4_t chi = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            chi = __builtin_amdgcn_mfma_f32_16x16x32_f16(AL, WH, chi, 0, 0, 0);
+            f32x4_t clo = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WL, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            clo = __builtin_amdgcn_mfma_f32_16x16x32_f16(AL, WL, clo, 0, 0, 0);
+            const float sck = rsc[ub] * 1024.0f;                 // (q = 1024 * high + low, the low pieces carry 2^-24)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(sck, fmaf(clo[j], 16384.0f, chi[j]), acc[j]);
+          }
+        }
+        if constexpr (U > XG) __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
 #pragma unroll
     for (int h = 0; h < U; h += XG) {
@@ -2428,9 +2522,15 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
     if (i < 4)                                                     // epilogue layout: lane = row i, columns n0 + 4g .. +3
       for (int w = 0; w < S; ++w) acc += *reinterpret_cast<const f32x4_t*>(red + (w * 4 + i) * 16 + 4 * g);
   } else {
-    *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
+    if constexpr (HP) {       // lane (g, i) holds rows 4g..4g+3 of column n0 + i: into the epilogue's layout (lane = row, four columns)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(wave * 64 + ((i >> 2) << 4) + 4 * g + j) * 4 + (i & 3)] = acc[j];
+    } else {
+      *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
+    }
     __syncthreads();
     if (wave != 0) return;
+    if constexpr (HP) acc = *reinterpret_cast<const f32x4_t*>(red + lane * 4);
     for (int w = 1; w < S; ++w) acc += *reinterpret_cast<const f32x4_t*>(red + (w * 64 + lane) * 4);
   }
 
@@ -2517,6 +2617,12 @@ void launch_gemv2(const GemmParams& p, dim3 grid, dim3 block, size_t lds, hipStr
       else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8, 24>), grid, block, lds, s, p, S, kw, x_pitch);
       return;
     }
+    if (p.w_tiled == 3 && p.hp) {      // block-scaled 16-bit weights, 3..16 rows: fp16 pieces on the fp16 MFMA
+      if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, 16, false, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, 16, false, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      else hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 8, 16, false, true>), grid, block, lds, s, p, S, kw, x_pitch);
+      return;
+    }
     if (p.w_tiled == 3) {              // block-scaled 16-bit weights
       if (p.ln_g) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, true, 8, 16>), grid, block, lds, s, p, S, kw, x_pitch);
       else if (deep) hipLaunchKernelGGL((gemv_fused_kernel2<T, ACT, false, 16, 16>), grid, block, lds, s, p, S, kw, x_pitch);
@@ -2541,6 +2647,9 @@ void gemv2_lds_attr() {
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, true, 8, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 16, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gemv_fused_kernel2<T, ACT, false, 8, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2592,6 +2701,8 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
       lds += (size_t)p.M * x_pitch;
     }
   }
+  // block-scaled 16-bit planes and more rows than the VALU form takes: fp16 pieces on the fp16 MFMA (tuning key 8 = 5: exact-f32 MFMA)
+  p.hp = ES == 4 && p.w_tiled == 3 && !p.valu && v2 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 5 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 4;
   // row-in-registers LayerNorm prologue (5..8 rows): gamma | beta go through 8K bytes of LDS when two workgroups still fit a CU
   p.gb_staged = p.ln_g && !p.no_rowreg && gemv_rowreg(p.M, p.K, S, p.a_add != nullptr) && lds + 8 * (size_t)p.K <= 80 * 1024;
   if (p.gb_staged) lds += 8 * (size_t)p.K;

@@ -71,9 +71,10 @@ def test_f16c_decode_step_forms(B, monkeypatch):
     tok = torch.randint(0, 502, (B, 30), generator=torch.Generator().manual_seed(6))
     ref = O.kosmos_language_forward(oracle_weights(lm0), tok, CFG)[:, 9:30]
     outs = {}
+    from kosmosx import _hip
     for name, env in (("w16", {}), ("w24", {"KOSMOSX_DECODE_EXACT": "w24"}), ("fp32", {"KOSMOSX_DECODE_EXACT": "fp32"}),
                       ("tiles", {"KOSMOSX_DECODE_EXACT": "0"}), ("w16_rowmajor", {"KOSMOSX_DECODE_TILED": "0"}),
-                      ("w24_rowmajor", {"KOSMOSX_DECODE_EXACT": "w24", "KOSMOSX_DECODE_TILED": "0"})):
+                      ("w24_rowmajor", {"KOSMOSX_DECODE_EXACT": "w24", "KOSMOSX_DECODE_TILED": "0"}), ("w16_f32mfma", {})):
         for k in ("KOSMOSX_DECODE_EXACT", "KOSMOSX_DECODE_TILED"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -82,12 +83,20 @@ def test_f16c_decode_step_forms(B, monkeypatch):
         lm.precision = "f16c"
         st = {}
         lm(tok[:, :9].cuda(), incremental_state=st)
-        outs[name] = torch.cat([lm(tok[:, : t + 1].cuda(), incremental_state=st) for t in range(9, 30)], 1)
+        try:
+            _hip.load().kx_set_tuning(8, 5 if name == "w16_f32mfma" else 0)      # 5: the planes' 3..16-row launches on the exact-f32 MFMA
+            outs[name] = torch.cat([lm(tok[:, : t + 1].cuda(), incremental_state=st) for t in range(9, 30)], 1)
+        finally:
+            _hip.load().kx_set_tuning(8, 0)
         assert rel_err(outs[name], ref) < 1e-3, name
         if name in ("w16", "w24"):
             w = lm.decoder._pack(name)[0]
             assert bool(w.wout_t) and bool(w.layer[0].wqkv_t)                      # the compressed planes were the ones streamed
-    assert torch.equal(outs["w24"], outs["w24_rowmajor"]) and torch.equal(outs["w16"], outs["w16_rowmajor"])
+    assert torch.equal(outs["w24"], outs["w24_rowmajor"]) and torch.equal(outs["w16_f32mfma"], outs["w16_rowmajor"])
+    if B == 1:  # every launch on the VALU
+        assert torch.equal(outs["w16"], outs["w16_rowmajor"])
+    else:       # the planes' launches the VALU form does not take: fp16 pieces on the fp16 MFMA — the same weights, activations to 2^-22
+        assert rel_err(outs["w16"], outs["w16_rowmajor"]) < 2e-5
     assert rel_err(outs["w24"], outs["fp32"].cpu()) < 2e-4 and rel_err(outs["w16"], outs["fp32"].cpu()) < 5e-4
 
 

@@ -614,9 +614,11 @@ def test_gemm_weight_streaming_24_bit_weight_planes(M, N, K):
 @pytest.mark.parametrize("N,K", [(264, 2048), (2048, 8192), (1002, 320), (6144, 2048), (512, 64)])
 def test_gemm_weight_streaming_block_scaled_16_bit_weights(M, N, K):
     """kx_gemm_args.w_tiled = 3: int16 weights with one fp32 scale per row and block of 32 columns (2.125 bytes per weight),
-    rebuilt as (float)q * scale and multiplied on the exact-f32 MFMA.  On those values the fp32 kernel computes the same
-    products in the same order: bit-identical outputs; against the un-quantised weights every weight moved by at most half
-    a step of its block (max|w| / 65534).  With the LayerNorm prologue and the pair form."""
+    rebuilt as (float)q * scale and multiplied on the exact-f32 MFMA (tuning key 8 = 5 for three rows and more, whose default
+    is the fp16-pieces form below).  On those values the fp32 kernel computes the same products in the same order:
+    bit-identical outputs; against the un-quantised weights every weight moved by at most half a step of its block
+    (max|w| / 65534).  With the LayerNorm prologue and the pair form."""
+    from kosmosx import _hip
     g = _g(19 * M + N + K)
     a = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / 40
@@ -629,26 +631,105 @@ def test_gemm_weight_streaming_block_scaled_16_bit_weights(M, N, K):
     assert bool(((wq - w).abs() <= 0.51 * step + 1e-30).all())          # half a step (+ the fp32 roundings of w / scale and q * scale)
     planes = ops.tile_weight_rows_w16(q.to(DEV), sc.to(DEV))
     assert planes.dtype == torch.uint8 and planes.shape == ((N + 15) // 16, K // 32, 1088)
-    out = res.to(DEV).clone()
-    ops.gemm(a.to(DEV), planes, bias.to(DEV), out, "gelu", out=out, tile=16, w_tiled_rows=N)
-    same = res.to(DEV).clone()
-    ops.gemm(a.to(DEV), wq.to(DEV), bias.to(DEV), same, "gelu", out=same, tile=16)
-    assert torch.equal(out, same)
-    ref = _gemm_ref(a.double(), w.double(), bias.double(), res.double(), "gelu")
-    bound = 1.2 * (a.abs().double() @ (0.5 * step).double().t()) + 1e-5
-    assert bool(((out.cpu().double() - ref).abs() <= bound).all())
-    if K <= 2048:
+    try:
+        _hip.load().kx_set_tuning(8, 5)
+        out = res.to(DEV).clone()
+        ops.gemm(a.to(DEV), planes, bias.to(DEV), out, "gelu", out=out, tile=16, w_tiled_rows=N)
+        same = res.to(DEV).clone()
+        ops.gemm(a.to(DEV), wq.to(DEV), bias.to(DEV), same, "gelu", out=same, tile=16)
+        assert torch.equal(out, same)
+        ref = _gemm_ref(a.double(), w.double(), bias.double(), res.double(), "gelu")
+        bound = 1.2 * (a.abs().double() @ (0.5 * step).double().t()) + 1e-5
+        assert bool(((out.cpu().double() - ref).abs() <= bound).all())
+        if K <= 2048:
+            gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+            ln = (gam.to(DEV), bet.to(DEV), 1e-5)
+            x = (a * 3 + 0.5).to(DEV)
+            assert torch.equal(ops.gemm(x, planes, bias.to(DEV), act="gelu", tile=16, ln=ln, w_tiled_rows=N),
+                               ops.gemm(x, wq.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=ln))
+        if N % 16 == 0 and K % 128 == 0:
+            c1, c2, d1, d2 = (torch.empty(M, N, device=DEV) for _ in range(4))
+            rb = (res * 0.1).to(DEV)
+            ops.gemm(a.to(DEV), planes, bias.to(DEV), res.to(DEV), out=c1, tile=16, ksplit=2, out2=c2, residual2=rb, w_tiled_rows=N)
+            ops.gemm(a.to(DEV), wq.to(DEV), bias.to(DEV), res.to(DEV), out=d1, tile=16, ksplit=2, out2=d2, residual2=rb)
+            assert torch.equal(c1, d1) and torch.equal(c2, d2)
+    finally:
+        _hip.load().kx_set_tuning(8, 0)
+
+
+@pytest.mark.parametrize("M", [3, 4, 5, 8, 11, 16])
+@pytest.mark.parametrize("N,K", [(264, 2048), (2048, 8192), (1002, 320), (6144, 2048), (512, 64), (2048, 2048)])
+def test_gemm_weight_streaming_fp16_pieces_form(M, N, K):
+    """Block-scaled 16-bit planes, three rows and more (the VALU form takes one and two): q = 1024 (q >> 10) + (q & 1023) as two
+    fp16 pieces (the low one a subnormal), the activation as fp16 hi + lo, four fp16 MFMAs per block of 32 k instead of eight
+    exact-f32 ones.  Every product is exact; what differs from the fp32 form (tuning key 8 = 5) is the activation's bits below
+    2^-22 (below an absolute 2^-25 for tiny values) and the summation order: equal to it within 2^-20 sum |a||w| elementwise,
+    deterministic, inside the same bound against float64.  Plain and residual epilogues, the statistics consumer (folded LayerNorm), the LayerNorm prologue in its three
+    forms (<= 4 rows, 5..8, 9..16), activations with outlier channels and tiny rows, the pair form."""
+    from kosmosx import _hip
+    g = _g(29 * M + N + K)
+    a = torch.randn(M, K, generator=g)
+    a[:, 3] *= 300.0                                                        # an outlier channel
+    a[0] *= 1e-3                                                            # a small row: its lo pieces are fp16 subnormals
+    w = torch.randn(N, K, generator=g) / 40
+    w[1, :32] = 0.0
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    q, sc, wq = ops.quantize_block16(w)
+    planes = ops.tile_weight_rows_w16(q.to(DEV), sc.to(DEV))
+    lib = _hip.load()
+
+    def both(fn):
+        v = fn()
+        assert torch.equal(v, fn())                                         # deterministic
+        try:
+            lib.kx_set_tuning(8, 5)
+            f = fn()
+        finally:
+            lib.kx_set_tuning(8, 0)
+        return v, f
+    # sum |a||w| per output; the lo piece of an activation is an fp16: 22 significant bits down to an ABSOLUTE 2^-25 (the small row)
+    mag = (a.abs().double() @ wq.abs().double().t()).to(DEV) + 2.0 ** -5 * wq.abs().double().sum(1).to(DEV)[None, :]
+    tol = 2.0 ** -20
+    hp, f32 = both(lambda: ops.gemm(a.to(DEV), planes, bias.to(DEV), res.to(DEV), out=torch.empty(M, N, device=DEV), tile=16,
+                                    w_tiled_rows=N))
+    assert bool(((hp.double() - f32.double()).abs() <= tol * mag + 1e-6).all())
+    assert not torch.equal(hp, f32) or K <= 64                              # (it IS another kernel)
+    ref = _gemm_ref(a.double(), wq.double(), bias.double(), res.double(), "none")
+    assert bool(((hp.cpu().double() - ref).abs() <= (tol * mag).cpu() + 1e-5).all())
+    hp, f32 = both(lambda: ops.gemm(a.to(DEV), planes, bias.to(DEV), act="gelu", tile=16, w_tiled_rows=N))
+    assert bool(((hp.double() - f32.double()).abs() <= 1.2 * tol * mag + 1e-6).all())
+    if K <= 2048 and M * (K * 4 + 16) <= 128 * 1024:                        # LayerNorm prologue: pieces are made of the normalised rows
         gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
         ln = (gam.to(DEV), bet.to(DEV), 1e-5)
         x = (a * 3 + 0.5).to(DEV)
-        assert torch.equal(ops.gemm(x, planes, bias.to(DEV), act="gelu", tile=16, ln=ln, w_tiled_rows=N),
-                           ops.gemm(x, wq.to(DEV), bias.to(DEV), act="gelu", tile=16, ln=ln))
-    if N % 16 == 0 and K % 128 == 0:
-        c1, c2, d1, d2 = (torch.empty(M, N, device=DEV) for _ in range(4))
+        y = torch.nn.functional.layer_norm(x.double(), (K,), gam.to(DEV).double(), bet.to(DEV).double(), 1e-5)
+        magl = y.abs() @ wq.abs().double().t().to(DEV)
+        hp, f32 = both(lambda: ops.gemm(x, planes, bias.to(DEV), tile=16, ln=ln, w_tiled_rows=N))
+        assert bool(((hp.double() - f32.double()).abs() <= tol * magl + 1e-6).all())
+        so = torch.empty(M, N // 16, 2, device=DEV) if N % 16 == 0 else None     # + the statistics producer (fc1)
+        if so is not None:
+            hp2 = ops.gemm(x, planes, bias.to(DEV), act="gelu", tile=16, ln=ln, w_tiled_rows=N, stats_out=so, stats_out_seg=16)
+            seg = hp2.reshape(M, N // 16, 16)
+            assert float((so[..., 0] - seg.sum(-1)).abs().max()) <= 1e-4 * float(seg.abs().sum(-1).max())
+    if N % 16 == 0 and K % 64 == 0:                                         # statistics consumer: rstd * (acc - mean * colsum)
+        nseg = K // 64
+        xs = a.to(DEV).reshape(M, nseg, 64)
+        mu = xs.mean(-1)
+        part = torch.stack([xs.sum(-1), ((xs - mu[..., None]) ** 2).sum(-1)], -1).contiguous()
+        colsum = wq.sum(1).to(DEV)
+        kw = dict(tile=16, w_tiled_rows=N, stats_partials=part, colsum=colsum, stats_in_seg=64)
+        hp, f32 = both(lambda: ops.gemm(a.to(DEV), planes, bias.to(DEV), res.to(DEV), out=torch.empty(M, N, device=DEV), **kw))
+        rstd = 1.0 / torch.sqrt(a.double().var(1, unbiased=False) + 1e-5)
+        assert bool(((hp.double() - f32.double()).abs() <= tol * mag * rstd.to(DEV)[:, None] + 1e-5).all())
+    if N % 16 == 0 and K % 128 == 0 and M <= 4:                             # the pair form of the residual stream
         rb = (res * 0.1).to(DEV)
-        ops.gemm(a.to(DEV), planes, bias.to(DEV), res.to(DEV), out=c1, tile=16, ksplit=2, out2=c2, residual2=rb, w_tiled_rows=N)
-        ops.gemm(a.to(DEV), wq.to(DEV), bias.to(DEV), res.to(DEV), out=d1, tile=16, ksplit=2, out2=d2, residual2=rb)
-        assert torch.equal(c1, d1) and torch.equal(c2, d2)
+
+        def pair():
+            c1, c2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+            ops.gemm(a.to(DEV), planes, bias.to(DEV), res.to(DEV), out=c1, tile=16, ksplit=2, out2=c2, residual2=rb, w_tiled_rows=N)
+            return c1 + c2
+        hp, f32 = both(pair)
+        assert bool(((hp.double() - f32.double()).abs() <= tol * mag + 1e-5).all())
 
 
 @pytest.mark.parametrize("M", [1, 2, 3])
@@ -683,7 +764,11 @@ def test_gemm_weight_streaming_valu_form_for_one_or_two_rows(M, N, K):
         planes = ops.tile_weight_rows_w16(q.to(DEV), sc.to(DEV))
         v, mf = both(lambda: ops.gemm(a.to(DEV), planes, bias.to(DEV), res.to(DEV).clone(), "gelu", tile=16, w_tiled_rows=N))
         assert rel_err(v, mf.cpu()) < 5e-6
-        assert torch.equal(v, ops.gemm(a.to(DEV), wq.to(DEV), bias.to(DEV), res.to(DEV).clone(), "gelu", tile=16))
+        rows = ops.gemm(a.to(DEV), wq.to(DEV), bias.to(DEV), res.to(DEV).clone(), "gelu", tile=16)
+        if M <= 2 and M * (K * 4 + 16) <= 48 * 1024:       # both on the VALU: the same bits (else the planes take the fp16-pieces form)
+            assert torch.equal(v, rows)
+        else:
+            assert rel_err(v, rows.cpu()) < 5e-6
     if K <= 2048:
         gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
         ln = (gam.to(DEV), bet.to(DEV), 1e-5)
