@@ -72,7 +72,11 @@ typedef enum {
 /* KX_PREC_F32W16: the same with block-scaled 16-bit streaming copies (kx_gemm_args.w_tiled = 3): 2.125 bytes per weight. */
 typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3, KX_PREC_F16 = 4, KX_PREC_F32W24 = 5,
                KX_PREC_F32W16 = 6 } kx_precision;
-typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3, KX_F16 = 4 } kx_dtype;
+/* KX_F16P (weight-streaming decode step only): fp32-pitched rows of fp16 PIECE pairs, value = hi + lo with hi = fp16(x) toward
+ * zero and lo = fp16(x - hi) — per 32 values 128 bytes: [hi pieces, 64 B][lo pieces, 64 B], each as four 16-byte chunks g =
+ * 0..3 holding values 4g..4g+3 then 16+4g..16+4g+3 of the 32 (the fragment order of kx_gemm_args.w_tiled = 3's fp16-pieces
+ * kernel).  Written by kx_gemm(tile 16) / kx_attention_decode as `cdt` / `odt`, read by kx_gemm(tile 16, w_tiled = 4). */
+typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3, KX_F16 = 4, KX_F16P = 5 } kx_dtype;
 typedef enum { KX_ACT_NONE = 0, KX_ACT_GELU = 1, KX_ACT_QUICK_GELU = 2 } kx_act;
 typedef enum { KX_ATTN_FULL = 0, KX_ATTN_CAUSAL = 1 } kx_attn_mask;
 
@@ -185,7 +189,11 @@ typedef struct {
    * weight; the row-major fp32 operand beside it holds exactly (float)q * scale.  Launches the VALU form does not take
    * (three rows and more; two rows of K = 8192) multiply fp16 PIECES on the fp16 MFMA: q = 1024 (q >> 10) + (q & 1023), the
    * activation as fp16 hi + lo (21-22 significant bits, absolute floor 2^-25); exact products, the block's scale applied to
-   * each 32-k partial sum: within 2^-20 sum|a||w| of the exact-f32 form (tuning key 8 = 5). */
+   * each 32-k partial sum: within 2^-20 sum|a||w| of the exact-f32 form (tuning key 8 = 5).
+   * w_tiled = 4: w_tiled = 3's planes, and A holds KX_F16P piece rows (lda in fp32 units, as for fp32 rows) that a producer
+   * (this kernel with cdt = KX_F16P, kx_attention_decode with odt = KX_F16P) wrote: the fp16-pieces kernel then takes its
+   * activation fragments as they are — the same bits it would make of the fp32 rows.  No ln_gamma; refused where the launch
+   * would not be the fp16-pieces form (M <= 2 on the VALU, tuning key 8 = 4 / 5). */
   int32_t w_tiled;
   /* tile 16 (weight streaming) only — the residual stream of a decode step as a PAIR (x = xa + xb, always summed in that
    * order).  A residual GEMM with few columns (out_proj / fc2: N = 2048 -> 128 workgroups for 256 CUs) is launched with its
@@ -561,7 +569,9 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  * key 9: KV-cache layout per layer and sequence (0 = [heads][Tmax][64]; 1 = the first layout [Tmax][heads*64]; set it
  *        before a prefill and keep it for that cache's steps).
  * key 10: 1 = the fp32 decode step keeps the split-K tile kernels instead of the fp32 weight-streaming kernel (A/B).
- * key 11: 1 = the streamed decode step keeps ONE workgroup per 16 columns in its residual GEMMs (no kx_gemm_args.ksplit pair). */
+ * key 11: 1 = the streamed decode step keeps ONE workgroup per 16 columns in its residual GEMMs (no kx_gemm_args.ksplit pair).
+ * key 12: 1 = the fp16-pieces decode step keeps fp32 rows between its kernels (each consumer splits them itself) instead of
+ *         KX_F16P rows written by the producers (A/B). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -1009,7 +1009,7 @@ struct DecodeParams {
   const char* qkv; long long qkv_row;        // [B, 3*D] rows: q | k | v of the new token (elements)
   char* kcache; char* vcache;                // [B, Tmax, D]
   long long cache_batch, cache_head, cache_row;   // element strides (head-major cache: head = Tmax*64, row = 64)
-  void* out; long long out_row; int o_bf16, o_f16c;  // [B, D] (o_f16c: KX_F16C rows of D values, out_row in 2-byte units)
+  void* out; long long out_row; int o_bf16, o_f16c, o_pieces;  // [B, D] (o_f16c: KX_F16C rows of D values, out_row in 2-byte units; o_pieces: KX_F16P)
   float* stats_out;                          // [B, H, 2] or null
   int H, D, t;                               // t = number of tokens already cached (the new one goes to row t)
 };
@@ -1120,6 +1120,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
       reinterpret_cast<_Float16*>(row)[n] = hv;
       reinterpret_cast<unsigned char*>(row + 2 * D)[n] = (unsigned char)(pack_fp8x4(ov, 0.f, 0.f, 0.f) & 0xffu);
       reinterpret_cast<unsigned char*>(row + 3 * D)[n] = (unsigned char)(pack_fp8x4((ov - (float)hv) * 2048.0f, 0.f, 0.f, 0.f) & 0xffu);
+    } else if (p.o_pieces) {                          // KX_F16P: value n of a row = [hi | lo] fp16 pieces in the fragment order of the
+      unsigned hi, lo;                                // weight-streaming kernel's fp16-pieces form (see kx_dtype)
+      split_f16_pieces(ov, 0.f, hi, lo);
+      const int n = h * 64 + lane;
+      char* d = reinterpret_cast<char*>(p.out) + (long long)b * p.out_row * 4 + (n >> 5) * 128 + (((n & 15) >> 2) << 4) +
+                (((n >> 4) & 1) << 3) + ((n & 3) << 1);
+      *reinterpret_cast<unsigned short*>(d) = (unsigned short)(hi & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d + 64) = (unsigned short)(lo & 0xffffu);
     } else if (p.o_bf16) reinterpret_cast<bf16_t*>(p.out)[ooff] = f32_to_bf16(ov);
     else reinterpret_cast<float*>(p.out)[ooff] = ov;
   }
@@ -1177,7 +1185,9 @@ extern "C" int kx_attention_decode(const void* qkv, void* kcache, void* vcache, 
   const bool head_major = kx_tuning_get(KX_TUNE_CACHE_LAYOUT) != 1;
   p.kcache = (char*)kcache; p.vcache = (char*)vcache; p.cache_batch = Tmax * D;
   p.cache_head = head_major ? Tmax * 64 : 64; p.cache_row = head_major ? 64 : D;
+  KX_REQUIRE(odt != KX_F16P || (prec == KX_PREC_F32 && ((uintptr_t)out & 15) == 0), "kx_attention_decode: KX_F16P rows come from the fp32 step, 16-byte aligned");
   p.out = out; p.out_row = odt == KX_F16C ? 2 * D : D; p.o_bf16 = odt == KX_BF16; p.o_f16c = odt == KX_F16C; p.stats_out = stats_out;
+  p.o_pieces = odt == KX_F16P;
   p.H = (int)H; p.D = (int)D; p.t = (int)t;
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(prec == KX_PREC_BF16 ? KX_K_ATTN_BF16 : KX_K_ATTN_F32, B * H, 1, t + 1, s);

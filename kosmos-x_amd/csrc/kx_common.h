@@ -41,7 +41,7 @@ void kx_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- runtime tuning knobs (kx_set_tuning) ----
-enum { KX_TUNE_LN_VARIANT = 0, KX_TUNE_GEMM_TILE = 1, KX_TUNE_ATTN_VARIANT = 2, KX_TUNE_GEMM_STAGGER = 3, KX_TUNE_GEMM_EPILOGUE = 4, KX_TUNE_GEMM_IDLE_SKIP = 5, KX_TUNE_PREPROCESS_NO_LDS = 6, KX_TUNE_GEMM_PERSISTENT = 7, KX_TUNE_GEMV_VARIANT = 8, KX_TUNE_CACHE_LAYOUT = 9, KX_TUNE_DECODE_STREAM_F32 = 10, KX_TUNE_DECODE_KSPLIT = 11, KX_TUNE_COUNT = 12 };
+enum { KX_TUNE_LN_VARIANT = 0, KX_TUNE_GEMM_TILE = 1, KX_TUNE_ATTN_VARIANT = 2, KX_TUNE_GEMM_STAGGER = 3, KX_TUNE_GEMM_EPILOGUE = 4, KX_TUNE_GEMM_IDLE_SKIP = 5, KX_TUNE_PREPROCESS_NO_LDS = 6, KX_TUNE_GEMM_PERSISTENT = 7, KX_TUNE_GEMV_VARIANT = 8, KX_TUNE_CACHE_LAYOUT = 9, KX_TUNE_DECODE_STREAM_F32 = 10, KX_TUNE_DECODE_KSPLIT = 11, KX_TUNE_DECODE_PIECES = 12, KX_TUNE_COUNT = 13 };
 int kx_tuning_get(int key);
 // number of K slices kx_gemm's automatic choice gives an (M, N, K) problem with `ws_bytes` of split-K scratch (1 = no split)
 int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_bytes);
@@ -85,6 +85,14 @@ typedef _Float16 kx_f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float clamp_f16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
 __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((kx_f32x2_t){clamp_f16(lo), clamp_f16(hi)}, kx_f16x2_t));
+}
+// fp16 PIECES of an fp32 value (KX_F16P; the weight-streaming kernel's fp16-pieces form): x = hi + lo, hi = fp16(x) rounded toward
+// zero (one instruction for the pair, saturating at 65504 instead of overflowing: the remainder is exact in fp32), lo = fp16(x - hi)
+__device__ __forceinline__ void split_f16_pieces(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const kx_f16x2_t h = __builtin_bit_cast(kx_f16x2_t, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  hi = __builtin_bit_cast(unsigned, h);
+  const kx_f16x2_t l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};      // (|x - hi| <= 2^-10 |x|: no clamp needed)
+  lo = __builtin_bit_cast(unsigned, l);
 }
 // v_cvt_pk_fp8_f32 rounds to nearest even but turns |x| > 448 into NaN (probed: tools/probes/f8_probe.hip) -> clamp first
 __device__ __forceinline__ float clamp_fp8(float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); }

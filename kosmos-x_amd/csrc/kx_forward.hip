@@ -642,6 +642,11 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
                       D / 16 <= (cu_count() * 3) / 4 && D % 128 == 0 && F % 128 == 0 &&
                       M <= 4;   // (five rows and more take the wave-per-row LayerNorm prologue, which walks each row three times: reading a
                                 //  pair there cost more than the idle CUs — B = 8: 1.43 -> 1.55 ms per step in bf16)
+    // Block-scaled 16-bit planes, three rows and more: the residual GEMMs multiply fp16 pieces (kx_gemm_args.w_tiled = 3), and what
+    // they read — the attention output, gelu(fc1) — is written AS pieces by its producer (KX_F16P, w_tiled = 4): the same bits the
+    // consumer would make of the fp32 rows, made once instead of in every lane of every workgroup.
+    const int gv = kx_tuning_get(KX_TUNE_GEMV_VARIANT);
+    const bool pieces = tfmt == 3 && M >= 3 && gv != 1 && gv != 4 && gv != 5 && gv < 10 && kx_tuning_get(KX_TUNE_DECODE_PIECES) != 1;
     float *pa = x, *pb = nullptr;                                 // the stream as the next reader finds it
     for (int i = 0; i < w->layers; ++i) {
       const kx_decoder_layer& L = w->layer[i];
@@ -650,16 +655,16 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
       if (w->xpos) { q.xq_cs = xq_cs; q.xq_ss = xq_ss; q.xk_cs = xk_cs; q.xk_ss = xk_ss; q.xT = 1; q.xdim = D; }
       q.W_tiled = L.wqkv_t; q.tiled_fmt = tfmt; q.prec = prec;
       KX_TRY(gemv16(q, s));
-      KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, ct,
+      KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, pieces ? KX_F16P : ct,
                                  w->subln ? d.partials : nullptr, B, w->heads, t, Tmax, prec, stream));
       float *qa = pair ? d.ya : pa, *qb = pair ? d.yb : nullptr;   // what out_proj writes
       Gemv16 o{d.att, D, L.wo, D, qa, D, KX_F32, M, D};
       o.bias = L.bo; o.residual = pa; o.residual2 = pb; o.eps = w->eps;
       if (pair) { o.ksplit = 2; o.C2 = qb; }
       if (w->subln) { o.partials_in = d.partials; o.nseg_in = w->heads; o.seg_in = 64; o.colsum = L.wo_colsum; }
-      o.W_tiled = L.wo_t; o.tiled_fmt = tfmt; o.prec = prec;
+      o.W_tiled = L.wo_t; o.tiled_fmt = pieces ? 4 : tfmt; o.prec = prec;
       KX_TRY(gemv16(o, s));
-      Gemv16 f1{qa, D, L.w1, D, d.g, F, ct, M, F};
+      Gemv16 f1{qa, D, L.w1, D, d.g, F, pieces ? KX_F16P : ct, M, F};
       f1.bias = L.b1; f1.act = w->act; f1.ln_g = L.fl_g; f1.ln_b = L.fl_b; f1.eps = w->eps; f1.a_add = qb;
       if (w->subln) f1.stats_out = d.partials;
       f1.W_tiled = L.w1_t; f1.tiled_fmt = tfmt; f1.prec = prec;
@@ -669,7 +674,7 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
       f2.bias = L.b2; f2.residual = qa; f2.residual2 = qb; f2.eps = w->eps;
       if (pair) { f2.ksplit = 2; f2.C2 = pb; }
       if (w->subln) { f2.partials_in = d.partials; f2.nseg_in = F / 16; f2.seg_in = 16; f2.colsum = L.w2_colsum; }
-      f2.W_tiled = L.w2_t; f2.tiled_fmt = tfmt; f2.prec = prec;
+      f2.W_tiled = L.w2_t; f2.tiled_fmt = pieces ? 4 : tfmt; f2.prec = prec;
       KX_TRY(gemv16(f2, s));
     }
     Gemv16 lo{pa, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab};

@@ -74,6 +74,10 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   p.lda_b = a->lda * es; p.ldw_b = a->ldw * es;
   p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->cdt == KX_BF16 || a->cdt == KX_BF16X3 || a->cdt == KX_F16C || a->cdt == KX_F16;
   p.c_x3 = a->cdt == KX_BF16X3; p.c_f16c = a->cdt == KX_F16C; p.c_f16 = a->cdt == KX_F16;
+  p.c_pieces = a->cdt == KX_F16P;
+  KX_REQUIRE(a->cdt != KX_F16P || (a->tile == 16 && a->prec == KX_PREC_F32 && a->N % 32 == 0 && a->ldc % 32 == 0 &&
+                                   ((uintptr_t)a->C & 15) == 0 && !a->residual && a->ksplit <= 1),
+             "kx_gemm: KX_F16P rows come from tile 16 on fp32 operands, N %% 32 == 0, ldc %% 32 == 0, no residual / ksplit");
   p.nk_main = f16c ? (int)(a->K / 64) : 0x7fffffff; p.wscale = a->w_scale;
   KX_REQUIRE(a->cdt != KX_F16C || (a->N % 8 == 0 && a->ldc >= 2 * a->N && a->ldc % 8 == 0 && a->tile != 16 &&
                                     ((uintptr_t)a->C & 15) == 0),
@@ -111,7 +115,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
              "operand dtype and the prefetching store loop");
   p.stagger_ticks = 0; p.w_tiled = 0;
   p.gsplit = 1; p.kfull = p.K; p.C2 = nullptr; p.residual2 = nullptr; p.a_add = nullptr;
-  p.no_rowreg = kx_tuning_get(KX_TUNE_GEMV_VARIANT) == 3;
+  p.no_rowreg = kx_tuning_get(KX_TUNE_GEMV_VARIANT) == 3; p.a_pieces = 0; p.hp = 0; p.valu = 0; p.gb_staged = 0;
   p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
   p.stats_partials = nullptr; p.stats_in_nseg = 0; p.stats_in_seg = p.stats_eps = 0.f;
   p.ln_out = nullptr; p.ln_out_dt = 0; p.ln_out_g = p.ln_out_b = nullptr; p.ln_out_eps = 0.f;
@@ -201,9 +205,11 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     KX_REQUIRE((a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32) && a->M <= 16,
                "kx_gemm: tile 16 (weight streaming) takes bf16 or fp32 operands, M <= 16 only");
     KX_REQUIRE(!a->w_tiled || a->K % 32 == 0, "kx_gemm: the streaming weight layout needs K %% 32 == 0");
-    KX_REQUIRE(a->w_tiled >= 0 && a->w_tiled <= 3 && (a->w_tiled < 2 || (a->prec == KX_PREC_F32 && a->K % 32 == 0)),
-               "kx_gemm: w_tiled is 0, 1 or (fp32 operands, K %% 32 == 0) 2 = 24-bit planes / 3 = block-scaled 16-bit weights");
-    p.w_tiled = a->w_tiled;
+    KX_REQUIRE(a->w_tiled >= 0 && a->w_tiled <= 4 && (a->w_tiled < 2 || (a->prec == KX_PREC_F32 && a->K % 32 == 0)),
+               "kx_gemm: w_tiled is 0, 1 or (fp32 operands, K %% 32 == 0) 2 = 24-bit planes / 3 = block-scaled 16-bit weights / 4 = 3 with KX_F16P rows in A");
+    KX_REQUIRE(a->w_tiled != 4 || (!a->ln_gamma && a->lda % 32 == 0), "kx_gemm: w_tiled = 4 takes KX_F16P rows (lda %% 32 == 0), no ln_gamma");
+    p.w_tiled = a->w_tiled == 4 ? 3 : a->w_tiled;
+    p.a_pieces = a->w_tiled == 4;
     KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * es + 16) <= 128 * 1024 && a->K % 4 == 0),
                "kx_gemm: LayerNorm prologue needs beta and M*(K*%d+16) <= 128 KB", es);
     KX_REQUIRE(!a->ln_operand_out, "kx_gemm: tile 16 does not produce ln_operand_out");

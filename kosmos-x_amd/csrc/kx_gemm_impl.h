@@ -59,6 +59,8 @@ struct GemmParams {
   int no_rowreg;        // A/B (tuning key 8 = 3): the 5..8-row LayerNorm prologue keeps the three-walk form
   int valu;             // fp32 operands, M <= 4: multiply on the VALU (gemv_fused_kernel2<..., VAL>), set by launch_gemv_fused
   int gb_staged;        // row-in-registers prologue: gamma | beta are passed through LDS (else read from global when needed)
+  int c_pieces;         // tile 16: C holds KX_F16P piece rows (fp32-pitched)
+  int a_pieces;         // tile 16, fp16-pieces form: A holds KX_F16P piece rows
   int hp;               // block-scaled 16-bit planes, 3..16 rows: fp16 pieces on the fp16 MFMA (gemv_fused_kernel2<..., HP>), set by launch_gemv_fused
   // row-owning split-K reduce: optional LayerNorm of the finished row as a second output
   void* ln_out; int ln_out_dt; const float *ln_out_g, *ln_out_b; float ln_out_eps;
@@ -2022,18 +2024,14 @@ __host__ __device__ inline bool gemv_rowreg(int M, int K, int S, bool pair) {
 // the weight row whose scale it already holds; the accumulators are transposed once, on their way through LDS to wave 0.
 // Not bit-identical to the fp32 form: equal to ~2^-21 relative to sum |a||w| (tests/test_ops_gpu.py); tuning key 8 = 5 keeps the
 // exact-f32 MFMA.
-typedef _Float16 kx_h2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_f16_pieces(float x0, float x1, unsigned& hi, unsigned& lo) {
-  // hi rounded toward zero (one instruction for the pair, saturating at 65504 instead of overflowing): the remainder is exact in fp32
-  const kx_h2_t h = __builtin_bit_cast(kx_h2_t, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-  hi = __builtin_bit_cast(unsigned, h);
-  const kx_h2_t l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};      // (|x - hi| <= 2^-11 |x|: no clamp needed)
-  lo = __builtin_bit_cast(unsigned, l);
-}
-// two int16 weights -> their high pieces (q >> 10, in [-32, 31]) as two fp16 values
+// two int16 weights -> their high pieces (q >> 10, in [-32, 31]) as two fp16 values, three packed instructions: the arithmetic
+// shift, + 0x6420 on the BITS (fp16 1056 + h: unit spacing between 1024 and 2048), - 1056 in fp16 (exact)
+typedef short kx_s2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short kx_us2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned f16_high_pieces(unsigned q2) {
-  const short h0 = (short)(((int)(q2 << 16)) >> 26), h1 = (short)(((int)q2) >> 26);
-  const kx_h2_t v = {(_Float16)h0, (_Float16)h1};
+  const kx_s2_t h = __builtin_bit_cast(kx_s2_t, q2) >> 10;
+  const kx_us2_t b = __builtin_bit_cast(kx_us2_t, h) + (kx_us2_t){0x6420, 0x6420};
+  const kx_f16x2_t v = __builtin_bit_cast(kx_f16x2_t, b) - (kx_f16x2_t){(_Float16)1056.0f, (_Float16)1056.0f};
   return __builtin_bit_cast(unsigned, v);
 }
 // one 16-byte chunk of fp16 pieces per k-group: [k-step 0: 4 halves][k-step 1: 4 halves]; hi pieces at +0, lo pieces at +64 of a
@@ -2462,6 +2460,8 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
               alo = *reinterpret_cast<const u32x4_t*>(xlh + ub * 128 + 64);
             } else {
               const u32x4_t x0 = xf[2 * u2], x1 = xf[2 * u2 + 1];
+              if (p.a_pieces) { ahi = x0; alo = x1; }            // KX_F16P rows: the two chunks ARE this lane's hi / lo fragments
+              else {
               unsigned ph[4], pl[4];
               split_f16_pieces(__uint_as_float(x0[0]), __uint_as_float(x0[1]), ph[0], pl[0]);
               split_f16_pieces(__uint_as_float(x0[2]), __uint_as_float(x0[3]), ph[1], pl[1]);
@@ -2469,6 +2469,7 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
               split_f16_pieces(__uint_as_float(x1[2]), __uint_as_float(x1[3]), ph[3], pl[3]);
               ahi = (u32x4_t){ph[0], ph[1], ph[2], ph[3]};
               alo = (u32x4_t){pl[0], pl[1], pl[2], pl[3]};
+              }
             }
             const u32x4_t hh = rawh[ub];
             u32x4_t whi, wlo;
@@ -2581,7 +2582,9 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   const bool full = n + 3 < p.N && p.vec_ok;
   const long long off = (long long)m * p.ldc + n;
   void* const Cout = ksp ? p.C2 : p.C;
-  if (p.c_bf16) {
+  if (p.c_pieces) {                                              // KX_F16P rows (N % 32 == 0 and aligned rows: checked on the host)
+    store_f16_pieces4(reinterpret_cast<char*>(Cout) + (long long)m * p.ldc * 4, n >> 2, x[0], x[1], x[2], x[3]);
+  } else if (p.c_bf16) {
     bf16_t* c = reinterpret_cast<bf16_t*>(Cout) + off;
     if (full) { uint2 o; o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); *reinterpret_cast<uint2*>(c) = o; }
     else for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = f32_to_bf16(x[j]);
@@ -2703,6 +2706,11 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
   }
   // block-scaled 16-bit planes and more rows than the VALU form takes: fp16 pieces on the fp16 MFMA (tuning key 8 = 5: exact-f32 MFMA)
   p.hp = ES == 4 && p.w_tiled == 3 && !p.valu && v2 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 5 && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 4;
+  if (p.a_pieces && !(p.hp && !p.ln_g)) {
+    kx_set_error("kx_gemm: w_tiled = 4 (KX_F16P activation rows) needs the fp16-pieces launch (M = %d, tuning key 8 = %d)", p.M,
+                 kx_tuning_get(KX_TUNE_GEMV_VARIANT));
+    return KX_ERR_INVALID_ARG;
+  }
   // row-in-registers LayerNorm prologue (5..8 rows): gamma | beta go through 8K bytes of LDS when two workgroups still fit a CU
   p.gb_staged = p.ln_g && !p.no_rowreg && gemv_rowreg(p.M, p.K, S, p.a_add != nullptr) && lds + 8 * (size_t)p.K <= 80 * 1024;
   if (p.gb_staged) lds += 8 * (size_t)p.K;

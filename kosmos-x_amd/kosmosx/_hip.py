@@ -16,7 +16,7 @@ _lib = None
 ABI_VERSION = 5   # KX_ABI_VERSION of include/kosmosx_hip.h
 
 KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16, KX_PREC_F32W24, KX_PREC_F32W16 = 0, 1, 2, 3, 4, 5, 6
-KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16 = 0, 1, 2, 3, 4
+KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16, KX_F16P = 0, 1, 2, 3, 4, 5
 KX_ACT_NONE, KX_ACT_GELU, KX_ACT_QUICK_GELU = 0, 1, 2
 KX_ATTN_FULL, KX_ATTN_CAUSAL = 0, 1
 ACTS = {"none": KX_ACT_NONE, "gelu": KX_ACT_GELU, "quick_gelu": KX_ACT_QUICK_GELU}

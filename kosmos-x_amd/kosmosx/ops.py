@@ -71,7 +71,8 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32, pre_add=None, o
 def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qscale=1.0, qcols=0,
          xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None, splitk_ws=None,
          splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0, out_x3=False,
-         ln_out=None, ln_operand=None, w_tiled_rows=0, ksplit=0, out2=None, residual2=None, a_add=None):
+         ln_out=None, ln_operand=None, w_tiled_rows=0, ksplit=0, out2=None, residual2=None, a_add=None, out_pieces=False,
+         a_pieces=False):
     """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32].
     tile=16 (weight streaming, bf16, M <= 16) extras: ln = (gamma, beta, eps) with `a` the raw fp32 rows;
     stats_partials [M,nseg,2] instead of row_stats; stats_out_seg=16.
@@ -89,7 +90,10 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
     g.A, g.lda, g.W, g.ldw = H.ptr(a), a.stride(0), H.ptr(w), (K if w_tiled_rows else w.stride(0))
     # uint8 tiles: 24-bit planes (tile_weight_rows_w24, 1536-byte blocks) or block-scaled 16-bit weights (_w16, 1088-byte blocks)
     g.w_tiled = ((3 if w.shape[-1] == 1088 else 2) if w.dtype == torch.uint8 else 1) if w_tiled_rows else 0
-    g.C, g.ldc, g.cdt = H.ptr(out), out.stride(0), (H.KX_BF16X3 if out_x3 else _cdt(out.dtype))
+    g.C, g.ldc, g.cdt = H.ptr(out), out.stride(0), (H.KX_BF16X3 if out_x3 else H.KX_F16P if out_pieces else _cdt(out.dtype))
+    if a_pieces:                                   # `a` holds KX_F16P rows (f16_pieces_rows, or a producer's out_pieces output)
+        assert g.w_tiled == 3, "a_pieces rides on the block-scaled 16-bit planes"
+        g.w_tiled = 4
     g.bias, g.residual, g.ldr = H.ptr(bias), H.ptr(residual), (residual.stride(0) if residual is not None else 0)
     g.M, g.N, g.K = M, N, K
     g.act, g.qscale, g.qcols = H.ACTS[act], float(qscale), qcols
@@ -202,6 +206,30 @@ def tile_weight_rows_w16(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     qb = v.view(Np // 16, K // 32, 64 * 8).view(torch.uint8).view(Np // 16, K // 32, 1024)
     sb = scale.float().view(Np // 16, 16, K // 32).permute(0, 2, 1).contiguous().view(torch.uint8).view(Np // 16, K // 32, 64)
     return torch.cat([qb, sb], dim=2).contiguous()
+
+
+def f16_pieces_rows(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [M, K] (K % 32 == 0) -> KX_F16P rows as an fp32-typed [M, K] tensor: value = hi + lo, hi = fp16(x) toward zero
+    (saturating at 65504), lo = fp16(x - hi); per 32 values [hi: 4 chunks of (4g..4g+3, 16+4g..16+4g+3) | lo: the same]."""
+    M, K = x.shape
+    assert K % 32 == 0 and x.dtype == torch.float32
+    xc = x.clamp(-65504.0, 65504.0)
+    h = xc.to(torch.float16)
+    over = h.float().abs() > xc.abs()                                 # round-to-nearest went away from zero: one step back
+    h = torch.where(over, (h.view(torch.int16) - 1).view(torch.float16), h)
+    lo = (x - h.float()).to(torch.float16)
+
+    def order(t):                                                     # [M, K/32, half, g, j] -> [M, K/32, g, half, j]
+        return t.reshape(M, K // 32, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(M, K // 32, 32)
+    return torch.cat([order(h), order(lo)], dim=2).contiguous().view(torch.float32).reshape(M, K)
+
+
+def f16_pieces_values(rows: torch.Tensor) -> torch.Tensor:
+    """KX_F16P rows (fp32-typed [M, K]) -> the fp32 values hi + lo they stand for."""
+    M, K = rows.shape
+    p = rows.contiguous().view(torch.float16).reshape(M, K // 32, 2, 4, 2, 4).float()      # [M, blk, piece, g, half, j]
+    v = p[:, :, 0] + p[:, :, 1]
+    return v.permute(0, 1, 3, 2, 4).reshape(M, K)
 
 
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,

@@ -74,7 +74,8 @@ def test_f16c_decode_step_forms(B, monkeypatch):
     from kosmosx import _hip
     for name, env in (("w16", {}), ("w24", {"KOSMOSX_DECODE_EXACT": "w24"}), ("fp32", {"KOSMOSX_DECODE_EXACT": "fp32"}),
                       ("tiles", {"KOSMOSX_DECODE_EXACT": "0"}), ("w16_rowmajor", {"KOSMOSX_DECODE_TILED": "0"}),
-                      ("w24_rowmajor", {"KOSMOSX_DECODE_EXACT": "w24", "KOSMOSX_DECODE_TILED": "0"}), ("w16_f32mfma", {})):
+                      ("w24_rowmajor", {"KOSMOSX_DECODE_EXACT": "w24", "KOSMOSX_DECODE_TILED": "0"}), ("w16_f32mfma", {}),
+                      ("w16_fp32rows", {})):
         for k in ("KOSMOSX_DECODE_EXACT", "KOSMOSX_DECODE_TILED"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -85,14 +86,17 @@ def test_f16c_decode_step_forms(B, monkeypatch):
         lm(tok[:, :9].cuda(), incremental_state=st)
         try:
             _hip.load().kx_set_tuning(8, 5 if name == "w16_f32mfma" else 0)      # 5: the planes' 3..16-row launches on the exact-f32 MFMA
+            _hip.load().kx_set_tuning(12, 1 if name == "w16_fp32rows" else 0)    # 1: fp32 rows between the kernels, not KX_F16P
             outs[name] = torch.cat([lm(tok[:, : t + 1].cuda(), incremental_state=st) for t in range(9, 30)], 1)
         finally:
             _hip.load().kx_set_tuning(8, 0)
+            _hip.load().kx_set_tuning(12, 0)
         assert rel_err(outs[name], ref) < 1e-3, name
         if name in ("w16", "w24"):
             w = lm.decoder._pack(name)[0]
             assert bool(w.wout_t) and bool(w.layer[0].wqkv_t)                      # the compressed planes were the ones streamed
     assert torch.equal(outs["w24"], outs["w24_rowmajor"]) and torch.equal(outs["w16_f32mfma"], outs["w16_rowmajor"])
+    assert torch.equal(outs["w16"], outs["w16_fp32rows"])     # pieces made by the producers = pieces made by the consumers
     if B == 1:  # every launch on the VALU
         assert torch.equal(outs["w16"], outs["w16_rowmajor"])
     else:       # the planes' launches the VALU form does not take: fp16 pieces on the fp16 MFMA — the same weights, activations to 2^-22

@@ -694,10 +694,24 @@ def test_gemm_weight_streaming_fp16_pieces_form(M, N, K):
                                     w_tiled_rows=N))
     assert bool(((hp.double() - f32.double()).abs() <= tol * mag + 1e-6).all())
     assert not torch.equal(hp, f32) or K <= 64                              # (it IS another kernel)
+    # KX_F16P rows: the activation pieces made by a producer (here: by torch) instead of in the consumer's registers — the same bits
+    ap = ops.f16_pieces_rows(a).to(DEV)
+    assert float((ops.f16_pieces_values(ap).cpu() - a).abs().max()) <= 2.0 ** -21 * float(a.abs().max())
+    assert torch.equal(hp, ops.gemm(ap, planes, bias.to(DEV), res.to(DEV), out=torch.empty(M, N, device=DEV), tile=16,
+                                    w_tiled_rows=N, a_pieces=True))
+    with pytest.raises(RuntimeError):                                       # ... only where the launch is the fp16-pieces form
+        try:
+            lib.kx_set_tuning(8, 5)
+            ops.gemm(ap, planes, bias.to(DEV), tile=16, w_tiled_rows=N, a_pieces=True)
+        finally:
+            lib.kx_set_tuning(8, 0)
     ref = _gemm_ref(a.double(), wq.double(), bias.double(), res.double(), "none")
     assert bool(((hp.cpu().double() - ref).abs() <= (tol * mag).cpu() + 1e-5).all())
     hp, f32 = both(lambda: ops.gemm(a.to(DEV), planes, bias.to(DEV), act="gelu", tile=16, w_tiled_rows=N))
     assert bool(((hp.double() - f32.double()).abs() <= 1.2 * tol * mag + 1e-6).all())
+    if N % 32 == 0:                                                         # ... and written as KX_F16P rows by the producer's epilogue
+        op = ops.gemm(a.to(DEV), planes, bias.to(DEV), act="gelu", tile=16, w_tiled_rows=N, out_pieces=True)
+        assert torch.equal(op.view(torch.int32), ops.f16_pieces_rows(hp.cpu()).to(DEV).view(torch.int32))
     if K <= 2048 and M * (K * 4 + 16) <= 128 * 1024:                        # LayerNorm prologue: pieces are made of the normalised rows
         gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
         ln = (gam.to(DEV), bet.to(DEV), 1e-5)
