@@ -149,7 +149,7 @@ typedef struct {
    * MFMA fragments, the partial sums meet in LDS (fixed order) and wave 0 runs the epilogue above.  It takes three
    * extra inputs that remove the small kernels around a decode-step GEMM (all optional, this variant only):
    *   ln_gamma/ln_beta/ln_eps : A is then the raw fp32 rows [M,K] (lda in floats) and LayerNorm(A)*gamma+beta, rounded
-   *       to bf16 exactly as kx_layernorm does (kept in fp32 for fp32 operands), is the operand (M*(K*es+16) <= 128 KB);
+   *       to bf16 exactly as kx_layernorm does (kept in fp32 for fp32 operands), is the operand (M*(K*es+16) <= 144 KB);
    *   stats_partials [M, stats_in_nseg, 2] + stats_in_seg + stats_eps : the consumer side of the folded sub-LayerNorm
    *       takes the producer's partial statistics directly (what kx_row_stats_finalize would turn into row_stats);
    *   stats_out_seg : the producer side emits its statistics per 16-column segment ([M, N/16, 2]; must be 16 here,

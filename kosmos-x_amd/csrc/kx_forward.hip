@@ -632,7 +632,7 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
   // statistics-finalize kernels in as prologues: 5 launches per layer instead of 13.  bf16 operands, or fp32 operands on the
   // exact-f32 MFMA (KX_PREC_F32: what the Python side asks for in every precision that holds the north star's tolerance).
   if ((prec == KX_PREC_BF16 || prec == KX_PREC_F32) && M <= 16 && kx_tuning_get(KX_TUNE_GEMM_TILE) == 0 && D % 32 == 0 &&
-      F % 32 == 0 && (size_t)M * (es * D + 16) <= 128 * 1024 && !(prec == KX_PREC_F32 && kx_tuning_get(KX_TUNE_DECODE_STREAM_F32) == 1)) {
+      F % 32 == 0 && (size_t)M * (es * D + 16) <= 144 * 1024 && !(prec == KX_PREC_F32 && kx_tuning_get(KX_TUNE_DECODE_STREAM_F32) == 1)) {
     // The residual GEMMs have N = D columns = D / 16 workgroups (128 at full size: half the CUs stream).  Where that leaves
     // CUs idle they run as TWO workgroups per column block, each over half of K, and the residual stream becomes a pair
     // x = xa + xb (kx_gemm_args.ksplit): part 0 writes (xa' + xb') + bias + its product to the next pair's first member,

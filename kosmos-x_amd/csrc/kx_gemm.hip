@@ -210,8 +210,8 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     KX_REQUIRE(a->w_tiled != 4 || (!a->ln_gamma && a->lda % 32 == 0), "kx_gemm: w_tiled = 4 takes KX_F16P rows (lda %% 32 == 0), no ln_gamma");
     p.w_tiled = a->w_tiled == 4 ? 3 : a->w_tiled;
     p.a_pieces = a->w_tiled == 4;
-    KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * es + 16) <= 128 * 1024 && a->K % 4 == 0),
-               "kx_gemm: LayerNorm prologue needs beta and M*(K*%d+16) <= 128 KB", es);
+    KX_REQUIRE(!a->ln_gamma || (a->ln_beta && (size_t)a->M * (a->K * es + 16) <= 144 * 1024 && a->K % 4 == 0),     // (+ 16 KB of accumulators: 160)
+               "kx_gemm: LayerNorm prologue needs beta and M*(K*%d+16) <= 144 KB", es);
     KX_REQUIRE(!a->ln_operand_out, "kx_gemm: tile 16 does not produce ln_operand_out");
     KX_REQUIRE(!a->residual2 || a->residual, "kx_gemm: residual2 is the second addend of `residual`");
     KX_REQUIRE(!a->a_add || a->ln_gamma, "kx_gemm: a_add is the second addend of the LayerNorm-prologue rows (ln_gamma)");

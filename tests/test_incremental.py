@@ -60,7 +60,7 @@ def test_hip_prefill_and_decode_steps_match_full_forward(prec, tol):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 3, 6])
+@pytest.mark.parametrize("B", [1, 3, 6, 16])
 def test_f16c_decode_step_forms(B, monkeypatch):
     """The decode step of f16c / mixed: default = fp32 products on block-scaled 16-bit weights, streamed as 2.125 bytes each
     (KX_PREC_F32W16); KOSMOSX_DECODE_EXACT=w24 streams weights rounded to 16 significant bits as 3 bytes; =fp32 the full

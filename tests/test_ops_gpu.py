@@ -712,7 +712,7 @@ def test_gemm_weight_streaming_fp16_pieces_form(M, N, K):
     if N % 32 == 0:                                                         # ... and written as KX_F16P rows by the producer's epilogue
         op = ops.gemm(a.to(DEV), planes, bias.to(DEV), act="gelu", tile=16, w_tiled_rows=N, out_pieces=True)
         assert torch.equal(op.view(torch.int32), ops.f16_pieces_rows(hp.cpu()).to(DEV).view(torch.int32))
-    if K <= 2048 and M * (K * 4 + 16) <= 128 * 1024:                        # LayerNorm prologue: pieces are made of the normalised rows
+    if K <= 2048 and M * (K * 4 + 16) <= 144 * 1024:                        # LayerNorm prologue: pieces are made of the normalised rows
         gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
         ln = (gam.to(DEV), bet.to(DEV), 1e-5)
         x = (a * 3 + 0.5).to(DEV)
