@@ -325,6 +325,117 @@ __global__ __launch_bounds__(256) void ln_bwd_param_final_kernel(const float* __
   dgamma[c] = sg; dbeta[c] = sb;
 }
 
+// ---- LayerNorm backward in ONE pass over x and dy (cols = NV * NW * 256).  A workgroup of NW waves owns a row at a time
+//   with the row resident in registers (NV float4 of x and of dy per thread), walks `rows_per_block` consecutive rows
+//   with the NEXT row's loads issued before this row's reductions, and carries its threads' dgamma / dbeta partials in
+//   registers across the rows; one [2][cols] partial per workgroup, summed in fixed order by the final kernel below.
+//   Two block reductions per row instead of four (mean; then the centred second moment, sum(g) and sum(g*(x-mean))
+//   together), each one DPP wave sum + one barrier (the LDS slots alternate, so no second barrier is needed).
+//   Traffic: x + dy (+ dres) read once, dx written once — the two-kernel form read x and dy twice.
+template <int NV, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ dy, const float* __restrict__ dres,
+                                                               float* __restrict__ dx, float* __restrict__ part,
+                                                               long long rows, int rows_per_block, float eps) {
+  constexpr int NT = NW * 64, COLS = NV * NT * 4;
+  __shared__ float red[2][NW][4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  float4 ag[NV], ab[NV], xv[NV], dv[NV], xn[NV], dn[NV], rn[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; rn[i] = ag[i]; xn[i] = ag[i]; dn[i] = ag[i]; }
+  if (r0 < r1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xn[i] = reinterpret_cast<const float4*>(x + r0 * COLS)[t + i * NT];
+      dn[i] = reinterpret_cast<const float4*>(dy + r0 * COLS)[t + i * NT];
+      if (dres) rn[i] = reinterpret_cast<const float4*>(dres + r0 * COLS)[t + i * NT];
+    }
+  }
+  for (long long r = r0; r < r1; ++r) {
+    float4 rv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { xv[i] = xn[i]; dv[i] = dn[i]; rv[i] = rn[i]; }
+    if (r + 1 < r1) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        xn[i] = reinterpret_cast<const float4*>(x + (r + 1) * COLS)[t + i * NT];
+        dn[i] = reinterpret_cast<const float4*>(dy + (r + 1) * COLS)[t + i * NT];
+        if (dres) rn[i] = reinterpret_cast<const float4*>(dres + (r + 1) * COLS)[t + i * NT];
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    s = wave_sum_dpp(s);
+    if (lane == 0) red[0][w][0] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) mean += red[0][k][0];
+    mean *= 1.0f / (float)COLS;
+    float q = 0.f, a = 0.f, b = 0.f;
+    float4 gv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 gm = g4[t + i * NT];
+      xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;                  // centred from here on
+      gv[i] = make_float4(dv[i].x * gm.x, dv[i].y * gm.y, dv[i].z * gm.z, dv[i].w * gm.w);
+      q += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+      a += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
+      b += (gv[i].x * xv[i].x + gv[i].y * xv[i].y) + (gv[i].z * xv[i].z + gv[i].w * xv[i].w);
+    }
+    q = wave_sum_dpp(q); a = wave_sum_dpp(a); b = wave_sum_dpp(b);
+    if (lane == 0) { red[1][w][0] = q; red[1][w][1] = a; red[1][w][2] = b; }
+    __syncthreads();
+    q = 0.f; a = 0.f; b = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { q += red[1][k][0]; a += red[1][k][1]; b += red[1][k][2]; }
+    const float rstd = rsqrtf(q * (1.0f / (float)COLS) + eps);
+    a *= 1.0f / (float)COLS;
+    b *= rstd * (1.0f / (float)COLS);                                                         // mean(g * xhat)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 xh = make_float4(xv[i].x * rstd, xv[i].y * rstd, xv[i].z * rstd, xv[i].w * rstd);
+      float4 v;
+      v.x = rstd * (gv[i].x - a - xh.x * b) + rv[i].x; v.y = rstd * (gv[i].y - a - xh.y * b) + rv[i].y;
+      v.z = rstd * (gv[i].z - a - xh.z * b) + rv[i].z; v.w = rstd * (gv[i].w - a - xh.w * b) + rv[i].w;
+      reinterpret_cast<float4*>(dx + r * COLS)[t + i * NT] = v;
+      ag[i].x += dv[i].x * xh.x; ag[i].y += dv[i].y * xh.y; ag[i].z += dv[i].z * xh.z; ag[i].w += dv[i].w * xh.w;
+      ab[i].x += dv[i].x; ab[i].y += dv[i].y; ab[i].z += dv[i].z; ab[i].w += dv[i].w;
+    }
+  }
+  if (part) {
+    float4* pg = reinterpret_cast<float4*>(part + (long long)blockIdx.x * 2 * COLS);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { pg[t + i * NT] = ag[i]; pg[COLS / 4 + t + i * NT] = ab[i]; }
+  }
+}
+// part [nb][2][cols] -> dgamma, dbeta: 64 columns x 16 slice groups per workgroup, fixed summation order
+__global__ __launch_bounds__(1024) void ln_bwd_fused_final_kernel(const float* __restrict__ part, int nb, int cols,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float sg[16][64], sb[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
+  int i = ty;
+  for (; i + 16 < nb; i += 32) {
+    g0 += part[(2LL * i) * cols + c];        b0 += part[(2LL * i + 1) * cols + c];
+    g1 += part[(2LL * (i + 16)) * cols + c]; b1 += part[(2LL * (i + 16) + 1) * cols + c];
+  }
+  if (i < nb) { g0 += part[(2LL * i) * cols + c]; b0 += part[(2LL * i + 1) * cols + c]; }
+  sg[ty][tx] = g0 + g1; sb[ty][tx] = b0 + b1;
+  __syncthreads();
+  if (ty == 0) {
+    float g = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { g += sg[k][tx]; b += sb[k][tx]; }
+    dgamma[c] = g; dbeta[c] = b;
+  }
+}
+
 // ---- GELU (erf) forward on a saved pre-activation (the training forward keeps both) ----
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ out, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -424,12 +535,27 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
 template <bool SQ>
 __global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
   __shared__ float red[4];
-  float s = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float v = x[i];
-    s += SQ ? v * v : v;
+  // 16-byte loads, four in flight per thread with their own accumulators (a scalar loop with one dependent sum kept
+  // ~1 MB in flight chip-wide: 2.2 TB/s on the 5 GB gradient); the unaligned head and the tail go one by one.
+  const long long head = ((16 - ((uintptr_t)x & 15)) & 15) >> 2;
+  const long long h = head < n ? head : n;
+  const float4* x4 = reinterpret_cast<const float4*>(x + h);
+  const long long n4 = (n - h) >> 2, stride = (long long)gridDim.x * 256;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  auto acc = [](float& s, const float4 v) {
+    s += SQ ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : (v.x + v.y) + (v.z + v.w);
+  };
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    acc(s0, a); acc(s1, b); acc(s2, c); acc(s3, d);
   }
-  s = wave_sum(s);
+  for (; i < n4; i += stride) acc(s0, x4[i]);
+  if (blockIdx.x == 0) {
+    for (long long j = threadIdx.x; j < h; j += 256) { const float v = x[j]; s1 += SQ ? v * v : v; }
+    for (long long j = h + 4 * n4 + threadIdx.x; j < n; j += 256) { const float v = x[j]; s2 += SQ ? v * v : v; }
+  }
+  float s = wave_sum((s0 + s1) + (s2 + s3));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -1280,6 +1406,14 @@ extern "C" int kx_colsum(const float* x, int64_t rows, int64_t cols, int64_t ld,
   return KX_OK;
 }
 
+// cols the one-pass LayerNorm backward is instantiated for (multiples of 1024 up to 4096, 6144, 8192): cols / 1024, else 0
+static int fused_ln_bwd_shape(int64_t cols) {
+  if (cols % 1024 != 0) return 0;
+  const int n = (int)(cols / 1024);
+  return (n >= 1 && n <= 4) || n == 6 || n == 8 ? n : 0;
+}
+extern "C" size_t kx_layernorm_backward_workspace_bytes(int64_t rows, int64_t cols);
+
 extern "C" int kx_layernorm_backward(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                                      float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps, void* workspace,
                                      size_t workspace_bytes, void* stream) {
@@ -1287,13 +1421,39 @@ extern "C" int kx_layernorm_backward(const float* x, const float* gamma, const f
   KX_REQUIRE(rows > 0 && cols > 0 && cols <= 65536, "kx_layernorm_backward: bad shape");
   KX_REQUIRE(!dgamma == !dbeta, "kx_layernorm_backward: dgamma and dbeta go together");
   const int ns = slices_for(rows);
-  const size_t need = (size_t)rows * 8 + 256 + (size_t)ns * 2 * cols * 4;
+  const size_t need = kx_layernorm_backward_workspace_bytes(rows, cols);
   KX_REQUIRE(workspace_bytes >= need, "kx_layernorm_backward: workspace %zu < %zu", workspace_bytes, need);
   float* stats = (float*)workspace;
   float* part = (float*)((char*)workspace + (((size_t)rows * 8 + 255) & ~(size_t)255));
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(KX_K_LAYERNORM, rows, cols, 1, s);
   const bool aligned = ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)dx) & 15) == 0);
+  const int fused = fused_ln_bwd_shape(cols);          // KOSMOSX_LN_BWD_TWO_KERNELS=1: the two-kernel form (A/B)
+  static const bool two_kernels = [] { const char* e = getenv("KOSMOSX_LN_BWD_TWO_KERNELS"); return e && e[0] == '1'; }();
+  if (fused && aligned && !two_kernels) {
+    // resident workgroups: four of 256 threads per CU (101 VGPRs at NV = 2), one of 768 / 1024 threads for the wide rows
+    const int target = fused >= 6 ? 256 : 1024;
+    const int rpb = (int)((rows + target - 1) / target);
+    const int nb = (int)((rows + rpb - 1) / rpb);
+    float* pp = dgamma ? part : nullptr;
+#define KX_LNB(NV, NW)                                                                                              \
+    hipLaunchKernelGGL((ln_bwd_fused_kernel<NV, NW>), dim3((unsigned)nb), dim3(NW * 64), 0, s, x, gamma, dy, dres, dx, pp, \
+                       (long long)rows, rpb, eps)
+    switch (fused) {
+      case 1: KX_LNB(1, 4); break;
+      case 2: KX_LNB(2, 4); break;
+      case 3: KX_LNB(3, 4); break;
+      case 4: KX_LNB(4, 4); break;
+      case 6: KX_LNB(2, 12); break;
+      default: KX_LNB(2, 16); break;
+    }
+#undef KX_LNB
+    if (dgamma)
+      hipLaunchKernelGGL(ln_bwd_fused_final_kernel, dim3((unsigned)(cols / 64)), dim3(1024), 0, s, (const float*)part, nb,
+                         (int)cols, dgamma, dbeta);
+    KX_CHECK_LAUNCH("kx_layernorm_backward");
+    return KX_OK;
+  }
   if (cols % 4 == 0 && cols <= 8192 && aligned)
     hipLaunchKernelGGL(ln_bwd_row_block_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, gamma, dy, dres, dx, stats, (int)cols,
                        eps);
@@ -1312,7 +1472,8 @@ extern "C" int kx_layernorm_backward(const float* x, const float* gamma, const f
 }
 
 extern "C" size_t kx_layernorm_backward_workspace_bytes(int64_t rows, int64_t cols) {
-  return (((size_t)rows * 8 + 255) & ~(size_t)255) + (size_t)slices_for(rows) * 2 * (size_t)cols * 4 + 256;
+  const size_t slices = fused_ln_bwd_shape(cols) ? 1024 : (size_t)slices_for(rows);      // one-pass form: a partial per workgroup
+  return (((size_t)rows * 8 + 255) & ~(size_t)255) + slices * 2 * (size_t)cols * 4 + 256;
 }
 
 extern "C" int kx_gelu_forward(const float* pre, float* out, int64_t n, void* stream) {

@@ -33,7 +33,10 @@ def test_colsum(shape):
     assert torch.equal(G.colsum(x.to(DEV)), G.colsum(x.to(DEV)))           # deterministic
 
 
-@pytest.mark.parametrize("rows,cols", [(3, 64), (114, 2048), (1000, 256)])
+# (114, 2048), (4096, 2048), (300, 8192), (77, 6144), (50, 3072), (1000, 1024), (2051, 4096): the one-pass kernel (cols a
+# multiple of 1024: rows in registers, dgamma / dbeta partials carried across a workgroup's rows); the others the two-kernel form
+@pytest.mark.parametrize("rows,cols", [(3, 64), (114, 2048), (1000, 256), (4096, 2048), (300, 8192), (77, 6144), (50, 3072),
+                                       (1000, 1024), (2051, 4096), (1, 2048), (40, 5120)])
 def test_layernorm_backward(rows, cols):
     g = _g(3)
     x = (torch.randn(rows, cols, generator=g) * 2 + 0.5).requires_grad_()
@@ -44,6 +47,36 @@ def test_layernorm_backward(rows, cols):
     dx, dg, db = G.layernorm_backward(x.detach().to(DEV), gam.detach().to(DEV), dy.to(DEV), dres=dres.to(DEV))
     assert rel_err(dx, x.grad + dres) < 2e-5
     assert rel_err(dg, gam.grad) < 2e-5 and rel_err(db, bet.grad) < 2e-5
+    dx2, dg2, db2 = G.layernorm_backward(x.detach().to(DEV), gam.detach().to(DEV), dy.to(DEV), dres=dres.to(DEV))
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)        # fixed summation order
+    dx3, dg3, db3 = G.layernorm_backward(x.detach().to(DEV), gam.detach().to(DEV), dy.to(DEV), want_param_grads=False)
+    assert dg3 is None and db3 is None and rel_err(dx3, x.grad) < 2e-5
+
+
+def test_layernorm_backward_rows_far_from_zero():
+    """Row means of 1e3 with unit spread: the second moment is taken on centred values (no E[x^2] - mean^2 cancellation)."""
+    g = _g(33)
+    rows, cols = 600, 2048
+    x = (torch.randn(rows, cols, generator=g) + 1000.0 * torch.randn(rows, 1, generator=g)).requires_grad_()
+    gam, bet = torch.randn(cols, generator=g).requires_grad_(), torch.randn(cols, generator=g).requires_grad_()
+    dy = torch.randn(rows, cols, generator=g)
+    xd, gd, bd = x.detach().double().requires_grad_(), gam.detach().double().requires_grad_(), bet.detach().double().requires_grad_()
+    (torch.nn.functional.layer_norm(xd, (cols,), gd, bd, 1e-5) * dy.double()).sum().backward()
+    dx, dg, db = G.layernorm_backward(x.detach().to(DEV), gam.detach().to(DEV), dy.to(DEV))
+    assert rel_err(dx, xd.grad.float()) < 1e-3          # fp32 centring of |x| ~ 1e3 leaves ~1e-4 of the unit spread
+    assert rel_err(dg, gd.grad.float()) < 1e-3 and rel_err(db, bd.grad.float()) < 2e-5
+
+
+@pytest.mark.parametrize("n,off", [(1, 0), (1023, 1), (4096 * 37 + 5, 3), (3_000_001, 0), (70_000_003, 2)])
+def test_reduce_sum_vector_loads(n, off):
+    """kx_reduce_sum reads 16 bytes per lane, four loads in flight: unaligned heads and ragged tails go one by one."""
+    buf = torch.randn(n + off, generator=_g(5))
+    x = buf.to(DEV)[off:]
+    for sq in (False, True):
+        ref = (buf[off:].double() ** 2).sum() if sq else buf[off:].double().sum()
+        got = G.reduce_sum(x, squares=sq)
+        assert abs(float(got) - float(ref)) <= 2e-6 * float((buf[off:].double().abs() ** (2 if sq else 1)).sum())
+        assert torch.equal(got, G.reduce_sum(x, squares=sq))
 
 
 def test_gelu_backward_and_cross_entropy_and_sum():
