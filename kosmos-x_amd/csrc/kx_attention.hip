@@ -13,6 +13,7 @@
 //
 // f32 path (fp32 parity mode): one wave per query row, scores staged in LDS, exact expf.
 #include "kx_common.h"
+#include "kx_dropout.h"
 
 namespace {
 
@@ -201,9 +202,13 @@ __device__ __forceinline__ unsigned pack16x2(float lo, float hi) { return F16 ? 
 // (nx - 1) * 128 ... — so the launch has nx - 1 blocks per (batch, head) instead of nx.  A workgroup's time is the K / V
 // stream it walks, whatever its queries: the third block of the tower's launches streamed all 257 keys for ONE query
 // (1536 workgroups = three rounds of the chip; folded: 1024 = two).  Bit-identical, and measured 0.8 % SLOWER in situ: off by default.
-template <bool CAUSAL, bool F16 = false, bool FOLD = false>
+// DROP (training): attention dropout on this kernel — the normaliser l sums the un-dropped probabilities (their ones-MFMA is
+// unchanged), O^T += V^T P^T takes the kept ones, 1 / (1 - p) goes into the final 1 / l; mask bits from kx_dropout.h, one
+// Philox block per (query, four keys) = per accumulator register quadruple.  Needs Tk % 4 == 0 (the dispatcher checks).
+template <bool CAUSAL, bool F16 = false, bool FOLD = false, bool DROP = false>
 __global__ __launch_bounds__(FOLD ? 320 : 256, 2) void attn_bf16_v2_kernel(const AttnParams p) {
   static_assert(!(CAUSAL && FOLD), "the tail fold is for unmasked launches (causal blocks are paired instead)");
+  static_assert(!(DROP && (F16 || FOLD)), "attention dropout: the bf16 training kernel");
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * VSTR];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -357,6 +362,25 @@ __global__ __launch_bounds__(FOLD ? 320 : 256, 2) void attn_bf16_v2_kernel(const
           for (int c = 0; c < 2; ++c)
             lt[qb] = mma16<F16>(ones, pf[qb][c], lt[qb]);
       }
+      if (DROP) {   // the PV product takes the kept probabilities: re-pack P with the dropped elements zeroed
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const unsigned long long row = (((unsigned long long)b * p.H + h) * p.Tq + (unsigned)(qw0 + qb * 16 + li)) * (unsigned long long)p.Tk;
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            const unsigned keep = kx_dropout_keep4(p.drop_seed, p.drop_site, (row + (unsigned)(kv0 + kb * 16 + 4 * g)) >> 2, p.drop_thresh);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[qb][kb][r] = ((keep >> r) & 1u) ? st[qb][kb][r] : 0.f;
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            pf[qb][c][0] = pack16x2<F16>(st[qb][2 * c][0], st[qb][2 * c][1]);
+            pf[qb][c][1] = pack16x2<F16>(st[qb][2 * c][2], st[qb][2 * c][3]);
+            pf[qb][c][2] = pack16x2<F16>(st[qb][2 * c + 1][0], st[qb][2 * c + 1][1]);
+            pf[qb][c][3] = pack16x2<F16>(st[qb][2 * c + 1][2], st[qb][2 * c + 1][3]);
+          }
+        }
+      }
       // ---- O^T += V^T P^T : V fragment by transpose-read, k index (g,v) <-> key 32c + 16(v>>2) + 4g + (v&3) ----
 #pragma unroll
       for (int d = 0; d < 4; ++d)
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(FOLD ? 320 : 256, 2) void attn_bf16_v2_kernel(const
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const float l = lt[qb][0];           // sum over all keys of the bf16 P the PV product used
-    const float inv = 1.0f / l;
+    const float inv = (DROP ? p.drop_inv_keep : 1.0f) / l;
     const int qi = wave_live ? qw0 + qb * 16 + li : p.Tq;      // (a FOLD workgroup's idle fifth wave owns no query)
     if (p.lse_out && g == 0 && qi < p.Tq)            // log-sum-exp of the query's scores, for the backward pass
       p.lse_out[((long long)b * p.H + h) * p.Tq + qi] = m_run[qb] + logf(l);
@@ -935,8 +959,10 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.stats_out = a->stats_out;
   p.lse_out = a->lse_out;
   const bool drop = a->dropout_p > 0.f;
-  KX_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (!drop || (a->prec == KX_PREC_F32 && a->odt == KX_F32 && !a->stats_out)),
-             "kx_attention: dropout_p must be in [0, 1) and needs fp32 q/k/v, an fp32 output and no stats_out");
+  // attention dropout: fp32 q/k/v on the wave-per-query kernel, or bf16 q/k/v (Tk % 4 == 0) on the matrix-core kernel
+  const bool drop_mfma = drop && a->prec == KX_PREC_BF16 && a->Tk % 4 == 0 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1;
+  KX_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (!drop || ((a->prec == KX_PREC_F32 || drop_mfma) && a->odt == KX_F32 && !a->stats_out)),
+             "kx_attention: dropout_p must be in [0, 1) and needs fp32 q/k/v (or bf16 with Tk %% 4 == 0), an fp32 output and no stats_out");
   p.drop_thresh = drop ? (unsigned)fminf(4294967295.0f, a->dropout_p * 4294967296.0f) : 0u;
   p.drop_inv_keep = 1.0f / (1.0f - a->dropout_p);
   p.drop_seed = a->dropout_seed; p.drop_site = (unsigned)a->dropout_site;
@@ -973,6 +999,12 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
     dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, p);
+  } else if (drop_mfma) {
+    const unsigned nx = (unsigned)((a->Tq + 127) / 128);
+    if (a->mask == KX_ATTN_CAUSAL)
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<true, false, false, true>), dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false, false, true>), dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
   } else if (a->prec == KX_PREC_BF16) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     if (a->mask == KX_ATTN_CAUSAL)   // causal workgroups take query-block pairs (x, nx-1-x)

@@ -5,6 +5,7 @@
 // deterministic (fixed summation order, no atomics).  Row kernels are HBM-bound; the attention backward runs on the
 // exact-f32 matrix instruction (a plain LDS-tiled VALU version is kept as tuning key 2 = 1).
 #include "kx_common.h"
+#include "kx_dropout.h"
 
 namespace {
 
@@ -1109,13 +1110,18 @@ __device__ __forceinline__ void pack_blocks(const f32x4_t (&y)[4], u32x4_t (&pf)
   }
 }
 
-template <bool CAUSAL, typename QT>   // QT: element type of q, k, v (fp32 rounded on the way in, or bf16 as stored)
+// DROP (training, T % 4 == 0): attention dropout — O = (P (.) M / (1-p)) V, so dV takes the dropped P, dP arrives through the
+// same mask and scale, dS = P (.) (dP - delta) with delta = rowsum(dO (.) O) as before; mask bits from kx_dropout.h (here the
+// transposed block: the lanes of a quad each draw one query's Philox block and exchange the keep bits).
+template <bool CAUSAL, typename QT, bool DROP = false>   // QT: element type of q, k, v (fp32 rounded on the way in, or bf16 as stored)
 __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __restrict__ q, const QT* __restrict__ k,
                                                                 const QT* __restrict__ v, const float* __restrict__ dout,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 float* __restrict__ dk, float* __restrict__ dv, int T, int H,
                                                                 long long row_stride, long long batch_stride,
-                                                                long long do_row, long long do_batch) {
+                                                                long long do_row, long long do_batch, float inv_keep = 1.0f,
+                                                                unsigned drop_thresh = 0u, unsigned long long drop_seed = 0ull,
+                                                                unsigned drop_site = 0u) {
   __shared__ __attribute__((aligned(16))) bf16_t Qb[2][64 * XS], dOb[2][64 * XS];
   __shared__ __attribute__((aligned(16))) float Lb[2][64], Db[2][64];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1178,14 +1184,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __rest
         const float4 L4 = *reinterpret_cast<const float4*>(Ls + 16 * qbk + 4 * g);
         const float4 D4 = *reinterpret_cast<const float4*>(Ds + 16 * qbk + 4 * g);
         const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+        unsigned keepq = 0xFu;                           // bit r: (query 4g + r, this lane's key) is kept
+        if (DROP) {   // this lane draws the block of query 4g + (i & 3) over the quad's four keys, then the quad transposes
+          const unsigned long long row = (((unsigned long long)b * H + h) * T + (unsigned)(q0 + 16 * qbk + 4 * g + (i & 3))) * (unsigned long long)T;
+          keepq = kx_dropout_quad_transpose(kx_dropout_keep4(drop_seed, drop_site, (row + (unsigned)(kw0 + (i & ~3))) >> 2, drop_thresh), i & 3);
+        }
   #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qi = q0 + 16 * qbk + 4 * g + r;
           const bool ok = qi < T && ki < T && (!CAUSAL || ki <= qi);
           const float e = __builtin_amdgcn_exp2f(fmaf(sa[r], 1.44269504088896340736f, -Lr[r]));
           const float pv = ok ? e : 0.f;
-          pb[qbk][r] = pv;
-          sb[qbk][r] = pv * (pa[r] - Dr[r]);
+          const float km = DROP ? (((keepq >> r) & 1u) ? inv_keep : 0.f) : 1.0f;
+          pb[qbk][r] = DROP ? pv * km : pv;
+          sb[qbk][r] = pv * ((DROP ? pa[r] * km : pa[r]) - Dr[r]);
         }
       }
       u32x4_t pfP[2], pfS[2];
@@ -1212,12 +1224,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __rest
   }
 }
 
-template <bool CAUSAL, typename QT>
+template <bool CAUSAL, typename QT, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const QT* __restrict__ q, const QT* __restrict__ k,
                                                                const QT* __restrict__ v, const float* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ dq, int T, int H, long long row_stride,
-                                                               long long batch_stride, long long do_row, long long do_batch) {
+                                                               long long batch_stride, long long do_row, long long do_batch,
+                                                               float inv_keep = 1.0f, unsigned drop_thresh = 0u,
+                                                               unsigned long long drop_seed = 0ull, unsigned drop_site = 0u) {
   __shared__ __attribute__((aligned(16))) bf16_t Kb[2][64 * XS], Vb[2][64 * XS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1266,12 +1280,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const QT* __restr
           st = mfma_bf16(tile_row_frag(Ks, kbk, s2, g, i), qfix[s2], st);       // St[key, q]
           dpt = mfma_bf16(tile_row_frag(Vs, kbk, s2, g, i), dofix[s2], dpt);    // dPt[key, q]
         }
+        unsigned keep = 0xFu;                            // one Philox block = this query's keys 4g .. 4g + 3 of the block
+        if (DROP)
+          keep = kx_dropout_keep4(drop_seed, drop_site,
+                                  ((((unsigned long long)b * H + h) * T + (unsigned)qi) * (unsigned long long)T + (unsigned)(k0 + 16 * kbk + 4 * g)) >> 2,
+                                  drop_thresh);
   #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kj = k0 + 16 * kbk + 4 * g + r;
           const bool ok = qi < T && kj < T && (!CAUSAL || kj <= qi);
           const float e = __builtin_amdgcn_exp2f(fmaf(st[r], 1.44269504088896340736f, -lse2_i));
-          sb[kbk][r] = (ok ? e : 0.f) * (dpt[r] - del_i);
+          const float dp = DROP ? (((keep >> r) & 1u) ? dpt[r] * inv_keep : 0.f) : dpt[r];
+          sb[kbk][r] = (ok ? e : 0.f) * (dp - del_i);
         }
       }
       u32x4_t pfS[2];
@@ -1686,6 +1706,47 @@ extern "C" int kx_attention_backward_dropout(const float* q, const float* k, con
   else { KX_ATTN_BWD_D(0, false); KX_ATTN_BWD_D(1, false); }
 #undef KX_ATTN_BWD_D
   KX_CHECK_LAUNCH("kx_attention_backward_dropout");
+  return KX_OK;
+}
+
+// ... and on the matrix-core passes with bf16 products (q/k/v fp32 or bf16 as kx_attention_backward with KX_PREC_BF16 takes
+// them): the training step's attention backward in train mode.  T % 4 == 0 (one Philox block = four consecutive keys).
+extern "C" int kx_attention_backward_dropout_bf16(const void* qv_, const void* kv_, const void* vv_, int32_t qkv_dt,
+                                                  const float* out, const float* dout, const float* lse, float* dq, float* dk,
+                                                  float* dv, float* delta, int64_t B, int64_t H, int64_t T,
+                                                  int64_t qkv_row_stride, int64_t qkv_batch_stride, int64_t out_row_stride,
+                                                  int64_t out_batch_stride, int32_t mask, float dropout_p, uint64_t seed,
+                                                  int32_t site, void* stream) {
+  KX_REQUIRE(qv_ && kv_ && vv_ && out && dout && lse && dq && dk && dv && delta, "kx_attention_backward_dropout_bf16: null pointer");
+  KX_REQUIRE(qkv_dt == KX_F32 || qkv_dt == KX_BF16, "kx_attention_backward_dropout_bf16: q/k/v are fp32 or bf16");
+  KX_REQUIRE(B > 0 && H > 0 && T > 0 && T % 4 == 0 && B < 65536 && H < 65536 && dropout_p >= 0.f && dropout_p < 1.f,
+             "kx_attention_backward_dropout_bf16: bad shape (T %% 4 == 0) or dropout_p outside [0, 1)");
+  const int es = qkv_dt == KX_BF16 ? 2 : 4;
+  KX_REQUIRE((qkv_row_stride * es) % 16 == 0 && out_row_stride % 4 == 0 && (qkv_batch_stride * es) % 16 == 0 &&
+                 out_batch_stride % 4 == 0 && qkv_row_stride % 4 == 0 && qkv_batch_stride % 4 == 0 &&
+                 (((uintptr_t)qv_ | (uintptr_t)kv_ | (uintptr_t)vv_ | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+             "kx_attention_backward_dropout_bf16: pointers and strides must keep 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_ATTN_F32, B * H, T, -T, s);
+  const long long nw = (long long)B * T * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, out, dout, delta, (int)B, (int)T,
+                     (int)H, (long long)out_row_stride, (long long)out_batch_stride);
+  const dim3 grid((unsigned)((T + 63) / 64), (unsigned)H, (unsigned)B);
+  const unsigned thresh = dropout_p > 0.f ? (unsigned)fminf(4294967295.0f, dropout_p * 4294967296.0f) : 0u;
+  const float inv_keep = 1.0f / (1.0f - dropout_p);
+#define KX_ATTN_BWD_BD(CAUSAL, QT)                                                                                            \
+  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<CAUSAL, QT, true>), grid, dim3(256), 0, s, (const QT*)qv_, (const QT*)kv_,      \
+                     (const QT*)vv_, dout, lse, (const float*)delta, dk, dv, (int)T, (int)H, (long long)qkv_row_stride,        \
+                     (long long)qkv_batch_stride, (long long)out_row_stride, (long long)out_batch_stride, inv_keep, thresh,    \
+                     (unsigned long long)seed, (unsigned)site);                                                               \
+  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<CAUSAL, QT, true>), grid, dim3(256), 0, s, (const QT*)qv_, (const QT*)kv_,       \
+                     (const QT*)vv_, dout, lse, (const float*)delta, dq, (int)T, (int)H, (long long)qkv_row_stride,            \
+                     (long long)qkv_batch_stride, (long long)out_row_stride, (long long)out_batch_stride, inv_keep, thresh,    \
+                     (unsigned long long)seed, (unsigned)site)
+  if (qkv_dt == KX_BF16) { if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD_BD(true, bf16_t); } else { KX_ATTN_BWD_BD(false, bf16_t); } }
+  else if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD_BD(true, float); } else { KX_ATTN_BWD_BD(false, float); }
+#undef KX_ATTN_BWD_BD
+  KX_CHECK_LAUNCH("kx_attention_backward_dropout_bf16");
   return KX_OK;
 }
 

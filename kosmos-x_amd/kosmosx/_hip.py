@@ -177,6 +177,7 @@ SYMBOLS = {
     "kx_adamw": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, f32, vp]),
     "kx_lion": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp]),
     "kx_attention_backward_dropout": (C.c_int, [vp] * 10 + [i64] * 7 + [i32, f32, C.c_uint64, i32, vp]),
+    "kx_attention_backward_dropout_bf16": (C.c_int, [vp] * 3 + [i32] + [vp] * 7 + [i64] * 7 + [i32, f32, C.c_uint64, i32, vp]),
     "kx_dropout": (C.c_int, [vp, vp, vp, i64, f32, C.c_uint64, i32, vp]),
     "kx_dropout_mask": (C.c_int, [vp, i64, f32, C.c_uint64, i32, vp]),
     "kx_quick_gelu_forward": (C.c_int, [vp, vp, i64, vp]),

@@ -298,6 +298,70 @@ def test_dropout_ops_masks_are_a_function_of_seed_site_and_index():
     assert float((dqkv.cpu() - qr.grad).abs().max() / qr.grad.pow(2).mean().sqrt()) < 1e-4
 
 
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("T", [72, 132, 320])
+def test_attention_dropout_on_the_matrix_core_kernels(T, causal):
+    """Train mode in bf16: the flash forward and both backward passes carry the Philox mask themselves (one block per
+    query and four keys; the dK/dV pass transposes keep bits inside lane quads).  Reference: fp64 autograd over the SAME
+    bf16-rounded q/k/v with the exported mask — what is left is the rounding of P / dS / dO to bf16, far below what one
+    wrong mask bit costs (>= 1.33 * v / T on an output row)."""
+    from kosmosx import grad_ops as G, ops
+    B, Hh, D, p = 2, 3, 192, 0.25
+    g = torch.Generator().manual_seed(7 + T)
+    qkv16 = (torch.randn(B * T, 3 * D, generator=g) * 0.7).to(torch.bfloat16)
+    dout = torch.randn(B, T, D, generator=g)
+    qb = qkv16.to(DEV)
+    q3, k3, v3 = (qb[:, i * D:(i + 1) * D].unflatten(0, (B, T)).unflatten(2, (Hh, 64)) for i in range(3))
+    lse = torch.empty(B, Hh, T, device=DEV)
+    out = ops.attention(q3, k3, v3, causal, out_dtype=torch.float32, lse_out=lse, dropout=(p, 4321, 9))
+    mask = G.dropout_mask(B * Hh * T * T, p, 4321, 9, DEV).view(B, Hh, T, T).double().cpu() / (1.0 - p)
+    qr = qkv16.double().requires_grad_()
+    qq, kk, vv = (qr[:, i * D:(i + 1) * D].view(B, T, Hh, 64).transpose(1, 2) for i in range(3))
+    sc = qq @ kk.transpose(-1, -2)
+    if causal:
+        sc = sc + torch.triu(torch.full((T, T), float("-inf"), dtype=torch.float64), 1)
+    ref = ((torch.softmax(sc, -1) * mask) @ vv).transpose(1, 2).reshape(B, T, D)
+    assert rel_err(out, ref.detach().float()) < 1e-2                       # one wrong bit: >= 2.5e-2 at T = 132
+    assert float((lse.cpu().double() - torch.logsumexp(sc, -1).detach()).abs().max()) < 2e-2
+    ref.backward(dout.double())
+    for src in (qb, qb.float()):                                           # q/k/v as stored in bf16, or fp32 rounded on the way in
+        dqkv = G.attention_backward(src, out, dout.to(DEV), lse, B, T, Hh, causal, bf16_products=True, dropout=(p, 4321, 9))
+        for i, name in enumerate("qkv"):
+            got, want = dqkv[:, i * D:(i + 1) * D].cpu().double(), qr.grad[:, i * D:(i + 1) * D]
+            rms = float((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+            assert rms < 1.2e-2, (name, rms)
+    # the same launch twice: masks are a function of (seed, site, index), nothing else
+    assert torch.equal(out, ops.attention(q3, k3, v3, causal, out_dtype=torch.float32, lse_out=lse, dropout=(p, 4321, 9)))
+    # T % 4 != 0 has no whole Philox block per register quadruple: refused here (the trainer keeps the fp32 kernels for it)
+    if T == 72:
+        with pytest.raises((RuntimeError, ValueError)):
+            ops.attention(q3[:, :70], k3[:, :70], v3[:, :70], causal, out_dtype=torch.float32, dropout=(p, 1, 1))
+
+
+@pytest.mark.parametrize("T", [32, 30])
+def test_train_mode_in_bf16_matches_autograd_with_the_same_masks(T):
+    """precision="bf16", train_mode=True: T = 32 runs the matrix-core attention kernels with the mask inside, T = 30 the
+    fp32 wave-per-query ones; every gradient against autograd over the oracle with the exported masks at the
+    mixed-precision tolerance of test_mixed_precision_gradients."""
+    lm = _tiny_lm(seed=8)
+    cfg = O.DecoderCfg(layers=2, dim=256, ffn=512, heads=4, vocab=1002, max_pos=128)
+    w = _leaf_weights(lm)
+    tr = LanguageModelTrainer(lm.to(DEV), precision="bf16", train_mode=True, dropout_seed=11)
+    tok = torch.randint(2, 1002, (2, T), generator=torch.Generator().manual_seed(13))
+    drop = {k: v.cpu() for k, v in tr.dropout_masks(2, T).items()}
+    ref = TO.lm_loss(w, tok, cfg, drop=drop)
+    TO.backward(ref, w)
+    loss = tr.step(tok.to(DEV), apply_update=False)
+    assert abs(float(loss) - float(ref.detach())) < 5e-3 * abs(float(ref.detach()))
+    worst = 0.0
+    for name in dict(lm.named_parameters()):
+        if ".B." in name:
+            continue
+        gq, r = tr.grads[name].float().cpu(), w[name].grad
+        worst = max(worst, float((gq - r).pow(2).mean().sqrt() / (r.pow(2).mean().sqrt() + 1e-30)))
+    assert worst < 3e-2, worst
+
+
 @pytest.mark.parametrize("zero_stage", [1, 3])
 def test_train_mode_dropout_matches_autograd_with_the_same_masks(zero_stage):
     """train_mode=True (the reference's model.train(): dropout = attention_dropout = 0.1): the loss, every gradient and the

@@ -23,6 +23,8 @@ ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--layers", type=int, default=24)
 ap.add_argument("--cpu-seconds", type=float, default=20.0)
 ap.add_argument("--checkpoint", action="store_true", help="keep only layer inputs, recompute each layer before its backward")
+ap.add_argument("--train-mode", action="store_true", help="the reference's model.train(): dropout = attention_dropout = 0.1 "
+                "(/root/reference/train.py:642, kosmosx/model.py:175-177), Philox masks; default: the deterministic step")
 ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"], help="arithmetic of the matrix products")
 a = ap.parse_args()
 import torch.distributed as dist
@@ -34,7 +36,8 @@ if world > 1 or force:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 lm = KosmosLanguage(vocab_size=32002, dim=2048, depth=a.layers, _seed=0).eval().to(dev)      # same seed: replicated weights
-tr = LanguageModelTrainer(lm, precision=a.precision, force_collectives=force, checkpoint_activations=a.checkpoint)
+tr = LanguageModelTrainer(lm, precision=a.precision, force_collectives=force, checkpoint_activations=a.checkpoint,
+                          train_mode=a.train_mode, dropout_seed=1234)
 g = torch.Generator().manual_seed(1000 + rank)                                               # per-rank batch shard
 batches = [torch.randint(2, 32002, (a.batch, a.seq), generator=g).to(dev) for _ in range(a.warmup + a.steps + 1)]
 losses = []
@@ -80,7 +83,8 @@ for kind, x, y, z, ms in recs:
 nparams = sum(p.numel() for p in lm.parameters())
 tokens = a.batch * a.seq * world
 flops = 6.0 * (nparams - 32002 * 2048 - lm.embed_positions.weight.numel()) * tokens   # matmul parameters x 6 (fwd + 2x bwd)
-res = {"workload": f"KosmosLanguage train step (fwd+bwd+clip+AdamW), {a.layers}L/2048d, B={a.batch} T={a.seq}, {a.precision} products on fp32 master weights",
+res = {"workload": f"KosmosLanguage train step (fwd+bwd+clip+AdamW), {a.layers}L/2048d, B={a.batch} T={a.seq}, {a.precision} products on fp32 master weights"
+                   + (f", train mode (dropout {tr.p_drop}, attention dropout {tr.p_attn})" if a.train_mode else ""),
        "n_gpus": world, "scaling": "weak", "ms_per_step": round(dt * 1e3, 1), "tokens_per_s": round(tokens / dt, 1), "losses": [round(l, 4) for l in losses],
        "approx_model_tflops": round(flops / dt / 1e12, 1),
        "kernels_ms": {k: {"n": v[0], "ms": round(v[1], 1), **({"tflops": round(v[2] / v[1] / 1e9, 1)} if v[2] else {})}
