@@ -17,7 +17,10 @@ def _g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.mark.parametrize("shape,dt", [((70, 130), torch.float32), ((257, 64), torch.bfloat16), ((1, 5), torch.float32)])
+# bf16 shapes that are multiples of 8 take the 16-byte kernel (partial 64 x 64 tiles at the edges included)
+@pytest.mark.parametrize("shape,dt", [((70, 130), torch.float32), ((257, 64), torch.bfloat16), ((1, 5), torch.float32),
+                                      ((512, 2048), torch.bfloat16), ((72, 200), torch.bfloat16), ((8, 8), torch.bfloat16),
+                                      ((136, 64), torch.bfloat16)])
 def test_transpose(shape, dt):
     x = torch.randn(*shape, generator=_g(1)).to(dt)
     assert torch.equal(G.transpose(x.to(DEV)).cpu(), x.t().contiguous())
@@ -85,6 +88,11 @@ def test_gelu_backward_and_cross_entropy_and_sum():
     dg = torch.randn(50, 300, generator=g)
     (torch.nn.functional.gelu(pre) * dg).sum().backward()
     assert rel_err(G.gelu_backward(pre.detach().to(DEV), dg.to(DEV)), pre.grad) < 1e-5
+    assert rel_err(G.gelu(pre.detach().to(DEV)), torch.nn.functional.gelu(pre.detach())) < 1e-6
+    odd = pre.detach().flatten()[:14999].to(DEV)                    # n % 4 != 0: the one-value-per-lane kernels
+    assert torch.equal(G.gelu(odd), G.gelu(pre.detach().to(DEV)).flatten()[:14999])
+    assert torch.equal(G.gelu_backward(odd, dg.flatten()[:14999].to(DEV)),
+                       G.gelu_backward(pre.detach().to(DEV), dg.to(DEV)).flatten()[:14999])
     logits = (torch.randn(37, 1002, generator=g) * 3).requires_grad_()
     tgt = torch.randint(0, 1002, (37,), generator=g)
     tgt[5] = -100                                                   # ignore_index

@@ -37,4 +37,13 @@ for n in (1_270_000_000, 100_000_000):
     x = torch.randn(n, device=dev)
     us = timed(lambda: G.reduce_sum(x, squares=True), n=10, warm=2)
     out[f"sum_squares_{n}"] = {"us": round(us, 1), "TBps": round(n * 4 / us / 1e6, 2)}
+for rows, cols in [(4096, 2048), (4096, 8192)]:
+    xb = torch.randn(rows, cols, device=dev).to(torch.bfloat16)
+    us = timed(lambda: G.transpose(xb, 64))
+    out[f"transpose_bf16_{rows}x{cols}"] = {"us": round(us, 1), "TBps": round(rows * cols * 4 / us / 1e6, 2)}
+pre, dgr = torch.randn(4096, 8192, device=dev), torch.randn(4096, 8192, device=dev)
+us = timed(lambda: G.gelu(pre))
+out["gelu_fwd_4096x8192"] = {"us": round(us, 1), "TBps": round(pre.numel() * 8 / us / 1e6, 2)}
+us = timed(lambda: G.gelu_backward(pre, dgr))
+out["gelu_bwd_4096x8192"] = {"us": round(us, 1), "TBps": round(pre.numel() * 12 / us / 1e6, 2)}
 print(json.dumps(out))
