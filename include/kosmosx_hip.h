@@ -476,6 +476,13 @@ int kx_to_operand(const float* src, void* dst, int64_t rows, int64_t cols, int64
 size_t kx_to_operand_pair_workspace_bytes(int64_t rows, int64_t cols);
 int kx_to_operand_pair(const float* src, void* dst, void* dst_t, int64_t rows, int64_t cols, int64_t ld_src, int64_t kp,
                        int64_t kpt, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
+/* The same pass over dpre = dg * gelu'(pre) (erf GELU; `pre` = the saved pre-activation, shape and pitch of dg): the GELU
+ * backward of the training step's FFN folded into the operand conversion — outputs and column sums (fc1's bias gradient)
+ * as kx_to_operand_pair's, the fp32 dpre is never written (torchscale FeedForwardNetwork: fc1 -> gelu -> ffn_layernorm ->
+ * fc2; /root/reference/kosmosx/model.py:170-183 selects it). */
+int kx_gelu_backward_operand_pair(const float* dg, const float* pre, void* dst, void* dst_t, int64_t rows, int64_t cols,
+                                  int64_t ld_src, int64_t kp, int64_t kpt, float* colsum, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 /* out[c] (+)= sum_r x[r][c] (bias gradients) */
 size_t kx_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int kx_colsum(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, int32_t accumulate, void* workspace,

@@ -87,10 +87,20 @@ __global__ __launch_bounds__(256) void to_operand_rows_kernel(const float* __res
 // for the data gradient and as dY^T rows for the weight gradient; a weight as W rows forward and W^T rows backward).
 // 64 x 64 tile through LDS; both outputs leave as 16-byte stores (8 bf16 per lane).  dst [rows, kp] / dst_t [cols, kpt],
 // padding columns zero; either may be null.
+// GELU_GRAD: src is the gradient arriving at the GELU's output and `pre` its saved pre-activation (same shape and pitch):
+// the tile holds src * gelu'(pre) — the GELU backward folded into the pass that makes its result a GEMM operand pair (the
+// fp32 gradient of the pre-activation is never written: 2 x 134 MB per layer of the 24L / 2048-d step).
+__device__ __forceinline__ float gelu_erf_grad_pair(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+template <bool GELU_GRAD>
 __global__ __launch_bounds__(256) void to_operand_pair_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                               bf16_t* __restrict__ dst_t, long long rows, long long cols,
                                                               long long ld_src, long long kp, long long kpt,
-                                                              float* __restrict__ colsum_part) {
+                                                              float* __restrict__ colsum_part,
+                                                              const float* __restrict__ pre = nullptr) {
   __shared__ float tile[64][65];
   const long long r0 = (long long)blockIdx.y * 64, c0 = (long long)blockIdx.x * 64;
   const int tid = threadIdx.x;
@@ -103,6 +113,12 @@ __global__ __launch_bounds__(256) void to_operand_pair_kernel(const float* __res
       if (r < rows) {
         if (c + 3 < cols) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
         else { const float* q = src + r * ld_src + c; if (c < cols) v.x = q[0]; if (c + 1 < cols) v.y = q[1]; if (c + 2 < cols) v.z = q[2]; }
+        if (GELU_GRAD) {
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c + 3 < cols) x = *reinterpret_cast<const float4*>(pre + r * ld_src + c);
+          else { const float* q = pre + r * ld_src + c; if (c < cols) x.x = q[0]; if (c + 1 < cols) x.y = q[1]; if (c + 2 < cols) x.z = q[2]; }
+          v.x *= gelu_erf_grad_pair(x.x); v.y *= gelu_erf_grad_pair(x.y); v.z *= gelu_erf_grad_pair(x.z); v.w *= gelu_erf_grad_pair(x.w);
+        }
       }
       float* t = &tile[ty + 16 * i][4 * tx];
       t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
@@ -1430,9 +1446,24 @@ extern "C" size_t kx_to_operand_pair_workspace_bytes(int64_t rows, int64_t cols)
   return (size_t)(((rows + 63) / 64 * 64 + 64) / 64) * (size_t)cols * sizeof(float);      // one partial row per 64-row slice
 }
 
+static int operand_pair(const float* src, const float* gelu_pre, void* dst, void* dst_t, int64_t rows, int64_t cols,
+                        int64_t ld_src, int64_t kp, int64_t kpt, float* colsum, void* workspace, size_t workspace_bytes,
+                        void* stream);
 extern "C" int kx_to_operand_pair(const float* src, void* dst, void* dst_t, int64_t rows, int64_t cols, int64_t ld_src,
                                   int64_t kp, int64_t kpt, float* colsum, void* workspace, size_t workspace_bytes,
                                   void* stream) {
+  return operand_pair(src, nullptr, dst, dst_t, rows, cols, ld_src, kp, kpt, colsum, workspace, workspace_bytes, stream);
+}
+// dpre = dg * gelu'(pre) as an operand pair (and its column sums: fc1's bias gradient), without the fp32 dpre in between
+extern "C" int kx_gelu_backward_operand_pair(const float* dg, const float* pre, void* dst, void* dst_t, int64_t rows,
+                                             int64_t cols, int64_t ld_src, int64_t kp, int64_t kpt, float* colsum,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+  KX_REQUIRE(pre && (((uintptr_t)pre) & 15) == 0, "kx_gelu_backward_operand_pair: pre is null or not 16-byte aligned");
+  return operand_pair(dg, pre, dst, dst_t, rows, cols, ld_src, kp, kpt, colsum, workspace, workspace_bytes, stream);
+}
+static int operand_pair(const float* src, const float* gelu_pre, void* dst, void* dst_t, int64_t rows, int64_t cols,
+                        int64_t ld_src, int64_t kp, int64_t kpt, float* colsum, void* workspace, size_t workspace_bytes,
+                        void* stream) {
   KX_REQUIRE(src && (dst || dst_t) && rows > 0 && cols > 0 && ld_src >= cols, "kx_to_operand_pair: bad arguments");
   KX_REQUIRE(!dst || (kp >= cols && kp % 8 == 0 && (((uintptr_t)dst) & 15) == 0),
              "kx_to_operand_pair: kp=%lld must cover %lld columns, be a multiple of 8, dst 16-byte aligned", (long long)kp,
@@ -1450,8 +1481,14 @@ extern "C" int kx_to_operand_pair(const float* src, void* dst, void* dst_t, int6
   const dim3 grid((unsigned)((ec + 63) / 64), (unsigned)gy);
   hipStream_t s = (hipStream_t)stream;
   KxProfScope prof(KX_K_MISC, rows, cols, 28, s);
-  hipLaunchKernelGGL(to_operand_pair_kernel, grid, dim3(256), 0, s, src, (bf16_t*)dst, (bf16_t*)dst_t, (long long)rows,
-                     (long long)cols, (long long)ld_src, (long long)kp, (long long)kpt, colsum ? (float*)workspace : nullptr);
+  if (gelu_pre)
+    hipLaunchKernelGGL(to_operand_pair_kernel<true>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (bf16_t*)dst_t, (long long)rows,
+                       (long long)cols, (long long)ld_src, (long long)kp, (long long)kpt, colsum ? (float*)workspace : nullptr,
+                       gelu_pre);
+  else
+    hipLaunchKernelGGL(to_operand_pair_kernel<false>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (bf16_t*)dst_t, (long long)rows,
+                       (long long)cols, (long long)ld_src, (long long)kp, (long long)kpt, colsum ? (float*)workspace : nullptr,
+                       (const float*)nullptr);
   if (colsum)
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
                        (int)gy, (long long)cols, colsum, 0);

@@ -164,6 +164,7 @@ SYMBOLS = {
     "kx_to_operand": (C.c_int, [vp, vp, i64, i64, i64, i64, i32, i32, vp]),
     "kx_to_operand_pair_workspace_bytes": (C.c_size_t, [i64, i64]),
     "kx_to_operand_pair": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, vp, vp, C.c_size_t, vp]),
+    "kx_gelu_backward_operand_pair": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, i64, vp, vp, C.c_size_t, vp]),
     "kx_colsum_workspace_bytes": (C.c_size_t, [i64, i64]),
     "kx_colsum": (C.c_int, [vp, i64, i64, i64, vp, i32, vp, C.c_size_t, vp]),
     "kx_layernorm_backward_workspace_bytes": (C.c_size_t, [i64, i64]),

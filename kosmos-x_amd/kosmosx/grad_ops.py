@@ -58,6 +58,26 @@ def to_operand_pair(x: torch.Tensor, straight: bool = True, transposed: bool = T
     return a, t
 
 
+def gelu_backward_pair(pre: torch.Tensor, dg: torch.Tensor, colsum_out: torch.Tensor | None = None):
+    """dpre = dg * gelu'(pre) as the bf16 operand pair of to_operand_pair (and its column sums), in one pass over pre and dg."""
+    _need_cuda(pre, dg, colsum_out)
+    if pre.shape != dg.shape or pre.stride(0) != dg.stride(0):
+        raise ValueError("gelu_backward_pair: pre and dg must share shape and row pitch")
+    R, Cc = dg.shape
+    kp, kpt = (Cc + 63) // 64 * 64, (R + 63) // 64 * 64
+    a = torch.empty((R, kp), dtype=torch.bfloat16, device=dg.device)
+    t = torch.empty((Cc, kpt), dtype=torch.bfloat16, device=dg.device)
+    lib = H.load()
+    ws, n = None, 0
+    if colsum_out is not None:
+        n = lib.kx_to_operand_pair_workspace_bytes(R, Cc)
+        ws = _ws(n, dg.device)
+    H.check(lib.kx_gelu_backward_operand_pair(H.ptr(dg), H.ptr(pre), H.ptr(a), H.ptr(t), R, Cc, dg.stride(0), kp, kpt,
+                                              H.ptr(colsum_out), H.ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+            "kx_gelu_backward_operand_pair")
+    return a, t
+
+
 def gelu(pre: torch.Tensor) -> torch.Tensor:
     _need_cuda(pre)
     out = torch.empty_like(pre)

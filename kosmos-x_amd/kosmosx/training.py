@@ -279,6 +279,8 @@ class LanguageModelTrainer:
         if self.precision == "bf16":
             o.pairW = lambda t: G.to_operand_pair(t)
             o.pairA = lambda t, bias_out=None: G.to_operand_pair(t, colsum_out=bias_out)
+            # the FFN's GELU backward folded into that pass (the fp32 gradient of the pre-activation is never written)
+            o.pairA_gelu = lambda pre, dg, bias_out=None: G.gelu_backward_pair(pre, dg, colsum_out=bias_out)
         else:
             o.pairW = lambda t: (o.opW(t), o.opWT(t))
 
@@ -287,6 +289,7 @@ class LanguageModelTrainer:
                     G.colsum(t, out=bias_out)
                 return o.opA(t), o.opAT(t)
             o.pairA = pairA
+            o.pairA_gelu = lambda pre, dg, bias_out=None: pairA(G.gelu_backward(pre, dg), bias_out)
 
         def lin(x, w, b=None, **kw):                      # x [M,K] · w[N,K]ᵀ (+ b); returns (y, wᵀ operand for the backward)
             wa, wt = o.pairW(w.detach())
@@ -411,8 +414,7 @@ class LanguageModelTrainer:
             dgn = o.dgrad(dx_a, s["w2_t"])
             del dx_a, dx_t
             dg = dgn if P["ffn_ln"] is None else self._ln_bwd(s["g"], pfx + f"ffn{mw}.ffn_layernorm", P["ffn_ln"].weight, dgn, eps)
-            dpre = G.gelu_backward(s["pre"], dg)
-            dp_a, dp_t = o.pairA(dpre, grads[pfx + f"ffn{mw}.fc1.bias"])
+            dp_a, dp_t = o.pairA_gelu(s["pre"], dg, grads[pfx + f"ffn{mw}.fc1.bias"])
             o.wgrad(dp_t, s["h2"], out=grads[pfx + f"ffn{mw}.fc1.weight"])
             dh2 = o.dgrad(dp_a, s["w1_t"])
             del dp_a, dp_t

@@ -207,6 +207,18 @@ def test_attention_backward(B, Hh, T, causal):
     assert rms < 2e-2, rms
 
 
+@pytest.mark.parametrize("shape", [(70, 132), (64, 64), (300, 2048), (129, 8), (512, 8192)])
+def test_gelu_backward_folded_into_the_operand_pair(shape):
+    """kx_gelu_backward_operand_pair == kx_gelu_backward followed by kx_to_operand_pair, bit for bit (operands and the
+    bias column sums): the training step's FFN backward never writes the fp32 gradient of the pre-activation."""
+    g = _g(11 + sum(shape))
+    pre, dg = (torch.randn(*shape, generator=g) * 2).to(DEV), torch.randn(*shape, generator=g).to(DEV)
+    bias_a, bias_b = torch.empty(shape[1], device=DEV), torch.empty(shape[1], device=DEV)
+    a, t = G.gelu_backward_pair(pre, dg, colsum_out=bias_a)
+    ra, rt = G.to_operand_pair(G.gelu_backward(pre, dg), colsum_out=bias_b)
+    assert torch.equal(a, ra) and torch.equal(t, rt) and torch.equal(bias_a, bias_b)
+
+
 @pytest.mark.parametrize("shape", [(70, 132), (64, 64), (5, 260), (300, 2048), (129, 8)])
 def test_to_operand_pair_matches_the_two_single_conversions(shape):
     """One pass over an fp32 matrix -> bf16 operand rows and the rows of its transpose, both zero-padded to 64."""
