@@ -15,6 +15,9 @@ timeout 300 python tools/bench_decode.py --batch 4 > $O/decode_b4.log 2>&1
 timeout 300 python tools/bench_decode.py --tune 8=1 > $O/decode_first_form.log 2>&1
 timeout 300 python tools/bench_train.py --precision bf16 > $O/train_bf16.json 2>/dev/null
 timeout 300 python tools/bench_train.py --precision bf16 --batch 32 --seq 1024 > $O/train_bf16_b32.json 2>/dev/null
+timeout 300 python tools/bench_train.py --precision bf16 --train-mode --cpu-seconds 0 > $O/train_bf16_trainmode.json 2>/dev/null
+timeout 300 python tools/bench_train.py --precision bf16 --train-mode --cpu-seconds 0 --batch 32 --seq 1024 > $O/train_bf16_trainmode_b32.json 2>/dev/null
+timeout 200 python tools/rowops_train_bench.py > $O/rowops_train.json 2>/dev/null
 rm -rf $O/prof
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OLDPWD/$O/prof" -o kx -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --prof-steps 0 > "$OLDPWD/$O/prof_bench.log" 2>&1)
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && cp "$f" $O/kernel_stats_b32.csv && head -12 "$f"
