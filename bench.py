@@ -419,6 +419,20 @@ def main():
                                     "AdamW, 8 x 512 tokens, bf16 products on fp32 master weights (tools/bench_train.py)",
                         "tokens_per_s": round(8 * 512 / dt_t, 1), "ms_per_step": round(dt_t * 1e3, 2),
                         "loss": round(float(tloss), 4)}
+            del tr
+            # ... and the reference's own mode of that step: model.train() (/root/reference/train.py:642) = dropout and
+            # attention dropout 0.1 (kosmosx/model.py:175-177), Philox masks drawn inside the kernels
+            tr = LanguageModelTrainer(lm, precision="bf16", train_mode=True, dropout_seed=1234)
+            tr.step(tb[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(1, 4):
+                tloss = tr.step(tb[i])
+            torch.cuda.synchronize()
+            dt_t = (time.perf_counter() - t1) / 3
+            training["train_mode"] = {"dropout": tr.p_drop, "attention_dropout": tr.p_attn,
+                                      "tokens_per_s": round(8 * 512 / dt_t, 1), "ms_per_step": round(dt_t * 1e3, 2),
+                                      "loss": round(float(tloss), 4)}
             del tr, lm, tb
             torch.cuda.empty_cache()
         except Exception as e:                      # the headline line must not depend on the extra leg

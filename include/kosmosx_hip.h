@@ -227,8 +227,8 @@ typedef struct {
   /* ABI 4, training only (torchscale MultiheadAttention's dropout_module on the probabilities; the reference trains with
    * attention_dropout = 0.1, kosmosx/model.py:177): dropout_p > 0 keeps probability (b,h,q,k) iff Philox4x32-10(seed;
    * ((b*H + h)*Tq + q)*Tk + k, site) says so and scales it by 1/(1-p); the softmax normaliser stays un-dropped.  fp32
-   * q/k/v (the wave-per-query kernel), or KX_PREC_BF16 q/k/v with Tk % 4 == 0 (the matrix-core kernel: one Philox block
-   * per query and four keys); fp32 output, no stats_out; zero = off. */
+   * q/k/v (the wave-per-query kernel), or KX_PREC_BF16 q/k/v (the matrix-core kernel: one Philox block per query and four
+   * keys, two when Tk % 4 != 0); fp32 output, no stats_out; zero = off. */
   float dropout_p; int32_t dropout_site; uint64_t dropout_seed;
 } kx_attn_args;
 int kx_attention(const kx_attn_args* args, void* stream);
@@ -548,9 +548,8 @@ int kx_attention_backward_dropout(const float* q, const float* k, const float* v
                                   int64_t out_batch_stride, int32_t mask, float dropout_p, uint64_t seed, int32_t site,
                                   void* stream);
 /* The same on the matrix-core passes with bf16 products (q/k/v: KX_F32 rounded on the way in, or KX_BF16 as stored — what
- * kx_attention_backward takes with KX_PREC_BF16), for a KX_PREC_BF16 forward that ran with dropout_p > 0.  T % 4 == 0: one
- * Philox block covers four consecutive keys of a query (reference: attention_dropout = 0.1 under model.train(),
- * /root/reference/kosmosx/model.py:177, /root/reference/train.py:642). */
+ * kx_attention_backward takes with KX_PREC_BF16), for a KX_PREC_BF16 forward that ran with dropout_p > 0 (reference:
+ * attention_dropout = 0.1 under model.train(), /root/reference/kosmosx/model.py:177, /root/reference/train.py:642). */
 int kx_attention_backward_dropout_bf16(const void* q, const void* k, const void* v, int32_t qkv_dt, const float* out,
                                        const float* dout, const float* lse, float* dq, float* dk, float* dv, float* delta,
                                        int64_t B, int64_t H, int64_t T, int64_t qkv_row_stride, int64_t qkv_batch_stride,

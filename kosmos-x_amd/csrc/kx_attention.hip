@@ -204,7 +204,8 @@ __device__ __forceinline__ unsigned pack16x2(float lo, float hi) { return F16 ? 
 // (1536 workgroups = three rounds of the chip; folded: 1024 = two).  Bit-identical, and measured 0.8 % SLOWER in situ: off by default.
 // DROP (training): attention dropout on this kernel — the normaliser l sums the un-dropped probabilities (their ones-MFMA is
 // unchanged), O^T += V^T P^T takes the kept ones, 1 / (1 - p) goes into the final 1 / l; mask bits from kx_dropout.h, one
-// Philox block per (query, four keys) = per accumulator register quadruple.  Needs Tk % 4 == 0 (the dispatcher checks).
+// Philox block per (query, four keys) = per accumulator register quadruple (two when Tk % 4 != 0: the rows of the mask then
+// do not start on block boundaries).
 template <bool CAUSAL, bool F16 = false, bool FOLD = false, bool DROP = false>
 __global__ __launch_bounds__(FOLD ? 320 : 256, 2) void attn_bf16_v2_kernel(const AttnParams p) {
   static_assert(!(CAUSAL && FOLD), "the tail fold is for unmasked launches (causal blocks are paired instead)");
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(FOLD ? 320 : 256, 2) void attn_bf16_v2_kernel(const
           const unsigned long long row = (((unsigned long long)b * p.H + h) * p.Tq + (unsigned)(qw0 + qb * 16 + li)) * (unsigned long long)p.Tk;
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb) {
-            const unsigned keep = kx_dropout_keep4(p.drop_seed, p.drop_site, (row + (unsigned)(kv0 + kb * 16 + 4 * g)) >> 2, p.drop_thresh);
+            const unsigned keep = kx_dropout_keep4_at(p.drop_seed, p.drop_site, row + (unsigned)(kv0 + kb * 16 + 4 * g), p.drop_thresh, (p.Tk & 3) != 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) st[qb][kb][r] = ((keep >> r) & 1u) ? st[qb][kb][r] : 0.f;
           }
@@ -959,10 +960,10 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.stats_out = a->stats_out;
   p.lse_out = a->lse_out;
   const bool drop = a->dropout_p > 0.f;
-  // attention dropout: fp32 q/k/v on the wave-per-query kernel, or bf16 q/k/v (Tk % 4 == 0) on the matrix-core kernel
-  const bool drop_mfma = drop && a->prec == KX_PREC_BF16 && a->Tk % 4 == 0 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1;
+  // attention dropout: fp32 q/k/v on the wave-per-query kernel, or bf16 q/k/v on the matrix-core kernel
+  const bool drop_mfma = drop && a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1;
   KX_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (!drop || ((a->prec == KX_PREC_F32 || drop_mfma) && a->odt == KX_F32 && !a->stats_out)),
-             "kx_attention: dropout_p must be in [0, 1) and needs fp32 q/k/v (or bf16 with Tk %% 4 == 0), an fp32 output and no stats_out");
+             "kx_attention: dropout_p must be in [0, 1) and needs fp32 or bf16 q/k/v, an fp32 output and no stats_out");
   p.drop_thresh = drop ? (unsigned)fminf(4294967295.0f, a->dropout_p * 4294967296.0f) : 0u;
   p.drop_inv_keep = 1.0f / (1.0f - a->dropout_p);
   p.drop_seed = a->dropout_seed; p.drop_site = (unsigned)a->dropout_site;

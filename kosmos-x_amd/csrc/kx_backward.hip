@@ -1202,7 +1202,7 @@ __device__ __forceinline__ void pack_blocks(const f32x4_t (&y)[4], u32x4_t (&pf)
   }
 }
 
-// DROP (training, T % 4 == 0): attention dropout — O = (P (.) M / (1-p)) V, so dV takes the dropped P, dP arrives through the
+// DROP (training): attention dropout — O = (P (.) M / (1-p)) V, so dV takes the dropped P, dP arrives through the
 // same mask and scale, dS = P (.) (dP - delta) with delta = rowsum(dO (.) O) as before; mask bits from kx_dropout.h (here the
 // transposed block: the lanes of a quad each draw one query's Philox block and exchange the keep bits).
 template <bool CAUSAL, typename QT, bool DROP = false>   // QT: element type of q, k, v (fp32 rounded on the way in, or bf16 as stored)
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __rest
         unsigned keepq = 0xFu;                           // bit r: (query 4g + r, this lane's key) is kept
         if (DROP) {   // this lane draws the block of query 4g + (i & 3) over the quad's four keys, then the quad transposes
           const unsigned long long row = (((unsigned long long)b * H + h) * T + (unsigned)(q0 + 16 * qbk + 4 * g + (i & 3))) * (unsigned long long)T;
-          keepq = kx_dropout_quad_transpose(kx_dropout_keep4(drop_seed, drop_site, (row + (unsigned)(kw0 + (i & ~3))) >> 2, drop_thresh), i & 3);
+          keepq = kx_dropout_quad_transpose(kx_dropout_keep4_at(drop_seed, drop_site, row + (unsigned)(kw0 + (i & ~3)), drop_thresh, (T & 3) != 0), i & 3);
         }
   #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1374,9 +1374,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const QT* __restr
         }
         unsigned keep = 0xFu;                            // one Philox block = this query's keys 4g .. 4g + 3 of the block
         if (DROP)
-          keep = kx_dropout_keep4(drop_seed, drop_site,
-                                  ((((unsigned long long)b * H + h) * T + (unsigned)qi) * (unsigned long long)T + (unsigned)(k0 + 16 * kbk + 4 * g)) >> 2,
-                                  drop_thresh);
+          keep = kx_dropout_keep4_at(drop_seed, drop_site,
+                                     (((unsigned long long)b * H + h) * T + (unsigned)qi) * (unsigned long long)T + (unsigned)(k0 + 16 * kbk + 4 * g),
+                                     drop_thresh, (T & 3) != 0);
   #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kj = k0 + 16 * kbk + 4 * g + r;
@@ -1834,7 +1834,7 @@ extern "C" int kx_attention_backward_dropout(const float* q, const float* k, con
 }
 
 // ... and on the matrix-core passes with bf16 products (q/k/v fp32 or bf16 as kx_attention_backward with KX_PREC_BF16 takes
-// them): the training step's attention backward in train mode.  T % 4 == 0 (one Philox block = four consecutive keys).
+// them): the training step's attention backward in train mode (one Philox block per query and four keys; two when T % 4 != 0).
 extern "C" int kx_attention_backward_dropout_bf16(const void* qv_, const void* kv_, const void* vv_, int32_t qkv_dt,
                                                   const float* out, const float* dout, const float* lse, float* dq, float* dk,
                                                   float* dv, float* delta, int64_t B, int64_t H, int64_t T,
@@ -1843,8 +1843,8 @@ extern "C" int kx_attention_backward_dropout_bf16(const void* qv_, const void* k
                                                   int32_t site, void* stream) {
   KX_REQUIRE(qv_ && kv_ && vv_ && out && dout && lse && dq && dk && dv && delta, "kx_attention_backward_dropout_bf16: null pointer");
   KX_REQUIRE(qkv_dt == KX_F32 || qkv_dt == KX_BF16, "kx_attention_backward_dropout_bf16: q/k/v are fp32 or bf16");
-  KX_REQUIRE(B > 0 && H > 0 && T > 0 && T % 4 == 0 && B < 65536 && H < 65536 && dropout_p >= 0.f && dropout_p < 1.f,
-             "kx_attention_backward_dropout_bf16: bad shape (T %% 4 == 0) or dropout_p outside [0, 1)");
+  KX_REQUIRE(B > 0 && H > 0 && T > 0 && B < 65536 && H < 65536 && dropout_p >= 0.f && dropout_p < 1.f,
+             "kx_attention_backward_dropout_bf16: bad shape or dropout_p outside [0, 1)");
   const int es = qkv_dt == KX_BF16 ? 2 : 4;
   KX_REQUIRE((qkv_row_stride * es) % 16 == 0 && out_row_stride % 4 == 0 && (qkv_batch_stride * es) % 16 == 0 &&
                  out_batch_stride % 4 == 0 && qkv_row_stride % 4 == 0 && qkv_batch_stride % 4 == 0 &&

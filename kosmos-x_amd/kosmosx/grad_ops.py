@@ -246,7 +246,7 @@ def attention_backward(qkv, out, dout, lse, B, T, Hh, causal=True, bf16_products
     es = qkv.element_size()
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es
     dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * 4, dqkv.data_ptr() + 2 * D * 4
-    if dropout is not None and bf16_products:      # train mode on the matrix-core passes (bf16 products; T % 4 == 0)
+    if dropout is not None and bf16_products:      # train mode on the matrix-core passes (bf16 products)
         H.check(H.load().kx_attention_backward_dropout_bf16(q, k, v, H.KX_BF16 if qkv.dtype == torch.bfloat16 else H.KX_F32,
                                                             H.ptr(out), H.ptr(dout), H.ptr(lse), dq, dk, dv, H.ptr(delta), B, Hh,
                                                             T, 3 * D, T * 3 * D, D, T * D,

@@ -325,8 +325,8 @@ class LanguageModelTrainer:
             # bf16 mode: q, k, v live in bf16 (flash kernel with bf16 products forward and backward, fp32 statistics)
             wqkv_a, wqkv_t = o.pairW(wqkv)
             adrop = (self.p_attn, self._seed, 1 + 3 * li) if self.p_attn > 0 else None
-            # bf16 mode: the matrix-core flash kernels, with attention dropout too when T % 4 == 0 (one Philox block = four keys)
-            bf16_attn = self.precision == "bf16" and (adrop is None or T % 4 == 0)
+            # bf16 mode: the matrix-core flash kernels, attention dropout included (the Philox mask is drawn inside them)
+            bf16_attn = self.precision == "bf16"
             qkv = ops.gemm(o.opA(h1), wqkv_a, bqkv, qscale=0.125, qcols=D, xpos=tabs, xpos_dim=D if tabs else 0,
                            out_dtype=torch.bfloat16 if bf16_attn else torch.float32)
             del wqkv_a
@@ -430,7 +430,7 @@ class LanguageModelTrainer:
                                                                    P["inner_ln"].weight, dan, eps)
             adrop = (self.p_attn, self._seed, 1 + 3 * li) if self.p_attn > 0 else None
             dqkv = G.attention_backward(s["qkv"], s["att"].reshape(B, T, D), datt.reshape(B, T, D), s["lse"], B, T, Hh, True,
-                                        bf16_products=self.precision == "bf16" and (adrop is None or T % 4 == 0), dropout=adrop)
+                                        bf16_products=self.precision == "bf16", dropout=adrop)
             G.xpos_backward_(dqkv, D, T, tabs, 0.125)
             # q | k | v are adjacent in the flat layout: one GEMM output / one column sum covers the three
             dq_a, dq_t = o.pairA(dqkv, self._gspan(pfx + f"self_attn.q_proj{mw}.bias", 3 * D))

@@ -299,10 +299,11 @@ def test_dropout_ops_masks_are_a_function_of_seed_site_and_index():
 
 
 @pytest.mark.parametrize("causal", [True, False])
-@pytest.mark.parametrize("T", [72, 132, 320])
+@pytest.mark.parametrize("T", [72, 132, 320, 70, 114, 131])
 def test_attention_dropout_on_the_matrix_core_kernels(T, causal):
     """Train mode in bf16: the flash forward and both backward passes carry the Philox mask themselves (one block per
-    query and four keys; the dK/dV pass transposes keep bits inside lane quads).  Reference: fp64 autograd over the SAME
+    query and four keys — two when T % 4 != 0 (70, 114 = the multimodal decoder's length, 131): a row of the mask then
+    starts inside a block; the dK/dV pass transposes keep bits inside lane quads).  Reference: fp64 autograd over the SAME
     bf16-rounded q/k/v with the exported mask — what is left is the rounding of P / dS / dO to bf16, far below what one
     wrong mask bit costs (>= 1.33 * v / T on an output row)."""
     from kosmosx import grad_ops as G, ops
@@ -332,16 +333,12 @@ def test_attention_dropout_on_the_matrix_core_kernels(T, causal):
             assert rms < 1.2e-2, (name, rms)
     # the same launch twice: masks are a function of (seed, site, index), nothing else
     assert torch.equal(out, ops.attention(q3, k3, v3, causal, out_dtype=torch.float32, lse_out=lse, dropout=(p, 4321, 9)))
-    # T % 4 != 0 has no whole Philox block per register quadruple: refused here (the trainer keeps the fp32 kernels for it)
-    if T == 72:
-        with pytest.raises((RuntimeError, ValueError)):
-            ops.attention(q3[:, :70], k3[:, :70], v3[:, :70], causal, out_dtype=torch.float32, dropout=(p, 1, 1))
 
 
 @pytest.mark.parametrize("T", [32, 30])
 def test_train_mode_in_bf16_matches_autograd_with_the_same_masks(T):
-    """precision="bf16", train_mode=True: T = 32 runs the matrix-core attention kernels with the mask inside, T = 30 the
-    fp32 wave-per-query ones; every gradient against autograd over the oracle with the exported masks at the
+    """precision="bf16", train_mode=True: the matrix-core attention kernels with the mask inside (T = 30: rows of the mask
+    that straddle Philox blocks); every gradient against autograd over the oracle with the exported masks at the
     mixed-precision tolerance of test_mixed_precision_gradients."""
     lm = _tiny_lm(seed=8)
     cfg = O.DecoderCfg(layers=2, dim=256, ffn=512, heads=4, vocab=1002, max_pos=128)
