@@ -493,6 +493,18 @@ size_t kx_layernorm_backward_workspace_bytes(int64_t rows, int64_t cols);
 int kx_layernorm_backward(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                           float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* LayerNorm(gelu(pre)) and its backward with the activation rebuilt on load: torchscale's FeedForwardNetwork runs fc1 -> gelu ->
+ * ffn_layernorm -> fc2 (subln; /root/reference/kosmosx/model.py:170-183), the training step keeps the pre-activation only and
+ * never writes the activation.  kx_gelu_layernorm: y (KX_F32 or KX_BF16 rows) = LN(gelu(pre)) * gamma + beta, cols % 4 == 0,
+ * cols <= 8192.  kx_gelu_layernorm_backward: kx_layernorm_backward with x = gelu(pre); dx is the gradient at the activation
+ * (kx_gelu_backward_operand_pair continues from it); one-pass shapes only — kx_gelu_layernorm_backward_supported(cols) != 0:
+ * cols a multiple of 1024 up to 4096, 6144 or 8192; workspace as kx_layernorm_backward_workspace_bytes. */
+int kx_gelu_layernorm(const float* pre, const float* gamma, const float* beta, void* y, kx_dtype ydt, int64_t rows,
+                      int64_t cols, float eps, void* stream);
+int kx_gelu_layernorm_backward_supported(int64_t cols);
+int kx_gelu_layernorm_backward(const float* pre, const float* gamma, const float* dy, const float* dres, float* dx,
+                               float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps, void* workspace,
+                               size_t workspace_bytes, void* stream);
 /* exact (erf) GELU forward on a kept pre-activation, and its backward: dpre = dg * (Phi(pre) + pre*phi(pre)) */
 int kx_gelu_forward(const float* pre, float* out, int64_t n, void* stream);
 int kx_gelu_backward(const float* pre, const float* dg, float* dpre, int64_t n, void* stream);

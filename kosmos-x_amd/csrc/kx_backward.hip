@@ -5,6 +5,7 @@
 // deterministic (fixed summation order, no atomics).  Row kernels are HBM-bound; the attention backward runs on the
 // exact-f32 matrix instruction (a plain LDS-tiled VALU version is kept as tuning key 2 = 1).
 #include "kx_common.h"
+#include "kx_gelu_load.h"
 #include "kx_dropout.h"
 
 namespace {
@@ -406,7 +407,9 @@ __global__ __launch_bounds__(256) void ln_bwd_param_final_kernel(const float* __
 //   Two block reductions per row instead of four (mean; then the centred second moment, sum(g) and sum(g*(x-mean))
 //   together), each one DPP wave sum + one barrier (the LDS slots alternate, so no second barrier is needed).
 //   Traffic: x + dy (+ dres) read once, dx written once — the two-kernel form read x and dy twice.
-template <int NV, int NW>
+//   GELU_IN (kx_gelu_layernorm_backward): the normalised row is gelu(x) — x is the saved pre-activation, the activation
+//   itself was never written (kx_gelu_layernorm); dx is the gradient with respect to the ACTIVATION, as before.
+template <int NV, int NW, bool GELU_IN = false>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ dy, const float* __restrict__ dres,
                                                                float* __restrict__ dx, float* __restrict__ part,
@@ -431,7 +434,10 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_fused_kernel(const float* __re
   for (long long r = r0; r < r1; ++r) {
     float4 rv[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { xv[i] = xn[i]; dv[i] = dn[i]; rv[i] = rn[i]; }
+    for (int i = 0; i < NV; ++i) {
+      xv[i] = xn[i]; dv[i] = dn[i]; rv[i] = rn[i];
+      if (GELU_IN) xv[i] = gelu4_rounded(xv[i]);
+    }
     if (r + 1 < r1) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -1550,9 +1556,30 @@ static int fused_ln_bwd_shape(int64_t cols) {
 }
 extern "C" size_t kx_layernorm_backward_workspace_bytes(int64_t rows, int64_t cols);
 
+static int layernorm_backward_impl(bool gelu_in, const float* x, const float* gamma, const float* dy, const float* dres,
+                                   float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int kx_layernorm_backward(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                                      float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+  return layernorm_backward_impl(false, x, gamma, dy, dres, dx, dgamma, dbeta, rows, cols, eps, workspace, workspace_bytes, stream);
+}
+// The backward of kx_gelu_layernorm: `pre` is the saved pre-activation, the LayerNorm's input gelu(pre) is rebuilt on load;
+// dx = the gradient at the ACTIVATION (kx_gelu_backward_operand_pair takes it from there).  Shapes of the one-pass kernel only
+// (kx_gelu_layernorm_backward_supported: cols a multiple of 1024 up to 4096, 6144, 8192) and 16-byte aligned rows; a caller
+// with another width writes the activation (kx_gelu_forward) and takes kx_layernorm_backward.
+extern "C" int kx_gelu_layernorm_backward_supported(int64_t cols) { return fused_ln_bwd_shape(cols) != 0; }
+extern "C" int kx_gelu_layernorm_backward(const float* pre, const float* gamma, const float* dy, const float* dres, float* dx,
+                                          float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  KX_REQUIRE(fused_ln_bwd_shape(cols) != 0, "kx_gelu_layernorm_backward: cols=%lld is not a one-pass shape", (long long)cols);
+  KX_REQUIRE((((uintptr_t)pre | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)dx) & 15) == 0,
+             "kx_gelu_layernorm_backward: pointers must be 16-byte aligned");
+  return layernorm_backward_impl(true, pre, gamma, dy, dres, dx, dgamma, dbeta, rows, cols, eps, workspace, workspace_bytes, stream);
+}
+static int layernorm_backward_impl(bool gelu_in, const float* x, const float* gamma, const float* dy, const float* dres,
+                                   float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t cols, float eps,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
   KX_REQUIRE(x && gamma && dy && dx && workspace, "kx_layernorm_backward: null pointer");
   KX_REQUIRE(rows > 0 && cols > 0 && cols <= 65536, "kx_layernorm_backward: bad shape");
   KX_REQUIRE(!dgamma == !dbeta, "kx_layernorm_backward: dgamma and dbeta go together");
@@ -1566,15 +1593,19 @@ extern "C" int kx_layernorm_backward(const float* x, const float* gamma, const f
   const bool aligned = ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)dx) & 15) == 0);
   const int fused = fused_ln_bwd_shape(cols);          // KOSMOSX_LN_BWD_TWO_KERNELS=1: the two-kernel form (A/B)
   static const bool two_kernels = [] { const char* e = getenv("KOSMOSX_LN_BWD_TWO_KERNELS"); return e && e[0] == '1'; }();
-  if (fused && aligned && !two_kernels) {
+  if (fused && aligned && (!two_kernels || gelu_in)) {
     // resident workgroups: four of 256 threads per CU (101 VGPRs at NV = 2), one of 768 / 1024 threads for the wide rows
     const int target = fused >= 6 ? 256 : 1024;
     const int rpb = (int)((rows + target - 1) / target);
     const int nb = (int)((rows + rpb - 1) / rpb);
     float* pp = dgamma ? part : nullptr;
 #define KX_LNB(NV, NW)                                                                                              \
-    hipLaunchKernelGGL((ln_bwd_fused_kernel<NV, NW>), dim3((unsigned)nb), dim3(NW * 64), 0, s, x, gamma, dy, dres, dx, pp, \
-                       (long long)rows, rpb, eps)
+    if (gelu_in)                                                                                                    \
+      hipLaunchKernelGGL((ln_bwd_fused_kernel<NV, NW, true>), dim3((unsigned)nb), dim3(NW * 64), 0, s, x, gamma, dy, dres, dx, \
+                         pp, (long long)rows, rpb, eps);                                                            \
+    else                                                                                                            \
+      hipLaunchKernelGGL((ln_bwd_fused_kernel<NV, NW>), dim3((unsigned)nb), dim3(NW * 64), 0, s, x, gamma, dy, dres, dx, pp, \
+                         (long long)rows, rpb, eps)
     switch (fused) {
       case 1: KX_LNB(1, 4); break;
       case 2: KX_LNB(2, 4); break;

@@ -3,6 +3,7 @@
 // All are one-pass streaming kernels: 16-byte coalesced accesses, one workgroup per row, fp32
 // statistics with wave-64 shuffles + one LDS hop.  They are bound by HBM bandwidth, never by VALU.
 #include "kx_common.h"
+#include "kx_gelu_load.h"
 
 namespace {
 
@@ -21,7 +22,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // Variant 1 (A/B reference): one workgroup (256 threads) per row; a thread owns up to 8 float4 (cols <= 8192).
 // Two-pass statistics on the register-resident row: mean, then centred variance (what
 // torch.nn.functional.layer_norm computes), eps inside the rsqrt.
-template <int OUT>   // kx_dtype of y
+// GELU_IN (training, kx_gelu_layernorm): the row is gelu(x) — torchscale's ffn_layernorm reads the activation, and the
+// step keeps only the pre-activation (the activation is never written: 134 MB per layer of the 24L / 2048-d step).
+template <int OUT, bool GELU_IN = false>   // kx_dtype of y
 __global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __restrict__ x, const float* __restrict__ pre_add,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ y,
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __res
     const int c = threadIdx.x + i * 256;
     if (c < nv) {
       v[i] = reinterpret_cast<const float4*>(xr)[c];
+      if (GELU_IN) v[i] = gelu4_rounded(v[i]);
       if (pre_add) {
         const float4 a = reinterpret_cast<const float4*>(pre_add)[c];
         v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const float* __res
 // Variant 0: one WAVE per row (4 rows per 256-thread workgroup): the row lives in registers (<= 32 float4 per lane for
 // cols <= 8192), statistics are pure wave-64 shuffles — no LDS, no barrier.  Two-pass statistics on the
 // register-resident row: mean, then centred variance (what torch.nn.functional.layer_norm computes).
-template <int OUT, int NV>  // OUT = kx_dtype of y, NV = float4 per lane (cols <= 256*NV)
+template <int OUT, int NV, bool GELU_IN = false>  // OUT = kx_dtype of y, NV = float4 per lane (cols <= 256*NV)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ pre_add,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ y,
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int c = lane + i * 64;
     if (c < nv) {
       v[i] = xr[c];
+      if (GELU_IN) v[i] = gelu4_rounded(v[i]);
       if (pre_add) {
         const float4 a = reinterpret_cast<const float4*>(pre_add)[c];
         v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
@@ -367,6 +372,40 @@ extern "C" int kx_layernorm(const float* x, const float* pre_add, const float* g
   else
     dispatch_ln<KX_F32>(x, pre_add, gamma, beta, y, rows, cols, eps, rows_per_group, out_group_stride, out_row_offset, s);
   KX_CHECK_LAUNCH("kx_layernorm");
+  return KX_OK;
+}
+
+// LayerNorm(gelu(pre)) — the training forward of torchscale's FeedForwardNetwork between fc1 and fc2 (fc1 -> gelu ->
+// ffn_layernorm; /root/reference/kosmosx/model.py:170-183 selects subln) without the activation in memory.  fp32 or bf16
+// rows out, identity row map.
+extern "C" int kx_gelu_layernorm(const float* pre, const float* gamma, const float* beta, void* y, kx_dtype ydt, int64_t rows,
+                                 int64_t cols, float eps, void* stream) {
+  KX_REQUIRE(pre && y, "kx_gelu_layernorm: null pointer");
+  KX_REQUIRE(rows > 0 && rows < (1ll << 31), "kx_gelu_layernorm: rows=%lld out of range", (long long)rows);
+  KX_REQUIRE(cols > 0 && cols % 4 == 0 && cols <= 8192, "kx_gelu_layernorm: cols=%lld must be a multiple of 4 and <= 8192",
+             (long long)cols);
+  KX_REQUIRE(ydt == KX_F32 || ydt == KX_BF16, "kx_gelu_layernorm: fp32 or bf16 rows out");
+  KX_REQUIRE((((uintptr_t)pre | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15) == 0,
+             "kx_gelu_layernorm: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  KxProfScope prof(KX_K_LAYERNORM, rows, cols, 0, s);
+  const float* none = nullptr;
+  if (cols > 2048) {
+    if (ydt == KX_BF16)
+      hipLaunchKernelGGL((layernorm_block_kernel<KX_BF16, true>), dim3((unsigned)rows), dim3(256), 0, s, pre, none, gamma, beta, y,
+                         (int)cols, eps, (long long)rows, 0ll, 0ll);
+    else
+      hipLaunchKernelGGL((layernorm_block_kernel<KX_F32, true>), dim3((unsigned)rows), dim3(256), 0, s, pre, none, gamma, beta, y,
+                         (int)cols, eps, (long long)rows, 0ll, 0ll);
+  } else {
+#define KX_GLN(OUT, NV)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_kernel<OUT, NV, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, pre, none, gamma, \
+                     beta, y, (long long)rows, (int)cols, eps, (long long)rows, 0ll, 0ll)
+    if (ydt == KX_BF16) { if (cols <= 1024) KX_GLN(KX_BF16, 4); else KX_GLN(KX_BF16, 8); }
+    else { if (cols <= 1024) KX_GLN(KX_F32, 4); else KX_GLN(KX_F32, 8); }
+#undef KX_GLN
+  }
+  KX_CHECK_LAUNCH("kx_gelu_layernorm");
   return KX_OK;
 }
 

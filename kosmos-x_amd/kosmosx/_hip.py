@@ -169,6 +169,9 @@ SYMBOLS = {
     "kx_colsum": (C.c_int, [vp, i64, i64, i64, vp, i32, vp, C.c_size_t, vp]),
     "kx_layernorm_backward_workspace_bytes": (C.c_size_t, [i64, i64]),
     "kx_layernorm_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, vp, C.c_size_t, vp]),
+    "kx_gelu_layernorm": (C.c_int, [vp, vp, vp, vp, C.c_int, i64, i64, f32, vp]),
+    "kx_gelu_layernorm_backward_supported": (C.c_int, [i64]),
+    "kx_gelu_layernorm_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, vp, C.c_size_t, vp]),
     "kx_gelu_forward": (C.c_int, [vp, vp, i64, vp]),
     "kx_gelu_backward": (C.c_int, [vp, vp, vp, i64, vp]),
     "kx_cross_entropy": (C.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, vp]),

@@ -112,6 +112,34 @@ def layernorm_backward(x, gamma, dy, eps=1e-5, dres=None, want_param_grads=True,
     return dx, dg, db
 
 
+def gelu_layernorm(pre, gamma, beta, eps=1e-5, out_dtype=torch.float32):
+    """LayerNorm(gelu(pre)) * gamma + beta without the activation in memory (fp32 or bf16 rows)."""
+    _need_cuda(pre, gamma, beta)
+    R, Cc = pre.shape
+    out = torch.empty((R, Cc), dtype=out_dtype, device=pre.device)
+    H.check(H.load().kx_gelu_layernorm(H.ptr(pre), H.ptr(gamma), H.ptr(beta), H.ptr(out),
+                                       H.KX_BF16 if out_dtype == torch.bfloat16 else H.KX_F32, R, Cc, float(eps), _stream()),
+            "kx_gelu_layernorm")
+    return out
+
+
+def gelu_layernorm_backward(pre, gamma, dy, eps=1e-5, dres=None, dgamma_out=None, dbeta_out=None):
+    """layernorm_backward with x = gelu(pre) rebuilt on load (dx = the gradient at the activation); widths the one-pass kernel
+    is not built for write the activation first."""
+    _need_cuda(pre, gamma, dy, dres, dgamma_out, dbeta_out)
+    R, Cc = pre.shape
+    lib = H.load()
+    if not lib.kx_gelu_layernorm_backward_supported(Cc):
+        return layernorm_backward(gelu(pre), gamma, dy, eps, dres=dres, dgamma_out=dgamma_out, dbeta_out=dbeta_out)
+    dx = torch.empty_like(pre)
+    dg = dgamma_out if dgamma_out is not None else torch.empty(Cc, dtype=torch.float32, device=pre.device)
+    db = dbeta_out if dbeta_out is not None else torch.empty(Cc, dtype=torch.float32, device=pre.device)
+    ws = _ws(lib.kx_layernorm_backward_workspace_bytes(R, Cc), pre.device)
+    H.check(lib.kx_gelu_layernorm_backward(H.ptr(pre), H.ptr(gamma), H.ptr(dy), H.ptr(dres), H.ptr(dx), H.ptr(dg), H.ptr(db), R,
+                                           Cc, float(eps), H.ptr(ws), ws.numel(), _stream()), "kx_gelu_layernorm_backward")
+    return dx, dg, db
+
+
 def gelu_backward(pre, dg):
     _need_cuda(pre, dg)
     out = torch.empty_like(pre)

@@ -343,9 +343,11 @@ class LanguageModelTrainer:
                 x, wo_t = o.lin(a_n, P["o"].weight, P["o"].bias, residual=x)
             h2 = ops.layernorm(x, P["fl_ln"].weight.detach(), P["fl_ln"].bias.detach(), eps, out_dtype=o.ln_dt)
             pre, w1_t = o.lin(h2, P["fc1"].weight, P["fc1"].bias)
-            g = G.gelu(pre)
-            g_n = g if P["ffn_ln"] is None else ops.layernorm(g, P["ffn_ln"].weight.detach(), P["ffn_ln"].bias.detach(), eps,
-                                                              out_dtype=o.ln_dt)
+            if P["ffn_ln"] is None:
+                g = g_n = G.gelu(pre)
+            else:                                          # ffn_layernorm(gelu(pre)): the activation itself is never written
+                g = None
+                g_n = G.gelu_layernorm(pre, P["ffn_ln"].weight.detach(), P["ffn_ln"].bias.detach(), eps, out_dtype=o.ln_dt)
             if self.p_drop > 0:                            # x + dropout(fc2(.)): torchscale FeedForwardNetwork
                 fo, w2_t = o.lin(g_n, P["fc2"].weight, P["fc2"].bias)
                 y = G.dropout(fo, self.p_drop, self._seed, 3 + 3 * li, residual=x)
@@ -413,7 +415,12 @@ class LanguageModelTrainer:
             o.wgrad(dx_t, s["g_n"], out=grads[pfx + f"ffn{mw}.fc2.weight"])
             dgn = o.dgrad(dx_a, s["w2_t"])
             del dx_a, dx_t
-            dg = dgn if P["ffn_ln"] is None else self._ln_bwd(s["g"], pfx + f"ffn{mw}.ffn_layernorm", P["ffn_ln"].weight, dgn, eps)
+            if P["ffn_ln"] is None:
+                dg = dgn
+            else:                                          # x = gelu(pre) rebuilt on load
+                nm = pfx + f"ffn{mw}.ffn_layernorm"
+                dg, _, _ = G.gelu_layernorm_backward(s["pre"], P["ffn_ln"].weight.detach(), dgn, eps,
+                                                     dgamma_out=self.grads[nm + ".weight"], dbeta_out=self.grads[nm + ".bias"])
             dp_a, dp_t = o.pairA_gelu(s["pre"], dg, grads[pfx + f"ffn{mw}.fc1.bias"])
             o.wgrad(dp_t, s["h2"], out=grads[pfx + f"ffn{mw}.fc1.weight"])
             dh2 = o.dgrad(dp_a, s["w1_t"])

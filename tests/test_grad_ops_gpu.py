@@ -56,6 +56,24 @@ def test_layernorm_backward(rows, cols):
     assert dg3 is None and db3 is None and rel_err(dx3, x.grad) < 2e-5
 
 
+@pytest.mark.parametrize("rows,cols", [(300, 8192), (50, 2048), (77, 6144), (33, 512), (20, 1024), (9, 4100)])
+def test_gelu_layernorm_forward_and_backward_rebuild_the_activation(rows, cols):
+    """kx_gelu_layernorm / kx_gelu_layernorm_backward == the LayerNorm kernels on a written gelu(pre), bit for bit (the same
+    erf GELU on load): the training step's FFN keeps the pre-activation only."""
+    g = _g(21 + cols)
+    pre = (torch.randn(rows, cols, generator=g) * 2).to(DEV)
+    gam, bet = torch.randn(cols, generator=g).to(DEV), torch.randn(cols, generator=g).to(DEV)
+    dy = torch.randn(rows, cols, generator=g).to(DEV)
+    act = G.gelu(pre)
+    for dt in (torch.float32, torch.bfloat16):
+        assert torch.equal(G.gelu_layernorm(pre, gam, bet, 1e-5, out_dtype=dt), ops.layernorm(act, gam, bet, 1e-5, out_dtype=dt))
+    dx, dg, db = G.gelu_layernorm_backward(pre, gam, dy)
+    rx, rg, rb = G.layernorm_backward(act, gam, dy)
+    assert torch.equal(dx, rx) and torch.equal(dg, rg) and torch.equal(db, rb)
+    ref = torch.nn.functional.layer_norm(torch.nn.functional.gelu(pre.cpu()), (cols,), gam.cpu(), bet.cpu(), 1e-5)
+    assert rel_err(G.gelu_layernorm(pre, gam, bet, 1e-5), ref) < 2e-5
+
+
 def test_layernorm_backward_rows_far_from_zero():
     """Row means of 1e3 with unit spread: the second moment is taken on centred values (no E[x^2] - mean^2 cancellation)."""
     g = _g(33)
