@@ -1132,14 +1132,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
 // the B operand (k-slice (g,v) <-> tile row 32c + 16(v>>2) + 4g + (v&3), the same map on both operands).
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+// LDS layout of the staged 64 x 64 bf16 tiles.  Two access patterns read them: ROW fragments (sixteen lanes = sixteen
+// consecutive rows, 16 bytes each — the A operands of S and dP) and TRANSPOSING reads (ds_read_b64_tr_b16: thirty-two lanes
+// = eight consecutive rows x four 8-byte pieces — the A operands of dV / dK / dQ).  A padded pitch serves one of them:
+// 160 B is conflict-free for the transposing reads and two-way conflicted for the row fragments (rows i and i + 8 share
+// their banks), 144 B the reverse.  So: pitch 128 B, no padding, and the 16-byte chunk index of a row XOR-ed with
+//   h(row) = ((row >> 1) & 3) << 1 | ((row >> 3) & 1)
+// — sixteen consecutive rows of one chunk column land in sixteen distinct 16-byte bank groups (bijective in (row >> 1) & 7,
+// rows r and r + 1 differ by the 128-byte pitch), and eight consecutive rows x two adjacent chunks in thirty-two distinct
+// 8-byte groups (bits 2:1 of h separate the row pairs).  Built, bit-identical, and measured 3-5 % SLOWER than the padded
+// layout (round 3, tools/attn_bwd_bench.py: 8 x 1024 causal 460.8 -> 482.8 us, 4 x 2048 803.7 -> 840.6): the passes are bound
+// by their VALU work (the attention-dropout variant, which only adds Philox rounds, takes 1.5x), not by LDS bandwidth, and the
+// swizzle adds address arithmetic to every fragment.  Kept as an A/B build (-DKX_ATTN_BWD_SWIZZLE=1); default: padded.
+#ifndef KX_ATTN_BWD_SWIZZLE
+#define KX_ATTN_BWD_SWIZZLE 0
+#endif
+#if KX_ATTN_BWD_SWIZZLE
+constexpr int XS = 64;   // LDS row pitch in bf16 elements (128 B), chunks swizzled
+__device__ __forceinline__ int xs_off(int row, int col) {   // element offset of (row, col); col a multiple of 4
+  const int h = (((row >> 1) & 3) << 1) | ((row >> 3) & 1);
+  return row * XS + ((((col >> 3) ^ h) << 3) | (col & 7));
+}
+#else
 constexpr int XS = 80;   // LDS row pitch in bf16 elements (160 B)
+__device__ __forceinline__ int xs_off(int row, int col) { return row * XS + col; }
+#endif
 __device__ __forceinline__ void stage_tile_bf16(bf16_t* dst, const float* src, long long stride, int r0, int T, int tid) {
   for (int i = tid; i < 64 * 16; i += 256) {
     const int r = i >> 4, c4 = (i & 15) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 + r < T) v = *reinterpret_cast<const float4*>(src + (long long)(r0 + r) * stride + c4);
     uint2 o; o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
-    *reinterpret_cast<uint2*>(dst + r * XS + c4) = o;
+    *reinterpret_cast<uint2*>(dst + xs_off(r, c4)) = o;
   }
 }
 // the same in two halves, so the global loads of tile t+1 fly while tile t is multiplied (4 float4 per thread and tile)
@@ -1156,7 +1180,7 @@ __device__ __forceinline__ void tile_lstore(bf16_t* dst, const float4 (&reg)[4],
   for (int j = 0; j < 4; ++j) {
     const int i = tid + 256 * j, r = i >> 4, c4 = (i & 15) * 4;
     uint2 o; o.x = pack_bf16x2(reg[j].x, reg[j].y); o.y = pack_bf16x2(reg[j].z, reg[j].w);
-    *reinterpret_cast<uint2*>(dst + r * XS + c4) = o;
+    *reinterpret_cast<uint2*>(dst + xs_off(r, c4)) = o;
   }
 }
 __device__ __forceinline__ u32x4_t row_frag_global(const bf16_t* rowp, int g, int s2) {  // bf16 source: one 16-byte load
@@ -1175,7 +1199,7 @@ __device__ __forceinline__ void tile_lstore_b(bf16_t* dst, const float4 (&reg)[4
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int i = tid + 256 * j, r = i >> 3, c8 = (i & 7) * 8;
-    *reinterpret_cast<float4*>(dst + r * XS + c8) = reg[j];
+    *reinterpret_cast<float4*>(dst + xs_off(r, c8)) = reg[j];
   }
 }
 __device__ __forceinline__ void tile_lstore_any(bf16_t* dst, const float4 (&reg)[4], int tid, const float*) { tile_lstore(dst, reg, tid); }
@@ -1186,10 +1210,10 @@ __device__ __forceinline__ u32x4_t row_frag_global(const float* rowp, int g, int
   return (u32x4_t){pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
 }
 __device__ __forceinline__ u32x4_t tile_row_frag(const bf16_t* X, int rb, int s2, int g, int i) {
-  return *reinterpret_cast<const u32x4_t*>(X + (rb * 16 + i) * XS + 32 * s2 + 8 * g);
+  return *reinterpret_cast<const u32x4_t*>(X + xs_off(rb * 16 + i, 32 * s2 + 8 * g));
 }
 __device__ __forceinline__ u32x4_t tile_tr_frag(const bf16_t* X, int c, int d, int g, int li) {
-  const bf16_t* vr = X + (32 * c + 4 * g + (li >> 2)) * XS + d * 16 + (li & 3) * 4;
+  const bf16_t* vr = X + xs_off(32 * c + 4 * g + (li >> 2), d * 16 + (li & 3) * 4);     // (h(row + 16) = h(row))
   const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)vr);
   const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vr + 16 * XS));
   const u32x2_t lo2 = __builtin_bit_cast(u32x2_t, lo), hi2 = __builtin_bit_cast(u32x2_t, hi);
@@ -1267,6 +1291,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __rest
     const float* Ds = Db[buf];
     if (t + 1 < ntiles) gload(t + 1);                 // in flight during this tile's MFMAs
     if (kw0 < T) {
+      // (A wave-uniform "this tile needs no mask" branch around the five mask instructions per probability was measured:
+      // -2.5 % on the plain passes, +4 % on the dropout variants — tools/attn_bwd_bench.py, round 3 — and not kept.)
       f32x4_t pb[4], sb[4];                              // P and dS of the four 16-query blocks: lane (g,i): key i, queries 4g+r
   #pragma unroll
       for (int qbk = 0; qbk < 4; ++qbk) {
