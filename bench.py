@@ -405,36 +405,31 @@ def main():
         try:
             from kosmosx.model import KosmosLanguage
             from kosmosx.training import LanguageModelTrainer
-            lm = KosmosLanguage(vocab_size=cfg.vocab, dim=cfg.decoder.decoder_embed_dim, _seed=0).eval().to(dev)
-            tr = LanguageModelTrainer(lm, precision="bf16")
             tb = [torch.randint(2, cfg.vocab, (8, 512), generator=g).to(dev) for _ in range(4)]
-            tr.step(tb[0])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(1, 4):
-                tloss = tr.step(tb[i])
-            torch.cuda.synchronize()
-            dt_t = (time.perf_counter() - t1) / 3
+
+            def train_leg(train_mode):                     # a fresh model per mode: the trainer updates its model's parameters
+                lm = KosmosLanguage(vocab_size=cfg.vocab, dim=cfg.decoder.decoder_embed_dim, _seed=0).eval().to(dev)
+                tr = LanguageModelTrainer(lm, precision="bf16", train_mode=train_mode, dropout_seed=1234)
+                tr.step(tb[0])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(1, 4):
+                    tloss = tr.step(tb[i])
+                torch.cuda.synchronize()
+                dt_t = (time.perf_counter() - t1) / 3
+                res = {"tokens_per_s": round(8 * 512 / dt_t, 1), "ms_per_step": round(dt_t * 1e3, 2), "loss": round(float(tloss), 4)}
+                if train_mode:
+                    res = {"dropout": tr.p_drop, "attention_dropout": tr.p_attn, **res}
+                del tr, lm
+                torch.cuda.empty_cache()
+                return res
             training = {"workload": "KosmosLanguage 24L/2048d next-token step: forward + backward + clip_grad_norm_(1.0) + "
                                     "AdamW, 8 x 512 tokens, bf16 products on fp32 master weights (tools/bench_train.py)",
-                        "tokens_per_s": round(8 * 512 / dt_t, 1), "ms_per_step": round(dt_t * 1e3, 2),
-                        "loss": round(float(tloss), 4)}
-            del tr
+                        **train_leg(False)}
             # ... and the reference's own mode of that step: model.train() (/root/reference/train.py:642) = dropout and
             # attention dropout 0.1 (kosmosx/model.py:175-177), Philox masks drawn inside the kernels
-            tr = LanguageModelTrainer(lm, precision="bf16", train_mode=True, dropout_seed=1234)
-            tr.step(tb[0])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(1, 4):
-                tloss = tr.step(tb[i])
-            torch.cuda.synchronize()
-            dt_t = (time.perf_counter() - t1) / 3
-            training["train_mode"] = {"dropout": tr.p_drop, "attention_dropout": tr.p_attn,
-                                      "tokens_per_s": round(8 * 512 / dt_t, 1), "ms_per_step": round(dt_t * 1e3, 2),
-                                      "loss": round(float(tloss), 4)}
-            del tr, lm, tb
-            torch.cuda.empty_cache()
+            training["train_mode"] = train_leg(True)
+            del tb
         except Exception as e:                      # the headline line must not depend on the extra leg
             training = {"error": f"{type(e).__name__}: {e}"}
 
