@@ -215,17 +215,21 @@ __global__ __launch_bounds__(FOLD ? 320 : 256, 2) void attn_bf16_v2_kernel(const
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.x, b = blockIdx.z;   // grid (H, query blocks, B): head fastest — a head's blocks share one XCD's L2 (H % 8 == 0)
+  // Workgroups are dispatched round-robin over the eight XCDs by their linear index.  With the query block as the fastest
+  // grid index the blocks of one (batch, head) — which all stream that head's K / V — ran on eight different XCDs, each
+  // fetching its own copy into its own L2 (rocprofv3 FETCH_SIZE of the backward passes, built the same way: 2.5x their
+  // operands; head-fastest: 8 x 512 backward 171 -> 131 us, 4 x 2048 800 -> 515 us).  Head fastest keeps them on one XCD.
   // Causal work grows linearly with the query-block index and the dispatcher does not rebalance it (measured:
   // with one query block per workgroup a causal launch took as long as the unmasked one).  So a causal workgroup
   // processes the PAIR (x, nx-1-x): every workgroup carries the same nx+1 tiles whatever the placement.
   const int nx = (p.Tq + 127) >> 7;
-  const int qb_second = nx - 1 - (int)blockIdx.x;
-  const int npass = (CAUSAL && qb_second > (int)blockIdx.x) ? 2 : 1;
+  const int qb_second = nx - 1 - (int)blockIdx.y;
+  const int npass = (CAUSAL && qb_second > (int)blockIdx.y) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  const int qblk0 = (pass == 0 ? (int)blockIdx.x : qb_second) * 128;
+  const int qblk0 = (pass == 0 ? (int)blockIdx.y : qb_second) * 128;
   const int qw0 = qblk0 + wave * 32;                        // first query of this wave
-  const bool wave_live = qw0 < p.Tq && (!FOLD || wave < 4 || blockIdx.x + 1 == gridDim.x);   // (FOLD: wave 4 = the tail, last block only)
+  const bool wave_live = qw0 < p.Tq && (!FOLD || wave < 4 || blockIdx.y + 1 == gridDim.y);   // (FOLD: wave 4 = the tail, last block only)
   const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + (long long)b * p.qbs + (long long)h * 64;
   const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + (long long)b * p.kbs + (long long)h * 64;
   const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + (long long)b * p.kbs + (long long)h * 64;
@@ -478,12 +482,12 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.x, b = blockIdx.z;   // grid (H, query blocks, B), as v2
   const int nx = (p.Tq + 127) >> 7;
-  const int qb_second = nx - 1 - (int)blockIdx.x;            // causal: query-block pairs (x, nx-1-x), see v2
-  const int npass = (CAUSAL && qb_second > (int)blockIdx.x) ? 2 : 1;
+  const int qb_second = nx - 1 - (int)blockIdx.y;            // causal: query-block pairs (x, nx-1-x), see v2
+  const int npass = (CAUSAL && qb_second > (int)blockIdx.y) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  const int qblk0 = (pass == 0 ? (int)blockIdx.x : qb_second) * 128;
+  const int qblk0 = (pass == 0 ? (int)blockIdx.y : qb_second) * 128;
   const int qw0 = qblk0 + wave * 32;
   const bool wave_live = qw0 < p.Tq;
   const float* qp = reinterpret_cast<const float*>(p.q) + (long long)b * p.qbs + (long long)h * 64;
@@ -980,7 +984,7 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   if (a->prec == KX_PREC_F16C) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     const bool pvs = kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 4;       // 4 = A/B: P and V as plain fp16 (misses the tolerance)
-    const dim3 gc((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), gf(nx, (unsigned)a->H, (unsigned)a->B);
+    const dim3 gc((unsigned)a->H, (nx + 1) / 2, (unsigned)a->B), gf((unsigned)a->H, nx, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) {
       if (pvs) hipLaunchKernelGGL((attn_f16s_kernel<true, true>), gc, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_f16s_kernel<true, false>), gc, dim3(256), 0, s, p);
@@ -991,11 +995,11 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   } else if (f16) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     if (a->mask == KX_ATTN_CAUSAL)
-      hipLaunchKernelGGL((attn_bf16_v2_kernel<true, true>), dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<true, true>), dim3((unsigned)a->H, (nx + 1) / 2, (unsigned)a->B), dim3(256), 0, s, p);
     else if (fold)
-      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, true, true>), dim3(nx - 1, (unsigned)a->H, (unsigned)a->B), dim3(320), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, true, true>), dim3((unsigned)a->H, nx - 1, (unsigned)a->B), dim3(320), 0, s, p);
     else
-      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, true>), dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, true>), dim3((unsigned)a->H, nx, (unsigned)a->B), dim3(256), 0, s, p);
   } else if (a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1) {   // v1, kept for A/B
     dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, p);
@@ -1003,17 +1007,17 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   } else if (drop_mfma) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     if (a->mask == KX_ATTN_CAUSAL)
-      hipLaunchKernelGGL((attn_bf16_v2_kernel<true, false, false, true>), dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<true, false, false, true>), dim3((unsigned)a->H, (nx + 1) / 2, (unsigned)a->B), dim3(256), 0, s, p);
     else
-      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false, false, true>), dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false, false, true>), dim3((unsigned)a->H, nx, (unsigned)a->B), dim3(256), 0, s, p);
   } else if (a->prec == KX_PREC_BF16) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     if (a->mask == KX_ATTN_CAUSAL)   // causal workgroups take query-block pairs (x, nx-1-x)
-      hipLaunchKernelGGL((attn_bf16_v2_kernel<true, false>), dim3((nx + 1) / 2, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<true, false>), dim3((unsigned)a->H, (nx + 1) / 2, (unsigned)a->B), dim3(256), 0, s, p);
     else if (fold)
-      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false, true>), dim3(nx - 1, (unsigned)a->H, (unsigned)a->B), dim3(320), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false, true>), dim3((unsigned)a->H, nx - 1, (unsigned)a->B), dim3(320), 0, s, p);
     else
-      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false>), dim3(nx, (unsigned)a->H, (unsigned)a->B), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bf16_v2_kernel<false, false>), dim3((unsigned)a->H, nx, (unsigned)a->B), dim3(256), 0, s, p);
   } else if (kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1 && !drop) {
     dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->H, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL(attn_f32_mfma_kernel<true>, grid, dim3(256), 0, s, p);

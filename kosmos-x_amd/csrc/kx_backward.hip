@@ -1249,8 +1249,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const QT* __rest
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int key0 = blockIdx.x * 64, kw0 = key0 + wave * 16, ki = kw0 + i;
+  // grid (H, T / 64, B): the head is the FASTEST grid index, so that (H % 8 == 0) the key blocks of one (batch, head) — which
+  // all stream that head's Q and dO tiles — run on ONE XCD and share its L2; with the key block fastest they landed on eight
+  // different XCDs and each fetched its own copy (rocprofv3 FETCH_SIZE: 253 MB per launch at 8 x 512 for ~100 MB of operands)
+  const int h = blockIdx.x, b = blockIdx.z;
+  const int key0 = blockIdx.y * 64, kw0 = key0 + wave * 16, ki = kw0 + i;
   const QT* qb = q + (long long)b * batch_stride + (long long)h * 64;
   const QT* kb = k + (long long)b * batch_stride + (long long)h * 64;
   const QT* vb = v + (long long)b * batch_stride + (long long)h * 64;
@@ -1360,8 +1363,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const QT* __restr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 64, qw0 = q0 + wave * 16, qi = qw0 + i;
+  const int h = blockIdx.x, b = blockIdx.z;               // grid (H, T / 64, B): a head's query blocks share one XCD's L2 (see the dK/dV pass)
+  const int q0 = blockIdx.y * 64, qw0 = q0 + wave * 16, qi = qw0 + i;
   const QT* qb = q + (long long)b * batch_stride + (long long)h * 64;
   const QT* kb = k + (long long)b * batch_stride + (long long)h * 64;
   const QT* vb = v + (long long)b * batch_stride + (long long)h * 64;
@@ -1820,11 +1823,12 @@ extern "C" int kx_attention_backward(const void* qv_, const void* kv_, const voi
   const dim3 grid((unsigned)((T + 63) / 64), (unsigned)H, (unsigned)B);
   KX_REQUIRE(prec == KX_PREC_F32 || prec == KX_PREC_BF16, "kx_attention_backward: products in fp32 or bf16");
   if (prec == KX_PREC_BF16) {                                      // bf16 products, fp32 inputs / statistics / accumulators
+    const dim3 gridh((unsigned)H, (unsigned)((T + 63) / 64), (unsigned)B);      // head fastest: XCD-local Q / dO / K / V tiles
 #define KX_ATTN_BWD_B(CAUSAL, QT)                                                                                      \
-  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<CAUSAL, QT>), grid, dim3(256), 0, s, (const QT*)qv_, (const QT*)kv_,     \
+  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<CAUSAL, QT>), gridh, dim3(256), 0, s, (const QT*)qv_, (const QT*)kv_,    \
                      (const QT*)vv_, dout, lse, (const float*)delta, dk, dv, (int)T, (int)H, (long long)qkv_row_stride, \
                      (long long)qkv_batch_stride, (long long)out_row_stride, (long long)out_batch_stride);              \
-  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<CAUSAL, QT>), grid, dim3(256), 0, s, (const QT*)qv_, (const QT*)kv_,      \
+  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<CAUSAL, QT>), gridh, dim3(256), 0, s, (const QT*)qv_, (const QT*)kv_,     \
                      (const QT*)vv_, dout, lse, (const float*)delta, dq, (int)T, (int)H, (long long)qkv_row_stride,     \
                      (long long)qkv_batch_stride, (long long)out_row_stride, (long long)out_batch_stride)
     if (qkv_dt == KX_BF16) { if (mask == KX_ATTN_CAUSAL) { KX_ATTN_BWD_B(true, bf16_t); } else { KX_ATTN_BWD_B(false, bf16_t); } }
@@ -1912,7 +1916,7 @@ extern "C" int kx_attention_backward_dropout_bf16(const void* qv_, const void* k
   const long long nw = (long long)B * T * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, out, dout, delta, (int)B, (int)T,
                      (int)H, (long long)out_row_stride, (long long)out_batch_stride);
-  const dim3 grid((unsigned)((T + 63) / 64), (unsigned)H, (unsigned)B);
+  const dim3 grid((unsigned)H, (unsigned)((T + 63) / 64), (unsigned)B);      // head fastest (XCD-local tiles)
   const unsigned thresh = dropout_p > 0.f ? (unsigned)fminf(4294967295.0f, dropout_p * 4294967296.0f) : 0u;
   const float inv_keep = 1.0f / (1.0f - dropout_p);
 #define KX_ATTN_BWD_BD(CAUSAL, QT)                                                                                            \
