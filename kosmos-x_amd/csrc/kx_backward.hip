@@ -1623,8 +1623,9 @@ static int layernorm_backward_impl(bool gelu_in, const float* x, const float* ga
   const int fused = fused_ln_bwd_shape(cols);          // KOSMOSX_LN_BWD_TWO_KERNELS=1: the two-kernel form (A/B)
   static const bool two_kernels = [] { const char* e = getenv("KOSMOSX_LN_BWD_TWO_KERNELS"); return e && e[0] == '1'; }();
   if (fused && aligned && (!two_kernels || gelu_in)) {
-    // resident workgroups: four of 256 threads per CU (101 VGPRs at NV = 2), one of 768 / 1024 threads for the wide rows
-    const int target = fused >= 6 ? 256 : 1024;
+    // workgroups: two of 256 threads per CU (four per CU = 1024 partials of [2][cols]: 16 MB written and read back on top of
+    // 134 MB at 4096 x 2048, measured 36.3 against 30.1 us), one of 768 / 1024 threads per CU for the wide rows
+    const int target = fused >= 6 ? 256 : 512;
     const int rpb = (int)((rows + target - 1) / target);
     const int nb = (int)((rows + rpb - 1) / rpb);
     float* pp = dgamma ? part : nullptr;
