@@ -210,6 +210,13 @@ int kx_gemm(const kx_gemm_args* args, void* stream);
  * Replaces torchscale MultiheadAttention's bmm/nan_to_num/+mask/softmax(fp32)/bmm chain,
  * HF eager_attention_forward, and flamingo PerceiverAttention's einsum/amax/softmax/einsum.
  * Q is expected pre-scaled (and XPos-rotated) by the producing GEMM epilogue.
+ * nan_to_num (torchscale applies torch.nan_to_num to the scores before the mask; HF CLIP and flamingo do not): reproduced
+ * where it can matter — KX_ATTN_CAUSAL launches (the decoder's self-attention) and kx_attention_decode in KX_PREC_F32, whose
+ * operands span the fp32 range: NaN -> 0, +-inf -> +-FLT_MAX, then mask and softmax (tests/test_xpos_kat_gpu.py pins it on
+ * an overflowing score row against the torch statement).  KX_PREC_F16 / KX_PREC_F16C operands saturate at +-65504, so a
+ * score cannot leave the fp32 range from finite inputs (|s| <= 64 * 65504^2).  DIVERGENCE: KX_PREC_BF16 operands do span
+ * the fp32 range and that kernel does not clamp — an overflowing bf16 score row yields NaN where the reference yields a
+ * one-hot row (bf16 is the throughput mode outside the north star's tolerance; the parity modes are fp32 / f16c / mixed).
  *   q: [B, Tq, H, 64] with element strides (q_batch_stride, q_row_stride), head h at +h*64.
  *   k, v: [B, Tk, H, 64] with (kv_batch_stride, kv_row_stride).   dtype of `prec`.
  *   out: [B, Tq, H*64] contiguous rows of out_row_stride elements, dtype odt. */
@@ -612,7 +619,16 @@ int kx_set_tuning(int key, int value);
 typedef enum {
   KX_K_GEMM_BF16_128 = 0, KX_K_GEMM_BF16_64 = 1, KX_K_GEMM_F32_128 = 2, KX_K_GEMM_F32_64 = 3,
   KX_K_LAYERNORM = 4, KX_K_ATTN_BF16 = 5, KX_K_ATTN_F32 = 6, KX_K_EMBED = 7, KX_K_MISC = 8,
-  KX_K_GEMM_BF16_160 = 9, KX_K_GEMM_BF16_256X128 = 10, KX_K_GEMM_BF16_256X256 = 11
+  KX_K_GEMM_BF16_160 = 9, KX_K_GEMM_BF16_256X128 = 10, KX_K_GEMM_BF16_256X256 = 11,
+  /* the same tile kernels on KX_PREC_F16C rows (fp16 MFMA + two fp8 correction MFMAs: 2x the matrix time per algorithmic
+   * flop) and on plain KX_PREC_F16 rows — named for what they multiply, so a reader of a kernel table never sees an f16c
+   * kernel under a bf16 label (round 4) */
+  KX_K_GEMM_F16C_128 = 12, KX_K_GEMM_F16C_64 = 13, KX_K_GEMM_F16C_160 = 14, KX_K_GEMM_F16C_256X128 = 15,
+  KX_K_GEMM_F16C_256X256 = 16,
+  KX_K_GEMM_F16_128 = 17, KX_K_GEMM_F16_64 = 18, KX_K_GEMM_F16_160 = 19, KX_K_GEMM_F16_256X128 = 20,
+  KX_K_GEMM_F16_256X256 = 21,
+  KX_K_ATTN_F16 = 22,      /* the v2 flash kernel on fp16 MFMAs (KX_PREC_F16) */
+  KX_K_ATTN_F16S = 23      /* split-fp16 (hi, lo) flash kernel of KX_PREC_F16C: three MFMAs per product */
 } kx_kernel_kind;
 typedef struct {
   int32_t kind;      /* kx_kernel_kind */

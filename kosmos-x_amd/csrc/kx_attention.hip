@@ -17,6 +17,18 @@
 
 namespace {
 
+// torchscale's MultiheadAttention runs `attn_weights = torch.nan_to_num(attn_weights)` on the q.k scores before the mask and
+// the fp32 softmax (component/multihead_attention.py): NaN -> 0, +-inf -> +-FLT_MAX.  Only reachable when a score
+// leaves the fp32 range, i.e. in the kernels whose operands ARE fp32 (the parity mode): those apply it to every score of a
+// KX_ATTN_CAUSAL launch (= the decoder's self-attention, the only torchscale attention on the path; HF CLIP's eager attention
+// and flamingo's PerceiverAttention — KX_ATTN_FULL — have no such step and keep inf / NaN semantics) and of the decode step; the
+// 16-bit kernels cannot get there from finite inputs — fp16 / f16c operands saturate at 65504 (|score| <= 64 * 65504^2 =
+// 2.7e11) — except plain bf16, whose operands span the fp32 range: documented divergence (include/kosmosx_hip.h, kx_attention).
+__device__ __forceinline__ float score_nan_to_num(float s) {
+  s = fminf(fmaxf(s, -3.402823466e38f), 3.402823466e38f);      // +-inf -> +-FLT_MAX (fminf / fmaxf return the non-NaN operand ...)
+  return s != s ? 0.f : s;                                     // ... so NaN is tested last: NaN -> 0
+}
+
 struct AttnParams {
   const char* q; long long qbs, qrs;          // element strides
   const char* k; const char* v; long long kbs, krs;
@@ -741,6 +753,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
       dot = fmaf(qs[4 * d4 + 2], kk.z, dot);
       dot = fmaf(qs[4 * d4 + 3], kk.w, dot);
     }
+    if (CAUSAL) dot = score_nan_to_num(dot);              // KX_ATTN_CAUSAL = torchscale's MultiheadAttention (see score_nan_to_num)
     if (CAUSAL && key > qc) dot = -INFINITY;
     sc[key] = dot;
     mx = fmaxf(mx, dot);
@@ -853,7 +866,7 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const AttnParams p) 
       for (int r = 0; r < 4; ++r) {
         const int key = kv0 + kb * 16 + 4 * g + r;
         const bool ok = key < p.Tk && (!CAUSAL || key <= qi);
-        st[kb][r] = ok ? st[kb][r] : -INFINITY;
+        st[kb][r] = ok ? (CAUSAL ? score_nan_to_num(st[kb][r]) : st[kb][r]) : -INFINITY;
         mloc = fmaxf(mloc, st[kb][r]);
       }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
@@ -976,7 +989,8 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   KX_REQUIRE(!a->stats_out || !(a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1),
              "kx_attention: stats_out is not implemented by the v1 A/B kernel");
   hipStream_t s = (hipStream_t)stream;
-  KxProfScope prof(a->prec == KX_PREC_F32 ? KX_K_ATTN_F32 : KX_K_ATTN_BF16, a->B * a->H, a->Tq, a->Tk, s);
+  KxProfScope prof(a->prec == KX_PREC_F32 ? KX_K_ATTN_F32 : a->prec == KX_PREC_F16C ? KX_K_ATTN_F16S
+                   : a->prec == KX_PREC_F16 ? KX_K_ATTN_F16 : KX_K_ATTN_BF16, a->B * a->H, a->Tq, a->Tk, s);
   // unmasked launch whose last 128-query block would hold <= 32 queries, folded into a fifth wave: A/B only (tuning key
   // 2 = 5).  Measured at B = 32 (same box, round 3): mixed 1096 -> 1088 samples/s, bf16 1728 -> 1712 — the tail block's
   // workgroup has one live wave and retires quickly; 320-thread workgroups cost the other blocks more than it saves.
@@ -1119,6 +1133,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
         Ld4<T>::unpack(vr[u], v);
         float s = (q[0] * k[0] + q[1] * k[1]) + (q[2] * k[2] + q[3] * k[3]);
         s = row16_sum_dpp(s);                               // (= the xor butterfly 1, 2, 4, 8, bit for bit)
+        if constexpr (sizeof(T) == 4) s = score_nan_to_num(s);   // fp32 cache: the reference's nan_to_num (see above)
         const float mn = fmaxf(m, s);
         const float a = __expf(m - mn), pj = __expf(s - mn);
         l = l * a + pj;

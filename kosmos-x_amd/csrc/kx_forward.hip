@@ -645,6 +645,14 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
     // Block-scaled 16-bit planes, three rows and more: the residual GEMMs multiply fp16 pieces (kx_gemm_args.w_tiled = 3), and what
     // they read — the attention output, gelu(fc1) — is written AS pieces by its producer (KX_F16P, w_tiled = 4): the same bits the
     // consumer would make of the fp32 rows, made once instead of in every lane of every workgroup.
+    // the compressed plane formats ARE the weights of such a step: a layer without its streaming copies would make gemv16 fall
+    // back to the row-major operand while its producers already wrote KX_F16P rows (garbage logits, no error)
+    if (tfmt >= 2) {
+      KX_REQUIRE(w->wout_t, "kx_decoder_decode_step: KX_PREC_F32W24 / KX_PREC_F32W16 need the streaming copy wout_t");
+      for (int i = 0; i < w->layers; ++i)
+        KX_REQUIRE(w->layer[i].wqkv_t && w->layer[i].wo_t && w->layer[i].w1_t && w->layer[i].w2_t,
+                   "kx_decoder_decode_step: KX_PREC_F32W24 / KX_PREC_F32W16 need wqkv_t / wo_t / w1_t / w2_t of layer %d", i);
+    }
     const int gv = kx_tuning_get(KX_TUNE_GEMV_VARIANT);
     const bool pieces = tfmt == 3 && M >= 3 && gv != 1 && gv != 4 && gv != 5 && gv < 10 && kx_tuning_get(KX_TUNE_DECODE_PIECES) != 1;
     float *pa = x, *pb = nullptr;                                 // the stream as the next reader finds it

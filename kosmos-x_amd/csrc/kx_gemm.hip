@@ -278,11 +278,14 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
                "kx_gemm: ln_out needs 16-byte aligned gamma / beta / output");
     KX_REQUIRE(!a->stats_out, "kx_gemm: the row reduce does not produce statistics");
   }
+  // 16-bit tile kernels: [bf16 | f16c | f16] x [128, 64, 160, 256x128, 256x256]
+  static const int kinds16[3][5] = {
+      {KX_K_GEMM_BF16_128, KX_K_GEMM_BF16_64, KX_K_GEMM_BF16_160, KX_K_GEMM_BF16_256X128, KX_K_GEMM_BF16_256X256},
+      {KX_K_GEMM_F16C_128, KX_K_GEMM_F16C_64, KX_K_GEMM_F16C_160, KX_K_GEMM_F16C_256X128, KX_K_GEMM_F16C_256X256},
+      {KX_K_GEMM_F16_128, KX_K_GEMM_F16_64, KX_K_GEMM_F16_160, KX_K_GEMM_F16_256X128, KX_K_GEMM_F16_256X256}};
+  const int tsel = (tile == 64 || tile == 16) ? 1 : tile == 160 ? 2 : (tile == 256 || tile == 257) ? 3 : (tile == 512 || tile == 384) ? 4 : 0;
   const int kind = a->prec == KX_PREC_F32 ? (tile == 64 || tile == 16 ? KX_K_GEMM_F32_64 : KX_K_GEMM_F32_128)
-                   : (tile == 64 || tile == 16) ? KX_K_GEMM_BF16_64
-                   : tile == 160 ? KX_K_GEMM_BF16_160
-                   : (tile == 256 || tile == 257) ? KX_K_GEMM_BF16_256X128
-                   : (tile == 512 || tile == 384) ? KX_K_GEMM_BF16_256X256 : KX_K_GEMM_BF16_128;
+                                          : kinds16[f16c ? 1 : f16 ? 2 : 0][tsel];
   KxProfScope prof(kind, a->M, a->N, a->K, s);
   if (tile == 512 || tile == 384) {
     const int st = kx_tuning_get(KX_TUNE_GEMM_STAGGER);

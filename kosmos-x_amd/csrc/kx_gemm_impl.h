@@ -2719,8 +2719,12 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
     return KX_ERR_INVALID_ARG;
   }
   const dim3 grid((unsigned)((p.N + 15) / 16), (unsigned)(p.gsplit > 1 ? p.gsplit : 1)), block(64 * S);
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
+  // per DEVICE (HIP applies a function attribute to the device current at the call): a second GPU used by the same
+  // process would otherwise launch these kernels with the 64 KB default and fail where more dynamic LDS is asked for
+  static std::once_flag attr_once[64];
+  int attr_dev = 0;
+  if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 64) attr_dev = 0;
+  std::call_once(attr_once[attr_dev], [] {   // the LayerNorm prologue may want more than the 64 KB default of dynamic LDS
     if constexpr (ES == 2) {
       (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)gemv_fused_kernel<KX_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -127,7 +127,10 @@ class ResamplePlan(C.Structure):
 
 KERNEL_KINDS = ["gemm_bf16_128x128", "gemm_bf16_64x64", "gemm_f32_128x128", "gemm_f32_64x64", "layernorm",
                 "attn_bf16", "attn_f32", "embed", "misc", "gemm_bf16_160x128", "gemm_bf16_256x128_phased",
-                "gemm_bf16_256x256_phased"]
+                "gemm_bf16_256x256_phased",
+                "gemm_f16c_128x128", "gemm_f16c_64x64", "gemm_f16c_160x128", "gemm_f16c_256x128_phased", "gemm_f16c_256x256_phased",
+                "gemm_f16_128x128", "gemm_f16_64x64", "gemm_f16_160x128", "gemm_f16_256x128_phased", "gemm_f16_256x256_phased",
+                "attn_f16", "attn_f16s"]
 
 
 # every symbol include/kosmosx_hip.h declares: name -> (restype, argtypes)

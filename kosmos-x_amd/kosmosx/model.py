@@ -44,9 +44,6 @@ def _prec_dtype(prec: str):
     return torch.float32 if prec in ("fp32", "w24", "w16") else torch.float16 if prec == "f16" else torch.bfloat16
 
 
-_W16_PARTS = {}     # data_ptr of a "w16" operand -> (q int16, scale fp32) it was built from
-
-
 def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
     """A weight matrix [N,K] as the GEMM operand of `prec`: bf16 / fp32 cast, or for "bf16x3" the split rows
     [hi(K) | lo(K) | hi(K)] in bf16 (hi = bf16(w), lo = bf16(w - hi)) that pair with [hi | hi | lo] activation rows —
@@ -60,10 +57,7 @@ def _operand(t: torch.Tensor, prec: str) -> torch.Tensor:
     if prec == "w16":       # fp32 values (float)q * scale of the block-scaled int16 representation (the 16-bit streaming planes)
         from .ops import quantize_block16
         q, sc, wq = quantize_block16(t.float())
-        import weakref
-        for k_ in [k_ for k_, v_ in _W16_PARTS.items() if v_[2]() is None]:      # operands that were dropped before a decode step
-            del _W16_PARTS[k_]
-        _W16_PARTS[wq.data_ptr()] = (q, sc, weakref.ref(wq))     # the planes are built from these on the first decode step
+        wq._kx_w16_parts = (q, sc)          # the planes are built from these on the first decode step; they live and die with wq
         return wq
     if prec != "bf16x3":
         return t.to(_prec_dtype(prec)).contiguous()
@@ -79,8 +73,9 @@ def _operand_f16c(f: torch.Tensor) -> torch.Tensor:
     is the row's exponent (max|w| * 2^s in (64, 128]).  Returned as a flat uint8 tensor."""
     N, K = f.shape
     if K % 128:
-        raise ValueError(f"f16c operands need K % 128 == 0 (K={K}); precision 'mixed' / 'f16c' fall back to bf16x3 per stage "
-                         f"for such widths (_stage_prec), or set KOSMOSX_PRECISION / model.precision explicitly")
+        raise ValueError(f"f16c operands need K % 128 == 0 (K={K}): the DEFAULT precision 'mixed' runs such a stage in bf16x3 "
+                         f"(fp32 when decoding incrementally) by itself (_hip.stage_precision); an explicit 'f16c' does not fall "
+                         f"back — choose 'mixed', 'bf16x3' or 'fp32' for this model (model.precision / KOSMOSX_PRECISION)")
     amax = f.abs().amax(dim=1).clamp_min(2.0 ** -100)
     sexp = (7 - torch.ceil(torch.log2(amax))).clamp(-100, 100)          # integer-valued
     sc = torch.exp2(sexp)[:, None]
@@ -704,11 +699,13 @@ class Decoder(_PackedMixin, nn.Module):
                     raise ValueError("the compressed streaming planes need K % 32 == 0")   # (decoder widths are multiples of 64)
                 continue
             if prec == "w16":       # t holds (float)q * scale; q and scale were kept when it was packed
-                q, sc, ref = _W16_PARTS.pop(t.data_ptr(), (None, None, lambda: None))
-                if q is None or ref() is not t:
+                q, sc = getattr(t, "_kx_w16_parts", (None, None))
+                if q is None:
                     q, sc, wq = quantize_block16(t)
                     if not torch.equal(wq, t):
                         raise RuntimeError("w16 operand without its (q, scale) parts")
+                else:
+                    del t._kx_w16_parts                     # 2 B / weight: only the planes are needed from here on
                 tt = tile_weight_rows_w16(q, sc)
             else:
                 tt = tile_weight_rows_w24(t) if prec == "w24" else tile_weight_rows(t)
@@ -786,7 +783,16 @@ class Decoder(_PackedMixin, nn.Module):
         """torchscale's incremental_state protocol: the first call runs the whole prefix and fills the KV cache,
         every later call is given the token history (only its last token and its length are used, as upstream's
         `tokens[:, -1:]`) and appends one position.  ``state`` is an opaque dict owned by the caller."""
+        model_prec = prec
         prec = H.stage_precision(prec, "decoder", self._gemm_widths())
+        if prec == "bf16x3":
+            # the cache kernels are offered in bf16, fp32 and f16c.  Under the default mode the bf16x3 stage fallback (widths
+            # that are not multiples of 128, ADVICE r3) decodes in fp32 — the other arithmetic inside the tolerance that
+            # the prefill / step kernels implement; an explicit bf16x3 is refused here, not by a C error three calls down.
+            if model_prec != "mixed":
+                raise ValueError("incremental decoding is offered in bf16, fp32, f16c and mixed; precision 'bf16x3' has no "
+                                 "KV-cache kernels (use 'fp32' for the same accuracy class)")
+            prec = "fp32"
         w, _, _, emb, pos = self._pack(prec)
         lib = H.load()
         D, L = self.args.decoder_embed_dim, self.num_layers
@@ -833,7 +839,12 @@ class Decoder(_PackedMixin, nn.Module):
         # bits and streamed as THREE bytes each ("w24": kx_gemm_args.w_tiled = 2; the activations and the products stay fp32).
         # KOSMOSX_DECODE_EXACT=fp32 streams the full fp32 weights (4 bytes), =0 keeps the f16c tile GEMMs.
         exact = os.environ.get("KOSMOSX_DECODE_EXACT", "1")
-        sprec = prec if (prec != "f16c" or exact == "0") else ({"fp32": "fp32", "w24": "w24"}.get(exact, "w16"))
+        # the compressed forms (w24 / w16) exist to be STREAMED: without streaming copies (more than 16 sequences, or
+        # KOSMOSX_DECODE_TILED=0) they would run plain fp32 GEMMs on rounded weights — accuracy lost, no byte saved, and a
+        # second fp32 pack held — so those steps keep the f16c tile GEMMs the prefill ran.
+        streams = B <= 16 and os.environ.get("KOSMOSX_DECODE_TILED", "1") != "0"
+        sprec = prec if (prec != "f16c" or exact == "0" or not (streams or exact == "fp32")) else (
+            {"fp32": "fp32", "w24": "w24"}.get(exact, "w16"))
         if sprec != prec:
             w = self._pack(sprec)[0]
         if sprec in ("bf16", "fp32", "w24", "w16") and B <= 16:

@@ -33,6 +33,11 @@ class LogitsGatherer:
     * ``algo="all_gather"``: one ``all_gather_into_tensor`` (RCCL picks ring / tree).  ``algo="direct"``: world - 1
       grouped send / recv pairs, every peer over its own xGMI link at once — the fully-connected schedule SURVEY 8e
       computes at ~1/7 of a ring's time for this message (233 MB per rank in bf16 at 32 samples per GPU).
+      ``algo="auto"`` (default) decides per call from the message: ``direct`` when more than two ranks exchange at least
+      ``DIRECT_MIN_BYTES`` per rank (bandwidth-bound: a ring moves world - 1 shards over ONE link per rank, the direct
+      schedule one shard over each of world - 1 links), RCCL's ``all_gather`` below that (latency-bound: RCCL's tuned
+      small-message protocols) and for two ranks (one link either way).  The decision uses the LARGEST shard of the size
+      list, which every rank holds identically, so all ranks take the same branch.
     * Ragged shards (global batch not divisible by world): rows are padded to the largest shard for ``all_gather`` and
       the padding is dropped; ``direct`` sends exact sizes.  The per-rank row counts come from the caller whenever it
       knows them — ``gather(local, total=global_batch)`` (the ``shard_range`` split: no collective, no host sync) or
@@ -42,9 +47,9 @@ class LogitsGatherer:
     """
 
     def __init__(self, group=None, wire_dtype: torch.dtype | None = torch.bfloat16, overlap: bool = True,
-                 force: bool = False, algo: str = "all_gather", slots: int = 3):
-        if algo not in ("all_gather", "direct"):
-            raise ValueError("algo must be 'all_gather' or 'direct'")
+                 force: bool = False, algo: str = "auto", slots: int = 3):
+        if algo not in ("auto", "all_gather", "direct"):
+            raise ValueError("algo must be 'auto', 'all_gather' or 'direct'")
         self.group = group
         self.force = force          # run the collective even with a single rank (exercises the RCCL path in tests)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -57,6 +62,14 @@ class LogitsGatherer:
         self._slot = 0
         self._out = [None] * max(2, int(slots))
         self.last_algo = None                                   # what the last gather() actually ran (bench line)
+
+    DIRECT_MIN_BYTES = 8 << 20
+
+    def _pick(self, wire, sizes) -> str:
+        if self.algo != "auto":
+            return self.algo
+        row_bytes = wire.element_size() * (wire.numel() // max(1, wire.shape[0]))
+        return "direct" if self.world > 2 and max(sizes) * row_bytes >= self.DIRECT_MIN_BYTES else "all_gather"
 
     def _shard_sizes(self, rows: int, device, total=None, sizes=None) -> list:
         """Rows of every rank.  Every rank must take the same branch: `total` / `sizes` are collective-free, the
@@ -81,14 +94,14 @@ class LogitsGatherer:
         """P2POp peers are GLOBAL ranks; self.rank / the staggered schedule are group-local."""
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
-    def _exchange(self, out, wire, sizes):
-        if self.algo == "direct" and self.world == 1:           # force=True on one rank: the P2P machinery against itself
+    def _exchange(self, out, wire, sizes, algo):
+        if algo == "direct" and self.world == 1:           # force=True on one rank: the P2P machinery against itself
             ops = [dist.P2POp(dist.isend, wire, self._peer(0), self.group),
                    dist.P2POp(dist.irecv, out, self._peer(0), self.group)]
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
             return out
-        if self.algo == "direct" and self.world > 1:
+        if algo == "direct" and self.world > 1:
             offs = [0]
             for n in sizes:
                 offs.append(offs[-1] + n)
@@ -122,7 +135,8 @@ class LogitsGatherer:
         wire = local if (self.wire_dtype is None or local.dtype == self.wire_dtype) else local.to(self.wire_dtype)
         wire = wire.contiguous()
         sizes = self._shard_sizes(wire.shape[0], wire.device, total, sizes) if self.world > 1 else [wire.shape[0]]
-        self.last_algo = self.algo if self.world > 1 else f"{self.algo} (forced on one rank)"
+        algo = self._pick(wire, sizes)
+        self.last_algo = (algo if self.world > 1 else f"{algo} (forced on one rank)") + (" [auto]" if self.algo == "auto" else "")
         shape = (sum(sizes),) + tuple(wire.shape[1:])
         slot = self._slot
         self._slot = (self._slot + 1) % len(self._out)
@@ -134,13 +148,13 @@ class LogitsGatherer:
                 self._stream = torch.cuda.Stream(device=wire.device)
             self._stream.wait_stream(torch.cuda.current_stream(wire.device))
             with torch.cuda.stream(self._stream):
-                self._exchange(out, wire, sizes)
+                self._exchange(out, wire, sizes, algo)
                 ev = torch.cuda.Event()
                 ev.record(self._stream)
             wire.record_stream(self._stream)
             self._pending.append((ev, wire))
         else:
-            self._exchange(out, wire, sizes)
+            self._exchange(out, wire, sizes, algo)
         return out
 
     def wait(self):

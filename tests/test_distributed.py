@@ -181,6 +181,44 @@ def _gather_worker(rank, world, port, algo, total, q):
     dist.destroy_process_group()
 
 
+def _gather_auto_worker(rank, world, port, q):
+    for p in (str(ROOT), str(ROOT / "kosmos-x_amd"), str(ROOT / "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KOSMOSX_NO_LOGGING_CONFIG="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kosmosx.parallel import LogitsGatherer, shard_range
+    ga = LogitsGatherer(wire_dtype=None, slots=2)                     # the default: algo="auto"
+    ga.DIRECT_MIN_BYTES = 4096                                        # (instance override: the rule, not 8 MiB of test data)
+    res = []
+    for total, cols in ((7, 8), (7, 512)):                            # ragged: 3 + 2 + 2 rows; 96-byte rows, then 6 KB rows
+        full = torch.arange(total * 3 * cols, dtype=torch.float32).reshape(total, 3, cols)
+        lo, hi = shard_range(total, rank, world)
+        out = ga.gather(full[lo:hi], total=total)
+        ga.wait()
+        res.append((ga.last_algo, bool(torch.equal(out, full))))
+    if rank == 0:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_logits_gatherer_auto_picks_by_message_size():
+    """small messages take RCCL's all_gather, bandwidth-bound ones (the 233 MB logits shard) the
+    one-link-per-peer schedule when more than two ranks exchange; the decision uses the largest shard, identical on all ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_auto_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == ("all_gather [auto]", True) and res[1] == ("direct [auto]", True), res
+
+
 @pytest.mark.parametrize("algo", ["all_gather", "direct"])
 @pytest.mark.parametrize("world,total", [(2, 8), (2, 7), (3, 8)])
 def test_logits_gatherer_algorithms_and_ragged_shards(algo, world, total):

@@ -127,6 +127,38 @@ def test_full_size_batch32_multimodal_rows_against_the_oracle(full_mm, mm_refere
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# (b2) BASELINE configs[2] at its REAL batch: KosmosLanguage(32002, 2048), B = 32 x T = 2046 (/root/reference/example_lang.py:5-15;
+#      T = 2046, not 2048: SURVEY H3).  At 65,472 rows the kernel selection differs from the B = 1 / 2 runs of
+#      tests/test_model_gpu.py (persistent 256-row tiles on every GEMM, the polynomial GELU epilogue in bf16, 512 causal query
+#      blocks per head) — VERDICT r3 missing #3: this exact path had only ever been timed (bench.py's `c3`), never compared.
+# ------------------------------------------------------------------------------------------------------------------
+C3_ROWS = [0, 19, 31]
+
+
+@pytest.fixture(scope="module")
+def c3_reference(full_lm):
+    tok = torch.randint(0, 32002, (32, 2046), generator=torch.Generator().manual_seed(2046))
+    ref = O.kosmos_language_forward(oracle_weights(full_lm.cpu()), tok[C3_ROWS], O.DecoderCfg(vocab=32002))   # rows are independent
+    return tok, ref
+
+
+@pytest.mark.parametrize("prec", ["f16c", "bf16"])
+def test_c3_batch32_seq2046_rows_against_the_oracle(full_lm, c3_reference, prec):
+    tok, ref = c3_reference
+    lm = full_lm.to(DEV)
+    lm.precision = prec
+    out = lm(tok.to(DEV))
+    assert out.shape == (32, 2046, 32002) and out.dtype == torch.float32
+    rms = float(ref.pow(2).mean().sqrt())
+    errs = [rel_err(out[r], ref[i]) for i, r in enumerate(C3_ROWS)]
+    print(f"C3 (B=32, T=2046) {prec}: max|d|/rms per checked row {['%.2e' % e for e in errs]}, logit rms {rms:.4f} "
+          f"(max|d| absolute {max(errs) * rms:.3e})")
+    assert max(errs) < TOL[prec], errs
+    del out
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # (c) f16c outside N(0, sigma): outlier channels, massive residual channels, the fp16 range
 # ------------------------------------------------------------------------------------------------------------------
 def _lm8(seed=31):

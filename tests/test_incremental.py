@@ -60,6 +60,34 @@ def test_hip_prefill_and_decode_steps_match_full_forward(prec, tol):
 
 
 @pytest.mark.gpu
+def test_mixed_falls_back_for_widths_that_are_not_multiples_of_128_forward_and_incremental():
+    """dim = 192 has no f16c rows (128-element fp8 blocks).  Under the default mode the full forward runs the
+    decoder stage in bf16x3 and the incremental path — whose cache kernels exist in bf16, fp32 and f16c only — in fp32;
+    both hold 1e-3.  An explicit 'f16c' raises the Python error that names the remedy, an explicit 'bf16x3' with
+    incremental_state a ValueError (it used to surface as a C error from kx_decoder_prefill)."""
+    lm = KosmosLanguage(vocab_size=502, dim=192, depth=2, ffn_dim=320, decoder_heads=3, _seed=9, _perturb=0.1,
+                        _max_positions=64).eval()
+    cfg = O.DecoderCfg(layers=2, dim=192, ffn=320, heads=3, vocab=502, max_pos=64)
+    tok = torch.randint(0, 502, (2, 30), generator=torch.Generator().manual_seed(3))
+    ref = O.kosmos_language_forward(oracle_weights(lm), tok, cfg)
+    lm = lm.to("cuda")
+    tokd = tok.cuda()
+    lm.precision = "mixed"
+    assert rel_err(lm(tokd), ref) < 1e-3
+    state = {}
+    out = lm(tokd[:, :11], incremental_state=state)
+    assert rel_err(out, ref[:, :11]) < 1e-3 and state["prec"] == "fp32"
+    for t in range(11, 30):
+        assert rel_err(lm(tokd[:, : t + 1], incremental_state=state), ref[:, t:t + 1]) < 1e-3, t
+    lm.precision = "f16c"
+    with pytest.raises(ValueError, match="does not fall"):
+        lm(tokd)
+    lm.precision = "bf16x3"
+    with pytest.raises(ValueError, match="no KV-cache kernels"):
+        lm(tokd[:, :11], incremental_state={})
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 3, 6, 16])
 def test_f16c_decode_step_forms(B, monkeypatch):
     """The decode step of f16c / mixed: default = fp32 products on block-scaled 16-bit weights, streamed as 2.125 bytes each
