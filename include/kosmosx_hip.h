@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KX_ABI_VERSION 5
+#define KX_ABI_VERSION 6
 
 typedef enum {
   KX_OK = 0,
@@ -203,6 +203,18 @@ typedef struct {
    * ln_gamma, N % 16 == 0, K % (64 * ksplit) == 0.  residual2 (optional, with `residual`): second addend of the residual.
    * a_add (optional, with ln_gamma): second addend of the raw rows, LayerNorm(A + a_add) is the operand. */
   int32_t ksplit; void* C2; const float* residual2; const float* a_add;
+  /* ABI 6 — scratch for the PAIR split of the 256x256 tile kernel (optional; 16-bit operand precisions).  A problem whose
+   * 256x256 tiles fill about half of the chip's CUs (the decoder's out_proj / fc2 at M = 32 x 114: 15 x 8 = 120 tiles for 256
+   * CUs) is launched as 2 x tiles workgroups: the two workgroups of a pair take one half of the K extent each, exchange half
+   * of their fp32 accumulators through this scratch (write-through stores + an agent-scope flag hand-off: correct under any
+   * workgroup placement) and each runs the epilogue of half of the tile's rows — the 256x256 main loop instead of the
+   * 256x128 one, every CU busy, and half an epilogue per CU.  a + b == b + a: the result does not depend on which workgroup
+   * finishes a row; it differs from the unsplit kernels by fp32 summation order only (two partial sums per element).
+   * Layout: bytes [0, 4096) are the hand-off words — zero when the call is issued, zero again when it has completed (the
+   * stage-level entry points clear them once per call); then one 128 KB slab per workgroup.  kx_gemm takes the split when
+   * pair_ws_bytes >= 4096 + 2 * tiles * 131072, tiles % 8 == 0, 0.85 * CUs <= 2 * tiles <= CUs, K-tiles even, and the
+   * epilogue has no activation / produced statistics (tile = 0: automatic; tile = 1024 asks for it and fails otherwise). */
+  void* pair_ws; size_t pair_ws_bytes;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 
@@ -606,7 +618,8 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  * key 10: 1 = the fp32 decode step keeps the split-K tile kernels instead of the fp32 weight-streaming kernel (A/B).
  * key 11: 1 = the streamed decode step keeps ONE workgroup per 16 columns in its residual GEMMs (no kx_gemm_args.ksplit pair).
  * key 12: 1 = the fp16-pieces decode step keeps fp32 rows between its kernels (each consumer splits them itself) instead of
- *         KX_F16P rows written by the producers (A/B). */
+ *         KX_F16P rows written by the producers (A/B).
+ * key 13: 1 = never take the pair split of the 256x256 kernel (kx_gemm_args.pair_ws) automatically (A/B). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((address_space(1))) unsigned int gu32_t;   // a global word touched by agent-scope atomics (inter-workgroup hand-offs)
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
@@ -41,7 +42,7 @@ void kx_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- runtime tuning knobs (kx_set_tuning) ----
-enum { KX_TUNE_LN_VARIANT = 0, KX_TUNE_GEMM_TILE = 1, KX_TUNE_ATTN_VARIANT = 2, KX_TUNE_GEMM_STAGGER = 3, KX_TUNE_GEMM_EPILOGUE = 4, KX_TUNE_GEMM_IDLE_SKIP = 5, KX_TUNE_PREPROCESS_NO_LDS = 6, KX_TUNE_GEMM_PERSISTENT = 7, KX_TUNE_GEMV_VARIANT = 8, KX_TUNE_CACHE_LAYOUT = 9, KX_TUNE_DECODE_STREAM_F32 = 10, KX_TUNE_DECODE_KSPLIT = 11, KX_TUNE_DECODE_PIECES = 12, KX_TUNE_COUNT = 13 };
+enum { KX_TUNE_LN_VARIANT = 0, KX_TUNE_GEMM_TILE = 1, KX_TUNE_ATTN_VARIANT = 2, KX_TUNE_GEMM_STAGGER = 3, KX_TUNE_GEMM_EPILOGUE = 4, KX_TUNE_GEMM_IDLE_SKIP = 5, KX_TUNE_PREPROCESS_NO_LDS = 6, KX_TUNE_GEMM_PERSISTENT = 7, KX_TUNE_GEMV_VARIANT = 8, KX_TUNE_CACHE_LAYOUT = 9, KX_TUNE_DECODE_STREAM_F32 = 10, KX_TUNE_DECODE_KSPLIT = 11, KX_TUNE_DECODE_PIECES = 12, KX_TUNE_GEMM_PAIRK = 13, KX_TUNE_COUNT = 14 };
 int kx_tuning_get(int key);
 // number of K slices kx_gemm's automatic choice gives an (M, N, K) problem with `ws_bytes` of split-K scratch (1 = no split)
 int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_bytes);

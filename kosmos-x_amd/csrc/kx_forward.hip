@@ -107,6 +107,15 @@ struct SplitkScope {
   SplitkScope(void* p, size_t n) { g_splitk_ws = p; g_splitk_ws_bytes = n; }
   ~SplitkScope() { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; }
 };
+// scratch of the 256x256 kernel's pair split (kx_gemm_args.pair_ws) of the stage being launched: 4 KB of hand-off words,
+// cleared once per stage call, + one 128 KB slab per workgroup of a full round
+thread_local void* g_pair_ws = nullptr;
+thread_local size_t g_pair_ws_bytes = 0;
+constexpr size_t KX_PAIR_WS = 4096 + (size_t)256 * 131072;
+struct PairScope {
+  PairScope(void* p, size_t n) { g_pair_ws = p; g_pair_ws_bytes = p ? n : 0; }
+  ~PairScope() { g_pair_ws = nullptr; g_pair_ws_bytes = 0; }
+};
 
 namespace {
 
@@ -169,6 +178,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
   g.row_stats = row_stats; g.colsum = colsum; g.stats_out = stats_out;
   g.splitk_ws = g_splitk_ws; g.splitk_ws_bytes = g_splitk_ws_bytes; g.splitk = 0;
+  g.pair_ws = g_pair_ws; g.pair_ws_bytes = g_pair_ws_bytes;
   if (rf) {
     g.stats_partials = rf->partials; g.stats_in_nseg = rf->nseg; g.stats_in_seg = rf->seg; g.stats_eps = rf->eps;
     g.ln_out = rf->ln_out; g.ln_out_dt = rf->ln_dt; g.ln_out_gamma = rf->ln_g; g.ln_out_beta = rf->ln_b; g.ln_out_eps = rf->eps;
@@ -301,7 +311,7 @@ PerBufs per_plan(const kx_perceiver_weights* w, int64_t B, int64_t m, int prec, 
 }
 
 // ---------------- Decoder ----------------
-struct DecBufs { void *h, *qkv, *att, *g, *splitk; float *partials, *stats, *partials2, *stats2, *xb, *ya, *yb; size_t total; };
+struct DecBufs { void *h, *qkv, *att, *g, *splitk, *pair; float *partials, *stats, *partials2, *stats2, *xb, *ya, *yb; size_t total; };
 DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, char* base) {
   const int64_t M = B * T;
   const size_t es = esz(prec);
@@ -322,6 +332,7 @@ DecBufs dec_plan(const kx_decoder_weights* w, int64_t B, int64_t T, int prec, ch
   d.xb = d.ya = d.yb = nullptr;
   if (T == 1) { d.xb = (float*)c.take((size_t)M * w->dim * 4); d.ya = (float*)c.take((size_t)M * w->dim * 4); d.yb = (float*)c.take((size_t)M * w->dim * 4); }
   d.splitk = c.take(KX_SPLITK_WS);
+  d.pair = T > 1 ? c.take(KX_PAIR_WS) : nullptr;    // the tile kernels' pair split (out_proj / fc2 at half a round of 256x256 tiles)
   d.total = c.off;
   return d;
 }
@@ -487,6 +498,11 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
   }
   const int64_t M = B * T, D = w->dim, F = w->ffn;
   SplitkScope sk(d.splitk, KX_SPLITK_WS);
+  PairScope pk(d.pair, KX_PAIR_WS);
+  if (d.pair && hipMemsetAsync(d.pair, 0, 4096, s) != hipSuccess) {      // hand-off words: zero when a call is issued
+    kx_set_error("kx_decoder_forward: clearing the pair-split hand-off words failed");
+    return KX_ERR_LAUNCH;
+  }
   const int ct = cdt(prec);
   const size_t es = esz(prec);
   // Batch-1-sized problems (M = T = 114: every GEMM is split-K): the residual GEMMs' row-owning reduce kernels take the

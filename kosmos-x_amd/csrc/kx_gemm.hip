@@ -114,6 +114,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
              "kx_gemm: ln_operand_out needs an fp32 output with residual, N %% 64 == 0, aligned rows, a 2-byte / KX_F16C "
              "operand dtype and the prefetching store loop");
   p.stagger_ticks = 0; p.w_tiled = 0;
+  p.pairk = 0; p.pk_slab = nullptr; p.pk_flag = nullptr; p.pk_epoch = 0;
   p.gsplit = 1; p.kfull = p.K; p.C2 = nullptr; p.residual2 = nullptr; p.a_add = nullptr;
   p.no_rowreg = kx_tuning_get(KX_TUNE_GEMV_VARIANT) == 3; p.a_pieces = 0; p.hp = 0; p.valu = 0; p.gb_staged = 0;
   p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
@@ -160,6 +161,32 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   //            GEMMs (520 tiles on 512 slots) — estimated with the cost model below;
   //   128x128  otherwise.
   int tile = a->tile;
+  // Pair split of the 256x256 kernel (kx_gemm_args.pair_ws): half a round of 256x256 tiles becomes a full round of
+  // (tile, K half) workgroups.  Measured on the decoder's N = 2048 GEMMs at M = 3648 (tools/gemm_bench.py).
+  auto pair_ok = [&]() {
+    if (!(a->prec == KX_PREC_BF16 || f16c || f16) || !a->pair_ws || ((uintptr_t)a->pair_ws & 255)) return false;
+    const long long t = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    const long long nkt = p.K / (128 / es);
+    const int cus = kx_cu_count();
+    // (automatic choice: >= 64 K-tiles — half a K extent of 16 tiles does not amortise the exchange: bf16 / fp16 K = 2048
+    //  measured 0.93-0.95x, K = 8192 1.16x; f16c rows hold twice the K-tiles: K = 2048 1.11x, K = 8192 1.25x)
+    return t % 8 == 0 && 2 * t <= cus && 2 * t >= (85 * cus) / 100 && nkt % 2 == 0 && nkt >= (tile == 1024 ? 8 : 64) && a->act == KX_ACT_NONE &&
+           !a->stats_out && !a->ln_out && !a->stats_partials && a->pair_ws_bytes >= 4096 + (size_t)(2 * t) * 131072;
+  };
+  if (tile == 1024) {
+    KX_REQUIRE(pair_ok(), "kx_gemm: tile 1024 (pair split of the 256x256 kernel) needs pair_ws, 16-bit operands, tiles %% 8 == 0 with "
+               "0.85 CUs <= 2 tiles <= CUs, an even number of K-tiles, no activation / statistics (M=%lld N=%lld K=%lld)",
+               (long long)a->M, (long long)a->N, (long long)a->K);
+    p.pairk = 1; tile = 512;
+  } else if (tile == 0 && kx_tuning_get(KX_TUNE_GEMM_PAIRK) != 1 && pair_ok()) {
+    p.pairk = 1; tile = 512;
+  }
+  if (p.pairk) {
+    static std::atomic<unsigned> epoch{0};
+    p.pk_flag = (unsigned*)a->pair_ws;
+    p.pk_slab = (float*)((char*)a->pair_ws + 4096);
+    p.pk_epoch = epoch.fetch_add(1, std::memory_order_relaxed) % 0xfffffff0u + 1u;   // never 0 (= consumed / not yet published)
+  }
   if (tile == 0) {
     auto cdiv = [](long long x, long long y) { return (x + y - 1) / y; };
     const long long t128 = cdiv(a->M, 128) * cdiv(a->N, 128);

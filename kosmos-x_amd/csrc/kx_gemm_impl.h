@@ -47,6 +47,11 @@ struct GemmParams {
   int gelu_poly;        // 256-column kernel, lean epilogues: KX_ACT_GELU_FAST may run as KX_ACT_GELU_POLY (plain bf16 in / out)
   int persistent;       // 256x256 kernel: > 0 = launch this many workgroups, each walking its tiles itself
   int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
+  // 256x256 kernel, K split over workgroup PAIRS (launch_p5, kx_gemm_args.pair_ws): a problem with half a round of
+  // 256x256 tiles (the decoder's N = 2048 GEMMs at M = 32 * 114: 120 tiles) runs 2 x tiles workgroups, workgroup h of a
+  // pair taking K-tiles [h * nk/2, (h + 1) * nk/2); the two exchange half of their accumulators through pk_slab
+  // [grid][128 KB] (flags pk_flag [grid]: pk_epoch when published, 0 once consumed) and each finishes half of the tile's rows
+  int pairk; float* pk_slab; unsigned* pk_flag; unsigned pk_epoch;
   // weight-streaming variant (gemv_fused_kernel) only
   const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
   const float* stats_partials; int stats_in_nseg; float stats_in_seg, stats_eps;
@@ -1402,8 +1407,10 @@ __device__ unsigned long long kx_tl[8];
 // EPI: 0 generic store loops, 1 lean bf16 tile store, 4 the same with produced row statistics — separate kernels (one
 // epilogue each:
 // with all three behind run-time branches the register allocator spilled accumulators inside the K loop)
-template <typename T, int ACT, int BM, int EPI>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
+// KS2 (generic epilogue only): K split over workgroup pairs, see GemmParams.pairk
+template <typename T, int ACT, int BM, int EPI, bool KS2 = false>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
+  static_assert(!KS2 || (EPI == 0 && BM == 256), "the pair split runs the 256-row kernel with the generic epilogue");
   constexpr int BN = 256, ROWB = 128;
   static_assert(BM % 64 == 0, "BM must split into 2 wave rows of whole 16-row fragments and 8 staging waves");
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;   // 64 KB
@@ -1414,7 +1421,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const int nwg = p.tiles_m * p.tiles_n;
   // persistent launch (grid = one workgroup per CU, p.persistent): the workgroup walks tiles bid, bid + grid, ... itself
   // instead of being retired and re-dispatched per tile — same tile->CU order, no dispatch/retire gap between tiles
-  for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+  // KS2: workgroup w = (slot, xcd); the pair (slot, slot ^ 1) of one XCD shares tile (slot >> 1) * 8 + xcd and splits its K
+  // extent (partners sit behind one L2; placement is a speed matter only, the hand-off is agent-scope)
+  const int ks_h = KS2 ? (int)((blockIdx.x >> 3) & 1) : 0;
+  for (int bid = KS2 ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x; bid < nwg; bid += gridDim.x) {
   KX_TL_STAMP(0);
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -1445,7 +1455,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
 #pragma unroll
   for (int j = 0; j < IA; ++j) {
     const int row = wave * (BM / 8) + j * 8 + srow;
-    const int gm = min(m0 + row, p.M - 1);
+    // KS2, partner 1: LDS row r holds tile row r ^ 64 — its accumulator half 0 (the half every workgroup keeps) then
+    // covers the tile rows that are partner 0's half 1 (the half every workgroup gives away)
+    const int gm = min(m0 + (KS2 && ks_h ? (row ^ 64) : row), p.M - 1);
     srcA[j] = p.A + (long long)gm * p.lda_b + ((schunk ^ (row & 7)) << 4);
   }
 #pragma unroll
@@ -1485,7 +1497,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   }
 
   const int nk = p.K / (ROWB / (int)sizeof(T));
-  stage(0, 0);
+  const int k0 = KS2 ? ks_h * (nk >> 1) : 0, k1 = KS2 ? k0 + (nk >> 1) : nk;     // this workgroup's K-tiles (KS2: nk is even)
+  if constexpr (KS2) stage(k0 & 1, k0); else stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   KX_TL_STAMP(1);
@@ -1499,11 +1512,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   auto kloop = [&](auto work_c) __attribute__((always_inline)) {
   constexpr bool W = decltype(work_c)::value;
   const int nk1 = kIsF16c<T> ? min(p.nk_main, nk) : nk;     // KX_F16C: the fp16 tiles; the fp8 correction tiles follow below
-  for (int kt = 0; kt < nk1; ++kt) {
+  for (int kt = k0; kt < (KS2 ? min(nk1, k1) : nk1); ++kt) {
     const char* base = smem + (kt & 1) * STAGE;
     u32x4_t fa[FM], fw[FN];
     // ---- R0 ----
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    if (kt + 1 < k1) stage((kt + 1) & 1, kt + 1);
     if constexpr (W) {
 #pragma unroll
     for (int a = 0; a < FN; ++a) fw[a] = *reinterpret_cast<const u32x4_t*>(base + offW[a]);
@@ -1560,11 +1573,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     int wsc[FN];
 #pragma unroll
     for (int a = 0; a < FN; ++a) wsc[a] = p.wscale ? p.wscale[min(n0 + wn * 64 + a * 16 + lk, p.N - 1)] : 127;
-    for (int kt = nk1; kt < nk; ++kt) {
+    for (int kt = KS2 ? max(nk1, k0) : nk1; kt < k1; ++kt) {
       const char* base = smem + (kt & 1) * STAGE;
       u32x4_t fw0[FN], fw1[FN], fa0[FH], fa1[FH];
       // ---- R0 ----
-      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      if (kt + 1 < k1) stage((kt + 1) & 1, kt + 1);
       if constexpr (W) {
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
@@ -1623,6 +1636,41 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   if (work) kloop(std::true_type{}); else kloop(std::false_type{});
   if (!lag) __builtin_amdgcn_s_barrier();
   KX_TL_STAMP(2);
+  if constexpr (KS2) {
+    // Exchange with the partner (blockIdx ^ 8), guide G16 recipe R1: accumulator half 1 (fragments b >= FM/2) goes to this
+    // workgroup's slab write-through, every wave drains, one lane publishes; then one lane polls the partner's flag, one
+    // acquire, and the partner's half 1 — the same tile rows as this workgroup's half 0 — is added to half 0.  a + b == b + a:
+    // both workgroups of a pair would compute identical sums, each finishes its own 2 x 64 rows.
+    constexpr int HSLAB = BM * BN / 2;               // floats per slab; fragment (a, b - FM/2) of thread t at ((a*FM/2 + b - FM/2)*512 + t)*16 B
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.pk_slab + (size_t)blockIdx.x * HSLAB, 0, HSLAB * 4, 0x00020000);
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = FM / 2; b < FM; ++b)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[a][b]), rs, (int)threadIdx.x * 16,
+                                               (a * (FM / 2) + b - FM / 2) * 512 * 16, /*aux: sc1 = write-through*/ 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned pw = blockIdx.x ^ 8u;
+    if (threadIdx.x == 0) {
+      __hip_atomic_store((gu32_t*)(p.pk_flag + blockIdx.x), p.pk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load((gu32_t*)(p.pk_flag + pw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pk_epoch)
+        __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const f32x4_t* ps = reinterpret_cast<const f32x4_t*>(p.pk_slab + (size_t)pw * HSLAB) + threadIdx.x;
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      f32x4_t t[FM / 2];
+#pragma unroll
+      for (int b = 0; b < FM / 2; ++b) t[b] = ps[(a * (FM / 2) + b) * 512];
+#pragma unroll
+      for (int b = 0; b < FM / 2; ++b) acc[a][b] += t[b];
+    }
+    __syncthreads();                                 // every wave holds the partner's values: re-arm its flag for the next launch
+    if (threadIdx.x == 0) __hip_atomic_store((gu32_t*)(p.pk_flag + pw), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---- epilogue staged through LDS in two 64-row halves (8 waves x 64x64 fp32 = 128 KB) ----
   // The lane index is laundered through an empty asm: everything the epilogue derives from it (row / chunk / swizzle
@@ -1676,15 +1724,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
         *reinterpret_cast<f32x4_t*>(cw + ml * WN + ((c ^ (ml & (CH - 1))) << 2)) = acc[a][half * (FM / 2) + b];
       }
     __syncthreads();
-    if (pre) store_loop<KX_ACT_NONE, WN, 32>(q, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
-    else store_loop<ACT, WN, 32>(p, cw, HR, lane, m0 + wm * (BM / 2) + half * HR, n0 + wn * WN);
+    const int hrow = KS2 ? ks_h : half;              // KS2: accumulator half 0 holds tile rows [64 h, 64 h + 64) of each wave row
+    if (pre) store_loop<KX_ACT_NONE, WN, 32>(q, cw, HR, lane, m0 + wm * (BM / 2) + hrow * HR, n0 + wn * WN);
+    else store_loop<ACT, WN, 32>(p, cw, HR, lane, m0 + wm * (BM / 2) + hrow * HR, n0 + wn * WN);
   };
   park_and_store(std::integral_constant<int, 0>{});
   KX_TL_STAMP(4);
-  park_and_store(std::integral_constant<int, 1>{});
+  if constexpr (!KS2) park_and_store(std::integral_constant<int, 1>{});
   KX_TL_STAMP(5);
   KX_TL_COMMIT();
   }  // generic epilogue
+  if constexpr (KS2) break;                          // one piece per workgroup
   if (bid + (int)gridDim.x < nwg) __syncthreads();   // the parked rows have been read back before the next tile's fill
   }  // tiles of this workgroup
 }
@@ -1729,6 +1779,14 @@ template <typename T, int BM>
 int launch_p5(GemmParams& p, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + 255) / 256;
+  if constexpr (BM == 256) {
+    if (p.pairk) {                            // K split over workgroup pairs (kx_gemm checked: no activation / statistics, even nk, tiles % 8 == 0)
+      const dim3 grid(2 * p.tiles_m * p.tiles_n), block(512);
+      hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, 256, 0, true>), grid, block, 0, s, p);
+      KX_CHECK_LAUNCH("kx_gemm(p5, pair split-K)");
+      return KX_OK;
+    }
+  }
   if constexpr (kIsF16c<T>) {
     // KX_F16C output on whole 256-column tiles, no residual / XPos: the three-plane lean store (else the generic loops)
     if (BM == 256 && p.lean_f16c && p.N % 256 == 0) return p.stats_out ? launch_p5e<T, BM, 7>(p, s) : launch_p5e<T, BM, 6>(p, s);

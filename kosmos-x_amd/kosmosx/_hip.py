@@ -13,7 +13,7 @@ from pathlib import Path
 
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
-ABI_VERSION = 5   # KX_ABI_VERSION of include/kosmosx_hip.h
+ABI_VERSION = 6   # KX_ABI_VERSION of include/kosmosx_hip.h
 
 KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16, KX_PREC_F32W24, KX_PREC_F32W16 = 0, 1, 2, 3, 4, 5, 6
 KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16, KX_F16P = 0, 1, 2, 3, 4, 5
@@ -55,7 +55,8 @@ class GemmArgs(C.Structure):
                 ("stats_out_seg", i32),
                 ("ln_out", vp), ("ln_out_dt", i32), ("ln_out_gamma", vp), ("ln_out_beta", vp), ("ln_out_eps", f32),
                 ("w_scale", vp), ("ln_operand_out", vp), ("ln_operand_dt", i32), ("ln_operand_stats", vp),
-                ("w_tiled", i32), ("ksplit", i32), ("C2", vp), ("residual2", vp), ("a_add", vp)]
+                ("w_tiled", i32), ("ksplit", i32), ("C2", vp), ("residual2", vp), ("a_add", vp),
+                ("pair_ws", vp), ("pair_ws_bytes", C.c_size_t)]
 
 
 class AttnArgs(C.Structure):

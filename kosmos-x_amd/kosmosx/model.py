@@ -839,10 +839,11 @@ class Decoder(_PackedMixin, nn.Module):
         # bits and streamed as THREE bytes each ("w24": kx_gemm_args.w_tiled = 2; the activations and the products stay fp32).
         # KOSMOSX_DECODE_EXACT=fp32 streams the full fp32 weights (4 bytes), =0 keeps the f16c tile GEMMs.
         exact = os.environ.get("KOSMOSX_DECODE_EXACT", "1")
-        # the compressed forms (w24 / w16) exist to be STREAMED: without streaming copies (more than 16 sequences, or
-        # KOSMOSX_DECODE_TILED=0) they would run plain fp32 GEMMs on rounded weights — accuracy lost, no byte saved, and a
-        # second fp32 pack held — so those steps keep the f16c tile GEMMs the prefill ran.
-        streams = B <= 16 and os.environ.get("KOSMOSX_DECODE_TILED", "1") != "0"
+        # the compressed forms (w24 / w16) exist to be STREAMED: with more than 16 sequences no streaming launch exists and
+        # they would run plain fp32 GEMMs on rounded weights — accuracy lost, no byte saved, and a second fp32 pack held
+        #  — so those steps keep the f16c tile GEMMs the prefill ran.  (KOSMOSX_DECODE_TILED=0 is the A/B switch
+        # that runs the SAME compressed weights from their row-major fp32 operands: bit-identical to the planes, test-only.)
+        streams = B <= 16
         sprec = prec if (prec != "f16c" or exact == "0" or not (streams or exact == "fp32")) else (
             {"fp32": "fp32", "w24": "w24"}.get(exact, "w16"))
         if sprec != prec:
