@@ -14,6 +14,35 @@ lib = C.CDLL(os.environ["KOSMOSX_HIP_LIB"])
 buf = (C.c_ulonglong * 8)()
 names = ["prologue (setup + first fill landed)", "K loop", "prepass (bias/act/stats on accumulators)", "park+store half 0",
          "park+store half 1"]
+if len(sys.argv) > 1 and sys.argv[1] == "pair":
+    # the pair split (tile 1024) against the whole-K 256x256 walk of the same tiles (tile 512): between "K loop" and
+    # "park+store half 0" sits the exchange with the partner ("prepass" column)
+    import pairk_bench as pb
+    from kosmosx import ops
+    from kosmosx.model import _operand_f16c
+    names[2] = "exchange with the partner (pair split) / prepass"
+    for kind in ("f16c", "bf16"):
+        for (M, N, K) in ((3648, 2048, 2048), (3648, 2048, 8192)):
+            g = torch.Generator().manual_seed(1)
+            x = (torch.rand(M, K, generator=g) * 2 - 1).cuda(); w = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.05).cuda()
+            bias, colsum = torch.randn(N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+            stats, res = torch.rand(M, 2, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+            ws = ops.pair_scratch()
+            if kind == "f16c":
+                a, wp = ops.pack_f16c_rows(x), _operand_f16c(w)
+                call = lambda t: ops.gemm_f16c(a, wp, N, K, bias=bias, residual=res, row_stats=stats, colsum=colsum, tile=t, pair_ws=ws)
+            else:
+                a, wd = x.bfloat16(), w.bfloat16()
+                call = lambda t: ops.gemm(a, wd, bias=bias, residual=res, out=res, row_stats=stats, colsum=colsum, tile=t, pair_ws=ws)
+            for t in (512, 1024):
+                call(t); torch.cuda.synchronize(); lib.kx_timeline_read(buf, 1)
+                for _ in range(3): call(t)
+                torch.cuda.synchronize(); lib.kx_timeline_read(buf, 1)
+                n = max(buf[5], 1)
+                print(json.dumps({"kind": kind, "M": M, "N": N, "K": K, "tile": t, "pieces_stamped": int(n),
+                                  "cycles_per_piece": {names[i]: int(buf[i] / n) for i in range(5)},
+                                  "sum_cycles": int(sum(buf[i] for i in range(5)) / n)}))
+    sys.exit(0)
 M = 65472
 for persistent in [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['0', '256'])]:
     _hip.load().kx_set_tuning(7, persistent)
