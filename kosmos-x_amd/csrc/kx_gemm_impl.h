@@ -1655,18 +1655,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     if (threadIdx.x == 0) {
       __hip_atomic_store((gu32_t*)(p.pk_flag + blockIdx.x), p.pk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       while (__hip_atomic_load((gu32_t*)(p.pk_flag + pw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pk_epoch)
-        __builtin_amdgcn_s_sleep(2);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_s_sleep(1);
     }
     __syncthreads();
-    const f32x4_t* ps = reinterpret_cast<const f32x4_t*>(p.pk_slab + (size_t)pw * HSLAB) + threadIdx.x;
+    // the partner stored write-through: sc1 loads (L1 bypassed, served by the L2 / fabric) see its bytes without an
+    // acquire fence (guide G16: "sc1 loads may replace the acquire only when the producer stored sc1") — ~1.7 us off the hand-off
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(p.pk_slab + (size_t)pw * HSLAB, 0, HSLAB * 4, 0x00020000);
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
-      f32x4_t t[FM / 2];
+      u32x4_t t[FM / 2];
 #pragma unroll
-      for (int b = 0; b < FM / 2; ++b) t[b] = ps[(a * (FM / 2) + b) * 512];
+      for (int b = 0; b < FM / 2; ++b)
+        t[b] = __builtin_amdgcn_raw_buffer_load_b128(rp, (int)threadIdx.x * 16, (a * (FM / 2) + b) * 512 * 16, /*aux: sc1*/ 16);
 #pragma unroll
-      for (int b = 0; b < FM / 2; ++b) acc[a][b] += t[b];
+      for (int b = 0; b < FM / 2; ++b) acc[a][b] += __builtin_bit_cast(f32x4_t, t[b]);
     }
     __syncthreads();                                 // every wave holds the partner's values: re-arm its flag for the next launch
     if (threadIdx.x == 0) __hip_atomic_store((gu32_t*)(p.pk_flag + pw), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -291,12 +291,24 @@ class LanguageModelTrainer:
             o.pairA = pairA
             o.pairA_gelu = lambda pre, dg, bias_out=None: pairA(G.gelu_backward(pre, dg), bias_out)
 
+        # scratch of the 256x256 kernel's pair split (kx_gemm_args.pair_ws): the step's GEMMs with half a round of 256x256 tiles
+        # and a long K — fc2 forward (N = dim, K = ffn), the data gradients of fc1 and qkv (N = dim) at 8 x 512 tokens — run as
+        # (tile, K half) workgroup pairs.  One scratch per trainer: its launches are ordered on one stream.
+        pw = {}
+
+        def pws(t):
+            if self.precision != "bf16" or not t.is_cuda:
+                return None
+            if t.device not in pw:
+                pw[t.device] = ops.pair_scratch(t.device)
+            return pw[t.device]
+
         def lin(x, w, b=None, **kw):                      # x [M,K] · w[N,K]ᵀ (+ b); returns (y, wᵀ operand for the backward)
             wa, wt = o.pairW(w.detach())
-            return ops.gemm(o.opA(x), wa, None if b is None else b.detach(), **kw), wt
+            return ops.gemm(o.opA(x), wa, None if b is None else b.detach(), pair_ws=pws(x), **kw), wt
         o.lin = lin
-        o.dgrad = lambda dy_a, w_t: ops.gemm(dy_a, w_t)                        # dX = dY · W   (operands dY and Wᵀ [K, N])
-        o.wgrad = lambda dy_t, xin, out=None: ops.gemm(dy_t, o.opWT(xin), out=out)   # dW = dYᵀ · X (dYᵀ [N, M], Xᵀ [K, M])
+        o.dgrad = lambda dy_a, w_t: ops.gemm(dy_a, w_t, pair_ws=pws(dy_a))     # dX = dY · W   (operands dY and Wᵀ [K, N])
+        o.wgrad = lambda dy_t, xin, out=None: ops.gemm(dy_t, o.opWT(xin), out=out, pair_ws=pws(dy_t))   # dW = dYᵀ · X (dYᵀ [N, M], Xᵀ [K, M])
         return o
 
     def _ln_bwd(self, xin, ln_name, gamma, dy, eps, dres=None):

@@ -26,7 +26,11 @@ ap.add_argument("--checkpoint", action="store_true", help="keep only layer input
 ap.add_argument("--train-mode", action="store_true", help="the reference's model.train(): dropout = attention_dropout = 0.1 "
                 "(/root/reference/train.py:642, kosmosx/model.py:175-177), Philox masks; default: the deterministic step")
 ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"], help="arithmetic of the matrix products")
+ap.add_argument("--tune", default="", help="A/B: kx_set_tuning key=value pairs, e.g. 13=1 (no pair split of the 256x256 GEMM kernel)")
 a = ap.parse_args()
+for kv in filter(None, a.tune.split(",")):
+    from kosmosx import _hip
+    _hip.load().kx_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 import torch.distributed as dist
 world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 force = os.environ.get("KOSMOSX_FORCE_DIST") == "1"          # single-rank run of the RCCL path
