@@ -2144,7 +2144,17 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
                              : wph + 1024 - (lane << 3);                // this lane's eight third bytes
   const int ulast2 = max(klen - 1, 0) >> 5;
   const int ulast = max(klen - 1, 0) >> KSH;
+  // the weight stream is read ONCE by ONE workgroup: non-temporal loads (the guide's nt-weights row: issued -> landed -18 %, a decode
+  // layer 5-10 % shorter) keep it from displacing the activations / KV rows the other launches re-read in the L2.
+#ifndef KX_GEMV_NO_NT
+  auto ldw = [&](const char* q) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(q)); };
+  auto ldw8 = [&](const char* q) { return __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(q)); };
+  auto ldw4 = [&](const char* q) { return __builtin_nontemporal_load(reinterpret_cast<const float*>(q)); };
+#else   // A/B build (-DKX_GEMV_NO_NT): default cache policy
   auto ldw = [&](const char* q) { return *reinterpret_cast<const u32x4_t*>(q); };
+  auto ldw8 = [&](const char* q) { return *reinterpret_cast<const u32x2_t*>(q); };
+  auto ldw4 = [&](const char* q) { return *reinterpret_cast<const float*>(q); };
+#endif
 
   // ---- (1) the small loads, in consumption order ----
   const bool coop = LNP && (p.K >> 2) <= 64 * S && p.M <= 4;
@@ -2247,9 +2257,9 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
   if constexpr (W24) {
 #pragma unroll
     for (int u2 = 0; u2 < U / 2; ++u2) {
-      rawh[u2] = *reinterpret_cast<const u32x4_t*>(wph + min(u2, ulast2) * WBLK);
-      if constexpr (WF == 16) rsc[u2] = *reinterpret_cast<const float*>(wpl + min(u2, ulast2) * WBLK);
-      else rawl[u2] = *reinterpret_cast<const u32x2_t*>(wpl + min(u2, ulast2) * WBLK);
+      rawh[u2] = ldw(wph + min(u2, ulast2) * WBLK);
+      if constexpr (WF == 16) rsc[u2] = ldw4(wpl + min(u2, ulast2) * WBLK);
+      else rawl[u2] = ldw8(wpl + min(u2, ulast2) * WBLK);
     }
   } else {
 #pragma unroll
@@ -2477,9 +2487,9 @@ __global__ __launch_bounds__(1024) void gemv_fused_kernel2(const GemmParams p, i
 #pragma unroll
         for (int u2 = 0; u2 < U / 2; ++u2)
           if (kk + 32 * u2 < klen) {
-            rawh[u2] = *reinterpret_cast<const u32x4_t*>(wph + ((kk >> 5) + u2) * WBLK);
-            if constexpr (WF == 16) rsc[u2] = *reinterpret_cast<const float*>(wpl + ((kk >> 5) + u2) * WBLK);
-            else rawl[u2] = *reinterpret_cast<const u32x2_t*>(wpl + ((kk >> 5) + u2) * WBLK);
+            rawh[u2] = ldw(wph + ((kk >> 5) + u2) * WBLK);
+            if constexpr (WF == 16) rsc[u2] = ldw4(wpl + ((kk >> 5) + u2) * WBLK);
+            else rawl[u2] = ldw8(wpl + ((kk >> 5) + u2) * WBLK);
           }
       } else {
 #pragma unroll
