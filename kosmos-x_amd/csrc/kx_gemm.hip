@@ -143,9 +143,17 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     p.lean_f16c = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 8 && p.c_f16c && f16c &&
                   !a->residual && !a->xpos_dim && a->qcols % 64 == 0 && a->N % 16 == 0 && (a->ldc * 2) % 16 == 0 &&
                   !a->ln_operand_out;
-    p.lean_xpos = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) == 3 && a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && p.vec8_ok &&
-                  a->xpos_dim > 0 && !a->residual && !a->row_stats && !a->stats_out && a->act == KX_ACT_NONE &&
-                  a->qcols % 256 == 0 && a->xpos_dim % 256 == 0;
+    // bias + q-scale + XPos at accumulator level (tables through LDS) and a whole-row tile store: bf16 operands -> bf16
+    // rows, f16c operands -> the fp32 q / k / v the split attention reads.  Eligible = 1 (launch_p5 takes it on the 192-row
+    // tiles), 2 = asked for on any tile (tuning key 4 = 3, A/B); tuning key 4 = 1 / 8 keep the generic loops.
+    {
+      const int k4 = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE);
+      const bool shape_ok = a->xpos_dim > 0 && !a->residual && !a->row_stats && !a->stats_out && a->act == KX_ACT_NONE &&
+                            a->qcols % 256 == 0 && a->xpos_dim % 256 == 0 && !a->ln_operand_out;
+      const bool bf = a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && p.vec8_ok;
+      const bool fc = f16c && a->cdt == KX_F32 && p.vec_ok && a->N % 4 == 0;
+      p.lean_xpos = (shape_ok && (bf || fc) && k4 != 1 && k4 != 8 && k4 != 9) ? ((k4 == 3 && bf) ? 2 : 1) : 0;   // (9: only this one off, A/B)
+    }
     p.ring = mode != 6 && !f16c;
     // A/B: tuning key 4 = 4 keeps the A&S erf in the lean epilogues
     p.gelu_poly = mode != 4 && a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && a->act == KX_ACT_GELU;

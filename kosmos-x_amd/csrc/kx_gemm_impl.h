@@ -623,6 +623,39 @@ __device__ __forceinline__ void lean_store_bf16(const GemmParams& p, const f32x4
   }
 }
 
+// fp32 output of the 256-column kernel after an accumulator-level epilogue (the decoder's qkv GEMM in f16c / mixed: the split
+// attention takes fp32 q / k / v).  A BM x 256 fp32 tile is BM KB: parked in two halves of BM / 2 tile rows (the b-fragments
+// [h * FM/2, (h+1) * FM/2) of both wave rows), 16-byte chunks XOR-swizzled by row (& 15: the sixteen rows of a fragment
+// write the same column block); after one barrier every wave instruction stores ONE whole 1 KB row.
+template <int BM, int FM, int FN>
+__device__ __forceinline__ void lean_store_f32(const GemmParams& p, const f32x4_t (&acc)[FN][FM], char* smem, int m0, int n0,
+                                               int wm, int wn, int wave, int lane, int g, int li) {
+  static_assert(FM % 2 == 0 && FN == 4 && (BM / 2) % 8 == 0, "two halves of whole fragments, eight rows per store pass");
+  constexpr int HR = BM / 4;                // rows of one wave row inside a half
+  float* const out = reinterpret_cast<float*>(p.C);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();                        // the K loop's last fragment reads / the table reads / the previous half's row reads are done
+#pragma unroll
+    for (int bb = 0; bb < FM / 2; ++bb) {
+      const int b = half * (FM / 2) + bb;
+      const int hr = wm * HR + bb * 16 + li;                       // row inside this half's BM / 2
+#pragma unroll
+      for (int a = 0; a < FN; ++a) {
+        const int ch = (wn * 16 + a * 4 + g) ^ (hr & 15);
+        *reinterpret_cast<f32x4_t*>(smem + hr * 1024 + ch * 16) = acc[a][b];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < BM / 16; ++ps) {                         // BM / 2 rows, eight (one per wave) per pass
+      const int hr = ps * 8 + wave, m = m0 + (hr / HR) * (BM / 2) + half * HR + (hr % HR);
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + hr * 1024 + ((lane ^ (hr & 15)) << 4));
+      if (m < p.M) *reinterpret_cast<f32x4_t*>(out + (long long)m * p.ldc + n0 + lane * 4) = v;
+    }
+  }
+}
+
 // KX_F16C output of the 256-column kernel (the decoder's fc1 in f16c / mixed: 4 bytes per value, [fp16 | fp8 | fp8 residual]
 // planes per row).  Round 2 sent these through the generic store loops (fp32 parking in two halves, ~100 instructions per
 // 8 values: fc1 ran at 535 TF/s where fc2 ran at 638 at C3's rows).  Here the values are packed ONCE at accumulator level
@@ -1693,6 +1726,19 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     KX_TL_STAMP(5);
     KX_TL_COMMIT();
   } else
+  if constexpr (EPI == 8) {                           // bias + q-scale + XPos on the accumulators, fp32 tile store (f16c qkv)
+    const bool rot = n0 < 2 * p.xpos_dim;                 // tile-uniform: xpos_dim % 256 == 0 (kx_gemm checks)
+    float* tab = reinterpret_cast<float*>(smem);
+    __syncthreads();                                      // the K loop's last fragment reads are done
+    if (rot) stage_xpos_rows<BM>(p, tab, m0, n0, threadIdx.x);
+    __syncthreads();
+    lean_bias_qscale_xpos<FM, FN>(p, acc, n0 + wn * WN, g, wm * (BM / 2), li, tab, rot);
+    KX_TL_STAMP(3);
+    lean_store_f32<BM, FM, FN>(p, acc, smem, m0, n0, wm, wn, wave, lane, g, li);
+    KX_TL_STAMP(4);
+    KX_TL_STAMP(5);
+    KX_TL_COMMIT();
+  } else
   if constexpr (EPI == 1 || EPI == 4 || EPI == 5) {   // bias / activation (/ statistics, / XPos) on the accumulators, bf16 tile store
     if constexpr (EPI == 5) {
       const bool rot = n0 < 2 * p.xpos_dim;                 // tile-uniform: xpos_dim % 256 == 0 (kx_gemm checks)
@@ -1746,6 +1792,10 @@ int launch_p5e(GemmParams& p, hipStream_t s) {
   const int nwg = p.tiles_m * p.tiles_n;
   const dim3 grid(p.persistent > 0 ? (nwg < p.persistent ? nwg : p.persistent) : nwg), block(512);
   // the lean variants are instantiated for the activations the forward uses them with; anything else takes EPI 0
+  if constexpr (EPI == 8) {                 // fp32 output, bias + q-scale + XPos at accumulator level (no activation)
+    if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, 8>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
+    return launch_p5e<T, BM, 0>(p, s);
+  } else
   if constexpr (EPI == 6 || EPI == 7) {     // KX_F16C output (BM = 256): plain and GELU, with (7) or without (6) produced statistics
     if constexpr (kIsF16c<T> && BM == 256) {
       if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, EPI>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
@@ -1789,12 +1839,18 @@ int launch_p5(GemmParams& p, hipStream_t s) {
       return KX_OK;
     }
   }
+  // lean_xpos: 2 = asked for (tuning key 4 = 3), 1 = eligible — taken on the 192-row tiles, where the rotated accumulators fit
+  // the registers (bf16 qkv at M = 3648: 109.6 -> 93.8 us, bit-identical; the 256-row form spills 352 B / lane and measured slower)
+  const bool lx = p.lean_xpos == 2 || (p.lean_xpos == 1 && BM == 192);
   if constexpr (kIsF16c<T>) {
     // KX_F16C output on whole 256-column tiles, no residual / XPos: the three-plane lean store (else the generic loops)
     if (BM == 256 && p.lean_f16c && p.N % 256 == 0) return p.stats_out ? launch_p5e<T, BM, 7>(p, s) : launch_p5e<T, BM, 6>(p, s);
+    if constexpr (BM == 192) {
+      if (lx && !p.c_bf16 && p.N % 256 == 0) return launch_p5e<T, BM, 8>(p, s);      // fp32 q / k / v of the f16c qkv GEMM
+    }
     return launch_p5e<T, BM, 0>(p, s);
   }
-  else if (p.lean_xpos && p.N % 256 == 0) return launch_p5e<T, BM, 5>(p, s);
+  else if (lx && p.c_bf16 && p.N % 256 == 0) return launch_p5e<T, BM, 5>(p, s);
   else if (p.lean_epilogue && p.N % 256 == 0) return p.stats_out ? launch_p5e<T, BM, 4>(p, s) : launch_p5e<T, BM, 1>(p, s);
   return launch_p5e<T, BM, 0>(p, s);
 }

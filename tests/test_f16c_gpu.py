@@ -67,6 +67,32 @@ def test_f16c_producers_write_the_format_bit_exactly():
     assert torch.equal(oc.view(-1, 4 * 192), ops.pack_f16c_rows(o32.view(-1, 192)))
 
 
+@pytest.mark.parametrize("M,N,K,T", [(3648, 6144, 2048, 114), (3600, 768, 256, 100), (192, 1536, 512, 7), (3648, 768, 1024, 2046)])
+def test_f16c_lean_xpos_fp32_store_of_the_192_row_kernel(M, N, K, T):
+    """The decoder's qkv GEMM in f16c / mixed (fp32 q | k | v for the split attention) on the 192-row form of the 256-column
+    kernel: round 4 applies bias + q-scale + XPos at accumulator level (tables through LDS) and stores whole fp32 rows from an
+    LDS-parked tile (EPI 8).  Same operation order as the generic store loop: bit-identical to it (tuning key 4 = 1), ragged M
+    and positions that wrap inside a tile included; and the bf16 form of the same epilogue (EPI 5) likewise."""
+    g = _g(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 1.3).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    a, wp = ops.pack_f16c_rows(x), _operand_f16c(w)
+    bias = torch.randn(N, generator=g).to(DEV)
+    tabs = tuple((torch.rand(T, 32, generator=g) * 2 - 1).to(DEV) for _ in range(4))
+    kw = dict(bias=bias, qscale=0.125, qcols=N // 3, xpos=tabs, xpos_dim=N // 3, tile=384)
+    lib = _hip.load()
+    try:
+        lean = ops.gemm_f16c(a, wp, N, K, **kw)
+        lean_b = ops.gemm(x.bfloat16(), w.bfloat16(), out_dtype=torch.bfloat16, **kw)
+        lib.kx_set_tuning(4, 1)
+        generic = ops.gemm_f16c(a, wp, N, K, **kw)
+        generic_b = ops.gemm(x.bfloat16(), w.bfloat16(), out_dtype=torch.bfloat16, **kw)
+    finally:
+        lib.kx_set_tuning(4, 0)
+    assert torch.equal(lean, generic) and torch.equal(lean_b, generic_b)
+    assert float(lean.abs().max()) > 0.1
+
+
 @pytest.mark.parametrize("M,N,K", [(200, 512, 256), (456, 1024, 512), (3648, 768, 256), (130, 256, 1024)])
 def test_f16c_lean_three_plane_store_of_the_256_column_kernel(M, N, K):
     """The decoder's fc1 in f16c / mixed writes KX_F16C rows from the 256-column kernel: round 3's lean store packs at
