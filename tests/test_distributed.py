@@ -11,6 +11,30 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+def _np(o):
+    """Queue payloads go by VALUE: torch.multiprocessing hands tensors over as shared-memory handles served by the producer,
+    and a worker that has left its barrier and exited before the parent opened them made q.get() fail (FileNotFoundError,
+    seen once in ~40 runs).  NumPy arrays are pickled whole."""
+    if isinstance(o, torch.Tensor):
+        return ("__t__", o.detach().cpu().float().numpy() if o.dtype == torch.bfloat16 else o.detach().cpu().numpy(), str(o.dtype))
+    if isinstance(o, (list, tuple)):
+        return type(o)(_np(x) for x in o)
+    if isinstance(o, dict):
+        return {k: _np(v) for k, v in o.items()}
+    return o
+
+
+def _pt(o):
+    if isinstance(o, tuple) and len(o) == 3 and isinstance(o[0], str) and o[0] == "__t__":
+        t = torch.from_numpy(o[1])
+        return t.to(torch.bfloat16) if o[2] == "torch.bfloat16" else t
+    if isinstance(o, (list, tuple)):
+        return type(o)(_pt(x) for x in o)
+    if isinstance(o, dict):
+        return {k: _pt(v) for k, v in o.items()}
+    return o
+
+
 ROOT = Path(__file__).resolve().parent.parent
 
 
@@ -40,7 +64,7 @@ def _worker(rank, world, port, total, wire_bf16, q):
     gathered = LogitsGatherer(wire_dtype=torch.bfloat16 if wire_bf16 else None).gather(local)
     if rank == 0:
         full = O.kosmos_forward(w, tok, img, cfg)
-        q.put((gathered.float(), full))
+        q.put(_np((gathered.float(), full)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,7 +77,7 @@ def test_sharded_forward_plus_allgather_equals_full_batch(wire_bf16):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, 4, wire_bf16, q)) for r in range(2)]
     for p in procs:
         p.start()
-    gathered, full = q.get(timeout=240)
+    gathered, full = _pt(q.get(timeout=240))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -112,7 +136,7 @@ def _zero_worker(rank, world, port, q):
         flat_g[:total] = per_rank[rank] * step / world                 # each rank's gradient already carries 1/world
         z.step(flat_p, flat_g, m, v, _ref_adamw(1e-2, (0.9, 0.95), 1e-8, 0.1, 1.0, step), lambda x: (x * x).sum().reshape(1))
     if rank == 0:
-        q.put(flat_p[:total].clone())
+        q.put(_np(flat_p[:total].clone()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -124,7 +148,7 @@ def test_zero_sharded_adamw_equals_single_process():
     procs = [ctx.Process(target=_zero_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=240)
+    got = _pt(q.get(timeout=240))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -176,7 +200,7 @@ def _gather_worker(rank, world, port, algo, total, q):
     outs = [ga.gather(full[lo:hi] + k).clone() for k in range(4)]     # more gathers than slots: buffers are recycled
     ga.wait()
     if rank == 0:
-        q.put(outs)
+        q.put(_np(outs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -198,7 +222,7 @@ def _gather_auto_worker(rank, world, port, q):
         ga.wait()
         res.append((ga.last_algo, bool(torch.equal(out, full))))
     if rank == 0:
-        q.put(res)
+        q.put(_np(res))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -212,7 +236,7 @@ def test_logits_gatherer_auto_picks_by_message_size():
     procs = [ctx.Process(target=_gather_auto_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
-    res = q.get(timeout=240)
+    res = _pt(q.get(timeout=240))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -228,7 +252,7 @@ def test_logits_gatherer_algorithms_and_ragged_shards(algo, world, total):
     procs = [ctx.Process(target=_gather_worker, args=(r, world, port, algo, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = q.get(timeout=240)
+    outs = _pt(q.get(timeout=240))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -261,7 +285,7 @@ def _gather_tail_worker(rank, world, port, algo, mode, q):
     except ValueError as e:
         bad = str(e)
     if rank == 0:
-        q.put((outs, bad))
+        q.put(_np((outs, bad)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -275,7 +299,7 @@ def test_logits_gatherer_ragged_tail_batch_through_one_gatherer(algo, mode):
     procs = [ctx.Process(target=_gather_tail_worker, args=(r, 2, port, algo, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
-    outs, bad = q.get(timeout=240)
+    outs, bad = _pt(q.get(timeout=240))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -301,7 +325,7 @@ def _subgroup_worker(rank, world, port, q):
         out = ga.gather(full[lo:hi], total=5).clone()
         ga.wait()
     if rank == 1:
-        q.put(out)
+        q.put(_np(out))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -313,7 +337,7 @@ def test_logits_gatherer_direct_in_a_subgroup():
     procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
-    out = q.get(timeout=240)
+    out = _pt(q.get(timeout=240))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -344,7 +368,7 @@ def _zero3_worker(rank, world, port, q):
         g = max(i for i in range(3) if z.goff[i] <= lo)
         assert hi <= z.goff[g] + z.shard[g]
         regs.append((g, lo - z.goff[g] + rank * z.shard[g], hi - z.goff[g] + rank * z.shard[g], decayed))
-    q.put((rank, ok, regs, z.n_decay, z.total))
+    q.put(_np((rank, ok, regs, z.n_decay, z.total)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -356,7 +380,7 @@ def test_zero3_layout_gathers_scatters_and_covers_every_parameter_once():
     procs = [ctx.Process(target=_zero3_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=240) for _ in range(2)]
+    got = [_pt(q.get(timeout=240)) for _ in range(2)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
