@@ -612,7 +612,8 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  *        16 KB variant; 3 = second form whose 5..8-row LayerNorm prologue walks its row three times instead of
  *        keeping it in registers; 4 = fp32 operands with one or two rows multiply on the matrix pipe instead of the VALU;
  *        5 = block-scaled 16-bit planes (w_tiled = 3) keep the exact-f32 MFMA where the default multiplies fp16 pieces;
- *        10 + n = the VALU form takes up to n rows (default 2));
+ *        7 = LayerNorm-prologue launches of 9..16 rows keep eight waves and the three-walk prologue (default: sixteen
+ *        waves, one row per wave in registers); 10 + n = the VALU form takes up to n rows (default 2));
  * key 9: KV-cache layout per layer and sequence (0 = [heads][Tmax][64]; 1 = the first layout [Tmax][heads*64]; set it
  *        before a prefill and keep it for that cache's steps).
  * key 10: 1 = the fp32 decode step keeps the split-K tile kernels instead of the fp32 weight-streaming kernel (A/B).

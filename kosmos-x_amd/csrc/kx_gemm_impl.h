@@ -2810,7 +2810,11 @@ int launch_gemv_fused(GemmParams& p, hipStream_t s) {
   // waves per workgroup: 8 while a wave's K slice is at most 512 values (bf16: 1 KB of row, fp32: 2 KB), else 16.  Two
   // 512-thread workgroups share a CU and overlap their phases: fp32 rows of K = 2048 on 16 waves (every k-step of a slice
   // in flight at once, one workgroup per CU) measured 20.7 / 23.0 us for the qkv / fc1 launches against 12.6 / 15.9.
-  const int S = p.K <= 4096 ? 8 : 16;
+  // ... and 16 for LayerNorm-prologue launches of 9..16 rows: the row-in-registers prologue keeps one row per wave, so sixteen
+  // sequences need sixteen waves (the three-walk prologue they took before: B = 16 2.00 ms / step in bf16 where B = 8 takes 1.29).
+  // A/B: tuning key 8 = 7 keeps 8 waves.
+  const bool rows16 = p.ln_g && p.M > 8 && p.M <= 16 && (p.K >> 2) <= 512 && !p.a_add && kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 7;
+  const int S = (p.K <= 4096 && !rows16) ? 8 : 16;
   const int kw = ((p.K + S - 1) / S + 31) / 32 * 32;
   const bool v2 = ES == 4 || kx_tuning_get(KX_TUNE_GEMV_VARIANT) != 1;     // (the first form exists in bf16 only)
   // second form, a wave's K slice longer than 8 k-steps (fc2: 512): 16 KB per wave in flight, operand rows through LDS

@@ -42,10 +42,15 @@ def lm_reference(full_lm):
 
 
 @pytest.mark.parametrize("prec,B", [("bf16", 1), ("bf16", 4), ("bf16", 8), ("f16c", 1), ("f16c", 4), ("f16c", 8),
-                                    ("mixed", 1), ("fp32", 1), ("fp32", 4), ("fp32", 8)])
+                                    ("mixed", 1), ("fp32", 1), ("fp32", 4), ("fp32", 8),
+                                    ("bf16", 16), ("f16c", 16), ("fp32", 12)])
 def test_full_size_prefill_and_decode_steps(full_lm, lm_reference, prec, B):
     tok, ref = lm_reference
-    tok, ref = tok[:B], ref[:B]
+    if B > 8:      # 9..16 sequences (round 4: the sixteen-wave, row-in-registers LayerNorm prologue): batch rows are independent,
+        idx = list(range(8)) + [3, 1, 7, 0, 5, 2, 6, 4][: B - 8]       # so rows 8.. re-use the eight oracle sequences in another order
+        tok, ref = tok[idx], ref[idx]
+    else:
+        tok, ref = tok[:B], ref[:B]
     lm = full_lm.to(DEV)
     lm.precision = prec
     tokd = tok.to(DEV)
