@@ -448,6 +448,26 @@ def main():
                 res = {"tokens_per_s": round(8 * 512 / dt_t, 1), "ms_per_step": round(dt_t * 1e3, 2), "loss": round(float(tloss), 4)}
                 if train_mode:
                     res = {"dropout": tr.p_drop, "attention_dropout": tr.p_attn, **res}
+                else:
+                    # roofline of the step's dominant kernel family: one more step, instrumented launch by
+                    # launch with HIP events on the launch stream, exactly as the headline's roofline leg
+                    _hip.prof_enable(True)
+                    tr.step(tb[0])
+                    torch.cuda.synchronize()
+                    trecs = _hip.prof_collect()
+                    _hip.prof_enable(False)
+                    tagg = kernel_report(trecs, 1)
+                    tagg.pop("_gemm_shapes", None)
+                    fam = {k: v for k, v in tagg.items() if k.startswith("gemm") and v["flops"] > 0 and k != "gemm_16bit_all_variants"}
+                    if fam:
+                        tdom = max(fam, key=lambda k: fam[k]["ms"])
+                        te = fam[tdom]
+                        tach = te["flops"] / (te["ms"] * 1e-3) / 1e12
+                        res["roofline"] = {"kernel": tdom, "bound": "mfma", "achieved": round(tach, 1), "peak": PEAK_BF16_TFLOPS,
+                                           "unit": "TFLOP/s", "frac": round(tach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                                           "launches_per_step": te["launches"], "ms_per_step": round(te["ms"], 2),
+                                           "step_ms_in_gemms": round(sum(v["ms"] for v in fam.values()), 2),
+                                           "measured_in": "one instrumented step (HIP events around every launch)"}
                 del tr, lm
                 torch.cuda.empty_cache()
                 return res
