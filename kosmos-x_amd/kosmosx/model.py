@@ -108,11 +108,12 @@ def _operand_colsum(wp: torch.Tensor, prec: str, shape=None) -> torch.Tensor:
 FOLD_PRECS = ("bf16", "f16", "f16c")      # stage precisions whose pre-LayerNorms are folded into qkv / fc1 / logits
 
 
-def _fold_pre_ln() -> bool:
+def _fold_pre_ln(stage: str = "") -> bool:
     """Opt-in (KOSMOSX_FOLD_PRE_LN=1).  Measured at B = 32: the 95 LayerNorm launches it removes cost
     1.5 ms, the residual epilogues' second store + lane exchanges, the consumers' row-statistics loads and the 96
     statistics-finalize launches it adds cost 2.3 ms — a 2 % loss on the headline and on C3, so it ships off."""
-    return os.environ.get("KOSMOSX_FOLD_PRE_LN", "0") == "1"
+    v = os.environ.get("KOSMOSX_FOLD_PRE_LN", "0")        # "1": every stage; "vit" / "decoder": that stage only (A/B)
+    return v == "1" or (v != "0" and v == stage)
 
 
 def _fold_ln_linear(ln_w, ln_b, w, b, prec: str):
@@ -309,7 +310,7 @@ class CLIPVisionTower(_PackedMixin, nn.Module):
             e.ln2_g, e.ln2_b = v(L.layer_norm2.weight), v(L.layer_norm2.bias)
             e.w1, e.b1 = op(L.mlp.fc1.weight), v(L.mlp.fc1.bias)
             e.w2, e.b2 = op(L.mlp.fc2.weight), v(L.mlp.fc2.bias)
-            if prec in FOLD_PRECS and _fold_pre_ln():      # layer_norm1 -> qkv, layer_norm2 -> fc1
+            if prec in FOLD_PRECS and _fold_pre_ln("vit"):      # layer_norm1 -> qkv, layer_norm2 -> fc1
                 for dst, ln, wt, bt in (("wqkv", L.layer_norm1, wqkv, bqkv), ("w1", L.layer_norm2, L.mlp.fc1.weight, L.mlp.fc1.bias)):
                     t3 = _fold_ln_linear(ln.weight, ln.bias, wt, bt, prec)
                     keep.extend(t3)
@@ -655,7 +656,7 @@ class Decoder(_PackedMixin, nn.Module):
             e.fl_g, e.fl_b = v(_a(L.final_layer_norm).weight), v(_a(L.final_layer_norm).bias)
             e.w1, e.b1 = op(ffn.fc1.weight), v(ffn.fc1.bias)
             src(i, "wo_t", e.wo); src(i, "w2_t", e.w2); src(i, "w1_t", e.w1)
-            if prec in FOLD_PRECS and _fold_pre_ln():      # self_attn_layer_norm -> qkv, final_layer_norm -> fc1
+            if prec in FOLD_PRECS and _fold_pre_ln("decoder"):      # self_attn_layer_norm -> qkv, final_layer_norm -> fc1
                 sl, fl = _a(L.self_attn_layer_norm), _a(L.final_layer_norm)
                 t3 = _fold_ln_linear(sl.weight, sl.bias, torch.cat([q.weight, k.weight, vv.weight], 0),
                                      torch.cat([q.bias, k.bias, vv.bias], 0), prec)
@@ -672,7 +673,7 @@ class Decoder(_PackedMixin, nn.Module):
         w.ln_g, w.ln_b = v(self.layer_norm.weight), v(self.layer_norm.bias)
         w.wout = op(self.output_projection.weight)
         src(-1, "wout_t", w.wout)
-        if prec in FOLD_PRECS and _fold_pre_ln():          # decoder.layer_norm -> output_projection
+        if prec in FOLD_PRECS and _fold_pre_ln("decoder"):          # decoder.layer_norm -> output_projection
             t3 = _fold_ln_linear(self.layer_norm.weight, self.layer_norm.bias, self.output_projection.weight, None, prec)
             keep.extend(t3)
             w.wout_f, w.bout_f, w.wout_colsum = (t.data_ptr() for t in t3)
