@@ -53,10 +53,13 @@ def parse():
                          "fp16 MFMA + two fp8 correction MFMAs); bf16 is reported next to it with its parity")
     ap.add_argument("--no-extra", action="store_true", help="skip the c3 / batch-1 / training legs (headline only)")
     ap.add_argument("--no-gather", action="store_true", help="skip the logits all-gather (N > 1)")
-    ap.add_argument("--gather-algo", default=os.environ.get("KOSMOSX_GATHER_ALGO", "auto"), choices=["auto", "all_gather", "direct"],
-                    help="auto (default): by message size — world-1 grouped send/recv pairs, one xGMI link per peer, for the "
-                         "233 MB logits shard at N > 2 (~1.5 ms by SURVEY 8e's arithmetic against ~10 ms for a ring), RCCL's "
-                         "all_gather for small messages and N = 2; all_gather / direct force one (A/B; KOSMOSX_GATHER_ALGO)")
+    ap.add_argument("--gather-algo", default=os.environ.get("KOSMOSX_GATHER_ALGO", "all_gather"), choices=["auto", "all_gather", "direct"],
+                    help="all_gather (default): RCCL's own collective — the only schedule that has run on more than one "
+                         "GPU-backed rank so far.  auto: by message size — world-1 grouped send/recv pairs, one xGMI link per "
+                         "peer, for the 233 MB logits shard at N > 2 (~1.5 ms by SURVEY 8e's arithmetic against ~10 ms for a "
+                         "ring), all_gather for small messages, N = 2 and whenever a shard is empty; direct forces the grouped "
+                         "schedule.  direct / auto stay opt-in (KOSMOSX_GATHER_ALGO) until an 8-GPU node has run them: "
+                         "gloo world 2 / 3 and RCCL world 1 are what cover them (ADVICE r4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3, help="instrumented steps for the roofline leg")
@@ -207,10 +210,20 @@ def modes_block(head, head_value, head_s_per_step, other, parity_all, flops_per_
     return rows
 
 
-def c3_leg(cfg, dev, _hip, steps=10, warmup=2):
+def c3_leg(cfg, dev, _hip, steps=10, warmup=2, check=True):
+    """BASELINE configs[2].  Every mode carries its parity against the CPU oracle on ONE row of the batch (rows are
+    independent; the full-size test checks more) and `meets_tolerance`; the block's own figures are those of the FASTEST
+    MODE INSIDE 1e-3 (VERDICT r4 next #6: bf16's 0.40 is context, never the target's number)."""
     from kosmosx.model import KosmosLanguage
     d = cfg.decoder
-    lm = KosmosLanguage(vocab_size=cfg.vocab, dim=d.decoder_embed_dim, _seed=0).eval().to(dev)   # example_lang.py:9-12
+    lm = KosmosLanguage(vocab_size=cfg.vocab, dim=d.decoder_embed_dim, _seed=0).eval()   # example_lang.py:9-12
+    lm_cpu = None
+    if check:
+        sys.path.insert(0, str(ROOT / "tests"))
+        from helpers import oracle_weights as _ow
+        lm_cpu = _ow(lm)
+    lm = lm.to(dev)
+    kept = {}
     B, T, D, F, V, L = 32, 2046, d.decoder_embed_dim, d.decoder_ffn_embed_dim, cfg.vocab, d.decoder_layers
     tok = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(0)).to(dev)
     flops = B * T * (L * (8 * D * D + 4 * D * F) + 2 * D * V) + B * L * 2 * D * T * (T + 1)     # causal-algorithmic, SURVEY 8d
@@ -229,10 +242,12 @@ def c3_leg(cfg, dev, _hip, steps=10, warmup=2):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / steps
             _hip.prof_enable(True)
-            lm(tok)
+            lg = lm(tok)
             torch.cuda.synchronize()
             recs = _hip.prof_collect()
             _hip.prof_enable(False)
+            kept[mode] = lg[B - 1].float().cpu()               # the LAST row of the batch: [T, V]
+            del lg
         agg, shapes = {}, {}
         for kind, x, y, z, ms in recs:
             e = agg.setdefault(kind, [0, 0.0]); e[0] += 1; e[1] += ms
@@ -246,6 +261,24 @@ def c3_leg(cfg, dev, _hip, steps=10, warmup=2):
                                      for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])]}
         lm.decoder.invalidate_packed()
     del lm
+    torch.cuda.empty_cache()
+    if lm_cpu is not None:
+        from oracle import kosmos_oracle as O
+        t0 = time.perf_counter()
+        ref = O.kosmos_language_forward(lm_cpu, tok[B - 1:].cpu(), O.DecoderCfg(vocab=cfg.vocab))[0]
+        rms = float(ref.pow(2).mean().sqrt())
+        for mode, got in kept.items():
+            e = float((got - ref).abs().max() / rms)
+            out[mode].update({"parity_max_abs_over_rms": float(f"{e:.3e}"), "tolerance": 1e-3, "meets_tolerance": bool(e <= 1e-3)})
+        out["parity_against"] = (f"fp32 CPU oracle forward of row {B - 1} of the batch, all {T} positions (logit rms {rms:.4f}; "
+                                 f"{time.perf_counter() - t0:.0f} s of host time, outside every timed region)")
+        ok = [m for m in kept if out[m]["meets_tolerance"]]
+        out["fastest_meeting_tolerance"] = min(ok, key=lambda m: out[m]["ms_per_forward"]) if ok else None
+        if ok:
+            b = out[out["fastest_meeting_tolerance"]]
+            out.update({k: b[k] for k in ("ms_per_forward", "tokens_per_s", "model_tflops", "frac_of_bf16_mfma_peak")})
+    else:
+        out["note"] = "parity not measured in this run (--no-cpu-baseline): no mode is headlined"
     return out
 
 
@@ -463,8 +496,9 @@ def main():
                         tdom = max(fam, key=lambda k: fam[k]["ms"])
                         te = fam[tdom]
                         tach = te["flops"] / (te["ms"] * 1e-3) / 1e12
-                        res["roofline"] = {"kernel": tdom, "bound": "mfma", "achieved": round(tach, 1), "peak": PEAK_BF16_TFLOPS,
-                                           "unit": "TFLOP/s", "frac": round(tach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        tpeak = PEAK_F32_TFLOPS if "_f32" in tdom else PEAK_BF16_TFLOPS   # the headline roofline's rule
+                        res["roofline"] = {"kernel": tdom, "bound": "mfma", "achieved": round(tach, 1), "peak": tpeak,
+                                           "unit": "TFLOP/s", "frac": round(tach / tpeak, 4), "traffic": None,
                                            "launches_per_step": te["launches"], "ms_per_step": round(te["ms"], 2),
                                            "step_ms_in_gemms": round(sum(v["ms"] for v in fam.values()), 2),
                                            "measured_in": "one instrumented step (HIP events around every launch)"}
@@ -486,7 +520,7 @@ def main():
     c3 = None
     if rank == 0 and world == 1 and not force_dist and not args.no_extra:
         try:
-            c3 = c3_leg(cfg, dev, _hip)
+            c3 = c3_leg(cfg, dev, _hip, check=not args.no_cpu_baseline)
         except Exception as e:
             c3 = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()

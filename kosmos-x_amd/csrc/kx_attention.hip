@@ -25,8 +25,10 @@ namespace {
 // 16-bit kernels cannot get there from finite inputs — fp16 / f16c operands saturate at 65504 (|score| <= 64 * 65504^2 =
 // 2.7e11) — except plain bf16, whose operands span the fp32 range: documented divergence (include/kosmosx_hip.h, kx_attention).
 __device__ __forceinline__ float score_nan_to_num(float s) {
-  s = fminf(fmaxf(s, -3.402823466e38f), 3.402823466e38f);      // +-inf -> +-FLT_MAX (fminf / fmaxf return the non-NaN operand ...)
-  return s != s ? 0.f : s;                                     // ... so NaN is tested last: NaN -> 0
+  // NaN FIRST: fmaxf(NaN, x) returns x, so a clamp ahead of the test would turn NaN into -FLT_MAX (probability 0) instead of
+  // torch.nan_to_num's 0 (weight exp(0 - max)) — ADVICE r4; tests/test_xpos_kat_gpu.py uses small scores so the two differ
+  s = __builtin_isnan(s) ? 0.f : s;
+  return fminf(fmaxf(s, -3.402823466e38f), 3.402823466e38f);   // +-inf -> +-FLT_MAX
 }
 
 struct AttnParams {

@@ -47,6 +47,7 @@ struct GemmParams {
   int gelu_poly;        // 256-column kernel, lean epilogues: KX_ACT_GELU_FAST may run as KX_ACT_GELU_POLY (plain bf16 in / out)
   int persistent;       // 256x256 kernel: > 0 = launch this many workgroups, each walking its tiles itself
   int skip_idle_waves;  // phased kernels: waves whose rows are all >= M skip their reads and MFMAs
+  int bal;              // 256x256 kernel: balanced K loop (half-tile LDS-DMA issue per read phase, counted vmcnt); tuning key 14 = 1: first form
   // 256x256 kernel, K split over workgroup PAIRS (launch_p5, kx_gemm_args.pair_ws): a problem with half a round of
   // 256x256 tiles (the decoder's N = 2048 GEMMs at M = 32 * 114: 120 tiles) runs 2 x tiles workgroups, workgroup h of a
   // pair taking K-tiles [h * nk/2, (h + 1) * nk/2); the two exchange half of their accumulators through pk_slab
@@ -1441,9 +1442,33 @@ __device__ unsigned long long kx_tl[8];
 // epilogue each:
 // with all three behind run-time branches the register allocator spilled accumulators inside the K loop)
 // KS2 (generic epilogue only): K split over workgroup pairs, see GemmParams.pairk
-template <typename T, int ACT, int BM, int EPI, bool KS2 = false>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
+#define KX_PIN_ACC(H)                                                                                   \
+  _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                     \
+  _Pragma("unroll") for (int b_ = 0; b_ < FM / 2; ++b_) asm volatile("" : "+v"(acc[a_][(H) * (FM / 2) + b_]));
+// BAL ("balanced K loop", round 5; BM = 256): the LDS-DMA of a K-tile is issued in two halves, four instructions per wave in
+// EACH read phase, and waited for with COUNTED vmcnt — never a drain (guide T3+T4: the gain of a phased loop is the counted
+// wait).  The first form issued a whole tile (eight LDS-DMA instructions per wave at 60-185 cycles of issue each) in R0 on
+// top of R0's twelve fragment reads, nothing in R1, and drained vmcnt(0) in R1: the R0 interval was the pole of every K-tile
+// while the partner wave group's 32 MFMAs (~550 cycles) sat beside it.  What makes the split legal on the same two-stage
+// ring is the phase decomposition the fp8 correction tiles already use — by activation HALVES instead of k-steps:
+//   R0: W(kt+1) issued (4) | read all W fragments + activation fragments [0, FM/2), both k-steps   | M0: FN x FM/2 x 2 MFMAs
+//   R1: Ah1(kt+1), Ah0(kt+2) issued (2 + 2) | read activation fragments [FM/2, FM), both k-steps   | M1: FN x FM/2 x 2 MFMAs
+// (Ah0 / Ah1 = the LDS rows of fragment halves 0 / 1 of both wave rows; every wave stages two 8-row pieces of each.)
+//   needed in R0(kt+1): W(kt+1), Ah0(kt+1) -> waited at the end of R1(kt) with vmcnt(4) (Ah1(kt+1), Ah0(kt+2) stay in flight)
+//   needed in R1(kt+1): Ah1(kt+1)          -> waited at the end of R0(kt+1) with vmcnt(6) (Ah0(kt+2), W(kt+2) stay in flight)
+// Each wait sits in a READ phase and is followed by that phase's closing barrier, so the lagging wave group's pieces are
+// waited for before the leading group reads them (the rule the first form's vmcnt(0) in R1 obeyed).  WAR: W(kt+1) lands in
+// the buffer last read in R0(kt-1), Ah1(kt+1) in the one last read in R1(kt-1), Ah0(kt+2) in the one read in R0(kt) — by
+// both groups before the barrier that opens the issuing group's R1(kt).  Same LDS image, same 128 KB, same fragment
+// offsets: only which wave stages which rows, when, and the order of the 64 MFMAs of a tile change (a fixed order per
+// accumulator: k-step 0 then 1, as before — results are bit-identical to the first form).
+template <typename T, int ACT, int BM, int EPI, bool KS2 = false, bool BAL = false>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   static_assert(!KS2 || (EPI == 0 && BM == 256), "the pair split runs the 256-row kernel with the generic epilogue");
+  // BAL at BM = 192: an activation half is 2 x 48 rows = twelve 8-row pieces for eight waves — waves 0-3 stage two pieces of half
+  // 0 and one of half 1, waves 4-7 one and two.  The waits use the smaller count of the two wave kinds (vmcnt(5) / vmcnt(3)):
+  // a wave with one piece more in flight waits for one piece more than it must — conservative, never early.
+  constexpr int VM_R0 = BM == 256 ? 6 : 5, VM_R1 = BM == 256 ? 4 : 3;
   constexpr int BN = 256, ROWB = 128;
   static_assert(BM % 64 == 0, "BM must split into 2 wave rows of whole 16-row fragments and 8 staging waves");
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;   // 64 KB
@@ -1483,34 +1508,74 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const int gk = lane_k >> 4, lk = lane_k & 15;
 
   const int srow = lane_k >> 3, schunk = lane_k & 7;
-  const char* srcA[IA];
-  const char* srcW[IW];
+  // per-lane source offsets relative to the tile's first operand row (32 bits: <= 256 rows of pitch; the tile base and the
+  // K offset are wave-uniform, so the LDS-DMA takes the SGPR-base + VGPR-offset address form — eight VGPRs less than eight
+  // 64-bit per-lane pointers, which the balanced K loop's 64 fragment registers need)
+  unsigned srcA[IA], srcW[IW];
+  const char* const tileA = p.A + (long long)m0 * p.lda_b;
+  const char* const tileW = p.W + (long long)n0 * p.ldw_b;
+  int ldsA[IA];                // LDS row of the first of the 8 rows piece j of this wave covers
 #pragma unroll
   for (int j = 0; j < IA; ++j) {
-    const int row = wave * (BM / 8) + j * 8 + srow;
+    // BAL, 256 rows: pieces 0, 1 belong to activation half 0 (fragments [0, FM/2) of both wave rows), pieces 2, 3 to half 1
+    // BAL, 192 rows: waves 0-3: pieces 0, 1 -> half 0, piece 2 -> half 1; waves 4-7: piece 0 -> half 0, pieces 1, 2 -> half 1
+    if constexpr (BAL && BM == 192) {
+      const int h = wave < 4 ? (j >> 1) : (j > 0);                                 // half of piece j
+      const int g = wave < 4 ? (h == 0 ? 2 * wave + j : wave)                      // 8-row group within the half: 0..11
+                             : (h == 0 ? 8 + (wave - 4) : 4 + 2 * (wave - 4) + (j - 1));
+      ldsA[j] = (g / 6) * (BM / 2) + h * (BM / 4) + (g % 6) * 8;
+    } else {
+      const int lr = wave * 16 + (j & 1) * 8;                                      // row within the half (BAL)
+      ldsA[j] = BAL ? (lr >> 6) * (BM / 2) + (j >> 1) * (BM / 4) + (lr & 63) : wave * (BM / 8) + j * 8;
+    }
+    const int row = ldsA[j] + srow;
     // KS2, partner 1: LDS row r holds tile row r ^ 64 — its accumulator half 0 (the half every workgroup keeps) then
     // covers the tile rows that are partner 0's half 1 (the half every workgroup gives away)
     const int gm = min(m0 + (KS2 && ks_h ? (row ^ 64) : row), p.M - 1);
-    srcA[j] = p.A + (long long)gm * p.lda_b + ((schunk ^ (row & 7)) << 4);
+    srcA[j] = (unsigned)((long long)(gm - m0) * p.lda_b) + ((schunk ^ (row & 7)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < IW; ++j) {
     const int row = wave * 32 + j * 8 + srow;
     const int gn = min(n0 + row, p.N - 1);
-    srcW[j] = p.W + (long long)gn * p.ldw_b + ((schunk ^ (row & 7)) << 4);
+    srcW[j] = (unsigned)((long long)(gn - n0) * p.ldw_b) + ((schunk ^ (row & 7)) << 4);
   }
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
     const long long koff = (long long)kt * ROWB;
 #pragma unroll
     for (int j = 0; j < IA; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff),
-                                       (lds_void_t*)(base + (wave * (BM / 8) + j * 8) * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(tileA + koff + srcA[j]), (lds_void_t*)(base + ldsA[j] * ROWB), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < IW; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcW[j] + koff),
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(tileW + koff + srcW[j]),
                                        (lds_void_t*)(base + A_BYTES + (wave * 32 + j * 8) * ROWB), 16, 0, 0);
   };
+  auto stage_w = [&](int kt) {          // BAL: the weight rows of K-tile kt (IW instructions)
+    char* base = smem + (kt & 1) * STAGE;
+    const long long koff = (long long)kt * ROWB;
+#pragma unroll
+    for (int j = 0; j < IW; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(tileW + koff + srcW[j]),
+                                       (lds_void_t*)(base + A_BYTES + (wave * 32 + j * 8) * ROWB), 16, 0, 0);
+  };
+  auto stage_ah = [&](auto h_c, int kt) {   // BAL: activation half h of K-tile kt (two instructions)
+    constexpr int h = decltype(h_c)::value;
+    char* base = smem + (kt & 1) * STAGE;
+    const long long koff = (long long)kt * ROWB;
+    if constexpr (BM == 192) {
+#pragma unroll
+      for (int j = 0; j < IA; ++j)
+        if ((wave < 4 ? (j >> 1) : (j > 0)) == h)                                  // wave-uniform
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(tileA + koff + srcA[j]), (lds_void_t*)(base + ldsA[j] * ROWB), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 2 * h; j < 2 * h + 2; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(tileA + koff + srcA[j]), (lds_void_t*)(base + ldsA[j] * ROWB), 16, 0, 0);
+    }
+  };
+  using Half0 = std::integral_constant<int, 0>;
+  using Half1 = std::integral_constant<int, 1>;
 
   f32x4_t acc[FN][FM];
 #pragma unroll
@@ -1532,6 +1597,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const int nk = p.K / (ROWB / (int)sizeof(T));
   const int k0 = KS2 ? ks_h * (nk >> 1) : 0, k1 = KS2 ? k0 + (nk >> 1) : nk;     // this workgroup's K-tiles (KS2: nk is even)
   if constexpr (KS2) stage(k0 & 1, k0); else stage(0, 0);
+  if constexpr (BAL) { if (k0 + 1 < k1) stage_ah(Half0{}, k0 + 1); }   // the loop's R1(kt) issues Ah1(kt+1), Ah0(kt+2)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   KX_TL_STAMP(1);
@@ -1542,9 +1608,88 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   // the fragment loads and again around the MFMAs inside ONE loop made the fragments conditionally-defined values whose
   // live ranges the register allocator stretched over both loops (the KX_F16C kernel spilled its weight fragments to
   // scratch inside the MFMA phases, with a vmcnt(0) that also drained the next tile's LDS-DMA).
+  // BAL: the conditional LDS-DMA issue of R1 puts basic-block boundaries between the phases, and the MFMAs of a phase —
+  // pure operations whose results are next used an iteration later — were SUNK past the phase's closing barrier into the
+  // next read phase (seen in the fp8 loop: M0 empty, 16 MFMAs inside R1).  An empty asm that "rewrites" the phase's
+  // accumulators keeps them where the phase structure needs them (sched_barrier only binds the scheduler within a block).
   auto kloop = [&](auto work_c) __attribute__((always_inline)) {
   constexpr bool W = decltype(work_c)::value;
   const int nk1 = kIsF16c<T> ? min(p.nk_main, nk) : nk;     // KX_F16C: the fp16 tiles; the fp8 correction tiles follow below
+  if constexpr (BAL) {
+  constexpr int FH = FM / 2;
+  for (int kt = k0; kt < (KS2 ? min(nk1, k1) : nk1); ++kt) {
+    const char* base = smem + (kt & 1) * STAGE;
+    u32x4_t fw0[FN], fw1[FN], fa0[FH], fa1[FH];
+    // ---- R0 ----
+    if (kt + 1 < k1) stage_w(kt + 1);
+    if constexpr (W) {
+#pragma unroll
+      for (int a = 0; a < FN; ++a) {
+        fw0[a] = *reinterpret_cast<const u32x4_t*>(base + offW[a]);
+        fw1[a] = *reinterpret_cast<const u32x4_t*>(base + (offW[a] ^ 64));
+      }
+#pragma unroll
+      for (int b = 0; b < FH; ++b) {
+        fa0[b] = *reinterpret_cast<const u32x4_t*>(base + offA[b]);
+        fa1[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ 64));
+      }
+    }
+    if (kt + 1 < k1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_R0) : "memory");   // Ah1(kt) landed; Ah0(kt+1), W(kt+1) in flight
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M0 ----
+    if constexpr (W) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FH; ++b) acc[a][b] = Mma<T>::step(fw0[a], fa0[b], acc[a][b]);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FH; ++b) acc[a][b] = Mma<T>::step(fw1[a], fa1[b], acc[a][b]);
+      __builtin_amdgcn_s_setprio(0);
+      KX_PIN_ACC(0)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- R1 ----
+    if (kt + 1 < k1) stage_ah(Half1{}, kt + 1);
+    if (kt + 2 < k1) stage_ah(Half0{}, kt + 2);
+    if constexpr (W) {
+#pragma unroll
+      for (int b = 0; b < FH; ++b) {
+        fa0[b] = *reinterpret_cast<const u32x4_t*>(base + offA[FH + b]);
+        fa1[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[FH + b] ^ 64));
+      }
+    }
+    if (kt + 2 < k1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_R1) : "memory");   // W(kt+1), Ah0(kt+1) landed; Ah1(kt+1), Ah0(kt+2) in flight
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M1 ----
+    if constexpr (W) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FH; ++b) acc[a][FH + b] = Mma<T>::step(fw0[a], fa0[b], acc[a][FH + b]);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FH; ++b) acc[a][FH + b] = Mma<T>::step(fw1[a], fa1[b], acc[a][FH + b]);
+      __builtin_amdgcn_s_setprio(0);
+      KX_PIN_ACC(1)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  } else
   for (int kt = k0; kt < (KS2 ? min(nk1, k1) : nk1); ++kt) {
     const char* base = smem + (kt & 1) * STAGE;
     u32x4_t fa[FM], fw[FN];
@@ -1610,7 +1755,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
       const char* base = smem + (kt & 1) * STAGE;
       u32x4_t fw0[FN], fw1[FN], fa0[FH], fa1[FH];
       // ---- R0 ----
-      if (kt + 1 < k1) stage((kt + 1) & 1, kt + 1);
+      if constexpr (BAL) { if (kt + 1 < k1) stage_w(kt + 1); }
+      else if (kt + 1 < k1) stage((kt + 1) & 1, kt + 1);
       if constexpr (W) {
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
@@ -1623,6 +1769,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
           fa1[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[b] ^ 64));
         }
       }
+      if constexpr (BAL) {                                     // see the fp16 loop: Ah1(kt) landed
+        if (kt + 1 < k1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_R0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -1635,11 +1785,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
 #pragma unroll
           for (int b = 0; b < FH; ++b) acc[a][b] = mma_fp8(fw0[a], fw1[a], fa0[b], fa1[b], acc[a][b], wsc[a]);
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (BAL) { KX_PIN_ACC(0) }
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---- R1 ----
+      if constexpr (BAL) {
+        if (kt + 1 < k1) stage_ah(Half1{}, kt + 1);
+        if (kt + 2 < k1) stage_ah(Half0{}, kt + 2);
+      }
       if constexpr (W) {
 #pragma unroll
         for (int b = 0; b < FH; ++b) {
@@ -1647,6 +1802,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
           fa1[b] = *reinterpret_cast<const u32x4_t*>(base + (offA[FH + b] ^ 64));
         }
       }
+      if constexpr (BAL) {                                     // W(kt+1), Ah0(kt+1) landed
+        if (kt + 2 < k1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_R1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed (this wave's pieces)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -1659,6 +1818,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
 #pragma unroll
           for (int b = 0; b < FH; ++b) acc[a][FH + b] = mma_fp8(fw0[a], fw1[a], fa0[b], fa1[b], acc[a][FH + b], wsc[a]);
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (BAL) { KX_PIN_ACC(1) }
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -1787,41 +1947,48 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   }  // tiles of this workgroup
 }
 
+// one launch site for both K-loop forms of the 256-row kernel (GemmParams.bal; tuning key 14)
+template <typename T, int ACT, int BM, int EPI, bool KS2 = false>
+void launch_p5k(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s) {
+  if (p.bal) { hipLaunchKernelGGL((gemm_kernel_p5<T, ACT, BM, EPI, KS2, true>), grid, block, 0, s, p); return; }
+  hipLaunchKernelGGL((gemm_kernel_p5<T, ACT, BM, EPI, KS2, false>), grid, block, 0, s, p);
+}
+
 template <typename T, int BM, int EPI>
 int launch_p5e(GemmParams& p, hipStream_t s) {
   const int nwg = p.tiles_m * p.tiles_n;
   const dim3 grid(p.persistent > 0 ? (nwg < p.persistent ? nwg : p.persistent) : nwg), block(512);
   // the lean variants are instantiated for the activations the forward uses them with; anything else takes EPI 0
   if constexpr (EPI == 8) {                 // fp32 output, bias + q-scale + XPos at accumulator level (no activation)
-    if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, 8>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
+    if (p.act == KX_ACT_NONE) { launch_p5k<T, KX_ACT_NONE, BM, 8>(p, grid, block, s); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
     return launch_p5e<T, BM, 0>(p, s);
   } else
   if constexpr (EPI == 6 || EPI == 7) {     // KX_F16C output (BM = 256): plain and GELU, with (7) or without (6) produced statistics
     if constexpr (kIsF16c<T> && BM == 256) {
-      if (p.act == KX_ACT_NONE) { hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, EPI>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
+      if (p.act == KX_ACT_NONE) { launch_p5k<T, KX_ACT_NONE, BM, EPI>(p, grid, block, s); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
       if constexpr (EPI == 7) {             // (GELU without statistics spills 248 B / lane in this form: it keeps the generic loops)
-        if (p.act == KX_ACT_GELU_FAST) { hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, EPI>), grid, block, 0, s, p); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
+        if (p.act == KX_ACT_GELU_FAST) { launch_p5k<T, KX_ACT_GELU_FAST, BM, EPI>(p, grid, block, s); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
       }
     }
     return launch_p5e<T, BM, 0>(p, s);
   } else
-  if (p.act == KX_ACT_NONE && EPI != 4) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, EPI>), grid, block, 0, s, p);
+  if (p.act == KX_ACT_NONE && EPI != 4) launch_p5k<T, KX_ACT_NONE, BM, EPI>(p, grid, block, s);
   else if (EPI == 5) return launch_p5e<T, BM, 0>(p, s);
   else if (p.act == KX_ACT_GELU_FAST && (EPI == 0 || EPI == 1 || EPI == 4)) {
     constexpr int E = (EPI == 1 || EPI == 4) ? EPI : 0;
     // plain bf16 in, plain bf16 out, accumulator-level epilogue: the transcendental-free packed GELU (KX_ACT_GELU_POLY)
     if constexpr (!kIsF16c<T> && E != 0) {
-      if (p.gelu_poly) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_POLY, BM, E>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, E>), grid, block, 0, s, p);
+      if (p.gelu_poly) launch_p5k<T, KX_ACT_GELU_POLY, BM, E>(p, grid, block, s);
+      else launch_p5k<T, KX_ACT_GELU_FAST, BM, E>(p, grid, block, s);
     } else {
-      hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU_FAST, BM, E>), grid, block, 0, s, p);
+      launch_p5k<T, KX_ACT_GELU_FAST, BM, E>(p, grid, block, s);
     }
   }
   else if (p.act == KX_ACT_QUICK_GELU && (EPI == 0 || EPI == 1))
-    hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_QUICK_GELU, BM, EPI == 1 ? 1 : 0>), grid, block, 0, s, p);
+    launch_p5k<T, KX_ACT_QUICK_GELU, BM, EPI == 1 ? 1 : 0>(p, grid, block, s);
   else if (EPI != 0) return launch_p5e<T, BM, 0>(p, s);
-  else if (p.act == KX_ACT_NONE) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, BM, 0>), grid, block, 0, s, p);
-  else if (p.act == KX_ACT_GELU) hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_GELU, BM, 0>), grid, block, 0, s, p);
+  else if (p.act == KX_ACT_NONE) launch_p5k<T, KX_ACT_NONE, BM, 0>(p, grid, block, s);
+  else if (p.act == KX_ACT_GELU) launch_p5k<T, KX_ACT_GELU, BM, 0>(p, grid, block, s);
   else { kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG; }
   KX_CHECK_LAUNCH("kx_gemm(p5)");
   return KX_OK;
@@ -1834,7 +2001,7 @@ int launch_p5(GemmParams& p, hipStream_t s) {
   if constexpr (BM == 256) {
     if (p.pairk) {                            // K split over workgroup pairs (kx_gemm checked: no activation / statistics, even nk, tiles % 8 == 0)
       const dim3 grid(2 * p.tiles_m * p.tiles_n), block(512);
-      hipLaunchKernelGGL((gemm_kernel_p5<T, KX_ACT_NONE, 256, 0, true>), grid, block, 0, s, p);
+      launch_p5k<T, KX_ACT_NONE, 256, 0, true>(p, grid, block, s);
       KX_CHECK_LAUNCH("kx_gemm(p5, pair split-K)");
       return KX_OK;
     }

@@ -230,6 +230,13 @@ def load():
         if lib.kx_struct_bytes(sid) != C.sizeof(cls):
             raise RuntimeError(f"ctypes mirror {cls.__name__} is {C.sizeof(cls)} bytes, the library's struct "
                                f"{lib.kx_struct_bytes(sid)}: _hip.py is out of date with include/kosmosx_hip.h")
+    # measurement hook: KOSMOSX_TUNING="14=1,4=8" applies kx_set_tuning(key, value) pairs once at load, so that a whole bench.py
+    # run can be A/B-ed against a kernel variant without code changes (defaults — all keys 0 — are the shipped configuration)
+    for kv in filter(None, os.environ.get("KOSMOSX_TUNING", "").split(",")):
+        k, v = kv.split("=")
+        if lib.kx_set_tuning(int(k), int(v)) != 0:
+            raise RuntimeError(f"KOSMOSX_TUNING: kx_set_tuning({k}, {v}) refused")
+        logging.warning(f"KOSMOSX_TUNING: tuning key {k} = {v} (not the shipped configuration)")
     _lib = lib
     return lib
 

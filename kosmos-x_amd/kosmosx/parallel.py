@@ -7,6 +7,8 @@ replicated weights, and ONE exchange step — the all-gather of logits over RCCL
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -68,7 +70,11 @@ class LogitsGatherer:
     def _pick(self, wire, sizes) -> str:
         if self.algo != "auto":
             return self.algo
-        row_bytes = wire.element_size() * (wire.numel() // max(1, wire.shape[0]))
+        # bytes per row from the TRAILING dims, which every rank shares: a rank with a zero-row shard must not compute 0
+        # here and enter a different collective than its peers (shard_range leaves empty shards when total < world)
+        row_bytes = wire.element_size() * math.prod(wire.shape[1:])
+        if min(sizes) == 0:                 # `direct` would post sends / receives of empty slices: take the library collective
+            return "all_gather"
         return "direct" if self.world > 2 and max(sizes) * row_bytes >= self.DIRECT_MIN_BYTES else "all_gather"
 
     def _shard_sizes(self, rows: int, device, total=None, sizes=None) -> list:

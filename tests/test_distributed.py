@@ -227,6 +227,43 @@ def _gather_auto_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _gather_auto_empty_worker(rank, world, port, q):
+    for p in (str(ROOT), str(ROOT / "kosmos-x_amd"), str(ROOT / "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KOSMOSX_NO_LOGGING_CONFIG="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kosmosx.parallel import LogitsGatherer, shard_range
+    ga = LogitsGatherer(wire_dtype=None, slots=2)                     # algo="auto"
+    ga.DIRECT_MIN_BYTES = 4096
+    total, cols = 2, 2048                                             # 2 rows over 3 ranks: rank 2 holds nothing; 24 KB rows
+    full = torch.arange(total * 3 * cols, dtype=torch.float32).reshape(total, 3, cols)
+    lo, hi = shard_range(total, rank, world)
+    out = ga.gather(full[lo:hi], total=total)
+    ga.wait()
+    q.put(_np([(rank, ga.last_algo, bool(torch.equal(out, full)))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_logits_gatherer_auto_with_an_empty_shard_takes_one_branch_on_every_rank():
+    """the auto rule sized the message from the LOCAL tensor, so a rank with a zero-row shard (total < world)
+    chose all_gather while its peers chose direct — different collectives, a hang.  Every rank must report the same
+    algorithm and the gathered batch must be whole."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_auto_empty_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [_pt(q.get(timeout=240))[0] for _ in range(3)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len({a for _, a, _ in res}) == 1 and all(ok for _, _, ok in res), res
+    assert res[0][1] == "all_gather [auto]", res                      # an empty shard rules the grouped send / recv schedule out
+
+
 def test_logits_gatherer_auto_picks_by_message_size():
     """small messages take RCCL's all_gather, bandwidth-bound ones (the 233 MB logits shard) the
     one-link-per-peer schedule when more than two ranks exchange; the decision uses the largest shard, identical on all ranks."""

@@ -162,3 +162,31 @@ def test_nan_to_num_on_overflowing_and_nan_scores_in_the_fp32_kernels():
     # HF CLIP / flamingo attention (KX_ATTN_FULL) has no nan_to_num: the unmasked fp32 launch keeps IEEE semantics
     outf = ops.attention(qd, kd, vd, causal=False).cpu()
     assert not torch.isfinite(outf[0, 40]).all()
+
+
+def test_nan_score_counts_as_zero_not_as_minus_flt_max():
+    """with |scores| << 1 a NaN score that becomes 0 keeps a weight of about 1 / (i + 1) in its row; clamped to
+    -FLT_MAX (what fmaxf(NaN, -FLT_MAX) returns when the clamp precedes the NaN test) it would get probability 0 — the two
+    readings differ by ~|v| / T here, four orders above the tolerance."""
+    T = 70
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(1, T, 1, HD, generator=g) for _ in range(3))
+    q *= 0.05
+    k *= 0.05                                                            # scores ~ N(0, 0.02): softmax is nearly uniform
+    k[0, 30, 0, 7] = float("nan")                                        # every query >= 30 has a NaN score against key 30
+    ref = _torchscale_attention(q, k, v)
+    assert torch.isfinite(ref).all()
+    wrong = _torchscale_attention(q, torch.nan_to_num(k, nan=-1e30), v)  # the other reading: key 30 never attended to
+    assert float((ref - wrong).abs().max()) > 1e-2                       # the input discriminates
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    from kosmosx import _hip
+    lib = _hip.load()
+    for variant in (0, 1):                                               # matrix-core fp32 kernel, first-version wave-per-query kernel
+        lib.kx_set_tuning(2, variant)
+        try:
+            out = ops.attention(qd, kd, vd, causal=True).cpu()
+        finally:
+            lib.kx_set_tuning(2, 0)
+        err = float((out - ref).abs().max())
+        print(f"fp32 causal kernel variant {variant}, NaN score at small magnitude: max|d| = {err:.2e}")
+        assert err < 2e-6, (variant, err)
