@@ -621,9 +621,9 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  * key 12: 1 = the fp16-pieces decode step keeps fp32 rows between its kernels (each consumer splits them itself) instead of
  *         KX_F16P rows written by the producers (A/B).
  * key 13: 1 = never take the pair split of the 256x256 kernel (kx_gemm_args.pair_ws) automatically (A/B).
- * key 14: K loop of the 256-column kernel (0 = auto: the balanced form — the LDS-DMA of a K-tile issued in two halves, one per
- *         read phase, counted vmcnt waits — for >= 32 K-tiles and N <= 16384; 1 = always the first form: whole tile issued in
- *         the first read phase, vmcnt(0) in the second; 2 = always the balanced form.  The two are bit-identical). */
+ * key 14: K loop of the 256-column kernel (0 = the balanced form: the LDS-DMA of a K-tile issued in two halves, one per read
+ *         phase, counted vmcnt waits; 1 = the first form: whole tile issued in the first read phase, vmcnt(0) in the second.
+ *         The two are bit-identical). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

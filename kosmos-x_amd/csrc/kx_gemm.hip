@@ -125,14 +125,10 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
     // statistics, XPos tables); bias-only bf16 epilogues measured ~5 % faster on the plain rolled loop.
     const int mode = kx_tuning_get(KX_TUNE_GEMM_EPILOGUE);   // 0 auto, 1 never, 2 always (A/B)
     p.skip_idle_waves = kx_tuning_get(KX_TUNE_GEMM_IDLE_SKIP) != 1;   // A/B: 1 = off
-    {   // K loop of the 256-column kernel (tuning key 14: 0 auto, 1 = first form, 2 = balanced form always).  Measured with
-        // tools/kloop_bench.py (profiles/r05_a_kloop_bench.jsonl): the balanced form gains 4-10 % where the K loop is long (>= 32
-        // K-tiles: the decoder's and C3's GEMMs, f16c and bf16) and loses 9 % on the logits GEMM, whose 262 MB of weight rows
-        // stream from HBM once per tile row; K = 1024 (16 K-tiles) is a wash
-      const int kl = kx_tuning_get(KX_TUNE_GEMM_KLOOP);
-      const long long nkt = (f16c ? 2 * a->K : a->K) / (128 / es);
-      p.bal = kl == 2 || (kl == 0 && nkt >= 32 && a->N <= 16384);
-    }
+    // K loop of the 256-column kernel (tuning key 14: 0 = balanced, 1 = the first form, A/B).  tools/kloop_bench.py,
+    // profiles/r05_c_kloop_bench.jsonl: +5...13 % on every shape of the forward at K >= 2048 (f16c, bf16, fp16), +3...7 % at
+    // K = 1024, bit-identical
+    p.bal = kx_tuning_get(KX_TUNE_GEMM_KLOOP) != 1;
     {   // one persistent workgroup per CU unless told otherwise (key 7: -1 = one workgroup per tile, n > 0 = n workgroups)
       const int pv = kx_tuning_get(KX_TUNE_GEMM_PERSISTENT);
       p.persistent = pv < 0 ? 0 : pv > 0 ? pv : kx_cu_count();

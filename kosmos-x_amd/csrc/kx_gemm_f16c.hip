@@ -11,3 +11,16 @@ int kx_gemm_launch_f16c(GemmParams& p, int tile, hipStream_t s) {
   kx_set_error("kx_gemm: unknown tile variant %d", tile);
   return KX_ERR_UNSUPPORTED;
 }
+
+#ifdef KX_TIMELINE
+// this translation unit's copy of the phase stamps (the f16c / fp16 kernels): see kx_timeline_phases_read
+extern "C" int kx_timeline_phases_read_f16c(unsigned long long* out48, int reset) {
+  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(kx_tlp), 256) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out48 + 32, HIP_SYMBOL(kx_tlp_n), 128) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(kx_tlp), z, 256) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(kx_tlp_n), z, 128) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

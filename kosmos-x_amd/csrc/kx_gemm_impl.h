@@ -1433,9 +1433,29 @@ __device__ unsigned long long kx_tl[8];
     atomicAdd(&kx_tl[2], kx_t3 - kx_t2); atomicAdd(&kx_tl[3], kx_t4 - kx_t3);           \
     atomicAdd(&kx_tl[4], kx_t5 - kx_t4); atomicAdd(&kx_tl[5], 1ull);                    \
   }
+// Phase-level stamps of the balanced K loop: lane 0 of wave 0 (leading group) and of wave 4 (lagging group) accumulate,
+// per phase kind (fp16 tiles: R0 M0 R1 M1 = 0..3, fp8 tiles: 4..7), the cycles from the phase's start to its arrival at the
+// closing barrier ("work") and to the barrier's release ("span"): kx_tlp[group][kind][work, span], kx_tlp_n[group][kind].
+__device__ unsigned long long kx_tlp[2][8][2];
+__device__ unsigned long long kx_tlp_n[2][8];
+#define KX_TLP_BEGIN() unsigned long long kx_p0 = __builtin_readcyclecounter(), kx_p1 = 0; (void)kx_p1
+#define KX_TLP_ARRIVE() kx_p1 = __builtin_readcyclecounter()
+#define KX_TLP_END(kind)                                                                               \
+  {                                                                                                    \
+    const unsigned long long kx_p2 = __builtin_readcyclecounter();                                      \
+    if ((threadIdx.x & 255) == 0) {                                                                    \
+      const int g_ = threadIdx.x >> 8;                                                                 \
+      atomicAdd(&kx_tlp[g_][kind][0], kx_p1 - kx_p0); atomicAdd(&kx_tlp[g_][kind][1], kx_p2 - kx_p0);  \
+      atomicAdd(&kx_tlp_n[g_][kind], 1ull);                                                            \
+    }                                                                                                  \
+    kx_p0 = kx_p2;                                                                                     \
+  }
 #else
 #define KX_TL_STAMP(i)
 #define KX_TL_COMMIT()
+#define KX_TLP_BEGIN()
+#define KX_TLP_ARRIVE()
+#define KX_TLP_END(kind)
 #endif
 
 // EPI: 0 generic store loops, 1 lean bf16 tile store, 4 the same with produced row statistics — separate kernels (one
@@ -1598,6 +1618,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const int k0 = KS2 ? ks_h * (nk >> 1) : 0, k1 = KS2 ? k0 + (nk >> 1) : nk;     // this workgroup's K-tiles (KS2: nk is even)
   if constexpr (KS2) stage(k0 & 1, k0); else stage(0, 0);
   if constexpr (BAL) { if (k0 + 1 < k1) stage_ah(Half0{}, k0 + 1); }   // the loop's R1(kt) issues Ah1(kt+1), Ah0(kt+2)
+  // The drain is written as the BUILTIN so that the compiler's wait-count pass sees it (inline asm is invisible to it): with
+  // the asm form alone it assumed that loads of the previous tile's epilogue could still be pending inside the K loop and,
+  // in the one instantiation whose register allocation reused such a register for a fragment (f16c, generic fp32 store),
+  // put its own s_waitcnt vmcnt(0) between R0's ds_reads — a drain of the LDS-DMA ring every K-tile: the balanced loop
+  // measured 9-11 % SLOWER than the first form there while every other instantiation gained (profiles/r05_b_*).
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   KX_TL_STAMP(1);
@@ -1617,6 +1643,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const int nk1 = kIsF16c<T> ? min(p.nk_main, nk) : nk;     // KX_F16C: the fp16 tiles; the fp8 correction tiles follow below
   if constexpr (BAL) {
   constexpr int FH = FM / 2;
+  KX_TLP_BEGIN();
   for (int kt = k0; kt < (KS2 ? min(nk1, k1) : nk1); ++kt) {
     const char* base = smem + (kt & 1) * STAGE;
     u32x4_t fw0[FN], fw1[FN], fa0[FH], fa1[FH];
@@ -1636,9 +1663,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     }
     if (kt + 1 < k1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_R0) : "memory");   // Ah1(kt) landed; Ah0(kt+1), W(kt+1) in flight
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    KX_TLP_ARRIVE();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    KX_TLP_END(0)
     // ---- M0 ----
     if constexpr (W) {
       __builtin_amdgcn_s_setprio(1);
@@ -1653,9 +1682,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
       __builtin_amdgcn_s_setprio(0);
       KX_PIN_ACC(0)
     }
+    KX_TLP_ARRIVE();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    KX_TLP_END(1)
     // ---- R1 ----
     if (kt + 1 < k1) stage_ah(Half1{}, kt + 1);
     if (kt + 2 < k1) stage_ah(Half0{}, kt + 2);
@@ -1668,9 +1699,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     }
     if (kt + 2 < k1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_R1) : "memory");   // W(kt+1), Ah0(kt+1) landed; Ah1(kt+1), Ah0(kt+2) in flight
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    KX_TLP_ARRIVE();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    KX_TLP_END(2)
     // ---- M1 ----
     if constexpr (W) {
       __builtin_amdgcn_s_setprio(1);
@@ -1685,9 +1718,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
       __builtin_amdgcn_s_setprio(0);
       KX_PIN_ACC(1)
     }
+    KX_TLP_ARRIVE();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    KX_TLP_END(3)
   }
   } else
   for (int kt = k0; kt < (KS2 ? min(nk1, k1) : nk1); ++kt) {
@@ -1751,6 +1786,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     int wsc[FN];
 #pragma unroll
     for (int a = 0; a < FN; ++a) wsc[a] = p.wscale ? p.wscale[min(n0 + wn * 64 + a * 16 + lk, p.N - 1)] : 127;
+    KX_TLP_BEGIN();
     for (int kt = KS2 ? max(nk1, k0) : nk1; kt < k1; ++kt) {
       const char* base = smem + (kt & 1) * STAGE;
       u32x4_t fw0[FN], fw1[FN], fa0[FH], fa1[FH];
@@ -1774,9 +1810,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (BAL) { KX_TLP_ARRIVE(); }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BAL) { KX_TLP_END(4) }
       // ---- M0 ----
       if constexpr (W) {
         __builtin_amdgcn_s_setprio(1);
@@ -1787,9 +1825,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
         __builtin_amdgcn_s_setprio(0);
         if constexpr (BAL) { KX_PIN_ACC(0) }
       }
+      if constexpr (BAL) { KX_TLP_ARRIVE(); }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BAL) { KX_TLP_END(5) }
       // ---- R1 ----
       if constexpr (BAL) {
         if (kt + 1 < k1) stage_ah(Half1{}, kt + 1);
@@ -1807,9 +1847,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed (this wave's pieces)
+      if constexpr (BAL) { KX_TLP_ARRIVE(); }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BAL) { KX_TLP_END(6) }
       // ---- M1 ----
       if constexpr (W) {
         __builtin_amdgcn_s_setprio(1);
@@ -1820,9 +1862,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
         __builtin_amdgcn_s_setprio(0);
         if constexpr (BAL) { KX_PIN_ACC(1) }
       }
+      if constexpr (BAL) { KX_TLP_ARRIVE(); }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BAL) { KX_TLP_END(7) }
     }
   }
   };

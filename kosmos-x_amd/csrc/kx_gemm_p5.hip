@@ -16,4 +16,14 @@ extern "C" int kx_timeline_read(unsigned long long* out8, int reset) {
   if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(kx_tl), z, 64) != hipSuccess) return 1; }
   return 0;
 }
+// phases of the balanced K loop: out = [2 groups][8 kinds][work, span] then [2][8] counts (48 values)
+extern "C" int kx_timeline_phases_read(unsigned long long* out48, int reset) {
+  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(kx_tlp), 256) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out48 + 32, HIP_SYMBOL(kx_tlp_n), 128) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(kx_tlp), z, 256) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(kx_tlp_n), z, 128) != hipSuccess) return 1;
+  }
+  return 0;
+}
 #endif

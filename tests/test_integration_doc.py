@@ -119,8 +119,9 @@ def test_stale_binding_is_refused_not_walked(built):
 @pytest.mark.parametrize("layers,dim,ffn,heads,T", [(2, 256, 512, 4, 24), (3, 512, 1024, 8, 130)])
 def test_doc_binding_runs_the_decoder_against_the_oracle(built, layers, dim, ffn, heads, T):
     """pack() + decoder_forward() exactly as INTEGRATION.md §B prints them, on a torchscale-shaped decoder (the product's
-    Decoder keeps torchscale's attribute tree: layers[i].self_attn.q_proj.A ...), against the CPU oracle in the bf16
-    tolerance of the mode the example binds (KX_PREC_BF16)."""
+    Decoder keeps torchscale's attribute tree: layers[i].self_attn.q_proj.A ...), against the CPU oracle: KX_PREC_F16C — the
+    arithmetic a parity-bound caller binds — inside the north star's 1e-3, KX_PREC_BF16 at that mode's
+    own distance; both bit-equal to the product's own binding of the same library."""
     from helpers import oracle_weights, rel_err
     from kosmosx.model import KosmosLanguage
     from oracle import kosmos_oracle as O
@@ -135,15 +136,26 @@ def test_doc_binding_runs_the_decoder_against_the_oracle(built, layers, dim, ffn
     ref16 = O.decoder_forward(w_or, x_in.clone(), cfg, O.Switches(emulate_bf16=True))
     lm = lm.to("cuda:0")
     dec = lm.decoder
-    w, keep = ns["pack"](dec)
-    assert w.struct_bytes == C.sizeof(ns["KxDecoderWeights"]) and w.layers == layers and w.dim == dim and w.ffn == ffn
     xp = dec.layers[0].self_attn.xpos
     tables = [t.to("cuda:0") for t in (*xp.tables(T, 0, False), *xp.tables(T, 0, True))]
+    # --- the parity mode: f16c operand rows packed by the document's own operand() ---
+    w, keep = ns["pack"](dec, ns["KX_PREC_F16C"])
+    assert w.struct_bytes == C.sizeof(ns["KxDecoderWeights"]) and w.layers == layers and w.dim == dim and w.ffn == ffn
+    out = ns["decoder_forward"](w, x_in.to("cuda:0"), tables, ns["KX_PREC_F16C"])
+    torch.cuda.synchronize()
+    assert out.shape == (2, T, 1002) and torch.isfinite(out).all()
+    e = rel_err(out, ref)
+    print(f"INTEGRATION.md binding, KX_PREC_F16C, {layers}L/{dim}d T={T}: max|d|/rms vs the fp32 oracle = {e:.2e}")
+    assert e < 1e-3, e                                   # the north star's tolerance, through the documented binding
+    lm.precision = "f16c"
+    assert torch.equal(out, dec.run(x_in.to("cuda:0").clone(), "f16c"))       # one library, two bindings: bit for bit
+    del w, keep
+    # --- the throughput mode the example defaults to ---
+    w, keep = ns["pack"](dec)
     out = ns["decoder_forward"](w, x_in.to("cuda:0"), tables)
     torch.cuda.synchronize()
     assert out.shape == (2, T, 1002) and torch.isfinite(out).all()
-    assert rel_err(out, ref) < 6e-2                      # bf16 operands against fp32 (the mode's own distance: 3.6e-2 at full size)
+    assert rel_err(out, ref) < 6e-2                      # bf16 operands against fp32 (the mode's own distance: 3.6e-2 at full size; NOT the tolerance)
     assert rel_err(out, ref16) < 6e-2                    # and against the oracle with emulated operand rounding (not bit-alike)
-    # the same call through the product's own binding gives the same logits bit for bit (one library, two bindings)
     lm.precision = "bf16"
     assert torch.equal(out, dec.run(x_in.to("cuda:0").clone(), "bf16"))

@@ -1,5 +1,5 @@
 """A/B of the two K-loop forms of the 256x256 GEMM kernel (tuning key 14: 0 = balanced half-tile LDS-DMA issue with counted
-vmcnt — forced with 2 —, 1 = the first form: whole tile issued in R0, vmcnt(0) in R1) on the shapes the forward runs it with.  Same operands,
+vmcnt, 1 = the first form: whole tile issued in R0, vmcnt(0) in R1) on the shapes the forward runs it with.  Same operands,
 same epilogue, interleaved rounds in one process (guide 5.4 rule 24), random operands (rule 25), and the two results compared
 BIT FOR BIT (the forms differ in issue order only).  GPU box only.
     python tools/kloop_bench.py [case,...]"""
@@ -107,15 +107,15 @@ def run(name, iters=10, rounds=5):
     kind, epi, M, N, K, tile = CASES[name]
     call = make_case(kind, epi, M, N, K)
     outs = {}
-    for form in (1, 2):
+    for form in (1, 0):
         LIB.kx_set_tuning(14, form)
         call(tile)
         outs[form] = call(tile).clone()
     torch.cuda.synchronize()
-    same = bool(torch.equal(outs[2], outs[1]))
-    ts = {2: [], 1: []}
+    same = bool(torch.equal(outs[0], outs[1]))
+    ts = {0: [], 1: []}
     for _ in range(rounds):
-        for form in (1, 2):
+        for form in (1, 0):
             LIB.kx_set_tuning(14, form)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -124,7 +124,7 @@ def run(name, iters=10, rounds=5):
             e1.record(); e1.synchronize()
             ts[form].append(e0.elapsed_time(e1) / iters)
     LIB.kx_set_tuning(14, 0)
-    t_old, t_new = statistics.median(ts[1]), statistics.median(ts[2])
+    t_old, t_new = statistics.median(ts[1]), statistics.median(ts[0])
     fl = 2.0 * M * N * K
     return {"case": name, "kind": kind, "epi": epi, "M": M, "N": N, "K": K, "tile": tile, "bit_identical": same,
             "first_form_us": round(t_old * 1e3, 1), "balanced_us": round(t_new * 1e3, 1),
