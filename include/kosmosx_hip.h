@@ -77,7 +77,11 @@ typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F1
  * 0..3 holding values 4g..4g+3 then 16+4g..16+4g+3 of the 32 (the fragment order of kx_gemm_args.w_tiled = 3's fp16-pieces
  * kernel).  Written by kx_gemm(tile 16) / kx_attention_decode as `cdt` / `odt`, read by kx_gemm(tile 16, w_tiled = 4). */
 typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3, KX_F16 = 4, KX_F16P = 5 } kx_dtype;
-typedef enum { KX_ACT_NONE = 0, KX_ACT_GELU = 1, KX_ACT_QUICK_GELU = 2 } kx_act;
+/* KX_ACT_RELU / KX_ACT_SWISH (x * sigmoid(x)): the other two names torchscale's get_activation_fn knows
+ * (`KosmosLanguage(activation_fn=...)`, /root/reference/tests/test_kosmos_lang.py:17-66).  Off the reference's default path:
+ * offered by the generic 128 x 128 tile kernel of every precision (kx_gemm takes that kernel whatever `tile` says), not by
+ * the weight-streaming decode kernels (tile 16).  Values 3 and 4 are internal variants of GELU. */
+typedef enum { KX_ACT_NONE = 0, KX_ACT_GELU = 1, KX_ACT_QUICK_GELU = 2, KX_ACT_RELU = 5, KX_ACT_SWISH = 6 } kx_act;
 typedef enum { KX_ATTN_FULL = 0, KX_ATTN_CAUSAL = 1 } kx_attn_mask;
 
 int kx_version(void);

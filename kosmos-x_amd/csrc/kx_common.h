@@ -175,6 +175,8 @@ __device__ __forceinline__ float apply_act(float x) {
   else if constexpr (ACT == KX_ACT_GELU_FAST) return gelu_erf_fast(x);
   else if constexpr (ACT == KX_ACT_GELU_POLY) return gelu_poly(x);
   else if constexpr (ACT == KX_ACT_QUICK_GELU) return quick_gelu(x);
+  else if constexpr (ACT == KX_ACT_RELU) return fmaxf(x, 0.f);
+  else if constexpr (ACT == KX_ACT_SWISH) return x / (1.f + __expf(-x));     // F.silu; __expf: 2 ulp, far inside every mode's tolerance but fp32's
   else return x;
 }
 template <int ACT>

@@ -173,6 +173,10 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   //            GEMMs (520 tiles on 512 slots) — estimated with the cost model below;
   //   128x128  otherwise.
   int tile = a->tile;
+  const bool rare_act = a->act == KX_ACT_RELU || a->act == KX_ACT_SWISH;    // see kx_act: the generic 128 x 128 kernel, unsplit
+  KX_REQUIRE(!rare_act || tile != 16, "kx_gemm: relu / swish are not offered by the weight-streaming kernel (tile 16)");
+  KX_REQUIRE(a->act == KX_ACT_NONE || a->act == KX_ACT_GELU || a->act == KX_ACT_QUICK_GELU || rare_act, "kx_gemm: unknown activation %d", a->act);
+  if (rare_act) tile = 128;
   // Pair split of the 256x256 kernel (kx_gemm_args.pair_ws): half a round of 256x256 tiles becomes a full round of
   // (tile, K half) workgroups.  Measured on the decoder's N = 2048 GEMMs at M = 3648 (tools/gemm_bench.py).
   auto pair_ok = [&]() {

@@ -1438,24 +1438,33 @@ __device__ unsigned long long kx_tl[8];
 // closing barrier ("work") and to the barrier's release ("span"): kx_tlp[group][kind][work, span], kx_tlp_n[group][kind].
 __device__ unsigned long long kx_tlp[2][8][2];
 __device__ unsigned long long kx_tlp_n[2][8];
-#define KX_TLP_BEGIN() unsigned long long kx_p0 = __builtin_readcyclecounter(), kx_p1 = 0; (void)kx_p1
+// (sums are kept in registers through the loop and flushed once per tile: a global atomic per phase is a VMEM operation in
+//  the middle of the counted-vmcnt pipeline — the first version of these stamps ran the kernel 12x slower)
+#define KX_TLP_DECL() unsigned long long kx_pw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kx_ps[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  unsigned kx_pn[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long kx_p0 = 0, kx_p1 = 0; (void)kx_p0; (void)kx_p1
+#define KX_TLP_BEGIN() kx_p0 = __builtin_readcyclecounter()
 #define KX_TLP_ARRIVE() kx_p1 = __builtin_readcyclecounter()
 #define KX_TLP_END(kind)                                                                               \
   {                                                                                                    \
     const unsigned long long kx_p2 = __builtin_readcyclecounter();                                      \
-    if ((threadIdx.x & 255) == 0) {                                                                    \
-      const int g_ = threadIdx.x >> 8;                                                                 \
-      atomicAdd(&kx_tlp[g_][kind][0], kx_p1 - kx_p0); atomicAdd(&kx_tlp[g_][kind][1], kx_p2 - kx_p0);  \
-      atomicAdd(&kx_tlp_n[g_][kind], 1ull);                                                            \
+    kx_pw[kind] += kx_p1 - kx_p0; kx_ps[kind] += kx_p2 - kx_p0; kx_pn[kind] += 1u; kx_p0 = kx_p2;      \
+  }
+#define KX_TLP_FLUSH()                                                                                 \
+  if ((threadIdx.x & 255) == 0) {                                                                      \
+    const int g_ = threadIdx.x >> 8;                                                                   \
+    _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) if (kx_pn[k_]) {                                  \
+      atomicAdd(&kx_tlp[g_][k_][0], kx_pw[k_]); atomicAdd(&kx_tlp[g_][k_][1], kx_ps[k_]);              \
+      atomicAdd(&kx_tlp_n[g_][k_], (unsigned long long)kx_pn[k_]);                                     \
     }                                                                                                  \
-    kx_p0 = kx_p2;                                                                                     \
   }
 #else
 #define KX_TL_STAMP(i)
 #define KX_TL_COMMIT()
+#define KX_TLP_DECL()
 #define KX_TLP_BEGIN()
 #define KX_TLP_ARRIVE()
 #define KX_TLP_END(kind)
+#define KX_TLP_FLUSH()
 #endif
 
 // EPI: 0 generic store loops, 1 lean bf16 tile store, 4 the same with produced row statistics — separate kernels (one
@@ -1640,6 +1649,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   // accumulators keeps them where the phase structure needs them (sched_barrier only binds the scheduler within a block).
   auto kloop = [&](auto work_c) __attribute__((always_inline)) {
   constexpr bool W = decltype(work_c)::value;
+  KX_TLP_DECL();
   const int nk1 = kIsF16c<T> ? min(p.nk_main, nk) : nk;     // KX_F16C: the fp16 tiles; the fp8 correction tiles follow below
   if constexpr (BAL) {
   constexpr int FH = FM / 2;
@@ -1869,6 +1879,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
       if constexpr (BAL) { KX_TLP_END(7) }
     }
   }
+  KX_TLP_FLUSH();
   };
   if (work) kloop(std::true_type{}); else kloop(std::false_type{});
   if (!lag) __builtin_amdgcn_s_barrier();
@@ -3154,6 +3165,12 @@ int launch(GemmParams& p, hipStream_t s) {
     case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU>), grid, block, 0, s, p); break;
     case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_GELU_FAST>), grid, block, 0, s, p); break;
     case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_QUICK_GELU>), grid, block, 0, s, p); break;
+    case KX_ACT_RELU:            // relu / swish: the 128 x 128 kernel only (kx_gemm routes them here)
+      if constexpr (BM == 128 && BN == 128) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_RELU>), grid, block, 0, s, p); break; }
+      kx_set_error("kx_gemm: relu is offered by the 128 x 128 tile kernel only"); return KX_ERR_UNSUPPORTED;
+    case KX_ACT_SWISH:
+      if constexpr (BM == 128 && BN == 128) { hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_SWISH>), grid, block, 0, s, p); break; }
+      kx_set_error("kx_gemm: swish is offered by the 128 x 128 tile kernel only"); return KX_ERR_UNSUPPORTED;
     default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
   }
   KX_CHECK_LAUNCH("kx_gemm");

@@ -19,7 +19,8 @@ KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16, KX_PREC_F3
 KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16, KX_F16P = 0, 1, 2, 3, 4, 5
 KX_ACT_NONE, KX_ACT_GELU, KX_ACT_QUICK_GELU = 0, 1, 2
 KX_ATTN_FULL, KX_ATTN_CAUSAL = 0, 1
-ACTS = {"none": KX_ACT_NONE, "gelu": KX_ACT_GELU, "quick_gelu": KX_ACT_QUICK_GELU}
+KX_ACT_RELU, KX_ACT_SWISH = 5, 6
+ACTS = {"none": KX_ACT_NONE, "gelu": KX_ACT_GELU, "quick_gelu": KX_ACT_QUICK_GELU, "relu": KX_ACT_RELU, "swish": KX_ACT_SWISH}
 PRECS = {"bf16": KX_PREC_BF16, "fp32": KX_PREC_F32, "bf16x3": KX_PREC_BF16X3, "f16c": KX_PREC_F16C, "f16": KX_PREC_F16}
 # model-level modes: the stage precisions above plus "mixed" — the error-budgeted mix (CLIP tower in plain fp16, Perceiver
 # and decoder in f16c; kx_precision in include/kosmosx_hip.h, tools/precision_study.py --budget)

@@ -64,6 +64,9 @@ class LanguageModelTrainer:
         self.weight_decay, self.max_grad_norm = weight_decay, max_grad_norm
         self.step_no = 0
         da = model.decoder.args
+        if getattr(da, "activation_fn", "gelu") != "gelu":
+            raise NotImplementedError(f"training with activation_fn={da.activation_fn!r}: the backward kernels implement gelu "
+                                      "(the reference path); relu / swish are forward-only")
         # train_mode = the reference's model.train() (/root/reference/train.py:642; dropout = attention_dropout = 0.1,
         # kosmosx/model.py:175-177): torchscale's dropout_module after the embedding, on the attention probabilities, after
         # out_proj and after fc2, masks from Philox4x32-10(seed = (dropout_seed, step call), site, element).  Default False: the

@@ -155,6 +155,10 @@ def act_fn(x, name: str):
         return F.gelu(x)                      # erf form
     if name == "quick_gelu":
         return x * torch.sigmoid(1.702 * x)   # HF activations.QuickGELUActivation
+    if name == "relu":                        # torchscale component/feedforward_network.py get_activation_fn: F.relu
+        return F.relu(x)
+    if name == "swish":                       # ... and F.silu
+        return F.silu(x)
     raise ValueError(name)
 
 
@@ -342,10 +346,12 @@ def decoder_layer(w: dict, x: torch.Tensor, i: int, cfg: DecoderCfg, sw: Switche
 
 
 def decoder_forward(w: dict, x: torch.Tensor, cfg: DecoderCfg, sw: Switches, prefix="decoder.",
-                    features_only: bool = False, drop: dict | None = None) -> torch.Tensor:
-    """Decoder.forward(..., passed_x=x)[0]: 24 layers, final LayerNorm, output_projection."""
+                    features_only: bool = False, drop: dict | None = None, mw: str = ".A") -> torch.Tensor:
+    """Decoder.forward(..., passed_x=x)[0]: 24 layers, final LayerNorm, output_projection.
+    mw = ".A": multiway=True wraps every LayerNorm / Linear / FFN in MultiwayNetwork, whose keys carry the branch name and
+    whose forward is the A branch (split_position == -1); mw = "": multiway=False, plain modules."""
     for i in range(cfg.layers):
-        x = decoder_layer(w, x, i, cfg, sw, prefix, drop=drop)
+        x = decoder_layer(w, x, i, cfg, sw, prefix, mw=mw, drop=drop)
     x = layer_norm(x, w[prefix + "layer_norm.weight"], w[prefix + "layer_norm.bias"], cfg.eps)
     if features_only:
         return x
@@ -452,9 +458,9 @@ def kosmos_forward(w: dict, text_tokens: torch.Tensor, images: torch.Tensor, cfg
         return decoder_forward(w, mi, cfg.decoder, sw)                   # :250
 
 
-def kosmos_language_forward(w: dict, tokens: torch.Tensor, cfg: DecoderCfg, sw: Switches | None = None):
+def kosmos_language_forward(w: dict, tokens: torch.Tensor, cfg: DecoderCfg, sw: Switches | None = None, mw: str = ".A"):
     """KosmosLanguage.forward (/root/reference/kosmosx/model.py:319-320), eval mode."""
     sw = sw or Switches()
     with torch.no_grad():
         x, _ = forward_embedding_tokens(w, tokens, cfg)
-        return decoder_forward(w, x, cfg, sw)
+        return decoder_forward(w, x, cfg, sw, mw=mw)
