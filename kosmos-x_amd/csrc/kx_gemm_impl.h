@@ -1497,7 +1497,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   // BAL at BM = 192: an activation half is 2 x 48 rows = twelve 8-row pieces for eight waves — waves 0-3 stage two pieces of half
   // 0 and one of half 1, waves 4-7 one and two.  The waits use the smaller count of the two wave kinds (vmcnt(5) / vmcnt(3)):
   // a wave with one piece more in flight waits for one piece more than it must — conservative, never early.
-  constexpr int VM_R0 = BM == 256 ? 6 : 5, VM_R1 = BM == 256 ? 4 : 3;
+  // Second step (measured phase by phase, tools/kloop_phases.py, profiles/r05_d_*): an LDS-DMA instruction costs ~62 cycles of
+  // issue and a ds_read_b128 ~26 in these phases, so 4 + 16 in R0 (~660 cycles) against 4 + 8 in R1 (~455) left R0 the pole of two
+  // of the four intervals of a K-tile (the MFMA phases take ~600).  The weight rows are staged in halves too (fragments 0, 1 /
+  // 2, 3 of every wave column), and half 1 joins the activation halves in R1 — two tiles ahead, like Ah0 (its buffer was last
+  // read in R0(kt) by both groups): R0 issues Wh0(kt+1) (2), R1 issues Ah1(kt+1), Ah0(kt+2), Wh1(kt+2) (6).
+  //   end of R0(kt): Ah1(kt) landed <=> at most Ah0(kt+1), Wh1(kt+1), Wh0(kt+1) outstanding: vmcnt(6)
+  //   end of R1(kt): everything of tile kt+1 but Ah1 landed <=> at most Ah1(kt+1), Ah0(kt+2), Wh1(kt+2) outstanding: vmcnt(6)
+  constexpr int VM_R0 = BM == 256 ? 6 : 5, VM_R1 = BM == 256 ? 6 : 5;
   constexpr int BN = 256, ROWB = 128;
   static_assert(BM % 64 == 0, "BM must split into 2 wave rows of whole 16-row fragments and 8 staging waves");
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;   // 64 KB
@@ -1563,9 +1570,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     const int gm = min(m0 + (KS2 && ks_h ? (row ^ 64) : row), p.M - 1);
     srcA[j] = (unsigned)((long long)(gm - m0) * p.lda_b) + ((schunk ^ (row & 7)) << 4);
   }
+  int ldsW[IW];                // weight-tile row of the first of the 8 rows piece j of this wave covers
 #pragma unroll
   for (int j = 0; j < IW; ++j) {
-    const int row = wave * 32 + j * 8 + srow;
+    // BAL: pieces 0, 1 belong to weight half 0 (fragments 0, 1 of every wave column: rows wn * 64 + [0, 32)), pieces 2, 3 to half 1
+    ldsW[j] = BAL ? (wave >> 1) * 64 + (j >> 1) * 32 + (wave & 1) * 16 + (j & 1) * 8 : wave * 32 + j * 8;
+    const int row = ldsW[j] + srow;
     const int gn = min(n0 + row, p.N - 1);
     srcW[j] = (unsigned)((long long)(gn - n0) * p.ldw_b) + ((schunk ^ (row & 7)) << 4);
   }
@@ -1578,15 +1588,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < IW; ++j)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(tileW + koff + srcW[j]),
-                                       (lds_void_t*)(base + A_BYTES + (wave * 32 + j * 8) * ROWB), 16, 0, 0);
+                                       (lds_void_t*)(base + A_BYTES + ldsW[j] * ROWB), 16, 0, 0);
   };
-  auto stage_w = [&](int kt) {          // BAL: the weight rows of K-tile kt (IW instructions)
+  auto stage_wh = [&](auto h_c, int kt) {   // BAL: weight half h of K-tile kt (two instructions)
+    constexpr int h = decltype(h_c)::value;
     char* base = smem + (kt & 1) * STAGE;
     const long long koff = (long long)kt * ROWB;
 #pragma unroll
-    for (int j = 0; j < IW; ++j)
+    for (int j = 2 * h; j < 2 * h + 2; ++j)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(tileW + koff + srcW[j]),
-                                       (lds_void_t*)(base + A_BYTES + (wave * 32 + j * 8) * ROWB), 16, 0, 0);
+                                       (lds_void_t*)(base + A_BYTES + ldsW[j] * ROWB), 16, 0, 0);
   };
   auto stage_ah = [&](auto h_c, int kt) {   // BAL: activation half h of K-tile kt (two instructions)
     constexpr int h = decltype(h_c)::value;
@@ -1626,7 +1637,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   const int nk = p.K / (ROWB / (int)sizeof(T));
   const int k0 = KS2 ? ks_h * (nk >> 1) : 0, k1 = KS2 ? k0 + (nk >> 1) : nk;     // this workgroup's K-tiles (KS2: nk is even)
   if constexpr (KS2) stage(k0 & 1, k0); else stage(0, 0);
-  if constexpr (BAL) { if (k0 + 1 < k1) stage_ah(Half0{}, k0 + 1); }   // the loop's R1(kt) issues Ah1(kt+1), Ah0(kt+2)
+  if constexpr (BAL) { if (k0 + 1 < k1) { stage_ah(Half0{}, k0 + 1); stage_wh(Half1{}, k0 + 1); } }   // R1(kt) issues Ah1(kt+1), Ah0(kt+2), Wh1(kt+2)
   // The drain is written as the BUILTIN so that the compiler's wait-count pass sees it (inline asm is invisible to it): with
   // the asm form alone it assumed that loads of the previous tile's epilogue could still be pending inside the K loop and,
   // in the one instantiation whose register allocation reused such a register for a fragment (f16c, generic fp32 store),
@@ -1658,7 +1669,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     const char* base = smem + (kt & 1) * STAGE;
     u32x4_t fw0[FN], fw1[FN], fa0[FH], fa1[FH];
     // ---- R0 ----
-    if (kt + 1 < k1) stage_w(kt + 1);
+    if (kt + 1 < k1) stage_wh(Half0{}, kt + 1);
     if constexpr (W) {
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
@@ -1699,7 +1710,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     KX_TLP_END(1)
     // ---- R1 ----
     if (kt + 1 < k1) stage_ah(Half1{}, kt + 1);
-    if (kt + 2 < k1) stage_ah(Half0{}, kt + 2);
+    if (kt + 2 < k1) { stage_ah(Half0{}, kt + 2); stage_wh(Half1{}, kt + 2); }
     if constexpr (W) {
 #pragma unroll
       for (int b = 0; b < FH; ++b) {
@@ -1801,7 +1812,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
       const char* base = smem + (kt & 1) * STAGE;
       u32x4_t fw0[FN], fw1[FN], fa0[FH], fa1[FH];
       // ---- R0 ----
-      if constexpr (BAL) { if (kt + 1 < k1) stage_w(kt + 1); }
+      if constexpr (BAL) { if (kt + 1 < k1) stage_wh(Half0{}, kt + 1); }
       else if (kt + 1 < k1) stage((kt + 1) & 1, kt + 1);
       if constexpr (W) {
 #pragma unroll
@@ -1843,7 +1854,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
       // ---- R1 ----
       if constexpr (BAL) {
         if (kt + 1 < k1) stage_ah(Half1{}, kt + 1);
-        if (kt + 2 < k1) stage_ah(Half0{}, kt + 2);
+        if (kt + 2 < k1) { stage_ah(Half0{}, kt + 2); stage_wh(Half1{}, kt + 2); }
       }
       if constexpr (W) {
 #pragma unroll
