@@ -627,7 +627,10 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  * key 13: 1 = never take the pair split of the 256x256 kernel (kx_gemm_args.pair_ws) automatically (A/B).
  * key 14: K loop of the 256-column kernel (0 = the balanced form: the LDS-DMA of a K-tile issued in two halves, one per read
  *         phase, counted vmcnt waits; 1 = the first form: whole tile issued in the first read phase, vmcnt(0) in the second.
- *         The two are bit-identical). */
+ *         The two are bit-identical).
+ * key 15: bit mask that switches automatic kernel-choice rules of round 5 OFF (A/B): 1 = 16-bit lean-store GEMMs whose padded
+ *         256 x 256 rounds cover <= 1.5x the problem take the 256-column kernel (the ViT's qkv / fc1); 2 = residual GEMMs
+ *         with a ragged last 160-row tile take 192 x 256 tiles (the ViT's fc2 / out_proj at M = 32 * 257). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

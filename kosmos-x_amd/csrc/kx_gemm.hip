@@ -223,6 +223,11 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       // 256x256 (128x64 per wave) is the fastest main loop (1.37 vs 1.09 PFLOP/s at 8192^3: 512 vs 768 B of LDS
       // traffic per MFMA) but needs >= ~0.85 of a 256-CU wave of tiles to pay: C3-sized problems, decoder fc1
       if (a->K >= 1024 && eff512 >= 0.85) tile = 512;
+      // ... and, for outputs that take its lean 16-bit tile store, already when the padded rounds cover <= 1.5x the problem:
+      // the ViT's qkv / fc1 at M = 32 * 257 (396 / 528 tiles = 2 / 3 rounds, the third one 16 tiles of 32 live rows) measured
+      // 63.7 / 95.4 us against 69.7 / 101.5 on the 160-row kernel in bf16 and 79 / 111 there in fp16 (tools/epi_probe.py)
+      else if (!(kx_tuning_get(KX_TUNE_GEMM_RULES) & 1) && a->K >= 1024 && p.lean_epilogue && !a->stats_out && a->N % 256 == 0 &&
+               (double)(cdiv(t512, 256) * 256) * 65536.0 <= 1.5 * (double)a->M * (double)a->N) tile = 512;
       else if (a->K >= 2048 && eff256 >= 0.85 && a->N <= 16384) tile = 256;
       else tile = cost(160) <= cost(128) ? 160 : 128;
       // 192x256 (96x64 per wave, same kernel): M = 32*114 = 19 x 192 exactly, and the decoder qkv GEMM (N = 6144)
@@ -234,6 +239,12 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
         const double cur = tile == 512 ? (double)cdiv(t512, 256) : 0.6 * (double)cdiv(t256, 256);
         if (c384 < 0.97 * cur) tile = 384;
       }
+      // The ViT's residual GEMMs (fc2, out_proj: N = 1024, fp32 residual epilogue) at M = 32 * 257: 43 x 4 tiles of 192 x 256 on
+      // the 256-column kernel measured 91.6 / 38.3 us against 101.4 / 40.2 on the 160-row kernel (fp16, tools/epi_probe.py tower)
+      if (!(kx_tuning_get(KX_TUNE_GEMM_RULES) & 2) && tile == 160 && (f16 || f16c || a->prec == KX_PREC_BF16) && a->residual &&
+          a->N % 256 == 0 && a->K >= 1024 && cdiv(a->M, 192) * cdiv(a->N, 256) <= kx_cu_count() &&
+          cdiv(a->M, 192) * cdiv(a->N, 256) >= kx_cu_count() / 2)
+        tile = 384;
       // A/B: tuning key 4 = 6 keeps the 128 / 160-row kernels for fp16 rows where bf16 takes the 256x128 ring
       if ((f16c || f16) && tile == 256 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) == 6) tile = cost(160) <= cost(128) ? 160 : 128;
     }

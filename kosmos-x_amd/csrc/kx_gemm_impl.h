@@ -2081,6 +2081,9 @@ int launch_p5(GemmParams& p, hipStream_t s) {
     if constexpr (BM == 192) {
       if (lx && !p.c_bf16 && p.N % 256 == 0) return launch_p5e<T, BM, 8>(p, s);      // fp32 q / k / v of the f16c qkv GEMM
     }
+    // plain fp16 rows out of fp16 / f16c operands (the CLIP tower's qkv and fc1 in mixed mode): the lean tile store, as for bf16 —
+    // these launches took the generic store loops until round 5 (+16 k cycles per tile: tools/epi_probe.py, profiles/r05_f_*)
+    if (p.lean_epilogue && p.c_f16 && !p.stats_out && p.N % 256 == 0) return launch_p5e<T, BM, 1>(p, s);
     return launch_p5e<T, BM, 0>(p, s);
   }
   else if (lx && p.c_bf16 && p.N % 256 == 0) return launch_p5e<T, BM, 5>(p, s);

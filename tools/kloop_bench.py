@@ -100,6 +100,11 @@ CASES = {   # name: (kind, epilogue, M, N, K, tile)
     "logits_f16c_n32768": ("f16c", "f32", 3648, 32768, 2048, 0),
     "logits_f16c_m3584": ("f16c", "f32", 3584, 32002, 2048, 0),
     "wide_f16c_n16384": ("f16c", "f32", 3648, 16384, 2048, 0),
+    "vitp_fc1_bf16": ("bf16", "gelu16", 8192, 4096, 1024, 512),
+    "vitp_qkv_bf16": ("bf16", "bias16", 8192, 3072, 1024, 512),
+    "vitp_fc2_bf16": ("bf16", "resid", 8192, 1024, 4096, 1024),
+    "vitp_out_bf16": ("bf16", "resid", 8192, 1024, 1024, 1024),
+    "dec_fc1_bf16": ("bf16", "gelu16", 3648, 8192, 2048, 0),
 }
 
 
