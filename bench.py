@@ -210,6 +210,45 @@ def modes_block(head, head_value, head_s_per_step, other, parity_all, flops_per_
     return rows
 
 
+def host_info() -> dict:
+    """What the cpu_baseline number was measured ON: logical CPUs, the affinity mask
+    of this process, the cgroup CPU quota (a container can see 128 CPUs and be allowed 16 cores' worth of time — then every
+    thread count above the quota oversubscribes), the CPU model, torch's thread settings."""
+    info = {"os_cpu_count": os.cpu_count(), "torch_num_threads_default": torch.get_num_threads()}
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = None
+    try:                                                     # cgroup v2, then v1
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        except Exception:
+            pass
+    info["cgroup_cpu_quota_cores"] = quota
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+        info["sockets"] = len({l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("physical id")}) or None
+    except Exception:
+        pass
+    info["omp_num_threads_env"] = os.environ.get("OMP_NUM_THREADS")
+    info["torch_version"] = torch.__version__
+    try:
+        info["mkl"] = bool(torch.backends.mkl.is_available())
+    except Exception:
+        pass
+    return info
+
+
+
 def c3_leg(cfg, dev, _hip, steps=10, warmup=2, check=True):
     """BASELINE configs[2].  Every mode carries its parity against the CPU oracle on ONE row of the batch (rows are
     independent; the full-size test checks more) and `meets_tolerance`; the block's own figures are those of the FASTEST
@@ -621,8 +660,11 @@ def main():
         # a fair CPU number: torch's default (all hardware threads) oversubscribes these small GEMMs on a many-core
         # host, so probe a few thread counts once and time the sample at the fastest
         ncpu = torch.get_num_threads()
+        hinfo = host_info()
+        quota = hinfo.get("cgroup_cpu_quota_cores")
+        qthr = max(1, min(ncpu, int(round(quota)))) if quota else ncpu        # the thread count the cgroup actually pays for
         best_t, best_n = None, ncpu
-        for nthr in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+        for nthr in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16), qthr}, reverse=True):
             torch.set_num_threads(nthr)
             O.kosmos_forward(cpu_weights, ctok, cimg, ocfg)
             t1 = time.perf_counter()
@@ -695,7 +737,7 @@ def main():
                         "logit_rms": float(f"{float(ref_logits.pow(2).mean().sqrt()):.4f}"),
                         "parity_max_abs_over_rms": {k: float(f"{v:.3e}") for k, v in parity.items()},
                         "fp32_vs_float64": fp32_vs_64,
-                        "host_threads_available": ncpu, "kind": "port",
+                        "host_threads_available": ncpu, "host": hinfo, "kind": "port",
                         "sample": (f"fp32 torch CPU oracle (oracle/kosmos_oracle.py) forward of (1 image + {Tt} tokens) samples: "
                                    f"{n} x batch 1 ({t_cpu:.1f} s) and one forward each at " +
                                    ", ".join(f"batch {r['batch']} / {r['threads']} threads" for r in batched) +

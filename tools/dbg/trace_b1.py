@@ -1,4 +1,4 @@
-"""Batch-1 forward, GEMM launches seen from the inside (needs the tools/dbg/gemm_trace.patch build): start / end of the first
+"""Batch-1 forward, GEMM launches seen from the inside (needs the profiles/rejected_experiments/r02_gemm_trace.patch build): start / end of the first
 and last workgroup of every tile GEMM and its split-K reduce, wall_clock64 ticks of 10 ns."""
 import sys, ctypes
 sys.path[:0] = [".", "kosmos-x_amd", "tests"]
