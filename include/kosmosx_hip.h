@@ -71,12 +71,16 @@ typedef enum {
  * operands beside them hold the same values (low mantissa byte zero).  The decode step of f16c / mixed: 3 bytes per weight. */
 /* KX_PREC_F32W16: the same with block-scaled 16-bit streaming copies (kx_gemm_args.w_tiled = 3): 2.125 bytes per weight. */
 typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3, KX_PREC_F16 = 4, KX_PREC_F32W24 = 5,
-               KX_PREC_F32W16 = 6 } kx_precision;
+               KX_PREC_F32W16 = 6, KX_PREC_F16CHL = 7 /* kx_attention only: KX_PREC_F16C on KX_F16HL q / k / v rows */ } kx_precision;
 /* KX_F16P (weight-streaming decode step only): fp32-pitched rows of fp16 PIECE pairs, value = hi + lo with hi = fp16(x) toward
  * zero and lo = fp16(x - hi) — per 32 values 128 bytes: [hi pieces, 64 B][lo pieces, 64 B], each as four 16-byte chunks g =
  * 0..3 holding values 4g..4g+3 then 16+4g..16+4g+3 of the 32 (the fragment order of kx_gemm_args.w_tiled = 3's fp16-pieces
  * kernel).  Written by kx_gemm(tile 16) / kx_attention_decode as `cdt` / `odt`, read by kx_gemm(tile 16, w_tiled = 4). */
-typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3, KX_F16 = 4, KX_F16P = 5 } kx_dtype;
+/* KX_F16HL (round 5): an fp32-PITCHED row of 64-value head slots, each slot (256 bytes) = [64 fp16 hi | 64 fp16 lo] of
+ * 2^8 x: hi = fp16(2^8 x) (saturating), lo = fp16(2^8 x - hi) — the operand pieces the KX_PREC_F16C attention kernel
+ * multiplies, written ONCE by the qkv GEMM's epilogue instead of being re-derived from fp32 q / k / v by every workgroup
+ * that loads a tile (kx_gemm: KX_PREC_F16C operands, XPos epilogue, N % 64 == 0; kx_attention: prec KX_PREC_F16CHL). */
+typedef enum { KX_F32 = 0, KX_BF16 = 1, KX_BF16X3 = 2, KX_F16C = 3, KX_F16 = 4, KX_F16P = 5, KX_F16HL = 6 } kx_dtype;
 /* KX_ACT_RELU / KX_ACT_SWISH (x * sigmoid(x)): the other two names torchscale's get_activation_fn knows
  * (`KosmosLanguage(activation_fn=...)`, /root/reference/tests/test_kosmos_lang.py:17-66).  Off the reference's default path:
  * offered by the generic 128 x 128 tile kernel of every precision (kx_gemm takes that kernel whatever `tile` says), not by

@@ -488,7 +488,12 @@ __device__ __forceinline__ f32x4_t mma_f16(u32x4_t a, u32x4_t b, f32x4_t c) {
 // (tools/precision_study.py --attn-list: q / k in plain fp16 leave 0.95 / 1.4e-3 on the logits on their own, p and v
 // together move 2.5e-4 to 3.5e-4); measured on the device at full size it does NOT: 1.5-1.7e-3 (B = 32 rows, T = 2046,
 // decode prefill — round 3, tests/test_fullsize_parity_gpu.py with key 2 = 4), for 0.5 % of the B = 32 step.  Kept off.
-template <bool CAUSAL, bool PVS>
+// HL (round 5): q, k, v arrive as KX_F16HL rows — the (hi, lo) pieces of 2^8 x written once by the qkv GEMM's epilogue, per
+// token and head [64 fp16 hi | 64 fp16 lo] in the 256 bytes the fp32 values would take.  The tile loads then copy pieces into
+// the LDS planes and Q needs no arithmetic at all: the ~160 VALU instructions per key tile and wave that re-derived the
+// pieces of K and V (of ~410, against 96 MFMAs: the kernel was VALU-bound, MfmaUtil 7-9 %) are gone.  Same pieces, same
+// products: bit-identical to the fp32-input form.
+template <bool CAUSAL, bool PVS, bool HL = false>
 __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned short Kh[2][64 * 64], Kl[2][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned short Vh[2][64 * VSTR], Vl[2][64 * VSTR];
@@ -514,9 +519,15 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
     const float* qr = qp + (long long)min(qw0 + qb * 16 + li, p.Tq - 1) * p.qrs + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (HL) {       // values 32 ks + 8 g .. + 7 of the head: hi at byte 2 * that of the slot, lo 128 bytes on
+        const char* slot = reinterpret_cast<const char*>(qr - 8 * g) + (32 * ks + 8 * g) * 2;
+        qh[qb][ks] = *reinterpret_cast<const u32x4_t*>(slot);
+        ql[qb][ks] = *reinterpret_cast<const u32x4_t*>(slot + 128);
+      } else {
       const float4 a = *reinterpret_cast<const float4*>(qr + 32 * ks), c = *reinterpret_cast<const float4*>(qr + 32 * ks + 4);
       const float x[8] = {a.x * SC, a.y * SC, a.z * SC, a.w * SC, c.x * SC, c.y * SC, c.z * SC, c.w * SC};
       split_f16x8(x, qh[qb][ks], ql[qb][ks]);
+      }
     }
   }
   f32x4_t ot[2][4];
@@ -532,19 +543,35 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
 
   // cooperative tile loads: thread owns (row c>>3, 8-value part c&7) for c = tid, tid + 256: two float4 each of K and V
   float4 kreg[2][2], vreg[2][2];
+  u32x4_t kpc[2][2], vpc[2][2];           // HL: [j][0] = hi pieces, [j][1] = lo pieces (native vectors: HIP's float4 struct, copied
+                                          // whole, kept these arrays in scratch)
   auto gload = [&](int t) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = tid + 256 * j, row = c >> 3, part = c & 7;
+      if constexpr (HL) {       // [0] = the eight hi pieces of values 8 part .. + 7, [1] = their lo pieces
+        const long long off = (long long)min(t * 64 + row, p.Tk - 1) * p.krs;
+        const char* ks_ = reinterpret_cast<const char*>(kp + off) + part * 16;
+        const char* vs_ = reinterpret_cast<const char*>(vp + off) + part * 16;
+        kpc[j][0] = *reinterpret_cast<const u32x4_t*>(ks_); kpc[j][1] = *reinterpret_cast<const u32x4_t*>(ks_ + 128);
+        vpc[j][0] = *reinterpret_cast<const u32x4_t*>(vs_); vpc[j][1] = *reinterpret_cast<const u32x4_t*>(vs_ + 128);
+      } else {
       const long long off = (long long)min(t * 64 + row, p.Tk - 1) * p.krs + part * 8;
       kreg[j][0] = *reinterpret_cast<const float4*>(kp + off); kreg[j][1] = *reinterpret_cast<const float4*>(kp + off + 4);
       vreg[j][0] = *reinterpret_cast<const float4*>(vp + off); vreg[j][1] = *reinterpret_cast<const float4*>(vp + off + 4);
+      }
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = tid + 256 * j, row = c >> 3, part = c & 7;
+      if constexpr (HL) {                 // the registers already hold the pieces: [0] = hi, [1] = lo
+        *reinterpret_cast<u32x4_t*>(&Kh[buf][row * 64 + ((part ^ (row & 7)) << 3)]) = kpc[j][0];
+        *reinterpret_cast<u32x4_t*>(&Kl[buf][row * 64 + ((part ^ (row & 7)) << 3)]) = kpc[j][1];
+        *reinterpret_cast<u32x4_t*>(&Vh[buf][row * VSTR + part * 8]) = vpc[j][0];
+        if constexpr (PVS) *reinterpret_cast<u32x4_t*>(&Vl[buf][row * VSTR + part * 8]) = vpc[j][1];
+      } else {
       u32x4_t hi, lo;
       const float kx[8] = {kreg[j][0].x * SC, kreg[j][0].y * SC, kreg[j][0].z * SC, kreg[j][0].w * SC,
                            kreg[j][1].x * SC, kreg[j][1].y * SC, kreg[j][1].z * SC, kreg[j][1].w * SC};
@@ -561,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
         for (int j2 = 0; j2 < 4; ++j2) hi[j2] = pack_f16x2(vx[2 * j2], vx[2 * j2 + 1]);
       }
       *reinterpret_cast<u32x4_t*>(&Vh[buf][row * VSTR + part * 8]) = hi;
+      }
     }
   };
 
@@ -951,7 +979,7 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   KX_REQUIRE(a->B > 0 && a->H > 0 && a->Tq > 0 && a->Tk > 0, "kx_attention: empty problem");
   KX_REQUIRE(a->H < 65536 && a->B < 65536, "kx_attention: B/H exceed the grid limits");
   KX_REQUIRE(a->mask != KX_ATTN_CAUSAL || a->Tq == a->Tk, "kx_attention: the causal mask needs Tq == Tk");
-  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32 || a->prec == KX_PREC_F16C || a->prec == KX_PREC_F16,
+  KX_REQUIRE(a->prec == KX_PREC_BF16 || a->prec == KX_PREC_F32 || a->prec == KX_PREC_F16C || a->prec == KX_PREC_F16 || a->prec == KX_PREC_F16CHL,
              "kx_attention: bad precision");
   const bool f16 = a->prec == KX_PREC_F16;                        // fp16 q, k, v on the v2 kernel
   const int es = (a->prec == KX_PREC_BF16 || f16) ? 2 : 4;        // KX_PREC_F16C takes fp32 q, k, v
@@ -969,9 +997,11 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.out = a->out; p.obs = a->out_batch_stride; p.ors = a->out_row_stride; p.o_bf16 = a->odt == KX_BF16 || a->odt == KX_F16;
   p.o_x3 = a->odt == KX_BF16X3;
   p.o_f16c = a->odt == KX_F16C;
-  KX_REQUIRE(!p.o_f16c || (a->prec == KX_PREC_F16C && a->out_row_stride >= 2 * a->H * 64),
+  const bool f16c_any = a->prec == KX_PREC_F16C || a->prec == KX_PREC_F16CHL;
+  KX_REQUIRE(!p.o_f16c || (f16c_any && a->out_row_stride >= 2 * a->H * 64),
              "kx_attention: a KX_F16C output is produced by the KX_PREC_F16C kernel (row stride >= 2*H*64 2-byte units)");
-  KX_REQUIRE(a->prec != KX_PREC_F16C || a->odt == KX_F16C || a->odt == KX_F32, "kx_attention: KX_PREC_F16C writes KX_F16C or fp32");
+  KX_REQUIRE(!f16c_any || a->odt == KX_F16C || a->odt == KX_F32, "kx_attention: KX_PREC_F16C writes KX_F16C or fp32");
+  KX_REQUIRE(a->prec != KX_PREC_F16CHL || (!a->lse_out && a->dropout_p == 0.f), "kx_attention: KX_PREC_F16CHL is the forward kernel only");
   KX_REQUIRE(!p.o_x3 || (a->prec == KX_PREC_F32 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1 &&
                          a->out_row_stride >= 3 * a->H * 64),
              "kx_attention: a KX_BF16X3 output is produced by the fp32 matrix-core kernel only (row stride >= 3*H*64)");
@@ -991,13 +1021,18 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   KX_REQUIRE(!a->stats_out || !(a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 1),
              "kx_attention: stats_out is not implemented by the v1 A/B kernel");
   hipStream_t s = (hipStream_t)stream;
-  KxProfScope prof(a->prec == KX_PREC_F32 ? KX_K_ATTN_F32 : a->prec == KX_PREC_F16C ? KX_K_ATTN_F16S
+  KxProfScope prof(a->prec == KX_PREC_F32 ? KX_K_ATTN_F32 : f16c_any ? KX_K_ATTN_F16S
                    : a->prec == KX_PREC_F16 ? KX_K_ATTN_F16 : KX_K_ATTN_BF16, a->B * a->H, a->Tq, a->Tk, s);
   // unmasked launch whose last 128-query block would hold <= 32 queries, folded into a fifth wave: A/B only (tuning key
   // 2 = 5).  Measured at B = 32 (same box, round 3): mixed 1096 -> 1088 samples/s, bf16 1728 -> 1712 — the tail block's
   // workgroup has one live wave and retires quickly; 320-thread workgroups cost the other blocks more than it saves.
   const bool fold = a->mask != KX_ATTN_CAUSAL && a->Tq > 128 && (a->Tq - 1) % 128 < 32 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 5;
-  if (a->prec == KX_PREC_F16C) {
+  if (a->prec == KX_PREC_F16CHL) {                                    // the same kernel on pre-split KX_F16HL rows
+    const unsigned nx = (unsigned)((a->Tq + 127) / 128);
+    const dim3 gc((unsigned)a->H, (nx + 1) / 2, (unsigned)a->B), gf((unsigned)a->H, nx, (unsigned)a->B);
+    if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL((attn_f16s_kernel<true, true, true>), gc, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_f16s_kernel<false, true, true>), gf, dim3(256), 0, s, p);
+  } else if (a->prec == KX_PREC_F16C) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     const bool pvs = kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 4;       // 4 = A/B: P and V as plain fp16 (misses the tolerance)
     const dim3 gc((unsigned)a->H, (nx + 1) / 2, (unsigned)a->B), gf((unsigned)a->H, nx, (unsigned)a->B);

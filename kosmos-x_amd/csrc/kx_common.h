@@ -84,8 +84,18 @@ typedef _Float16 kx_f16x2_t __attribute__((ext_vector_type(2)));
 // whole output row NaN).  The reference is fp32 and has no fp16 domain, so the behaviour past it is specified, not left to
 // the converter: finite logits, rows that never see such a value unaffected (header, KX_PREC_F16C; VERDICT r2 missing #6).
 __device__ __forceinline__ float clamp_f16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+// KX_F16HL pieces of four consecutive values (kx_dtype): hi = fp16(2^8 x) saturating, lo = fp16(2^8 x - hi) — the arithmetic of
+// the KX_PREC_F16C attention kernel's own operand split (split_f16x8 on 2^8 x), so pre-split rows give bit-identical products
+__device__ __forceinline__ void split_f16_hl4(const float (&x)[4], uint2& hi, uint2& lo);
 __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((kx_f32x2_t){clamp_f16(lo), clamp_f16(hi)}, kx_f16x2_t));
+}
+__device__ __forceinline__ void split_f16_hl4(const float (&x)[4], uint2& hi, uint2& lo) {
+  const float s0 = x[0] * 256.0f, s1 = x[1] * 256.0f, s2 = x[2] * 256.0f, s3 = x[3] * 256.0f;
+  const kx_f16x2_t h0 = __builtin_convertvector((kx_f32x2_t){clamp_f16(s0), clamp_f16(s1)}, kx_f16x2_t);
+  const kx_f16x2_t h1 = __builtin_convertvector((kx_f32x2_t){clamp_f16(s2), clamp_f16(s3)}, kx_f16x2_t);
+  hi.x = __builtin_bit_cast(unsigned, h0); hi.y = __builtin_bit_cast(unsigned, h1);
+  lo.x = pack_f16x2(s0 - (float)h0[0], s1 - (float)h0[1]); lo.y = pack_f16x2(s2 - (float)h1[0], s3 - (float)h1[1]);
 }
 // fp16 PIECES of an fp32 value (KX_F16P; the weight-streaming kernel's fp16-pieces form): x = hi + lo, hi = fp16(x) rounded toward
 // zero (one instruction for the pair, saturating at 65504 instead of overflowing: the remainder is exact in fp32), lo = fp16(x - hi)

@@ -516,6 +516,16 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
   const bool fold = w->layers > 0 && w->layer[0].wqkv_f && w->wout_f && fold_prec(prec) && !fuse_o && !fuse_2 && D % 64 == 0 &&
                     kx_tuning_get(KX_TUNE_GEMM_TILE) == 0 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1;
   const LnOp lop{d.h, ct, d.partials2};
+  // KX_PREC_F16C at tile-kernel sizes: the qkv GEMM writes the attention kernel's operand pieces itself (KX_F16HL rows, same
+  // bytes per value as fp32 q / k / v) instead of every attention workgroup re-deriving them per key tile (tuning key 15 & 4: off).
+  // Not with a KV cache (the cache and the decode steps read fp32 q / k / v) and not without XPos (the piece store lives in the
+  // prefetching store loop / the lean XPos epilogue).
+  // Only where keys are re-used: a key tile is loaded by every 128-query block after it, so at T = 2046 each piece was derived
+  // ~8 times and at T = 114 once — there the split just moves from the attention kernel into the GEMM epilogue (measured:
+  // qkv 192 -> 211 us against attention 42 -> ~35 at B = 32 x 114; tools/hl_probe.py).
+  const bool qkv_hl = prec == KX_PREC_F16C && w->xpos && !kcache && M >= 1024 && T >= 512 && D % 64 == 0 &&
+                      !(kx_tuning_get(KX_TUNE_GEMM_RULES) & 4) && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1 &&
+                      kx_tuning_get(KX_TUNE_GEMM_TILE) == 0 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) == 0;
   bool h_ready = false;                                   // d.h already holds the LayerNorm this layer starts with
   for (int i = 0; i < w->layers; ++i) {
     const kx_decoder_layer& L = w->layer[i];
@@ -523,7 +533,8 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     const bool st1 = fold && i > 0;                        // d.h = un-normalised rows of x + d.stats2 from the previous fc2
     if (fold && i == 0) KX_TRY(ln(x, nullptr, nullptr, nullptr, d.h, ct, M, D, w->eps, s));     // unit affine
     else if (!fold && !h_ready) KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
-    KX_TRY(gemm(d.h, D, fold ? L.wqkv_f : L.wqkv, D, d.qkv, 3 * D, qdt(prec), M, 3 * D, fold ? L.bqkv_f : L.bqkv, nullptr, 0,
+    KX_TRY(gemm(d.h, D, fold ? L.wqkv_f : L.wqkv, D, d.qkv, 3 * D, (qkv_hl && !st1) ? KX_F16HL : qdt(prec), M, 3 * D,
+                fold ? L.bqkv_f : L.bqkv, nullptr, 0,
                 0.125f, D, prec, s, w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? T : 0, w->xpos ? D : 0,
                 st1 ? d.stats2 : nullptr, st1 ? L.wqkv_colsum : nullptr));
     if (kcache) {   // incremental decoding: keep this layer's (XPos-rotated) keys and values
@@ -536,7 +547,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     a.q = d.qkv; a.q_batch_stride = T * 3 * D; a.q_row_stride = 3 * D;
     a.k = (char*)d.qkv + D * qes(prec); a.v = (char*)d.qkv + 2 * D * qes(prec);
     a.kv_batch_stride = T * 3 * D; a.kv_row_stride = 3 * D;
-    a.B = B; a.H = w->heads; a.Tq = T; a.Tk = T; a.mask = KX_ATTN_CAUSAL; a.prec = aprec(prec);
+    a.B = B; a.H = w->heads; a.Tq = T; a.Tk = T; a.mask = KX_ATTN_CAUSAL; a.prec = (qkv_hl && !st1) ? KX_PREC_F16CHL : aprec(prec);
     a.out = d.att; a.out_batch_stride = T * D * kmul(prec); a.out_row_stride = D * kmul(prec); a.odt = ct;
     RowFusion ro, r2;
     ro.ln_out = d.h; ro.ln_dt = ct; ro.ln_g = L.fl_g; ro.ln_b = L.fl_b; ro.eps = w->eps;

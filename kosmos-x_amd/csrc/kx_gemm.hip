@@ -75,6 +75,12 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->cdt == KX_BF16 || a->cdt == KX_BF16X3 || a->cdt == KX_F16C || a->cdt == KX_F16;
   p.c_x3 = a->cdt == KX_BF16X3; p.c_f16c = a->cdt == KX_F16C; p.c_f16 = a->cdt == KX_F16;
   p.c_pieces = a->cdt == KX_F16P;
+  p.c_hilo = a->cdt == KX_F16HL;
+  KX_REQUIRE(!p.c_hilo || (f16c && a->xpos_dim > 0 && a->N % 64 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0 &&
+                           !a->residual && !a->stats_out && !a->row_stats && a->act == KX_ACT_NONE && a->tile != 16 &&
+                           !a->ln_operand_out && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 1),
+             "kx_gemm: a KX_F16HL output comes from KX_PREC_F16C operands with the XPos epilogue (the prefetching store loop), "
+             "N %% 64 == 0, 16-byte aligned fp32-pitched rows, no residual / statistics / activation");
   KX_REQUIRE(a->cdt != KX_F16P || (a->tile == 16 && a->prec == KX_PREC_F32 && a->N % 32 == 0 && a->ldc % 32 == 0 &&
                                    ((uintptr_t)a->C & 15) == 0 && !a->residual && a->ksplit <= 1),
              "kx_gemm: KX_F16P rows come from tile 16 on fp32 operands, N %% 32 == 0, ldc %% 32 == 0, no residual / ksplit");
@@ -155,7 +161,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       const bool shape_ok = a->xpos_dim > 0 && !a->residual && !a->row_stats && !a->stats_out && a->act == KX_ACT_NONE &&
                             a->qcols % 256 == 0 && a->xpos_dim % 256 == 0 && !a->ln_operand_out;
       const bool bf = a->prec == KX_PREC_BF16 && a->cdt == KX_BF16 && p.vec8_ok;
-      const bool fc = f16c && a->cdt == KX_F32 && p.vec_ok && a->N % 4 == 0;
+      const bool fc = f16c && (a->cdt == KX_F32 || a->cdt == KX_F16HL) && p.vec_ok && a->N % 4 == 0;
       p.lean_xpos = (shape_ok && (bf || fc) && k4 != 1 && k4 != 8 && k4 != 9) ? ((k4 == 3 && bf) ? 2 : 1) : 0;   // (9: only this one off, A/B)
     }
     p.ring = mode != 6 && !f16c;
@@ -314,6 +320,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       sp = 1;
       p.ring = 8;
     }
+    if (sp > 1 && p.c_hilo) sp = 1;                      // the reduce kernel's epilogue does not write KX_F16HL rows
     if (sp > 1) {
       p.splitk = (int)sp;
       p.partial = (float*)a->splitk_ws;

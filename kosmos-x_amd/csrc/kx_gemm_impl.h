@@ -15,6 +15,7 @@ struct GemmParams {
   int c_x3;   // KX_BF16X3 output: [hi(N) | hi(N) | lo(N)] per row (c_bf16 is set too)
   int c_f16;  // KX_F16 output (c_bf16 is set too: same 2-byte layout, fp16 conversion)
   int c_f16c; // KX_F16C output: [fp16(N) | fp8(N) | fp8 residual(N)] per row, ldc in 2-byte units (c_bf16 is set too)
+  int c_hilo; // KX_F16HL output: fp32-pitched rows of [64 fp16 hi | 64 fp16 lo] head slots of 2^8 x (c_bf16 is NOT set: the fp32 paths)
   // KX_PREC_F16C operands: K-tiles [0, nk_main) hold fp16 (16x16x32 f16 MFMA), tiles [nk_main, nk) the fp8 correction
   // segments (block-scaled 16x16x128 MFMA, weight-row scale bytes from wscale, activation scale 2^-11)
   int nk_main; const unsigned char* wscale;
@@ -331,6 +332,12 @@ __device__ __forceinline__ void store_loop_fast(const GemmParams& p, const float
             o.z = pack16(p, x[1][0], x[1][1]); o.w = pack16(p, x[1][2], x[1][3]);
             *reinterpret_cast<uint4*>(c) = o;
           }
+        } else if (p.c_hilo) {                       // KX_F16HL: the four values' hi pieces at byte 2c of their head slot, lo at 128 + 2c
+          uint2 hi, lo;
+          split_f16_hl4(x[0], hi, lo);
+          char* slot = reinterpret_cast<char*>(reinterpret_cast<float*>(p.C) + (long long)m * p.ldc + (n & ~63)) + 2 * (n & 63);
+          *reinterpret_cast<uint2*>(slot) = hi;
+          *reinterpret_cast<uint2*>(slot + 128) = lo;
         } else {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long long)m * p.ldc + n) =
               make_float4(x[0][0], x[0][1], x[0][2], x[0][3]);
@@ -641,10 +648,24 @@ __device__ __forceinline__ void lean_store_f32(const GemmParams& p, const f32x4_
     for (int bb = 0; bb < FM / 2; ++bb) {
       const int b = half * (FM / 2) + bb;
       const int hr = wm * HR + bb * 16 + li;                       // row inside this half's BM / 2
+      if (p.c_hilo) {
+        // KX_F16HL: the wave's 64 columns are one head slot (16 chunks of 16 B): the lane's four values' hi pieces go to byte
+        // 2c = a*32 + 8g of the slot, their lo pieces to 128 + that — the row-store pass below is pure data movement either way
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+          const float x4[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+          uint2 hi, lo;
+          split_f16_hl4(x4, hi, lo);
+          const int c0 = wn * 16 + a * 2 + (g >> 1);
+          *reinterpret_cast<uint2*>(smem + hr * 1024 + ((c0 ^ (hr & 15)) << 4) + (g & 1) * 8) = hi;
+          *reinterpret_cast<uint2*>(smem + hr * 1024 + (((c0 + 8) ^ (hr & 15)) << 4) + (g & 1) * 8) = lo;
+        }
+      } else {
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
         const int ch = (wn * 16 + a * 4 + g) ^ (hr & 15);
         *reinterpret_cast<f32x4_t*>(smem + hr * 1024 + ch * 16) = acc[a][b];
+      }
       }
     }
     __syncthreads();

@@ -15,8 +15,8 @@ _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
 ABI_VERSION = 6   # KX_ABI_VERSION of include/kosmosx_hip.h
 
-KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16, KX_PREC_F32W24, KX_PREC_F32W16 = 0, 1, 2, 3, 4, 5, 6
-KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16, KX_F16P = 0, 1, 2, 3, 4, 5
+KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16, KX_PREC_F32W24, KX_PREC_F32W16, KX_PREC_F16CHL = 0, 1, 2, 3, 4, 5, 6, 7
+KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16, KX_F16P, KX_F16HL = 0, 1, 2, 3, 4, 5, 6
 KX_ACT_NONE, KX_ACT_GELU, KX_ACT_QUICK_GELU = 0, 1, 2
 KX_ATTN_FULL, KX_ATTN_CAUSAL = 0, 1
 KX_ACT_RELU, KX_ACT_SWISH = 5, 6

@@ -236,9 +236,10 @@ def f16_pieces_values(rows: torch.Tensor) -> torch.Tensor:
 
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,
               xpos=None, xpos_dim=0, tile=0, row_stats=None, colsum=None, stats_out=None, splitk_ws=None, splitk=0,
-              ln_operand=None, pair_ws=None):
+              ln_operand=None, pair_ws=None, out_hilo=False):
     """KX_PREC_F16C GEMM: a_rows [M, 4K] uint8 (KX_F16C activation rows), w_packed = the flat packed weight matrix
-    (N rows of 4K bytes + N scale bytes, model._operand_f16c).  Output fp32 [M, N] or KX_F16C rows [M, 4N] uint8."""
+    (N rows of 4K bytes + N scale bytes, model._operand_f16c).  Output fp32 [M, N] or KX_F16C rows [M, 4N] uint8.
+    out_hilo (with xpos): the fp32-shaped output holds KX_F16HL head slots — [64 fp16 hi | 64 fp16 lo] of 2^8 x per 64 columns."""
     _need_cuda(a_rows, w_packed, bias, residual)
     M = a_rows.shape[0]
     assert a_rows.dtype == torch.uint8 and a_rows.shape[1] == 4 * K and w_packed.numel() >= N * 4 * K + N
@@ -246,7 +247,7 @@ def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_
            torch.empty((M, N), dtype=torch.float32, device=a_rows.device))
     g = H.GemmArgs()
     g.A, g.lda, g.W, g.ldw = H.ptr(a_rows), a_rows.stride(0) // 2, H.ptr(w_packed), 2 * K
-    g.C, g.ldc, g.cdt = H.ptr(out), (2 * N if out_f16c else out.stride(0)), (H.KX_F16C if out_f16c else H.KX_F32)
+    g.C, g.ldc, g.cdt = H.ptr(out), (2 * N if out_f16c else out.stride(0)), (H.KX_F16C if out_f16c else H.KX_F16HL if out_hilo else H.KX_F32)
     g.w_scale = w_packed.data_ptr() + N * 4 * K
     g.bias, g.residual, g.ldr = H.ptr(bias), H.ptr(residual), (residual.stride(0) if residual is not None else 0)
     g.M, g.N, g.K = M, N, K
@@ -282,7 +283,7 @@ def row_stats_finalize(partials, seg_size, eps=1e-5):
 
 
 def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=False, lse_out=None, f16c=False,
-              out_f16c=False, dropout=None):
+              out_f16c=False, dropout=None, hilo=False):
     """q [B,Tq,H,64], k/v [B,Tk,H,64] (any row/batch strides, last two dims contiguous) -> [B,Tq,H*64]
     (out_x3, fp32 inputs only: KX_BF16X3 rows [hi | hi | lo], [B,Tq,3*H*64] bf16).
     f16c (fp32 inputs): the KX_PREC_F16C kernel — split fp16 (hi, lo) products; out_f16c: KX_F16C rows [B,Tq,4*H*64] uint8."""
@@ -292,7 +293,7 @@ def attention(q, k, v, causal=False, out_dtype=None, stats_out=None, out_x3=Fals
     assert hd == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and v.stride(2) == 64
     assert k.stride(0) == v.stride(0) and k.stride(1) == v.stride(1)
     prec = (H.KX_PREC_BF16 if q.dtype == torch.bfloat16 else H.KX_PREC_F16 if q.dtype == torch.float16
-            else (H.KX_PREC_F16C if f16c or out_f16c else H.KX_PREC_F32))
+            else (H.KX_PREC_F16CHL if hilo else H.KX_PREC_F16C if f16c or out_f16c else H.KX_PREC_F32))   # hilo: fp32-typed KX_F16HL rows
     out = (torch.empty((B, Tq, 4 * Hh * 64), dtype=torch.uint8, device=q.device) if out_f16c else
            torch.empty((B, Tq, 3 * Hh * 64), dtype=torch.bfloat16, device=q.device) if out_x3 else
            torch.empty((B, Tq, Hh * 64), dtype=out_dtype or q.dtype, device=q.device))

@@ -421,3 +421,44 @@ def test_full_size_mixed_meets_1e_3(B, Tt):
     e = rel_err(out, ref)
     print(f"full-size mixed B={B} Tt={Tt}: max|d|/rms vs fp32 CPU oracle = {e:.3e}")
     assert e < F16C_TOL, e
+
+
+def _hl_reference(x):
+    """KX_F16HL (kx_dtype): per 64-value head slot [64 fp16 hi | 64 fp16 lo] of 2^8 x, in the bytes of the fp32 values."""
+    M, N = x.shape
+    s = (x.float() * 256.0).clamp(-65504.0, 65504.0)
+    hi = s.to(torch.float16)
+    lo = (x.float() * 256.0 - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    return torch.cat([hi.reshape(M, N // 64, 64), lo.reshape(M, N // 64, 64)], dim=2).reshape(M, 2 * N).contiguous().view(torch.float32)
+
+
+@pytest.mark.parametrize("M,tile", [(3648, 0), (2046, 512), (1500, 128), (300, 64)])
+def test_qkv_gemm_writes_f16hl_pieces_and_the_attention_kernel_reads_them_bit_for_bit(M, tile):
+    """Round 5: the decoder's f16c qkv GEMM writes the split-fp16 attention kernel's operand pieces itself (KX_F16HL) — through
+    the lean XPos epilogue of the 192-row tiles (M = 3648, automatic choice), the generic prefetching store loop of the 256-row
+    tiles and of the 128 / 64 tile kernels.  The pieces equal the torch statement of the format applied to the fp32 output of the
+    same GEMM, and the attention kernel on them returns the bits of the fp32-input form."""
+    from kosmosx.model import _operand_f16c
+    heads, T = 4, (114 if M % 114 == 0 else M // 2 if M % 2 == 0 else M)
+    D, K = heads * 64, 256
+    g = torch.Generator().manual_seed(M)
+    a = ops.pack_f16c_rows(torch.randn(M, K, generator=g).to(DEV))
+    w = _operand_f16c((torch.randn(3 * D, K, generator=g) * 0.1).to(DEV))
+    bias = torch.randn(3 * D, generator=g).to(DEV)
+    xp = tuple(torch.rand(T, 32, generator=g).to(DEV) + 0.5 for _ in range(4))
+    kw = dict(bias=bias, qscale=0.125, qcols=D, xpos=xp, xpos_dim=D, tile=tile)
+    f32 = ops.gemm_f16c(a, w, 3 * D, K, **kw)
+    hl = ops.gemm_f16c(a, w, 3 * D, K, out_hilo=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(hl.view(torch.int32), _hl_reference(f32).view(torch.int32))
+    B = M // T
+    q32, qhl = f32.view(B, T, 3 * D), hl.view(B, T, 3 * D)
+    sl = lambda t, i: t[:, :, i * D:(i + 1) * D].unflatten(2, (heads, 64))
+    for causal in (True, False):
+        o32 = ops.attention(sl(q32, 0), sl(q32, 1), sl(q32, 2), causal=causal, f16c=True)
+        ohl = ops.attention(sl(qhl, 0), sl(qhl, 1), sl(qhl, 2), causal=causal, hilo=True)
+        torch.cuda.synchronize()
+        assert torch.equal(o32.view(torch.int32), ohl.view(torch.int32)), causal
+    of = ops.attention(sl(qhl, 0), sl(qhl, 1), sl(qhl, 2), causal=True, hilo=True, out_f16c=True)       # KX_F16C rows out, as the decoder asks
+    og = ops.attention(sl(q32, 0), sl(q32, 1), sl(q32, 2), causal=True, out_f16c=True)
+    assert torch.equal(of, og)
