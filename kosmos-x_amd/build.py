@@ -20,7 +20,7 @@ BUILD_DIR = HERE / "build"
 LIB = OUT_DIR / "libkosmosx_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: SLP-packed f32 math (v_pk_mul_f32 / v_pk_fma_f32 with op_sel swizzles next to a v_mov that rewrites a
-# source) gave NON-DETERMINISTIC XPos epilogue results on gfx950 (tools/dbg/f16c_xpos4.py); packed f32 VALU is
+# source) gave NON-DETERMINISTIC XPos epilogue results on gfx950 (tools/dbg/f16c_xpos4.py; HISTORY.md §5); packed f32 VALU is
 # also slower beside MFMAs (MI355X_MICROARCH.md), so nothing is lost.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
          "-I", str(HERE.parent / "include")]

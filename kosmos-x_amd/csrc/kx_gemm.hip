@@ -184,7 +184,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
   KX_REQUIRE(a->act == KX_ACT_NONE || a->act == KX_ACT_GELU || a->act == KX_ACT_QUICK_GELU || rare_act, "kx_gemm: unknown activation %d", a->act);
   if (rare_act) tile = 128;
   // Pair split of the 256x256 kernel (kx_gemm_args.pair_ws): half a round of 256x256 tiles becomes a full round of
-  // (tile, K half) workgroups.  Measured on the decoder's N = 2048 GEMMs at M = 3648 (tools/gemm_bench.py).
+  // (tile, K half) workgroups.  Measured on the decoder's N = 2048 GEMMs at M = 3648 (tools/gemm_bench.py, HISTORY §4.1).
   auto pair_ok = [&]() {
     if (!(a->prec == KX_PREC_BF16 || f16c || f16) || !a->pair_ws || ((uintptr_t)a->pair_ws & 255)) return false;
     const long long t = ((a->M + 255) / 256) * ((a->N + 255) / 256);

@@ -109,7 +109,7 @@ FOLD_PRECS = ("bf16", "f16", "f16c")      # stage precisions whose pre-LayerNorm
 
 
 def _fold_pre_ln(stage: str = "") -> bool:
-    """Opt-in (KOSMOSX_FOLD_PRE_LN=1).  Measured at B = 32: the 95 LayerNorm launches it removes cost
+    """Opt-in (KOSMOSX_FOLD_PRE_LN=1).  Measured at B = 32 (HISTORY.md §4.2b): the 95 LayerNorm launches it removes cost
     1.5 ms, the residual epilogues' second store + lane exchanges, the consumers' row-statistics loads and the 96
     statistics-finalize launches it adds cost 2.3 ms — a 2 % loss on the headline and on C3, so it ships off."""
     v = os.environ.get("KOSMOSX_FOLD_PRE_LN", "0")        # "1": every stage; "vit" / "decoder": that stage only (A/B)

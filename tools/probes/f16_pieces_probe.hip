@@ -1,4 +1,4 @@
-// Probe for an fp16-pieces form of the block-scaled 16-bit decode weights: does v_mfma_f32_16x16x32_f16
+// Probe for an fp16-pieces form of the block-scaled 16-bit decode weights (HISTORY §7b): does v_mfma_f32_16x16x32_f16
 //   1. keep SUBNORMAL fp16 inputs (an unsigned 10-bit integer u stored as raw bits is u * 2^-24), and
 //   2. accumulate 32 exact products with fp32-class error (against a double sum)?
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/f16_pieces_probe tools/probes/f16_pieces_probe.hip
