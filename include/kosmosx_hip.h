@@ -221,7 +221,12 @@ typedef struct {
    * Layout: bytes [0, 4096) are the hand-off words — zero when the call is issued, zero again when it has completed (the
    * stage-level entry points clear them once per call); then one 128 KB slab per workgroup.  kx_gemm takes the split when
    * pair_ws_bytes >= 4096 + 2 * tiles * 131072, tiles % 8 == 0, 0.85 * CUs <= 2 * tiles <= CUs, K-tiles even, and the
-   * epilogue has no activation / produced statistics (tile = 0: automatic; tile = 1024 asks for it and fails otherwise). */
+   * epilogue has no activation / produced statistics (tile = 0: automatic; tile = 1024 asks for it and fails otherwise).
+   * CONTRACT: (i) a workgroup spins on its partner's flag, so both must be RESIDENT — the rule 2 * tiles <= CUs with
+   * one workgroup per CU (128 KB of LDS each) and in-order dispatch gives that; it is the dispatcher's guarantee, not the code's,
+   * which is why the automatic rule never oversubscribes and the spin has no fallback; (ii) ONE scratch serves ONE stream at a
+   * time: launches in flight on two streams need two scratches (the library's stage entry points and the trainer key theirs by
+   * stream); a scratch shared across streams can clobber a flag, and a clobbered flag is a hang, not an error. */
   void* pair_ws; size_t pair_ws_bytes;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);

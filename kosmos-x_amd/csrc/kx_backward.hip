@@ -102,60 +102,70 @@ __global__ __launch_bounds__(256) void to_operand_pair_kernel(const float* __res
                                                               long long ld_src, long long kp, long long kpt,
                                                               float* __restrict__ colsum_part,
                                                               const float* __restrict__ pre = nullptr) {
-  __shared__ float tile[64][65];
+  // Round 5: a thread loads EIGHT consecutive values of a row (two float4), so the straight bf16 rows are packed and stored from
+  // registers (no LDS round trip), and the tile is parked with two ds_write_b128 per pass instead of sixteen scalar writes: 48 -> 20
+  // LDS instructions per thread.  Rows of 64 floats, 16-byte chunks XOR-swizzled by (row >> 3): the transposed read of element
+  // (row 8 ox + k, column rr) then lands on bank 4 ((rr >> 2) ^ ox) + (rr & 3) — 2-way over a wave, as the 65-float padding was.  This pass converts 10.8 GB per training step
+  // (the fp32 master weights -> both bf16 operand forms): 1.65 TB/s before.
+  __shared__ __attribute__((aligned(16))) float tile[64 * 64];
+  auto at = [](int row, int col) { return row * 64 + ((((col >> 2) ^ (row >> 3)) & 15) << 2) + (col & 3); };
   const long long r0 = (long long)blockIdx.y * 64, c0 = (long long)blockIdx.x * 64;
   const int tid = threadIdx.x;
-  {
-    const int tx = tid & 15, ty = tid >> 4;                 // 16 lanes x float4 per row, 16 rows per pass
+  const int ox = tid & 7, oy = tid >> 3;                     // 8 lanes x 8 values per row, 32 rows per pass
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long long r = r0 + ty + 16 * i, c = c0 + 4 * tx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < rows) {
-        if (c + 3 < cols) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
-        else { const float* q = src + r * ld_src + c; if (c < cols) v.x = q[0]; if (c + 1 < cols) v.y = q[1]; if (c + 2 < cols) v.z = q[2]; }
-        if (GELU_GRAD) {
-          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (c + 3 < cols) x = *reinterpret_cast<const float4*>(pre + r * ld_src + c);
-          else { const float* q = pre + r * ld_src + c; if (c < cols) x.x = q[0]; if (c + 1 < cols) x.y = q[1]; if (c + 2 < cols) x.z = q[2]; }
-          v.x *= gelu_erf_grad_pair(x.x); v.y *= gelu_erf_grad_pair(x.y); v.z *= gelu_erf_grad_pair(x.z); v.w *= gelu_erf_grad_pair(x.w);
-        }
+  for (int i = 0; i < 2; ++i) {
+    const int rr = oy + 32 * i;
+    const long long r = r0 + rr, c = c0 + 8 * ox;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      if (c + 7 < cols) {
+        const float4 a = *reinterpret_cast<const float4*>(src + r * ld_src + c), b2 = *reinterpret_cast<const float4*>(src + r * ld_src + c + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b2.x; v[5] = b2.y; v[6] = b2.z; v[7] = b2.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (c + j < cols) v[j] = src[r * ld_src + c + j];
       }
-      float* t = &tile[ty + 16 * i][4 * tx];
-      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+      if (GELU_GRAD) {
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c + 7 < cols) {
+          const float4 a = *reinterpret_cast<const float4*>(pre + r * ld_src + c), b2 = *reinterpret_cast<const float4*>(pre + r * ld_src + c + 4);
+          x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b2.x; x[5] = b2.y; x[6] = b2.z; x[7] = b2.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (c + j < cols) x[j] = pre[r * ld_src + c + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad_pair(x[j]);
+      }
+    }
+    *reinterpret_cast<float4*>(&tile[at(rr, 8 * ox)]) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(&tile[at(rr, 8 * ox + 4)]) = make_float4(v[4], v[5], v[6], v[7]);
+    if (dst && r < rows && c < kp) {                           // straight: row r0+rr, columns c0 + 8*ox .. +7 (zeros past cols)
+      uint4 o;
+      o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+      *reinterpret_cast<uint4*>(dst + r * kp + c) = o;
     }
   }
   __syncthreads();
   // bias gradient: this 64-row slice's column sums (fp32 source) — every wave sums sixteen rows of the 64 columns (two
-  // chains of eight), wave 0 adds the four after the outputs are on their way (one wave walking 64 rows serially held
-  // the workgroup for ~600 cycles: 40 -> 64 us per launch at 4096 x 8192)
+  // chains of eight), wave 0 adds the four after the outputs are on their way
   __shared__ float cs[4][64];
   if (colsum_part) {
     const int cx = tid & 63, cy = tid >> 6;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) { s0 += tile[16 * cy + r][cx]; s1 += tile[16 * cy + r + 1][cx]; }
+    for (int r = 0; r < 16; r += 2) { s0 += tile[at(16 * cy + r, cx)]; s1 += tile[at(16 * cy + r + 1, cx)]; }
     cs[cy][cx] = s0 + s1;
   }
-  const int ox = tid & 7, oy = tid >> 3;                     // 8 lanes x 8 values per output row, 32 rows per pass
+  if (dst_t) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rr = oy + 32 * i;
-    if (dst) {                                               // straight: row r0+rr, columns c0 + 8*ox .. +7
-      const long long r = r0 + rr, c = c0 + 8 * ox;
-      if (r < rows && c < kp) {
-        const float* t = &tile[rr][8 * ox];
-        uint4 o;
-        o.x = pack_bf16x2(t[0], t[1]); o.y = pack_bf16x2(t[2], t[3]); o.z = pack_bf16x2(t[4], t[5]); o.w = pack_bf16x2(t[6], t[7]);
-        *reinterpret_cast<uint4*>(dst + r * kp + c) = o;
-      }
-    }
-    if (dst_t) {                                             // transposed: row c0+rr, columns r0 + 8*ox .. +7
+    for (int i = 0; i < 2; ++i) {
+      const int rr = oy + 32 * i;                              // transposed: row c0+rr, columns r0 + 8*ox .. +7
       const long long r = c0 + rr, c = r0 + 8 * ox;
       if (r < cols && c < kpt) {
         uint4 o;
-        o.x = pack_bf16x2(tile[8 * ox][rr], tile[8 * ox + 1][rr]); o.y = pack_bf16x2(tile[8 * ox + 2][rr], tile[8 * ox + 3][rr]);
-        o.z = pack_bf16x2(tile[8 * ox + 4][rr], tile[8 * ox + 5][rr]); o.w = pack_bf16x2(tile[8 * ox + 6][rr], tile[8 * ox + 7][rr]);
+        o.x = pack_bf16x2(tile[at(8 * ox + 0, rr)], tile[at(8 * ox + 1, rr)]); o.y = pack_bf16x2(tile[at(8 * ox + 2, rr)], tile[at(8 * ox + 3, rr)]);
+        o.z = pack_bf16x2(tile[at(8 * ox + 4, rr)], tile[at(8 * ox + 5, rr)]); o.w = pack_bf16x2(tile[at(8 * ox + 6, rr)], tile[at(8 * ox + 7, rr)]);
         *reinterpret_cast<uint4*>(dst_t + r * kpt + c) = o;
       }
     }

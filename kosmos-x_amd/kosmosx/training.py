@@ -302,9 +302,12 @@ class LanguageModelTrainer:
         def pws(t):
             if self.precision != "bf16" or not t.is_cuda:
                 return None
-            if t.device not in pw:
-                pw[t.device] = ops.pair_scratch(t.device)
-            return pw[t.device]
+            # one scratch per (device, issuing stream): the hand-off slabs of two launches in flight on different streams must
+            # not alias — a clobbered flag is a GPU hang, not an error; launches on one stream are ordered
+            key = (t.device, torch.cuda.current_stream(t.device).cuda_stream)
+            if key not in pw:
+                pw[key] = ops.pair_scratch(t.device)
+            return pw[key]
 
         def lin(x, w, b=None, **kw):                      # x [M,K] · w[N,K]ᵀ (+ b); returns (y, wᵀ operand for the backward)
             wa, wt = o.pairW(w.detach())
