@@ -13,6 +13,11 @@ int kx_gemm_launch_f16c(GemmParams& p, int tile, hipStream_t s) {
 }
 
 #ifdef KX_TIMELINE
+extern "C" int kx_timeline_read_f16c(unsigned long long* out8, int reset) {      // this unit's copy of the per-tile stamps
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(kx_tl), 64) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(kx_tl), z, 64) != hipSuccess) return 1; }
+  return 0;
+}
 // this translation unit's copy of the phase stamps (the f16c / fp16 kernels): see kx_timeline_phases_read
 extern "C" int kx_timeline_phases_read_f16c(unsigned long long* out48, int reset) {
   if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(kx_tlp), 256) != hipSuccess) return 1;

@@ -1470,6 +1470,7 @@ __device__ unsigned long long kx_tlp_n[2][8];
     const unsigned long long kx_p2 = __builtin_readcyclecounter();                                      \
     kx_pw[kind] += kx_p1 - kx_p0; kx_ps[kind] += kx_p2 - kx_p0; kx_pn[kind] += 1u; kx_p0 = kx_p2;      \
   }
+#define KX_TLP_STASH()
 #define KX_TLP_FLUSH()                                                                                 \
   if ((threadIdx.x & 255) == 0) {                                                                      \
     const int g_ = threadIdx.x >> 8;                                                                   \
@@ -1482,6 +1483,7 @@ __device__ unsigned long long kx_tlp_n[2][8];
 #define KX_TL_STAMP(i)
 #define KX_TL_COMMIT()
 #define KX_TLP_DECL()
+#define KX_TLP_STASH()
 #define KX_TLP_BEGIN()
 #define KX_TLP_ARRIVE()
 #define KX_TLP_END(kind)
@@ -1679,9 +1681,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   // pure operations whose results are next used an iteration later — were SUNK past the phase's closing barrier into the
   // next read phase (seen in the fp8 loop: M0 empty, 16 MFMAs inside R1).  An empty asm that "rewrites" the phase's
   // accumulators keeps them where the phase structure needs them (sched_barrier only binds the scheduler within a block).
+  KX_TLP_DECL();
   auto kloop = [&](auto work_c) __attribute__((always_inline)) {
   constexpr bool W = decltype(work_c)::value;
-  KX_TLP_DECL();
   const int nk1 = kIsF16c<T> ? min(p.nk_main, nk) : nk;     // KX_F16C: the fp16 tiles; the fp8 correction tiles follow below
   if constexpr (BAL) {
   constexpr int FH = FM / 2;
@@ -1911,7 +1913,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
       if constexpr (BAL) { KX_TLP_END(7) }
     }
   }
-  KX_TLP_FLUSH();
+  KX_TLP_STASH();
   };
   if (work) kloop(std::true_type{}); else kloop(std::false_type{});
   if (!lag) __builtin_amdgcn_s_barrier();
@@ -2029,6 +2031,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   KX_TL_STAMP(5);
   KX_TL_COMMIT();
   }  // generic epilogue
+  KX_TLP_FLUSH();                                    // (side build: phase sums of this tile, after the last tile stamp)
   if constexpr (KS2) break;                          // one piece per workgroup
   if (bid + (int)gridDim.x < nwg) __syncthreads();   // the parked rows have been read back before the next tile's fill
   }  // tiles of this workgroup

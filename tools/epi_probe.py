@@ -40,6 +40,45 @@ if len(sys.argv) > 1 and sys.argv[1] == "tower":      # the four GEMMs of a towe
                 row[f"tile{tile}_us"] = str(e)[:60]
         print(json.dumps(row), flush=True)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "f16c":       # the decoder's f16c GEMMs: fixed cost per launch by epilogue
+    from kosmosx.model import _operand_f16c
+    def tf(M, N, K, iters=10, rounds=5, **kw):
+        g = torch.Generator().manual_seed(1)
+        a = ops.pack_f16c_rows((torch.rand(M, K, generator=g) * 2 - 1).cuda())
+        w = _operand_f16c(((torch.rand(N, K, generator=g) * 2 - 1) * 0.05).cuda())
+        extra = {}
+        if kw.pop("bias", False): extra["bias"] = torch.randn(N, generator=g).cuda()
+        if kw.pop("stats", False): extra["stats_out"] = torch.empty(M, N // 64, 2, device="cuda")
+        if kw.pop("resid", False):
+            extra.update(residual=torch.randn(M, N, generator=g).cuda(), row_stats=torch.rand(M, 2, generator=g).cuda(),
+                         colsum=torch.randn(N, generator=g).cuda(), pair_ws=ops.pair_scratch())
+        if kw.pop("xpos", False):
+            T = 114
+            extra.update(qscale=0.125, qcols=N // 3, xpos=tuple(torch.rand(T, 32, generator=g).cuda() for _ in range(4)), xpos_dim=N // 3)
+        f = lambda: ops.gemm_f16c(a, w, N, K, **extra, **kw)
+        for _ in range(3): f()
+        ts = []
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters): f()
+            e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1) / iters * 1e3)
+        return round(statistics.median(ts), 1)
+    cases = [("fc1 gelu+stats -> f16c rows (EPI 7)", 3648, 8192, dict(bias=True, act="gelu", out_f16c=True, stats=True)),
+             ("fc1 plain -> f16c rows (EPI 6)", 3648, 8192, dict(out_f16c=True)),
+             ("fc1 bias+stats, no activation -> f16c rows (EPI 7)", 3648, 8192, dict(bias=True, out_f16c=True, stats=True)),
+             ("fc1-shaped plain -> fp32 (generic)", 3648, 8192, dict()),
+             ("qkv bias+qscale+xpos -> fp32 (EPI 8, 192 rows)", 3648, 6144, dict(bias=True, xpos=True)),
+             ("fc2-shaped fold+bias+residual (pair split)", 3648, 2048, dict(bias=True, resid=True))]
+    for name, M, N, kw in cases:
+        row = {"case": name, "M": M, "N": N}
+        for K in (512, 1024, 2048, 4096):
+            row[f"K{K}_us"] = tf(M, N, K, **dict(kw))
+        row["us_per_1024K"] = round((row["K4096_us"] - row["K2048_us"]) / 2, 1)
+        row["fixed_us"] = round(row["K2048_us"] - 2 * row["us_per_1024K"], 1)
+        print(json.dumps(row), flush=True)
+    sys.exit(0)
 for dt, dn in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
     for (M, N, name) in ((8224, 4096, "fc1"), (8224, 3072, "qkv"), (8192, 4096, "fc1p"), (8192, 3072, "qkvp")):
         for tile in (0, 512):

@@ -28,8 +28,8 @@ def run(name):
     kind, epi, M, N, K, tile = kb.CASES[name]
     call = kb.make_case(kind, epi, M, N, K)
     call(tile, False); torch.cuda.synchronize(); read(kind, 1)
-    if kind == "bf16":
-        lib.kx_timeline_read((C.c_ulonglong * 8)(), 1)
+    tl_read = lib.kx_timeline_read if kind == "bf16" else lib.kx_timeline_read_f16c
+    tl_read((C.c_ulonglong * 8)(), 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3):
@@ -37,12 +37,11 @@ def run(name):
     e1.record(); torch.cuda.synchronize()
     b = read(kind, 1)
     out = {"case": name, "us_per_call_instrumented": round(e0.elapsed_time(e1) / 3 * 1e3, 1)}
-    if kind == "bf16":            # the per-tile stamps live in the bf16 translation unit only (kx_timeline_read)
-        tb = (C.c_ulonglong * 8)()
-        lib.kx_timeline_read(tb, 1)
-        n = max(tb[5], 1)
-        out["cycles_per_tile"] = dict(zip(("prologue", "k_loop", "prepass", "store_half0", "store_half1"), (int(tb[i] / n) for i in range(5))))
-        out["tiles_stamped"] = int(n)
+    tb = (C.c_ulonglong * 8)()
+    tl_read(tb, 1)
+    n = max(tb[5], 1)
+    out["cycles_per_tile"] = dict(zip(("prologue", "k_loop", "prepass_or_exchange", "store_half0", "store_half1"), (int(tb[i] / n) for i in range(5))))
+    out["tiles_stamped"] = int(n)
     for g, gname in enumerate(("lead", "lag")):
         for seg, sname in ((0, "fp16_tiles"), (4, "fp8_tiles")):
             row = {}
