@@ -639,7 +639,9 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  *         The two are bit-identical).
  * key 15: bit mask that switches automatic kernel-choice rules of round 5 OFF (A/B): 1 = 16-bit lean-store GEMMs whose padded
  *         256 x 256 rounds cover <= 1.5x the problem take the 256-column kernel (the ViT's qkv / fc1); 2 = residual GEMMs
- *         with a ragged last 160-row tile take 192 x 256 tiles (the ViT's fc2 / out_proj at M = 32 * 257). */
+ *         with a ragged last 160-row tile take 192 x 256 tiles (the ViT's fc2 / out_proj at M = 32 * 257); 4 = the f16c decoder's
+ *         qkv GEMM writes KX_F16HL pieces for the attention kernel at T >= 512.  Bit 8 switches one rule ON: plain fp16 GELU outputs of
+ *         the 256-column kernel's lean epilogue use the transcendental-free polynomial of the bf16 outputs (A/B: +0.6 %, not shipped). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

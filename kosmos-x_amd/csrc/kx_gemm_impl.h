@@ -2066,8 +2066,9 @@ int launch_p5e(GemmParams& p, hipStream_t s) {
   else if (EPI == 5) return launch_p5e<T, BM, 0>(p, s);
   else if (p.act == KX_ACT_GELU_FAST && (EPI == 0 || EPI == 1 || EPI == 4)) {
     constexpr int E = (EPI == 1 || EPI == 4) ? EPI : 0;
-    // plain bf16 in, plain bf16 out, accumulator-level epilogue: the transcendental-free packed GELU (KX_ACT_GELU_POLY)
-    if constexpr (!kIsF16c<T> && E != 0) {
+    // plain bf16 in, plain bf16 out, accumulator-level epilogue: the transcendental-free packed GELU (KX_ACT_GELU_POLY); round 5:
+    // plain fp16 in / out too (E == 1: the CLIP tower's fc1 in mixed mode — kx_gemm sets gelu_poly for those launches only)
+    if constexpr ((!kIsF16c<T> && E != 0) || (kIsF16c<T> && E == 1)) {
       if (p.gelu_poly) launch_p5k<T, KX_ACT_GELU_POLY, BM, E>(p, grid, block, s);
       else launch_p5k<T, KX_ACT_GELU_FAST, BM, E>(p, grid, block, s);
     } else {
