@@ -77,7 +77,7 @@ _PMC_TILES = {"160x128": "gemm_kernel<{T},160,128", "128x128": "gemm_kernel<{T},
               "256x128_phased": "gemm_kernel_p3<{T}", "256x256_phased": "gemm_kernel_p5<{T}"}
 _PMC_TYPES = {"bf16": "bf16", "f16c": "f16c_t", "f16": "f16c_t"}      # KX_PREC_F16 rows run the f16c_t kernels without correction tiles
 _PMC_FILES = {"mixed": ("profiles/r05_pmc.json", "profiles/r05_pmc_summary.md")}
-_PMC_DECODE = "profiles/r04_decode_pmc.json"      # tools/pmc_round.sh on tools/bench_decode.py (bf16 and mixed), same digest guard
+_PMC_DECODE = "profiles/r05_decode_pmc.json"      # tools/pmc_round.sh on tools/bench_decode.py (bf16 and mixed), same digest guard
 
 
 def pmc_kernel_prefix(kind):
