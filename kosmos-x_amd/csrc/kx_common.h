@@ -118,8 +118,10 @@ __device__ __forceinline__ void f16c_pack4(float a, float b, float c, float d, u
   const kx_f16x2_t h1 = __builtin_convertvector((kx_f32x2_t){clamp_f16(c), clamp_f16(d)}, kx_f16x2_t);
   h.x = __builtin_bit_cast(unsigned, h0); h.y = __builtin_bit_cast(unsigned, h1);
   e = pack_fp8x4(a, b, c, d);
-  r = pack_fp8x4((a - (float)h0[0]) * 2048.0f, (b - (float)h0[1]) * 2048.0f, (c - (float)h1[0]) * 2048.0f,
-                 (d - (float)h1[1]) * 2048.0f);
+  // (packed subtract / scale: both exact, two values per VALU slot)
+  const kx_f32x2_t rab = ((kx_f32x2_t){a, b} - (kx_f32x2_t){(float)h0[0], (float)h0[1]}) * (kx_f32x2_t){2048.0f, 2048.0f};
+  const kx_f32x2_t rcd = ((kx_f32x2_t){c, d} - (kx_f32x2_t){(float)h1[0], (float)h1[1]}) * (kx_f32x2_t){2048.0f, 2048.0f};
+  r = pack_fp8x4(rab.x, rab.y, rcd.x, rcd.y);
 }
 // Store 4 / 8 consecutive values of a KX_F16C row: `row` = row base (bytes), n = first column, N = values per row.
 __device__ __forceinline__ void f16c_store4(char* row, long long n, long long N, const float (&x)[4]) {
@@ -139,18 +141,46 @@ __device__ __forceinline__ void f16c_store8(char* row, long long n, long long N,
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
-// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + 5 fma instead of libm erff's two
-// divergent polynomial branches.  Used for GELU in bf16 mode only, where its error (<= 5e-7 on the GELU output
-// for |x| < 6) is three orders of magnitude below the bf16 operand rounding; fp32 mode keeps the exact erff.
+// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp instead of libm erff's two divergent polynomial
+// branches.  Used for GELU in the 16-bit-operand modes (bf16 / fp16 / f16c), where its error (<= 5e-7 on the GELU output for
+// |x| < 6) is far below the operand rounding; fp32 mode keeps the exact erff.  Written for TWO values with every step an
+// explicit packed operation (v_pk_mul / v_pk_fma issue two fp32 results per slot; the accumulator-level epilogue of the
+// 256-column kernel is VALU-bound: 26.5k cycles per fc1 tile, profiles/r05_k_*), and arranged so nothing is left to
+// contraction — the one-value form below is the same operation sequence and gives the same bits:
+//   GELU(x) = x/2 + |x|/2 * erf(|x|/sqrt2)            (x * sign(x) = |x|: no copysign)
+//   erf(z)  = 1 - t (a1 + t (a2 + ...)) 2^(-z^2 log2 e),  t = 1 / (1 + p z):  with z = |x|/sqrt2 folded into the constants
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t pk_splat(float a) { return (f32x2_t){a, a}; }
+__device__ __forceinline__ f32x2_t gelu_erf_fast2(f32x2_t x) {
+  constexpr float PZ = 0.3275911f * 0.70710678118654752440f;      // p / sqrt2
+  constexpr float NL = -0.5f * 1.44269504088896340736f;           // -log2(e) / 2:  2^(NL x^2) = exp(-z^2)
+  const f32x2_t ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+  const f32x2_t den = pk_fma(pk_splat(PZ), ax, pk_splat(1.0f));
+  const f32x2_t t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};     // raw v_rcp_f32 (1 ulp), not an IEEE divide
+  const f32x2_t arg = (x * x) * pk_splat(NL);
+  const f32x2_t ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};  // raw v_exp_f32
+  f32x2_t q = pk_fma(pk_splat(1.061405429f), t, pk_splat(-1.453152027f));
+  q = pk_fma(q, t, pk_splat(1.421413741f));
+  q = pk_fma(q, t, pk_splat(-0.284496736f));
+  q = pk_fma(q, t, pk_splat(0.254829592f));
+  const f32x2_t erf = pk_fma(-(q * t), ex, pk_splat(1.0f));       // erf(|x| / sqrt2)
+  return pk_fma(ax * pk_splat(0.5f), erf, x * pk_splat(0.5f));
+}
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // raw v_rcp_f32 (1 ulp), not an IEEE divide
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-z * z);   // erf(|x|/sqrt2)
-  return 0.5f * x * (1.0f + copysignf(e, x));
+  constexpr float PZ = 0.3275911f * 0.70710678118654752440f, NL = -0.5f * 1.44269504088896340736f;
+  const float ax = __builtin_fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(PZ, ax, 1.0f));
+  const float x2 = x * x;
+  const float ex = __builtin_amdgcn_exp2f(x2 * NL);
+  float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  q = __builtin_fmaf(q, t, 1.421413741f);
+  q = __builtin_fmaf(q, t, -0.284496736f);
+  q = __builtin_fmaf(q, t, 0.254829592f);
+  const float qt = q * t;
+  const float erf = __builtin_fmaf(-qt, ex, 1.0f);
+  const float ha = ax * 0.5f, h = x * 0.5f;
+  return __builtin_fmaf(ha, erf, h);
 }
 #define KX_ACT_GELU_FAST 3  /* internal: chosen by kx_gemm for KX_ACT_GELU when prec == bf16 */
 // GELU without transcendentals for the accumulator-level epilogues of the plain-bf16 256-column kernel, where the matrix
@@ -159,9 +189,6 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // fit of 0.5 * erf(3u) / u weighted by the error on the GELU output (tools/fit_gelu_poly.py).  |error| <= 5.5e-5 on the
 // output for every x (fp32 Horner included) — a fortieth of bf16's rounding step at 1.0; bf16 outputs only.
 #define KX_ACT_GELU_POLY 4  /* internal: gemm_kernel_p5's lean epilogues, bf16 operands and bf16 output */
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2_t pk_splat(float a) { return (f32x2_t){a, a}; }
 __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
   constexpr float C = 4.242640495300293f, RC = 0.2357022613286972f;
   f32x2_t u;
@@ -192,6 +219,7 @@ __device__ __forceinline__ float apply_act(float x) {
 template <int ACT>
 __device__ __forceinline__ f32x2_t apply_act2(f32x2_t x) {
   if constexpr (ACT == KX_ACT_GELU_POLY) return gelu_poly2(x);
+  else if constexpr (ACT == KX_ACT_GELU_FAST) return gelu_erf_fast2(x);
   else if constexpr (ACT == KX_ACT_NONE) return x;
   else return (f32x2_t){apply_act<ACT>(x.x), apply_act<ACT>(x.y)};
 }

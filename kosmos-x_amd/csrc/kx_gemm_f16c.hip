@@ -18,6 +18,13 @@ extern "C" int kx_timeline_read_f16c(unsigned long long* out8, int reset) {     
   if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(kx_tl), z, 64) != hipSuccess) return 1; }
   return 0;
 }
+// store-phase stamps of lean_store_f16c: [0..7] = cycles between consecutive stamps (entry, half 0: barrier / pack + LDS writes /
+// barrier / row reads + global stores issued, half 1: the same four), [8] = tiles
+extern "C" int kx_timeline_store_read_f16c(unsigned long long* out12, int reset) {
+  if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(kx_tls), sizeof(unsigned long long) * 12) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[12] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(kx_tls), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
 // this translation unit's copy of the phase stamps (the f16c / fp16 kernels): see kx_timeline_phases_read
 extern "C" int kx_timeline_phases_read_f16c(unsigned long long* out48, int reset) {
   if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(kx_tlp), 256) != hipSuccess) return 1;

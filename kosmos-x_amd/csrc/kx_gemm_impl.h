@@ -685,6 +685,20 @@ __device__ __forceinline__ void lean_store_f32(const GemmParams& p, const f32x4_
 // tile rows (the b-fragments [h * FM/2, (h+1) * FM/2) of both wave rows): H plane 128 x 512 B, E and R planes 128 x 256 B
 // (128 KB, the staging LDS), 16-byte chunks XOR-swizzled by row (H: & 7 as the bf16 store, E / R: & 15 — sixteen rows of a
 // fragment write the same column block); after one barrier every wave instruction stores whole rows of one plane.
+#ifdef KX_TIMELINE   // store-phase stamps of the three-plane tile store (tools/kloop_phases.py): see kx_timeline_store_read_f16c
+__device__ unsigned long long kx_tls[12];
+#define KX_TLS_DECL() unsigned long long kx_s[10]; (void)kx_s
+#define KX_TLS(i) kx_s[i] = __builtin_readcyclecounter()
+#define KX_TLS_COMMIT()                                                                       \
+  if (threadIdx.x == 0) {                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&kx_tls[i_], kx_s[i_ + 1] - kx_s[i_]); \
+    atomicAdd(&kx_tls[8], 1ull);                                                              \
+  }
+#else
+#define KX_TLS_DECL()
+#define KX_TLS(i)
+#define KX_TLS_COMMIT()
+#endif
 template <int BM, int FM, int FN>
 __device__ __forceinline__ void lean_store_f16c(const GemmParams& p, const f32x4_t (&acc)[FN][FM], char* smem, int m0, int n0,
                                                 int wm, int wn, int wave, int lane, int g, int li) {
@@ -694,9 +708,12 @@ __device__ __forceinline__ void lean_store_f16c(const GemmParams& p, const f32x4
   char* const Rp = Ep + 128 * 256;          // [128][256 B]
   char* const Cb = reinterpret_cast<char*>(p.C);
   const long long pitch = 2ll * p.ldc;      // bytes per output row (ldc counts 2-byte units)
+  KX_TLS_DECL();
+  KX_TLS(0);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();                        // the K loop's last fragment reads / the previous half's row reads are done
+    if (half == 0) { KX_TLS(1); } else { KX_TLS(5); }
 #pragma unroll
     for (int bb = 0; bb < FM / 2; ++bb) {
       const int b = half * (FM / 2) + bb;
@@ -712,7 +729,9 @@ __device__ __forceinline__ void lean_store_f16c(const GemmParams& p, const f32x4
         *reinterpret_cast<unsigned*>(Rp + hr * 256 + ce * 16 + g * 4) = r;
       }
     }
+    if (half == 0) { KX_TLS(2); } else { KX_TLS(6); }
     __syncthreads();
+    if (half == 0) { KX_TLS(3); } else { KX_TLS(7); }
     auto tile_row = [&](int hr) { return (hr >> 6) * 128 + half * 64 + (hr & 63); };
     {                                        // H plane: two 512-byte rows per wave instruction, 16 rows per pass
       const int cl = lane & 31, rl = lane >> 5;
@@ -736,7 +755,9 @@ __device__ __forceinline__ void lean_store_f16c(const GemmParams& p, const f32x4
         }
       }
     }
+    if (half == 0) { KX_TLS(4); } else { KX_TLS(8); }
   }
+  KX_TLS_COMMIT();
 }
 
 // NST = LDS stages.  2: tile kt+1 is requested when tile kt's multiplication starts (the large-M kernels: MFMA time per

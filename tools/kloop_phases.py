@@ -30,6 +30,7 @@ def run(name):
     call(tile, False); torch.cuda.synchronize(); read(kind, 1)
     tl_read = lib.kx_timeline_read if kind == "bf16" else lib.kx_timeline_read_f16c
     tl_read((C.c_ulonglong * 8)(), 1)
+    if hasattr(lib, "kx_timeline_store_read_f16c"): lib.kx_timeline_store_read_f16c((C.c_ulonglong * 12)(), 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3):
@@ -42,6 +43,13 @@ def run(name):
     n = max(tb[5], 1)
     out["cycles_per_tile"] = dict(zip(("prologue", "k_loop", "prepass_or_exchange", "store_half0", "store_half1"), (int(tb[i] / n) for i in range(5))))
     out["tiles_stamped"] = int(n)
+    if kind in ("f16c", "f16") and hasattr(lib, "kx_timeline_store_read_f16c"):      # three-plane tile store, per tile
+        sb = (C.c_ulonglong * 12)()
+        lib.kx_timeline_store_read_f16c(sb, 1)
+        if sb[8]:
+            names = ("h0_barrier", "h0_pack_lds_write", "h0_barrier2", "h0_row_reads_global_stores",
+                     "h1_barrier", "h1_pack_lds_write", "h1_barrier2", "h1_row_reads_global_stores")
+            out["f16c_store_cycles_per_tile"] = {k: int(sb[i] / sb[8]) for i, k in enumerate(names)}
     for g, gname in enumerate(("lead", "lag")):
         for seg, sname in ((0, "fp16_tiles"), (4, "fp8_tiles")):
             row = {}
