@@ -162,6 +162,12 @@ typedef struct {
    *       takes the producer's partial statistics directly (what kx_row_stats_finalize would turn into row_stats);
    *   stats_out_seg : the producer side emits its statistics per 16-column segment ([M, N/16, 2]; must be 16 here,
    *       0 or 64 for every other variant). */
+  /* The TILE kernels take stats_partials TOGETHER WITH row_stats (+ colsum): row_stats [M, 2] is then where kx_gemm puts the
+   * finalised (mean, rstd) — it runs kx_row_stats_finalize itself before the launch.  With tuning key 15 & 32 the pair split
+   * of the 256 x 256 kernel with the accumulator-level residual epilogue finalises them inside the launch instead (each
+   * workgroup the rows it finishes, while it waits for its partner; the same arithmetic bit for bit, row_stats untouched,
+   * stats_in_nseg <= 128): one launch fewer per folded sub-LayerNorm, and measured 1 % SLOWER on the headline step (two steps
+   * in flight hide the 5 us finalize launches; the in-launch walk sits on the hand-off) — opt-in, A/B. */
   const float* ln_gamma; const float* ln_beta; float ln_eps;
   const float* stats_partials; int64_t stats_in_nseg; int64_t stats_in_seg; float stats_eps;
   int32_t stats_out_seg;
@@ -641,7 +647,9 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  *         256 x 256 rounds cover <= 1.5x the problem take the 256-column kernel (the ViT's qkv / fc1); 2 = residual GEMMs
  *         with a ragged last 160-row tile take 192 x 256 tiles (the ViT's fc2 / out_proj at M = 32 * 257); 4 = the f16c decoder's
  *         qkv GEMM writes KX_F16HL pieces for the attention kernel at T >= 512.  Bit 8 switches one rule ON: plain fp16 GELU outputs of
- *         the 256-column kernel's lean epilogue use the transcendental-free polynomial of the bf16 outputs (A/B: +0.6 %, not shipped). */
+ *         the 256-column kernel's lean epilogue use the transcendental-free polynomial of the bf16 outputs (A/B: +0.6 %, not shipped).
+ *         16 = fp32-with-residual outputs of the 256-column kernel keep the generic store loop (lean_store_f32_res off); Bit 32 switches one rule ON:
+ *         folded sub-LayerNorm statistics given as row_stats + stats_partials are finalised inside the pair-split launch (slower). */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -561,9 +561,11 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
         KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
                     0, 0, nullptr, L.wo_colsum, nullptr, &ro));
       } else {
-        KX_TRY(kx_row_stats_finalize(d.partials, M, w->heads, 64, w->eps, d.stats, stream));
+        // (row_stats + stats_partials: kx_gemm finalises the partials inside the pair-split launch where it takes that, else
+        //  runs kx_row_stats_finalize into d.stats itself)
+        RowFusion fo; fo.partials = d.partials; fo.nseg = w->heads; fo.seg = 64; fo.eps = w->eps;
         KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
-                    0, 0, d.stats, L.wo_colsum, nullptr, nullptr, fold ? &lop : nullptr));
+                    0, 0, d.stats, L.wo_colsum, nullptr, &fo, fold ? &lop : nullptr));
       }
     } else {
       KX_TRY(kx_attention(&a, stream));
@@ -589,9 +591,9 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
         KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
                     0, 0, nullptr, L.w2_colsum, nullptr, &r2));
       } else {
-        KX_TRY(kx_row_stats_finalize(d.partials, M, F / 64, 64, w->eps, d.stats, stream));
+        RowFusion f2; f2.partials = d.partials; f2.nseg = F / 64; f2.seg = 64; f2.eps = w->eps;
         KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
-                    0, 0, d.stats, L.w2_colsum, nullptr, nullptr, fold ? &lop : nullptr));
+                    0, 0, d.stats, L.w2_colsum, nullptr, &f2, fold ? &lop : nullptr));
       }
     } else {
       KX_TRY(gemm(d.h, D, w1, D, d.g, F, ct, M, F, b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,

@@ -44,8 +44,27 @@ int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_byt
   return (int)splitk_slices(M, N, K, (prec == KX_PREC_BF16 || prec == KX_PREC_F16) ? 64 : 32, ws_bytes, 0);
 }
 
-extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
-  KX_REQUIRE(a != nullptr, "kx_gemm: null args");
+extern "C" int kx_row_stats_finalize(const float* partials, int64_t rows, int64_t nseg, int64_t seg_size, float eps, float* out,
+                                    void* stream);
+extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
+  KX_REQUIRE(a_in != nullptr, "kx_gemm: null args");
+  // row_stats AND stats_partials (tile kernels): the partials are what the producer wrote, row_stats is where their finalised
+  // (mean, rstd) go when this launch does not finalise them itself: kx_gemm runs kx_row_stats_finalize first.  The pair split
+  // with the lean residual epilogue CAN finalise them in the launch (each workgroup the 128 rows it finishes, while it waits for
+  // its partner's flag: kx_row_stats_finalize's arithmetic, wave per row; row_stats untouched) — opt-in, tuning key 15 & 32:
+  // measured SLOWER on the headline (25.14 vs 24.90 ms same-box alternating: with two steps in flight the 5 us finalize launches
+  // hide under the other stream, the in-launch walk sits on the hand-off).  Below this point the call looks like a row_stats
+  // call; `fin` remembers the partials.
+  kx_gemm_args a_copy;
+  const kx_gemm_args* a = a_in;
+  struct { const float* partials; int64_t nseg, seg; float eps; } fin = {nullptr, 0, 0, 0.f};
+  if (a_in->row_stats && a_in->stats_partials && a_in->tile != 16) {
+    KX_REQUIRE(a_in->stats_in_nseg > 0 && a_in->stats_in_seg > 0 && !a_in->ln_out,
+               "kx_gemm: row_stats + stats_partials needs nseg, seg size (and no ln_out: that is the row-owning reduce's form)");
+    fin = {a_in->stats_partials, a_in->stats_in_nseg, a_in->stats_in_seg, a_in->stats_eps};
+    a_copy = *a_in; a_copy.stats_partials = nullptr; a_copy.stats_in_nseg = 0; a_copy.stats_in_seg = 0;
+    a = &a_copy;
+  }
   KX_REQUIRE(a->A && a->W && a->C, "kx_gemm: null operand pointer");
   KX_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "kx_gemm: empty problem M=%lld N=%lld K=%lld", (long long)a->M,
              (long long)a->N, (long long)a->K);
@@ -164,6 +183,11 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
       const bool fc = f16c && (a->cdt == KX_F32 || a->cdt == KX_F16HL) && p.vec_ok && a->N % 4 == 0;
       p.lean_xpos = (shape_ok && (bf || fc) && k4 != 1 && k4 != 8 && k4 != 9) ? ((k4 == 3 && bf) ? 2 : 1) : 0;   // (9: only this one off, A/B)
     }
+    // fp32 output with residual on whole 256-column tiles (the decoder's out_proj / fc2; pair split or not): bias + folded-LN
+    // consume at accumulator level, residual rows requested before the tile is parked (tuning key 15 & 16: generic loops, A/B)
+    p.lean_res = mode != 1 && !(kx_tuning_get(KX_TUNE_GEMM_RULES) & 16) && a->cdt == KX_F32 && a->residual && p.vec_ok &&
+                 a->act == KX_ACT_NONE && !a->xpos_dim && !a->stats_out && !a->ln_operand_out && a->qcols % 64 == 0 &&
+                 a->N % 256 == 0 && !a->ln_out;
     p.ring = mode != 6 && !f16c;
     // A/B: tuning key 4 = 4 keeps the A&S erf in the lean epilogues
     // For plain fp16 rows out of plain fp16 operands (the tower in mixed mode) it is OPT-IN (tuning key 15 & 8): measured +0.6 %
@@ -257,6 +281,12 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
           a->N % 256 == 0 && a->K >= 1024 && cdiv(a->M, 192) * cdiv(a->N, 256) <= kx_cu_count() &&
           cdiv(a->M, 192) * cdiv(a->N, 256) >= kx_cu_count() / 2)
         tile = 384;
+      // ... and any N % 256 == 0 problem whose 192 x 256 tiles make one round that fills >= 0.8 of the CUs (the Perceiver's to_kv at
+      // B = 32: 10272 x 1024 x 1024 = 54 x 4 tiles: 55.8 us against 75.3 on 128 x 128, tools/tile_probe.py, profiles/r05_k_*)
+      if (!(kx_tuning_get(KX_TUNE_GEMM_RULES) & 2) && (tile == 160 || tile == 128) && (f16 || f16c || a->prec == KX_PREC_BF16) &&
+          a->N % 256 == 0 && a->K >= 1024 && cdiv(a->M, 192) * cdiv(a->N, 256) <= kx_cu_count() &&
+          cdiv(a->M, 192) * cdiv(a->N, 256) >= (4 * kx_cu_count()) / 5)
+        tile = 384;
       // A/B: tuning key 4 = 6 keeps the 128 / 160-row kernels for fp16 rows where bf16 takes the 256x128 ring
       if ((f16c || f16) && tile == 256 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) == 6) tile = cost(160) <= cost(128) ? 160 : 128;
     }
@@ -344,6 +374,14 @@ extern "C" int kx_gemm(const kx_gemm_args* a, void* stream) {
                                                                    (uintptr_t)a->ln_out_beta) & 15) == 0),
                "kx_gemm: ln_out needs 16-byte aligned gamma / beta / output");
     KX_REQUIRE(!a->stats_out, "kx_gemm: the row reduce does not produce statistics");
+  }
+  if (fin.partials) {
+    if (p.pairk && p.lean_res && fin.nseg <= 128 && (kx_tuning_get(KX_TUNE_GEMM_RULES) & 32)) {   // opt-in: measured slower (see the header)
+      p.stats_partials = fin.partials; p.stats_in_nseg = (int)fin.nseg; p.stats_in_seg = (float)fin.seg; p.stats_eps = fin.eps;
+    } else {
+      const int rc = kx_row_stats_finalize(fin.partials, a->M, fin.nseg, fin.seg, fin.eps, const_cast<float*>(a->row_stats), stream);
+      if (rc != KX_OK) return rc;
+    }
   }
   // 16-bit tile kernels: [bf16 | f16c | f16] x [128, 64, 160, 256x128, 256x256]
   static const int kinds16[3][5] = {

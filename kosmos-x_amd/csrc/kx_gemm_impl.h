@@ -42,6 +42,7 @@ struct GemmParams {
   int fast_epilogue;    // store loop with prefetched epilogue operands (store_loop_fast)
   int lean_epilogue;    // 256-column kernel: accumulator-level epilogue + pure data movement (see lean_store_*)
   int lean_xpos;        // 256-column kernel, bf16 output: q-scale + XPos at accumulator level too (lean_bias_qscale_xpos)
+  int lean_res;         // 256-column kernel, fp32 output with residual: accumulator-level epilogue, residual rows requested before the tile is parked (lean_store_f32_res)
   int lean_f16c;        // 256-column kernel, KX_F16C output: accumulator-level epilogue + three-plane tile store (lean_store_f16c)
   int w_tiled;          // tile 16: W in the streaming layout [N/16][K/32][1 KB] (kx_gemm_args.w_tiled)
   int ring;             // 64x64 launches: 4-stage LDS ring, three K-tiles in flight (A/B: tuning key 4 = 6 turns it off)
@@ -516,18 +517,22 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // stores two full 512-byte rows: 6.5k cycles.  Outputs with a residual / folded-LN consume (fp32) and the q-scale + XPos
 // epilogue keep the generic loops: an accumulator-level fp32 path measured the same 71k cycles (it waits on the
 // residual loads either way) and the XPos variant still spilled.
-template <int ACT, int FM, int FN>
-__device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc)[FN][FM], int ncol0, int g, int mrow0, int li) {
+// UNFUSED: rstd * (...) and + bias as two roundings — what the generic store loop computes (its bias add sits behind a run-time
+// branch, so it never contracts with the product): the fp32 residual epilogue is that loop bit for bit
+template <int ACT, int FM, int FN, int FMU = FM, bool UNFUSED = false>   // FMU: the first FMU row fragments are in use (the pair split finishes FM / 2)
+__device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc)[FN][FM], int ncol0, int g, int mrow0, int li,
+                                              const float2* rs_lds = nullptr) {   // rs_lds: (mean, rstd) of rows b*16 + li, finalised in this launch
   // Straight-line on purpose: a run-time branch whose two sides both rewrite the 128 accumulator registers made the
   // compiler keep two copies of them (spills) — which is also why the variants are separate kernel instantiations.
   // q-scale: a wave's 64 columns lie on one side of the boundary (qcols % 64 == 0, checked by kx_gemm) -> one scalar
   const float qsc = ncol0 < p.qcols ? p.qscale : 1.0f;
   // folded pre-LayerNorm consume: rstd * (acc - mean * colsum) first; without row statistics (mean, rstd) = (0, 1) and
   // colsum = 0 make it an exact no-op — same straight-line code either way
-  float2 rs[FM];
+  float2 rs[FMU];
 #pragma unroll
-  for (int b = 0; b < FM; ++b)
-    rs[b] = p.row_stats ? *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)min(mrow0 + b * 16 + li, p.M - 1))
+  for (int b = 0; b < FMU; ++b)
+    rs[b] = rs_lds ? rs_lds[b * 16 + li]
+          : p.row_stats ? *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)min(mrow0 + b * 16 + li, p.M - 1))
                         : make_float2(0.f, 1.f);
   const f32x2_t qs2 = pk_splat(qsc);
 #pragma unroll
@@ -538,12 +543,19 @@ __device__ __forceinline__ void lean_bias_act(const GemmParams& p, f32x4_t (&acc
     // packed fp32 arithmetic, see prepass_bias_act_stats
     const f32x2_t b0 = {bias.x, bias.y}, b1 = {bias.z, bias.w}, c0 = {cs.x, cs.y}, c1 = {cs.z, cs.w};
 #pragma unroll
-    for (int b = 0; b < FM; ++b) {
+    for (int b = 0; b < FMU; ++b) {
       const f32x4_t v = acc[a][b];
       const f32x2_t nmean = pk_splat(-rs[b].x), rstd = pk_splat(rs[b].y);
       f32x2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+      if constexpr (UNFUSED) {
+#pragma clang fp contract(off)
+        const f32x2_t tl = rstd * pk_fma(nmean, c0, lo), th = rstd * pk_fma(nmean, c1, hi);
+        lo = apply_act2<ACT>((tl + b0) * qs2);
+        hi = apply_act2<ACT>((th + b1) * qs2);
+      } else {
       lo = apply_act2<ACT>(pk_fma(rstd, pk_fma(nmean, c0, lo), b0) * qs2);
       hi = apply_act2<ACT>(pk_fma(rstd, pk_fma(nmean, c1, hi), b1) * qs2);
+      }
       acc[a][b] = (f32x4_t){lo.x, lo.y, hi.x, hi.y};
     }
   }
@@ -675,6 +687,47 @@ __device__ __forceinline__ void lean_store_f32(const GemmParams& p, const f32x4_
       const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + hr * 1024 + ((lane ^ (hr & 15)) << 4));
       if (m < p.M) *reinterpret_cast<f32x4_t*>(out + (long long)m * p.ldc + n0 + lane * 4) = v;
     }
+  }
+}
+
+// fp32 output WITH RESIDUAL of the 256-column kernel (the decoder's out_proj / fc2: x += ...; in place or not).  The generic store
+// loop walks 64-column sub-tiles with its operands prefetched pass by pass and still exposes a load latency per half
+// (20-23k cycles for the 128 rows a pair-split workgroup finishes, profiles/r05_k_*); here the residual rows are requested in
+// the layout of the row store below — lane l: 16 B at column 4l of one whole 1 KB tile row, BM / 16 rows per half — as soon as
+// the K loop ends (pair split: before the slab exchange, which hides them completely), the bias / folded-LN consume runs on
+// the accumulators (lean_bias_act: the generic loop's operation order), and the store pass is LDS read + add + store.
+// `hrow`: which 64-row half of each wave row accumulator half `half` holds (pair split: ks_h for half 0; else half).
+template <int BM>
+__device__ __forceinline__ void lean_res_request(const GemmParams& p, f32x4_t (&r)[BM / 16], int m0, int n0, int wave, int lane, int hrow) {
+  constexpr int HR = BM / 4;
+#pragma unroll
+  for (int ps = 0; ps < BM / 16; ++ps) {
+    const int hr = ps * 8 + wave, m = min(m0 + (hr / HR) * (BM / 2) + hrow * HR + (hr % HR), p.M - 1);   // clamped for the load; the store is predicated
+    r[ps] = *reinterpret_cast<const f32x4_t*>(p.residual + (long long)m * p.ldr + n0 + lane * 4);
+  }
+}
+template <int BM, int FM, int FN>
+__device__ __forceinline__ void lean_store_f32_res(const GemmParams& p, const f32x4_t (&acc)[FN][FM], const f32x4_t (&r)[BM / 16], char* smem,
+                                                   int m0, int n0, int wm, int wn, int wave, int lane, int g, int li, int half, int hrow) {
+  static_assert(FM % 2 == 0 && FN == 4 && (BM / 2) % 8 == 0, "two halves of whole fragments, eight rows per store pass");
+  constexpr int HR = BM / 4;                // rows of one wave row inside a half
+  float* const out = reinterpret_cast<float*>(p.C);
+  __syncthreads();                          // the K loop's last fragment reads / the previous half's row reads are done
+#pragma unroll
+  for (int bb = 0; bb < FM / 2; ++bb) {
+    const int hr = wm * HR + bb * 16 + li;                         // row inside this half's BM / 2
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const int ch = (wn * 16 + a * 4 + g) ^ (hr & 15);
+      *reinterpret_cast<f32x4_t*>(smem + hr * 1024 + ch * 16) = half ? acc[a][FM / 2 + bb] : acc[a][bb];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < BM / 16; ++ps) {                           // BM / 2 rows, eight (one per wave) per pass
+    const int hr = ps * 8 + wave, m = m0 + (hr / HR) * (BM / 2) + hrow * HR + (hr % HR);
+    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + hr * 1024 + ((lane ^ (hr & 15)) << 4)) + r[ps];
+    if (m < p.M) *reinterpret_cast<f32x4_t*>(out + (long long)m * p.ldc + n0 + lane * 4) = v;
   }
 }
 
@@ -1537,7 +1590,7 @@ __device__ unsigned long long kx_tlp_n[2][8];
 // accumulator: k-step 0 then 1, as before — results are bit-identical to the first form).
 template <typename T, int ACT, int BM, int EPI, bool KS2 = false, bool BAL = false>   // BM = 256 or 192 (M = B*114 = 19 x 192 exactly at B = 32)
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
-  static_assert(!KS2 || (EPI == 0 && BM == 256), "the pair split runs the 256-row kernel with the generic epilogue");
+  static_assert(!KS2 || ((EPI == 0 || EPI == 9) && BM == 256), "the pair split runs the 256-row kernel with the generic or the lean residual epilogue");
   // BAL at BM = 192: an activation half is 2 x 48 rows = twelve 8-row pieces for eight waves — waves 0-3 stage two pieces of half
   // 0 and one of half 1, waves 4-7 one and two.  The waits use the smaller count of the two wave kinds (vmcnt(5) / vmcnt(3)):
   // a wave with one piece more in flight waits for one piece more than it must — conservative, never early.
@@ -1939,6 +1992,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   if (work) kloop(std::true_type{}); else kloop(std::false_type{});
   if (!lag) __builtin_amdgcn_s_barrier();
   KX_TL_STAMP(2);
+  f32x4_t rres[EPI == 9 ? BM / 16 : 1];
+  if constexpr (EPI == 9) lean_res_request<BM>(p, rres, m0, n0, wave, (int)(threadIdx.x & 63), KS2 ? ks_h : 0);
   if constexpr (KS2) {
     // Exchange with the partner (blockIdx ^ 8), guide G16 recipe R1: accumulator half 1 (fragments b >= FM/2) goes to this
     // workgroup's slab write-through, every wave drains, one lane publishes; then one lane polls the partner's flag, one
@@ -1955,8 +2010,39 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned pw = blockIdx.x ^ 8u;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0)
       __hip_atomic_store((gu32_t*)(p.pk_flag + blockIdx.x), p.pk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (EPI == 9) {
+      // folded-LN statistics of the 128 rows this workgroup finishes, from the producer's partials (kx_gemm_args: row_stats +
+      // stats_partials): kx_row_stats_finalize's arithmetic, one wave per row, 16 rows per wave — under the flag's round trip.
+      // Every wave is past the K loop (barrier above): the staging LDS is free until the tile is parked, and lean_bias_act
+      // reads the 128 (mean, rstd) pairs back before that.
+      float2* const fin_rs = reinterpret_cast<float2*>(smem);
+      if (p.stats_partials) {
+        const int fl = threadIdx.x & 63;
+        const float segf = p.stats_in_seg, cnt = p.stats_in_seg * (float)p.stats_in_nseg;
+#pragma unroll 8
+        for (int j = 0; j < 16; ++j) {
+          const int r = wave * 16 + j;                                           // (wave row r / 64, row r % 64 of the half)
+          const int m = min(m0 + (r >> 6) * (BM / 2) + ks_h * (BM / 4) + (r & 63), p.M - 1);
+          const float2* pr = reinterpret_cast<const float2*>(p.stats_partials) + (long long)m * p.stats_in_nseg;
+          float2 v0 = make_float2(0.f, 0.f), v1 = make_float2(0.f, 0.f);
+          const bool h0 = fl < p.stats_in_nseg, h1 = fl + 64 < p.stats_in_nseg;
+          if (h0) v0 = pr[fl];
+          if (h1) v1 = pr[fl + 64];
+          float sm = 0.f;
+          if (h0) sm += v0.x;
+          if (h1) sm += v1.x;
+          const float mean = wave_sum(sm) / cnt;
+          float m2 = 0.f;
+          if (h0) { const float d = v0.x / segf - mean; m2 += v0.y + segf * d * d; }
+          if (h1) { const float d = v1.x / segf - mean; m2 += v1.y + segf * d * d; }
+          const float var = wave_sum(m2) / cnt;
+          if (fl == 0) fin_rs[r] = make_float2(mean, rsqrtf(var + p.stats_eps));
+        }
+      }
+    }
+    if (threadIdx.x == 0) {
       while (__hip_atomic_load((gu32_t*)(p.pk_flag + pw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pk_epoch)
         __builtin_amdgcn_s_sleep(1);
     }
@@ -1993,6 +2079,24 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     KX_TL_STAMP(3);
     lean_store_f16c<BM, FM, FN>(p, acc, smem, m0, n0, wm, wn, wave, lane, g, li);
     KX_TL_STAMP(4);
+    KX_TL_STAMP(5);
+    KX_TL_COMMIT();
+  } else
+  if constexpr (EPI == 9) {                           // fp32 output with residual: bias / folded-LN consume on the accumulators, residual rows already on their way
+    if constexpr (KS2) {
+      lean_bias_act<KX_ACT_NONE, FM, FN, FM / 2, true>(p, acc, n0 + wn * WN, g, m0 + wm * (BM / 2) + ks_h * (BM / 4), li,
+                                                       p.stats_partials ? reinterpret_cast<const float2*>(smem) + wm * 64 : nullptr);
+      KX_TL_STAMP(3);
+      lean_store_f32_res<BM, FM, FN>(p, acc, rres, smem, m0, n0, wm, wn, wave, lane, g, li, 0, ks_h);
+      KX_TL_STAMP(4);
+    } else {
+      lean_bias_act<KX_ACT_NONE, FM, FN, FM, true>(p, acc, n0 + wn * WN, g, m0 + wm * (BM / 2), li);
+      KX_TL_STAMP(3);
+      lean_store_f32_res<BM, FM, FN>(p, acc, rres, smem, m0, n0, wm, wn, wave, lane, g, li, 0, 0);
+      lean_res_request<BM>(p, rres, m0, n0, wave, lane, 1);
+      KX_TL_STAMP(4);
+      lean_store_f32_res<BM, FM, FN>(p, acc, rres, smem, m0, n0, wm, wn, wave, lane, g, li, 1, 1);
+    }
     KX_TL_STAMP(5);
     KX_TL_COMMIT();
   } else
@@ -2070,6 +2174,9 @@ int launch_p5e(GemmParams& p, hipStream_t s) {
   const int nwg = p.tiles_m * p.tiles_n;
   const dim3 grid(p.persistent > 0 ? (nwg < p.persistent ? nwg : p.persistent) : nwg), block(512);
   // the lean variants are instantiated for the activations the forward uses them with; anything else takes EPI 0
+  if constexpr (EPI == 9) {                 // fp32 output with residual, bias + folded-LN consume at accumulator level (no activation)
+    launch_p5k<T, KX_ACT_NONE, BM, 9>(p, grid, block, s); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK;
+  }
   if constexpr (EPI == 8) {                 // fp32 output, bias + q-scale + XPos at accumulator level (no activation)
     if (p.act == KX_ACT_NONE) { launch_p5k<T, KX_ACT_NONE, BM, 8>(p, grid, block, s); KX_CHECK_LAUNCH("kx_gemm(p5)"); return KX_OK; }
     return launch_p5e<T, BM, 0>(p, s);
@@ -2113,7 +2220,8 @@ int launch_p5(GemmParams& p, hipStream_t s) {
   if constexpr (BM == 256) {
     if (p.pairk) {                            // K split over workgroup pairs (kx_gemm checked: no activation / statistics, even nk, tiles % 8 == 0)
       const dim3 grid(2 * p.tiles_m * p.tiles_n), block(512);
-      launch_p5k<T, KX_ACT_NONE, 256, 0, true>(p, grid, block, s);
+      if (p.lean_res) launch_p5k<T, KX_ACT_NONE, 256, 9, true>(p, grid, block, s);
+      else launch_p5k<T, KX_ACT_NONE, 256, 0, true>(p, grid, block, s);
       KX_CHECK_LAUNCH("kx_gemm(p5, pair split-K)");
       return KX_OK;
     }
@@ -2121,6 +2229,7 @@ int launch_p5(GemmParams& p, hipStream_t s) {
   // lean_xpos: 2 = asked for (tuning key 4 = 3), 1 = eligible — taken on the 192-row tiles, where the rotated accumulators fit
   // the registers (bf16 qkv at M = 3648: 109.6 -> 93.8 us, bit-identical; the 256-row form spills 352 B / lane and measured slower)
   const bool lx = p.lean_xpos == 2 || (p.lean_xpos == 1 && BM == 192);
+  if (p.lean_res) return launch_p5e<T, BM, 9>(p, s);
   if constexpr (kIsF16c<T>) {
     // KX_F16C output on whole 256-column tiles, no residual / XPos: the three-plane lean store (else the generic loops)
     if (BM == 256 && p.lean_f16c && p.N % 256 == 0) return p.stats_out ? launch_p5e<T, BM, 7>(p, s) : launch_p5e<T, BM, 6>(p, s);

@@ -236,7 +236,7 @@ def f16_pieces_values(rows: torch.Tensor) -> torch.Tensor:
 
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,
               xpos=None, xpos_dim=0, tile=0, row_stats=None, colsum=None, stats_out=None, splitk_ws=None, splitk=0,
-              ln_operand=None, pair_ws=None, out_hilo=False):
+              ln_operand=None, pair_ws=None, out_hilo=False, stats_partials=None, stats_in_seg=64, stats_eps=1e-5):
     """KX_PREC_F16C GEMM: a_rows [M, 4K] uint8 (KX_F16C activation rows), w_packed = the flat packed weight matrix
     (N rows of 4K bytes + N scale bytes, model._operand_f16c).  Output fp32 [M, N] or KX_F16C rows [M, 4N] uint8.
     out_hilo (with xpos): the fp32-shaped output holds KX_F16HL head slots — [64 fp16 hi | 64 fp16 lo] of 2^8 x per 64 columns."""
@@ -257,6 +257,9 @@ def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_
         g.xpos_T, g.xpos_dim = xpos[0].shape[0], xpos_dim
     g.prec, g.tile = H.KX_PREC_F16C, tile
     g.row_stats, g.colsum, g.stats_out = H.ptr(row_stats), H.ptr(colsum), H.ptr(stats_out)
+    if stats_partials is not None:      # with row_stats (scratch): finalised inside the pair-split launch, else by kx_gemm's own pass
+        g.stats_partials, g.stats_in_nseg = H.ptr(stats_partials), stats_partials.shape[1]
+        g.stats_in_seg, g.stats_eps = stats_in_seg, float(stats_eps)
     if splitk_ws is not None:
         g.splitk_ws, g.splitk_ws_bytes, g.splitk = H.ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size(), splitk
     if pair_ws is not None:

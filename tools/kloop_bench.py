@@ -2,7 +2,9 @@
 vmcnt, 1 = the first form: whole tile issued in R0, vmcnt(0) in R1) on the shapes the forward runs it with.  Same operands,
 same epilogue, interleaved rounds in one process (guide 5.4 rule 24), random operands (rule 25), and the two results compared
 BIT FOR BIT (the forms differ in issue order only).  GPU box only.
-    python tools/kloop_bench.py [case,...]"""
+    python tools/kloop_bench.py [case,...]
+KLOOP_AB_KEY / KLOOP_AB_OLD: A/B another tuning key the same way (e.g. 15 / 16: the lean fp32 residual epilogue against the generic
+store loop); the columns keep their names (first_form = the key's OLD value, balanced = 0)."""
 import os, sys, json, statistics
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -13,6 +15,7 @@ from kosmosx import ops, _hip
 from kosmosx.model import _operand_f16c
 
 LIB = _hip.load()
+AB_KEY, AB_OLD = int(os.environ.get("KLOOP_AB_KEY", 14)), int(os.environ.get("KLOOP_AB_OLD", 1))
 
 
 def operands(kind, M, N, K, g):
@@ -113,7 +116,7 @@ def run(name, iters=10, rounds=5):
     call = make_case(kind, epi, M, N, K)
     outs = {}
     for form in (1, 0):
-        LIB.kx_set_tuning(14, form)
+        LIB.kx_set_tuning(AB_KEY, AB_OLD if form else 0)
         call(tile)
         outs[form] = call(tile).clone()
     torch.cuda.synchronize()
@@ -121,14 +124,14 @@ def run(name, iters=10, rounds=5):
     ts = {0: [], 1: []}
     for _ in range(rounds):
         for form in (1, 0):
-            LIB.kx_set_tuning(14, form)
+            LIB.kx_set_tuning(AB_KEY, AB_OLD if form else 0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
                 call(tile, False)
             e1.record(); e1.synchronize()
             ts[form].append(e0.elapsed_time(e1) / iters)
-    LIB.kx_set_tuning(14, 0)
+    LIB.kx_set_tuning(AB_KEY, 0)
     t_old, t_new = statistics.median(ts[1]), statistics.median(ts[0])
     fl = 2.0 * M * N * K
     return {"case": name, "kind": kind, "epi": epi, "M": M, "N": N, "K": K, "tile": tile, "bit_identical": same,
