@@ -694,7 +694,7 @@ __device__ __forceinline__ void lean_store_f32(const GemmParams& p, const f32x4_
 // loop walks 64-column sub-tiles with its operands prefetched pass by pass and still exposes a load latency per half
 // (20-23k cycles for the 128 rows a pair-split workgroup finishes, profiles/r05_k_*); here the residual rows are requested in
 // the layout of the row store below — lane l: 16 B at column 4l of one whole 1 KB tile row, BM / 16 rows per half — as soon as
-// the K loop ends (pair split: before the slab exchange, which hides them completely), the bias / folded-LN consume runs on
+// the K loop ends (pair split: once the slab has drained and the flag is out, under the flag's round trip and the partner's slab), the bias / folded-LN consume runs on
 // the accumulators (lean_bias_act: the generic loop's operation order), and the store pass is LDS read + add + store.
 // `hrow`: which 64-row half of each wave row accumulator half `half` holds (pair split: ks_h for half 0; else half).
 template <int BM>
@@ -1993,7 +1993,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   if (!lag) __builtin_amdgcn_s_barrier();
   KX_TL_STAMP(2);
   f32x4_t rres[EPI == 9 ? BM / 16 : 1];
-  if constexpr (EPI == 9) lean_res_request<BM>(p, rres, m0, n0, wave, (int)(threadIdx.x & 63), KS2 ? ks_h : 0);
+  // (pair split: requested after the slab has drained and the flag is out — ahead of the slab stores they sat in front of the
+  //  drain and held the flag back: exchange 18 k -> 30 k cycles, profiles/r05_m_*)
+  if constexpr (EPI == 9 && !KS2) lean_res_request<BM>(p, rres, m0, n0, wave, (int)(threadIdx.x & 63), 0);
   if constexpr (KS2) {
     // Exchange with the partner (blockIdx ^ 8), guide G16 recipe R1: accumulator half 1 (fragments b >= FM/2) goes to this
     // workgroup's slab write-through, every wave drains, one lane publishes; then one lane polls the partner's flag, one
@@ -2012,6 +2014,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     const unsigned pw = blockIdx.x ^ 8u;
     if (threadIdx.x == 0)
       __hip_atomic_store((gu32_t*)(p.pk_flag + blockIdx.x), p.pk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (EPI == 9) lean_res_request<BM>(p, rres, m0, n0, wave, (int)(threadIdx.x & 63), ks_h);   // under the flag's round trip
     if constexpr (EPI == 9) {
       // folded-LN statistics of the 128 rows this workgroup finishes, from the producer's partials (kx_gemm_args: row_stats +
       // stats_partials): kx_row_stats_finalize's arithmetic, one wave per row, 16 rows per wave — under the flag's round trip.
@@ -2083,20 +2086,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     KX_TL_COMMIT();
   } else
   if constexpr (EPI == 9) {                           // fp32 output with residual: bias / folded-LN consume on the accumulators, residual rows already on their way
-    if constexpr (KS2) {
+    if constexpr (KS2)
       lean_bias_act<KX_ACT_NONE, FM, FN, FM / 2, true>(p, acc, n0 + wn * WN, g, m0 + wm * (BM / 2) + ks_h * (BM / 4), li,
                                                        p.stats_partials ? reinterpret_cast<const float2*>(smem) + wm * 64 : nullptr);
-      KX_TL_STAMP(3);
-      lean_store_f32_res<BM, FM, FN>(p, acc, rres, smem, m0, n0, wm, wn, wave, lane, g, li, 0, ks_h);
-      KX_TL_STAMP(4);
-    } else {
+    else
       lean_bias_act<KX_ACT_NONE, FM, FN, FM, true>(p, acc, n0 + wn * WN, g, m0 + wm * (BM / 2), li);
-      KX_TL_STAMP(3);
-      lean_store_f32_res<BM, FM, FN>(p, acc, rres, smem, m0, n0, wm, wn, wave, lane, g, li, 0, 0);
-      lean_res_request<BM>(p, rres, m0, n0, wave, lane, 1);
-      KX_TL_STAMP(4);
-      lean_store_f32_res<BM, FM, FN>(p, acc, rres, smem, m0, n0, wm, wn, wave, lane, g, li, 1, 1);
-    }
+    KX_TL_STAMP(3);
+    lean_store_f32_res<BM, FM, FN>(p, acc, rres, smem, m0, n0, wm, wn, wave, lane, g, li, 0, KS2 ? ks_h : 0);
+    if constexpr (!KS2) lean_res_request<BM>(p, rres, m0, n0, wave, lane, 1);
+    KX_TL_STAMP(4);
+    if constexpr (!KS2) lean_store_f32_res<BM, FM, FN>(p, acc, rres, smem, m0, n0, wm, wn, wave, lane, g, li, 1, 1);
     KX_TL_STAMP(5);
     KX_TL_COMMIT();
   } else
