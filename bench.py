@@ -159,7 +159,10 @@ def kernel_report(records, steps):
         elif kind.startswith("attn"):
             e["flops"] += 4.0 * a * b * c * 64                # dense QK^T + PV, head_dim 64 (B*H, Tq, Tk)
         elif kind == "layernorm":
-            e["bytes"] += a * b * 6.0                         # fp32 row in, bf16 row out
+            # c = HBM bytes per value of the launch as kx_layernorm reports them (fp32 row in + pre_add row + the output
+            # format's bytes: 6 bf16 / fp16 rows, 8 KX_F16C or fp32 rows, 10 KX_BF16X3); 0 / 1 = entry points that do not
+            # report it (kx_gelu_layernorm, the backward): fp32 in, 16-bit out
+            e["bytes"] += a * b * (float(c) if c > 1 else 6.0)
     for e in agg.values():
         e["launches"] /= steps
         e["ms"] /= steps

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KX_ABI_VERSION 6
+#define KX_ABI_VERSION 7
 
 typedef enum {
   KX_OK = 0,
@@ -72,6 +72,8 @@ typedef enum {
 /* KX_PREC_F32W16: the same with block-scaled 16-bit streaming copies (kx_gemm_args.w_tiled = 3): 2.125 bytes per weight. */
 typedef enum { KX_PREC_BF16 = 0, KX_PREC_F32 = 1, KX_PREC_BF16X3 = 2, KX_PREC_F16C = 3, KX_PREC_F16 = 4, KX_PREC_F32W24 = 5,
                KX_PREC_F32W16 = 6, KX_PREC_F16CHL = 7 /* kx_attention only: KX_PREC_F16C on KX_F16HL q / k / v rows */ } kx_precision;
+/* kx_gemm_args.f16c_corr: the fp8 correction products of a KX_PREC_F16C launch (ABI 7) */
+typedef enum { KX_CORR_BOTH = 0, KX_CORR_WEIGHT = 1, KX_CORR_ACT = 2, KX_CORR_NONE = 3 } kx_f16c_corr;
 /* KX_F16P (weight-streaming decode step only): fp32-pitched rows of fp16 PIECE pairs, value = hi + lo with hi = fp16(x) toward
  * zero and lo = fp16(x - hi) — per 32 values 128 bytes: [hi pieces, 64 B][lo pieces, 64 B], each as four 16-byte chunks g =
  * 0..3 holding values 4g..4g+3 then 16+4g..16+4g+3 of the 32 (the fragment order of kx_gemm_args.w_tiled = 3's fp16-pieces
@@ -162,12 +164,14 @@ typedef struct {
    *       takes the producer's partial statistics directly (what kx_row_stats_finalize would turn into row_stats);
    *   stats_out_seg : the producer side emits its statistics per 16-column segment ([M, N/16, 2]; must be 16 here,
    *       0 or 64 for every other variant). */
-  /* The TILE kernels take stats_partials TOGETHER WITH row_stats (+ colsum): row_stats [M, 2] is then where kx_gemm puts the
-   * finalised (mean, rstd) — it runs kx_row_stats_finalize itself before the launch.  With tuning key 15 & 32 the pair split
-   * of the 256 x 256 kernel with the accumulator-level residual epilogue finalises them inside the launch instead (each
-   * workgroup the rows it finishes, while it waits for its partner; the same arithmetic bit for bit, row_stats untouched,
-   * stats_in_nseg <= 128): one launch fewer per folded sub-LayerNorm, and measured 1 % SLOWER on the headline step (two steps
-   * in flight hide the 5 us finalize launches; the in-launch walk sits on the hand-off) — opt-in, A/B. */
+  /* The TILE kernels take stats_partials TOGETHER WITH row_stats_scratch (+ colsum; ABI 7: the explicit, non-const field at the
+   * end of this struct — until ABI 6 the const `row_stats` doubled as that output): row_stats_scratch [M, 2] is where
+   * kx_gemm puts the finalised (mean, rstd) — it runs kx_row_stats_finalize itself before the launch — and `row_stats` must be
+   * NULL.  The scratch is OVERWRITTEN; its contents after the call are unspecified: with tuning key 15 & 32 the pair split of
+   * the 256 x 256 kernel with the accumulator-level residual epilogue finalises the partials inside the launch instead (each
+   * workgroup the rows it finishes, while it waits for its partner; the same arithmetic bit for bit, stats_in_nseg <= 128) and
+   * leaves the scratch untouched: one launch fewer per folded sub-LayerNorm, and measured 1 % SLOWER on the headline step (two
+   * steps in flight hide the 5 us finalize launches; the in-launch walk sits on the hand-off) — opt-in, A/B. */
   const float* ln_gamma; const float* ln_beta; float ln_eps;
   const float* stats_partials; int64_t stats_in_nseg; int64_t stats_in_seg; float stats_eps;
   int32_t stats_out_seg;
@@ -232,10 +236,26 @@ typedef struct {
    * one workgroup per CU (128 KB of LDS each) and in-order dispatch gives that; it is the dispatcher's guarantee, not the code's,
    * which is why the automatic rule never oversubscribes and the spin has no fallback; (ii) ONE scratch serves ONE stream at a
    * time: launches in flight on two streams need two scratches (the library's stage entry points and the trainer key theirs by
-   * stream); a scratch shared across streams can clobber a flag, and a clobbered flag is a hang, not an error. */
+   * stream); a scratch shared across streams can clobber a flag.  (iii) The poll is BOUNDED: a workgroup gives up after 1 s of
+   * the device's wall clock (a legitimate wait is the partner's K loop, < 1 ms), records 1 + its index in a sticky device word
+   * and finishes with wrong rows — kx_pair_split_errors() reports it; a broken contract is an error code, not a hung GPU. */
   void* pair_ws; size_t pair_ws_bytes;
+  /* ABI 7.  row_stats_scratch: see stats_partials above (tile kernels only; NULL otherwise).
+   * f16c_corr (KX_PREC_F16C operands only; kx_f16c_corr): which of the two fp8 correction products a launch contracts.
+   * A KX_F16C product is h_a.h_w + 2^-(s+11) (e_a.r_w + r_a.e_w); each correction term is half an fp16 pass of matrix time
+   * and a quarter of the row's bytes.  KX_CORR_BOTH (0, default) is the arithmetic every parity statement of this library is
+   * made for; KX_CORR_WEIGHT keeps e_a.r_w only (the weights stay 14-15 bits wide, the activations count as fp16: 1.5x the bf16
+   * matrix time instead of 2x, the operand rows' r plane is never read); KX_CORR_ACT keeps r_a.e_w only; KX_CORR_NONE is plain
+   * fp16 on KX_F16C rows.  The rows themselves do not change, so one packed weight matrix and one producer serve every value.
+   * The stage-level entry points take their per-family assignment from tuning key 16 (DESIGN.md §5 has the measured table). */
+  float* row_stats_scratch;
+  int32_t f16c_corr;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
+/* Diagnostics of the pair split's bounded hand-off: *word_out = 0 when every poll since the last call met its partner, else
+ * 1 + the index of the last workgroup that gave up (the word is then cleared).  SYNCHRONISES the device — call it after a
+ * batch of steps, never inside the step. */
+int kx_pair_split_errors(unsigned* word_out);
 
 /* Fused softmax(Q·Kᵀ [+causal mask])·V, head_dim 64, flash-style (no T×T tensor in HBM).
  * Replaces torchscale MultiheadAttention's bmm/nan_to_num/+mask/softmax(fp32)/bmm chain,
@@ -639,7 +659,9 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  * key 11: 1 = the streamed decode step keeps ONE workgroup per 16 columns in its residual GEMMs (no kx_gemm_args.ksplit pair).
  * key 12: 1 = the fp16-pieces decode step keeps fp32 rows between its kernels (each consumer splits them itself) instead of
  *         KX_F16P rows written by the producers (A/B).
- * key 13: 1 = never take the pair split of the 256x256 kernel (kx_gemm_args.pair_ws) automatically (A/B).
+ * key 13: 1 = never take the pair split of the 256x256 kernel (kx_gemm_args.pair_ws) automatically (A/B); 2 = FAULT INJECTION
+ *         (tests of the bounded hand-off): the odd workgroup of every pair never publishes its flag and the poll's bound is 2 ms
+ *         — the launch must complete and kx_pair_split_errors must report it.
  * key 14: K loop of the 256-column kernel (0 = the balanced form: the LDS-DMA of a K-tile issued in two halves, one per read
  *         phase, counted vmcnt waits; 1 = the first form: whole tile issued in the first read phase, vmcnt(0) in the second.
  *         The two are bit-identical).
@@ -648,8 +670,14 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  *         with a ragged last 160-row tile take 192 x 256 tiles (the ViT's fc2 / out_proj at M = 32 * 257); 4 = the f16c decoder's
  *         qkv GEMM writes KX_F16HL pieces for the attention kernel at T >= 512.  Bit 8 switches one rule ON: plain fp16 GELU outputs of
  *         the 256-column kernel's lean epilogue use the transcendental-free polynomial of the bf16 outputs (A/B: +0.6 %, not shipped).
- *         16 = fp32-with-residual outputs of the 256-column kernel keep the generic store loop (lean_store_f32_res off); Bit 32 switches one rule ON:
- *         folded sub-LayerNorm statistics given as row_stats + stats_partials are finalised inside the pair-split launch (slower). */
+ *         16 = fp32-with-residual outputs of the 256-column kernel keep the generic store loop (lean_store_f32_res off);
+         64 = one-round problems that fill >= 0.8 of the CUs with 192 x 256 tiles keep the 128 / 160-row kernels (the Perceiver's
+         to_kv; the rule never applies to launches with produced statistics, ln_operand_out, KX_F16C / KX_BF16X3 outputs or residual +
+         16-bit output, which were not measured on these tiles); Bit 32 switches one rule ON:
+ *         folded sub-LayerNorm statistics given as row_stats_scratch + stats_partials are finalised inside the pair-split launch (slower).
+ * key 16: per-family fp8-correction assignment of the KX_PREC_F16C stage entry points, two bits (a kx_f16c_corr value) per GEMM
+ *         family: bits 0-1 decoder qkv, 2-3 out_proj, 4-5 fc1, 6-7 fc2, 8-9 output projection, 10-11 every Perceiver GEMM.
+ *         0 = both corrections everywhere.  -1 = the library's shipped default. */
 int kx_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------
@@ -676,7 +704,8 @@ typedef enum {
 typedef struct {
   int32_t kind;      /* kx_kernel_kind */
   int32_t reserved;
-  int64_t a, b, c;   /* GEMM: M,N,K.  LayerNorm: rows, cols, 0.  Attention: B*H, Tq, Tk.  else rows, cols, 0 */
+  int64_t a, b, c;   /* GEMM: M,N,K.  LayerNorm: rows, cols, HBM bytes per value (fp32 in + pre_add + the output format's
+                        bytes; 0 / 1: not reported).  Attention: B*H, Tq, Tk.  else rows, cols, 0 */
   float ms;          /* device time of the launch */
   float reserved2;
 } kx_prof_record;

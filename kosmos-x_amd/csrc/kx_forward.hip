@@ -146,8 +146,23 @@ inline int aprec(int prec) {
 inline int64_t kmul(int prec) { return prec == KX_PREC_BF16X3 ? 3 : prec == KX_PREC_F16C ? 2 : 1; }
 
 // what the row-owning split-K reduce can absorb (kx_gemm_args: stats_partials, ln_out)
+// GEMM family of the NEXT gemm() call of this thread, for the per-family fp8-correction assignment of KX_PREC_F16C stages
+// (kx_gemm_args.f16c_corr, tuning key 16: two bits per family — 0 decoder qkv, 1 out_proj, 2 fc1, 3 fc2, 4 output projection,
+// 5 every Perceiver GEMM).  gemm() consumes it; a call without KX_FAM contracts both corrections.
+thread_local int g_gemm_family = -1;
+#define KX_FAM(f) g_gemm_family = (f)
+// The shipped assignment (tuning key 16 = -1 selects it too): DESIGN.md §5 "one correction instead of two, per family".
+constexpr int KX_F16C_CORR_DEFAULT = 0;
+static int f16c_corr_of(int family) {
+  if (family < 0) return KX_CORR_BOTH;
+  int v = kx_tuning_get(KX_TUNE_F16C_CORR);
+  if (v < 0) v = KX_F16C_CORR_DEFAULT;
+  return (v >> (2 * family)) & 3;
+}
+
 struct RowFusion {
   const float* partials = nullptr; int64_t nseg = 0, seg = 0;            // folded-LN statistics straight from the producer
+  float* scratch = nullptr;                                              // tile kernels: kx_gemm_args.row_stats_scratch (finalised (mean, rstd))
   void* ln_out = nullptr; int ln_dt = 0; const float* ln_g = nullptr; const float* ln_b = nullptr;   // the LayerNorm that follows
   float eps = 0.f;
 };
@@ -172,6 +187,8 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   g.ldc = cdtype == KX_BF16X3 ? 3 * ldc : cdtype == KX_F16C ? 2 * ldc : ldc; g.cdt = cdtype;
   g.bias = bias; g.residual = residual; g.ldr = ldc; g.M = M; g.N = N; g.K = f16c ? K : K * km;
   if (f16c) g.w_scale = (const uint8_t*)W + (size_t)N * (size_t)K * 4;
+  g.f16c_corr = f16c ? f16c_corr_of(g_gemm_family) : KX_CORR_BOTH;
+  g_gemm_family = -1;
   g.act = act; g.qscale = qscale; g.qcols = qcols;
   g.xq_cs = xq_cs; g.xq_ss = xq_ss; g.xk_cs = xk_cs; g.xk_ss = xk_ss; g.xpos_T = xT; g.xpos_dim = xdim;
   g.prec = km == 3 ? KX_PREC_BF16 : prec;   // bf16x3 runs the bf16 kernels over 3K
@@ -181,6 +198,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   g.pair_ws = g_pair_ws; g.pair_ws_bytes = g_pair_ws_bytes;
   if (rf) {
     g.stats_partials = rf->partials; g.stats_in_nseg = rf->nseg; g.stats_in_seg = rf->seg; g.stats_eps = rf->eps;
+    g.row_stats_scratch = rf->scratch;
     g.ln_out = rf->ln_out; g.ln_out_dt = rf->ln_dt; g.ln_out_gamma = rf->ln_g; g.ln_out_beta = rf->ln_b; g.ln_out_eps = rf->eps;
   }
   if (lo) { g.ln_operand_out = lo->out; g.ln_operand_dt = lo->dt; g.ln_operand_stats = lo->stats; }
@@ -444,7 +462,9 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
     KX_TRY(ln(x, w->media_pos, L.nm_g, L.nm_b, p.kvin, ct, B * m, D, w->eps, s, m, m + n, 0));
     KX_TRY(ln(p.lat, nullptr, L.nl_g, L.nl_b, p.kvin, ct, MQ, D, w->eps, s, n, m + n, m));
     KX_TRY(ln(p.lat, nullptr, L.nl_g, L.nl_b, p.lnq, ct, MQ, D, w->eps, s));
+    KX_FAM(5);
     KX_TRY(gemm(p.lnq, D, L.wq, D, p.qb, inner, qdt(prec), MQ, inner, nullptr, nullptr, 0, 0.125f, inner, prec, s));
+    KX_FAM(5);
     KX_TRY(gemm(p.kvin, D, L.wkv, D, p.kvb, 2 * inner, qdt(prec), MK, 2 * inner, nullptr, nullptr, 0, 1.f, 0, prec, s));
     kx_attn_args a;
     memset(&a, 0, sizeof(a));
@@ -454,14 +474,18 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
     a.out = p.att; a.out_batch_stride = n * inner * kmul(prec); a.out_row_stride = inner * kmul(prec); a.odt = ct;
     a.B = B; a.H = w->heads; a.Tq = n; a.Tk = m + n; a.mask = KX_ATTN_FULL; a.prec = aprec(prec);
     KX_TRY(kx_attention(&a, stream));
+    KX_FAM(5);
     KX_TRY(gemm(p.att, inner, L.wout, inner, p.lat, D, KX_F32, MQ, D, nullptr, p.lat, 0, 1.f, 0, prec, s));
     KX_TRY(ln(p.lat, nullptr, L.ff_g, L.ff_b, p.lnq, ct, MQ, D, w->eps, s));
+    KX_FAM(5);
     KX_TRY(gemm(p.lnq, D, L.w1, D, p.ffh, F, ct, MQ, F, nullptr, nullptr, KX_ACT_GELU, 1.f, 0, prec, s));
+    KX_FAM(5);
     KX_TRY(gemm(p.ffh, F, L.w2, F, p.lat, D, KX_F32, MQ, D, nullptr, p.lat, 0, 1.f, 0, prec, s));
   }
   if (lat_out) KX_TRY(ln(p.lat, nullptr, w->norm_g, w->norm_b, lat_out, KX_F32, MQ, D, w->eps, s));
   if (out && w->wproj) {
     KX_TRY(ln(p.lat, nullptr, w->norm_g, w->norm_b, p.fin, ct, MQ, D, w->eps, s));
+    KX_FAM(5);
     KX_TRY(gemm(p.fin, D, w->wproj, D, out, w->out_dim, KX_F32, MQ, w->out_dim, nullptr, nullptr, 0, 1.f, 0, prec,
                 s));
   }
@@ -533,6 +557,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     const bool st1 = fold && i > 0;                        // d.h = un-normalised rows of x + d.stats2 from the previous fc2
     if (fold && i == 0) KX_TRY(ln(x, nullptr, nullptr, nullptr, d.h, ct, M, D, w->eps, s));     // unit affine
     else if (!fold && !h_ready) KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
+    KX_FAM(0);
     KX_TRY(gemm(d.h, D, fold ? L.wqkv_f : L.wqkv, D, d.qkv, 3 * D, (qkv_hl && !st1) ? KX_F16HL : qdt(prec), M, 3 * D,
                 fold ? L.bqkv_f : L.bqkv, nullptr, 0,
                 0.125f, D, prec, s, w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? T : 0, w->xpos ? D : 0,
@@ -558,17 +583,20 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
       KX_TRY(kx_attention(&a, stream));
       if (fuse_o) {
         ro.partials = d.partials; ro.nseg = w->heads; ro.seg = 64;
+        KX_FAM(1);
         KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
                     0, 0, nullptr, L.wo_colsum, nullptr, &ro));
       } else {
-        // (row_stats + stats_partials: kx_gemm finalises the partials inside the pair-split launch where it takes that, else
+        // (row_stats_scratch + stats_partials: kx_gemm finalises the partials inside the pair-split launch where it takes that, else
         //  runs kx_row_stats_finalize into d.stats itself)
-        RowFusion fo; fo.partials = d.partials; fo.nseg = w->heads; fo.seg = 64; fo.eps = w->eps;
+        RowFusion fo; fo.partials = d.partials; fo.nseg = w->heads; fo.seg = 64; fo.eps = w->eps; fo.scratch = d.stats;
+        KX_FAM(1);
         KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
-                    0, 0, d.stats, L.wo_colsum, nullptr, &fo, fold ? &lop : nullptr));
+                    0, 0, nullptr, L.wo_colsum, nullptr, &fo, fold ? &lop : nullptr));
       }
     } else {
       KX_TRY(kx_attention(&a, stream));
+      KX_FAM(1);
       KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr, 0,
                   0, nullptr, nullptr, nullptr, fuse_o ? &ro : nullptr, fold ? &lop : nullptr));
     }
@@ -584,20 +612,25 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     const float* cs1 = fold ? L.w1_colsum : nullptr;
     if (w->subln) {
       // ffn_layernorm folded into fc2 the same way; fc1's epilogue emits the row statistics of gelu(fc1)
+      KX_FAM(2);
       KX_TRY(gemm(d.h, D, w1, D, d.g, F, ct, M, F, b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
                   nullptr, 0, 0, rs1, cs1, d.partials));
       if (fuse_2) {
         r2.partials = d.partials; r2.nseg = F / 64; r2.seg = 64;
+        KX_FAM(3);
         KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
                     0, 0, nullptr, L.w2_colsum, nullptr, &r2));
       } else {
-        RowFusion f2; f2.partials = d.partials; f2.nseg = F / 64; f2.seg = 64; f2.eps = w->eps;
+        RowFusion f2; f2.partials = d.partials; f2.nseg = F / 64; f2.seg = 64; f2.eps = w->eps; f2.scratch = d.stats;
+        KX_FAM(3);
         KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
-                    0, 0, d.stats, L.w2_colsum, nullptr, &f2, fold ? &lop : nullptr));
+                    0, 0, nullptr, L.w2_colsum, nullptr, &f2, fold ? &lop : nullptr));
       }
     } else {
+      KX_FAM(2);
       KX_TRY(gemm(d.h, D, w1, D, d.g, F, ct, M, F, b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
                   0, 0, rs1, cs1));
+      KX_FAM(3);
       KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr, 0, 0,
                   nullptr, nullptr, nullptr, fuse_2 ? &r2 : nullptr, fold ? &lop : nullptr));
     }
@@ -605,11 +638,13 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     h_ready = fuse_2;                                     // d.h = the next layer's (or the final) LayerNorm of x
   }
   if (fold) {                                             // decoder.layer_norm folded into the output projection
+    KX_FAM(4);
     KX_TRY(gemm(d.h, D, w->wout_f, D, logits, w->vocab, ldt, M, w->vocab, w->bout_f, nullptr, 0, 1.f, 0, prec, s, nullptr,
                 nullptr, nullptr, nullptr, 0, 0, d.stats2, w->wout_colsum));
     return KX_OK;
   }
   if (!h_ready) KX_TRY(ln(x, nullptr, w->ln_g, w->ln_b, d.h, ct, M, D, w->eps, s));
+  KX_FAM(4);
   KX_TRY(gemm(d.h, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab, nullptr, nullptr, 0, 1.f, 0, prec, s));
   return KX_OK;
 }
@@ -723,30 +758,38 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
     const kx_decoder_layer& L = w->layer[i];
     KX_TRY(ln(x, nullptr, L.sa_g, L.sa_b, d.h, ct, M, D, w->eps, s));
     // XPos rows of absolute position t (xpos_T = 1: every batch row is the same position)
+    KX_FAM(0);
     KX_TRY(gemm(d.h, D, L.wqkv, D, d.qkv, 3 * D, qdt(prec), M, 3 * D, L.bqkv, nullptr, 0, 0.125f, D, prec, s,
                 w->xpos ? xq_cs : nullptr, xq_ss, xk_cs, xk_ss, w->xpos ? 1 : 0, w->xpos ? D : 0));
     KX_TRY(kx_attention_decode(d.qkv, (char*)kcache + i * layer_bytes, (char*)vcache + i * layer_bytes, d.att, ct,
                                w->subln ? d.partials : nullptr, B, w->heads, t, Tmax, prec, stream));
     if (w->subln) {
       KX_TRY(kx_row_stats_finalize(d.partials, M, w->heads, 64, w->eps, d.stats, stream));
+      KX_FAM(1);
       KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
                   0, 0, d.stats, L.wo_colsum, nullptr));
     } else {
+      KX_FAM(1);
       KX_TRY(gemm(d.att, D, L.wo, D, x, D, KX_F32, M, D, L.bo, x, 0, 1.f, 0, prec, s));
     }
     KX_TRY(ln(x, nullptr, L.fl_g, L.fl_b, d.h, ct, M, D, w->eps, s));
     if (w->subln) {
+      KX_FAM(2);
       KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s, nullptr, nullptr, nullptr,
                   nullptr, 0, 0, nullptr, nullptr, d.partials));
       KX_TRY(kx_row_stats_finalize(d.partials, M, F / 64, 64, w->eps, d.stats, stream));
+      KX_FAM(3);
       KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s, nullptr, nullptr, nullptr, nullptr,
                   0, 0, d.stats, L.w2_colsum, nullptr));
     } else {
+      KX_FAM(2);
       KX_TRY(gemm(d.h, D, L.w1, D, d.g, F, ct, M, F, L.b1, nullptr, w->act, 1.f, 0, prec, s));
+      KX_FAM(3);
       KX_TRY(gemm(d.g, F, L.w2, F, x, D, KX_F32, M, D, L.b2, x, 0, 1.f, 0, prec, s));
     }
   }
   KX_TRY(ln(x, nullptr, w->ln_g, w->ln_b, d.h, ct, M, D, w->eps, s));
+  KX_FAM(4);
   KX_TRY(gemm(d.h, D, w->wout, D, logits, w->vocab, ldt, M, w->vocab, nullptr, nullptr, 0, 1.f, 0, prec, s));
   return KX_OK;
 }

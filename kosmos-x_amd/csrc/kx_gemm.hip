@@ -44,12 +44,36 @@ int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_byt
   return (int)splitk_slices(M, N, K, (prec == KX_PREC_BF16 || prec == KX_PREC_F16) ? 64 : 32, ws_bytes, 0);
 }
 
+// Sticky device word of the pair split's bounded hand-off (GemmParams.pk_err): 0, or 1 + the index of the last workgroup that
+// gave up waiting for its partner's flag.  One word per process and device context; kx_pair_split_errors reads and clears it.
+__device__ unsigned g_kx_pair_err;
+static unsigned* pair_err_word() {
+  static unsigned* ptr = [] {
+    void* q = nullptr;
+    return hipGetSymbolAddress(&q, HIP_SYMBOL(g_kx_pair_err)) == hipSuccess ? (unsigned*)q : (unsigned*)nullptr;
+  }();
+  return ptr;
+}
+extern "C" int kx_pair_split_errors(unsigned* word_out) {
+  KX_REQUIRE(word_out != nullptr, "kx_pair_split_errors: null output");
+  unsigned* w = pair_err_word();
+  KX_REQUIRE(w != nullptr, "kx_pair_split_errors: device word unavailable");
+  unsigned v = 0, zero = 0;
+  if (hipMemcpy(&v, w, sizeof v, hipMemcpyDeviceToHost) != hipSuccess ||        // synchronises the device: diagnostics, not the hot path
+      (v && hipMemcpy(w, &zero, sizeof zero, hipMemcpyHostToDevice) != hipSuccess)) {
+    kx_set_error("kx_pair_split_errors: reading the device word failed");
+    return KX_ERR_LAUNCH;
+  }
+  *word_out = v;
+  return KX_OK;
+}
+
 extern "C" int kx_row_stats_finalize(const float* partials, int64_t rows, int64_t nseg, int64_t seg_size, float eps, float* out,
                                     void* stream);
 extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
   KX_REQUIRE(a_in != nullptr, "kx_gemm: null args");
-  // row_stats AND stats_partials (tile kernels): the partials are what the producer wrote, row_stats is where their finalised
-  // (mean, rstd) go when this launch does not finalise them itself: kx_gemm runs kx_row_stats_finalize first.  The pair split
+  // row_stats_scratch AND stats_partials (tile kernels; ABI 7): the partials are what the producer wrote, the scratch is where
+  // their finalised (mean, rstd) go when this launch does not finalise them itself: kx_gemm runs kx_row_stats_finalize first.  The pair split
   // with the lean residual epilogue CAN finalise them in the launch (each workgroup the 128 rows it finishes, while it waits for
   // its partner's flag: kx_row_stats_finalize's arithmetic, wave per row; row_stats untouched) — opt-in, tuning key 15 & 32:
   // measured SLOWER on the headline (25.14 vs 24.90 ms same-box alternating: with two steps in flight the 5 us finalize launches
@@ -58,11 +82,18 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
   kx_gemm_args a_copy;
   const kx_gemm_args* a = a_in;
   struct { const float* partials; int64_t nseg, seg; float eps; } fin = {nullptr, 0, 0, 0.f};
-  if (a_in->row_stats && a_in->stats_partials && a_in->tile != 16) {
+  KX_REQUIRE(!(a_in->row_stats && a_in->stats_partials && a_in->tile != 16),
+             "kx_gemm: row_stats together with stats_partials was the ABI 6 form; ABI 7 takes the output scratch as row_stats_scratch");
+  KX_REQUIRE(!a_in->row_stats_scratch || (a_in->stats_partials && !a_in->row_stats && a_in->tile != 16),
+             "kx_gemm: row_stats_scratch goes with stats_partials on the tile kernels (row_stats NULL)");
+  float* fin_out = nullptr;
+  if (a_in->row_stats_scratch) {
     KX_REQUIRE(a_in->stats_in_nseg > 0 && a_in->stats_in_seg > 0 && !a_in->ln_out,
-               "kx_gemm: row_stats + stats_partials needs nseg, seg size (and no ln_out: that is the row-owning reduce's form)");
+               "kx_gemm: row_stats_scratch + stats_partials needs nseg, seg size (and no ln_out: that is the row-owning reduce's form)");
     fin = {a_in->stats_partials, a_in->stats_in_nseg, a_in->stats_in_seg, a_in->stats_eps};
+    fin_out = a_in->row_stats_scratch;
     a_copy = *a_in; a_copy.stats_partials = nullptr; a_copy.stats_in_nseg = 0; a_copy.stats_in_seg = 0;
+    a_copy.row_stats = fin_out; a_copy.row_stats_scratch = nullptr;     // below this point: a row_stats call
     a = &a_copy;
   }
   KX_REQUIRE(a->A && a->W && a->C, "kx_gemm: null operand pointer");
@@ -103,7 +134,9 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
   KX_REQUIRE(a->cdt != KX_F16P || (a->tile == 16 && a->prec == KX_PREC_F32 && a->N % 32 == 0 && a->ldc % 32 == 0 &&
                                    ((uintptr_t)a->C & 15) == 0 && !a->residual && a->ksplit <= 1),
              "kx_gemm: KX_F16P rows come from tile 16 on fp32 operands, N %% 32 == 0, ldc %% 32 == 0, no residual / ksplit");
-  p.nk_main = f16c ? (int)(a->K / 64) : 0x7fffffff; p.wscale = a->w_scale;
+  p.nk_main = f16c ? (int)(a->K / 64) : 0x7fffffff; p.wscale = a->w_scale; p.kskip = 0;
+  KX_REQUIRE(a->f16c_corr >= KX_CORR_BOTH && a->f16c_corr <= KX_CORR_NONE && (f16c || a->f16c_corr == KX_CORR_BOTH),
+             "kx_gemm: f16c_corr is a kx_f16c_corr value and belongs to KX_PREC_F16C operands");
   KX_REQUIRE(a->cdt != KX_F16C || (a->N % 8 == 0 && a->ldc >= 2 * a->N && a->ldc % 8 == 0 && a->tile != 16 &&
                                     ((uintptr_t)a->C & 15) == 0),
              "kx_gemm: a KX_F16C output needs N %% 8 == 0, ldc >= 2N (2-byte units), ldc %% 8 == 0 (and is not offered by tile 16)");
@@ -112,6 +145,11 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
              "kx_gemm: a KX_BF16X3 output needs N %% 8 == 0, ldc >= 3N, ldc %% 8 == 0 (and is not offered by tile 16)");
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)(f16c ? 2 * a->K : a->K);   // f16c: 2-byte units of the 4K-byte row
+  if (f16c && a->f16c_corr != KX_CORR_BOTH) {
+    // one correction product (K / 128 fp8 tiles after the K / 64 fp16 tiles) or none: the loop is shorter, the rows are not
+    p.K = (int)(a->f16c_corr == KX_CORR_NONE ? a->K : a->K + a->K / 2);
+    if (a->f16c_corr == KX_CORR_ACT) p.kskip = (int)(a->K / 128);            // ... and its fp8 tiles are the rows' second region
+  }
   p.act = (a->act == KX_ACT_GELU && (a->prec == KX_PREC_BF16 || f16c || f16)) ? KX_ACT_GELU_FAST : a->act;
   p.qscale = a->qscale; p.qcols = (int)a->qcols;
   p.xq_cs = a->xq_cs; p.xq_ss = a->xq_ss; p.xk_cs = a->xk_cs; p.xk_ss = a->xk_ss;
@@ -139,7 +177,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
              "kx_gemm: ln_operand_out needs an fp32 output with residual, N %% 64 == 0, aligned rows, a 2-byte / KX_F16C "
              "operand dtype and the prefetching store loop");
   p.stagger_ticks = 0; p.w_tiled = 0;
-  p.pairk = 0; p.pk_slab = nullptr; p.pk_flag = nullptr; p.pk_epoch = 0;
+  p.pairk = 0; p.pk_slab = nullptr; p.pk_flag = nullptr; p.pk_epoch = 0; p.pk_err = nullptr; p.pk_spin_ticks = 100000000u; p.pk_fault = 0;
   p.gsplit = 1; p.kfull = p.K; p.C2 = nullptr; p.residual2 = nullptr; p.a_add = nullptr;
   p.no_rowreg = kx_tuning_get(KX_TUNE_GEMV_VARIANT) == 3; p.a_pieces = 0; p.hp = 0; p.valu = 0; p.gb_staged = 0;
   p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
@@ -238,6 +276,9 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
     p.pk_flag = (unsigned*)a->pair_ws;
     p.pk_slab = (float*)((char*)a->pair_ws + 4096);
     p.pk_epoch = epoch.fetch_add(1, std::memory_order_relaxed) % 0xfffffff0u + 1u;   // never 0 (= consumed / not yet published)
+    p.pk_err = pair_err_word();
+    KX_REQUIRE(p.pk_err != nullptr, "kx_gemm: the pair split's error word is unavailable");
+    if (kx_tuning_get(KX_TUNE_GEMM_PAIRK) == 2) { p.pk_fault = 1; p.pk_spin_ticks = 200000u; }   // fault injection (tests): 2 ms
   }
   if (tile == 0) {
     auto cdiv = [](long long x, long long y) { return (x + y - 1) / y; };
@@ -283,7 +324,11 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
         tile = 384;
       // ... and any N % 256 == 0 problem whose 192 x 256 tiles make one round that fills >= 0.8 of the CUs (the Perceiver's to_kv at
       // B = 32: 10272 x 1024 x 1024 = 54 x 4 tiles: 55.8 us against 75.3 on 128 x 128, tools/tile_probe.py, profiles/r05_k_*)
-      if (!(kx_tuning_get(KX_TUNE_GEMM_RULES) & 2) && (tile == 160 || tile == 128) && (f16 || f16c || a->prec == KX_PREC_BF16) &&
+      // (measured with f16c rows -> fp32 rows + bias, the to_kv launch itself; the rule excludes the epilogue classes
+      //  nobody measured on these tiles — produced statistics, ln_operand_out, KX_F16C / KX_BF16X3 outputs, residual + 16-bit
+      //  output — and has its own off bit, tuning key 15 & 64)
+      if (!(kx_tuning_get(KX_TUNE_GEMM_RULES) & (2 | 64)) && (tile == 160 || tile == 128) && (f16 || f16c || a->prec == KX_PREC_BF16) &&
+          !a->stats_out && !a->ln_operand_out && !p.c_f16c && !p.c_x3 && !(a->residual && p.c_bf16) &&
           a->N % 256 == 0 && a->K >= 1024 && cdiv(a->M, 192) * cdiv(a->N, 256) <= kx_cu_count() &&
           cdiv(a->M, 192) * cdiv(a->N, 256) >= (4 * kx_cu_count()) / 5)
         tile = 384;
@@ -379,7 +424,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
     if (p.pairk && p.lean_res && fin.nseg <= 128 && (kx_tuning_get(KX_TUNE_GEMM_RULES) & 32)) {   // opt-in: measured slower (see the header)
       p.stats_partials = fin.partials; p.stats_in_nseg = (int)fin.nseg; p.stats_in_seg = (float)fin.seg; p.stats_eps = fin.eps;
     } else {
-      const int rc = kx_row_stats_finalize(fin.partials, a->M, fin.nseg, fin.seg, fin.eps, const_cast<float*>(a->row_stats), stream);
+      const int rc = kx_row_stats_finalize(fin.partials, a->M, fin.nseg, fin.seg, fin.eps, fin_out, stream);
       if (rc != KX_OK) return rc;
     }
   }

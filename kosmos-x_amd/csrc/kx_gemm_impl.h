@@ -19,6 +19,10 @@ struct GemmParams {
   // KX_PREC_F16C operands: K-tiles [0, nk_main) hold fp16 (16x16x32 f16 MFMA), tiles [nk_main, nk) the fp8 correction
   // segments (block-scaled 16x16x128 MFMA, weight-row scale bytes from wscale, activation scale 2^-11)
   int nk_main; const unsigned char* wscale;
+  // kx_gemm_args.f16c_corr = KX_CORR_ACT: the launch contracts the fp16 tiles and the SECOND fp8 region (r_a . e_w) only —
+  // K-tile kt >= nk_main is read from source tile kt + kskip (kskip = K / 128 tiles, else 0).  KX_CORR_WEIGHT / NONE only
+  // shorten K.  See ksrc().
+  int kskip;
   const float* bias; const float* residual; long long ldr;
   int M, N, K;
   int act; float qscale; int qcols;
@@ -55,6 +59,11 @@ struct GemmParams {
   // pair taking K-tiles [h * nk/2, (h + 1) * nk/2); the two exchange half of their accumulators through pk_slab
   // [grid][128 KB] (flags pk_flag [grid]: pk_epoch when published, 0 once consumed) and each finishes half of the tile's rows
   int pairk; float* pk_slab; unsigned* pk_flag; unsigned pk_epoch;
+  // bounded hand-off: the poll of the partner's flag gives up after pk_spin_ticks of the 100 MHz wall
+  // clock (1 s; a legitimate wait is the partner's K loop, < 1 ms) and writes 1 + blockIdx.x to *pk_err — a sticky device
+  // word the host reads with kx_pair_split_errors().  The launch then completes with WRONG rows instead of hanging the
+  // GPU.  pk_fault (tuning key 13 = 2, tests only): workgroups with an odd pair index never publish, spin bound 2 ms.
+  unsigned* pk_err; unsigned pk_spin_ticks; int pk_fault;
   // weight-streaming variant (gemv_fused_kernel) only
   const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
   const float* stats_partials; int stats_in_nseg; float stats_in_seg, stats_eps;
@@ -75,6 +84,13 @@ struct GemmParams {
 };
 
 namespace {
+
+// source K-tile of loop tile kt (see GemmParams.kskip): KX_F16C rows only, wave-uniform SALU arithmetic
+template <typename T>
+__device__ __forceinline__ int ksrc(const GemmParams& p, int kt) {
+  if constexpr (std::is_same<T, f16c_t>::value) return kt + (kt >= p.nk_main ? p.kskip : 0);
+  else return kt;
+}
 
 
 // Keeps a value in a scalar VGPR across this point: stops the SLP vectoriser from pairing the XPos products into
@@ -183,6 +199,12 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
     } else {
       for (int j = 0; j < 4; ++j) if (n + j < p.N) c[j] = cvt16(p, x[j]);
     }
+  } else if (p.c_hilo) {                          // KX_F16HL on the generic path: the fast loop's bytes — N % 64 == 0 and
+    uint2 hi, lo;                                 // 16-byte aligned rows are enforced on the host, so a lane's 4 columns are whole
+    split_f16_hl4(x, hi, lo);
+    char* slot = reinterpret_cast<char*>(reinterpret_cast<float*>(p.C) + (long long)m * p.ldc + (n & ~63)) + 2 * (n & 63);
+    *reinterpret_cast<uint2*>(slot) = hi;
+    *reinterpret_cast<uint2*>(slot + 128) = lo;
   } else {
     float* c = reinterpret_cast<float*>(p.C) + off;
     if (full && p.vec_ok) {
@@ -867,7 +889,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
-    const long long koff = (long long)kt * ROWB;
+    const long long koff = (long long)ksrc<T>(p, kt) * ROWB;
 #pragma unroll
     for (int j = 0; j < IA; ++j)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff),
@@ -1262,7 +1284,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p3(const GemmParams p) {
   }
   auto stage = [&](int slot, int kt) {
     char* base = smem + slot * STAGE;
-    const long long koff = (long long)kt * ROWB;
+    const long long koff = (long long)ksrc<T>(p, kt) * ROWB;
 #pragma unroll
     for (int j = 0; j < IA; ++j)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[j] + koff), (lds_void_t*)(base + (wave * 32 + j * 8) * ROWB),
@@ -1678,7 +1700,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   }
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
-    const long long koff = (long long)kt * ROWB;
+    const long long koff = (long long)ksrc<T>(p, kt) * ROWB;
 #pragma unroll
     for (int j = 0; j < IA; ++j)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(tileA + koff + srcA[j]), (lds_void_t*)(base + ldsA[j] * ROWB), 16, 0, 0);
@@ -1690,7 +1712,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   auto stage_wh = [&](auto h_c, int kt) {   // BAL: weight half h of K-tile kt (two instructions)
     constexpr int h = decltype(h_c)::value;
     char* base = smem + (kt & 1) * STAGE;
-    const long long koff = (long long)kt * ROWB;
+    const long long koff = (long long)ksrc<T>(p, kt) * ROWB;
 #pragma unroll
     for (int j = 2 * h; j < 2 * h + 2; ++j)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(tileW + koff + srcW[j]),
@@ -1699,7 +1721,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   auto stage_ah = [&](auto h_c, int kt) {   // BAL: activation half h of K-tile kt (two instructions)
     constexpr int h = decltype(h_c)::value;
     char* base = smem + (kt & 1) * STAGE;
-    const long long koff = (long long)kt * ROWB;
+    const long long koff = (long long)ksrc<T>(p, kt) * ROWB;
     if constexpr (BM == 192) {
 #pragma unroll
       for (int j = 0; j < IA; ++j)
@@ -2012,7 +2034,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned pw = blockIdx.x ^ 8u;
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0 && !(p.pk_fault && ks_h))
       __hip_atomic_store((gu32_t*)(p.pk_flag + blockIdx.x), p.pk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if constexpr (EPI == 9) lean_res_request<BM>(p, rres, m0, n0, wave, (int)(threadIdx.x & 63), ks_h);   // under the flag's round trip
     if constexpr (EPI == 9) {
@@ -2046,8 +2068,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
       }
     }
     if (threadIdx.x == 0) {
-      while (__hip_atomic_load((gu32_t*)(p.pk_flag + pw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pk_epoch)
+      // bounded: a partner that never publishes (a flag clobbered by a second stream on the same scratch, a partner that was
+      // not resident) ends the wait after pk_spin_ticks and leaves its mark in *pk_err — an error the host can read, not a
+      // hung GPU.  One clock read + compare per sleep.
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load((gu32_t*)(p.pk_flag + pw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pk_epoch) {
         __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > (unsigned long long)p.pk_spin_ticks) {
+          __hip_atomic_store((gu32_t*)p.pk_err, blockIdx.x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
     }
     __syncthreads();
     // the partner stored write-through: sc1 loads (L1 bypassed, served by the L2 / fabric) see its bytes without an

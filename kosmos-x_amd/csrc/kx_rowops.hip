@@ -347,7 +347,10 @@ extern "C" int kx_layernorm(const float* x, const float* pre_add, const float* g
   KX_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)pre_add) & 15) == 0,
              "kx_layernorm: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  KxProfScope prof(KX_K_LAYERNORM, rows, cols, 0, s);
+  // third profile field = HBM bytes per VALUE of this launch (fp32 row in, + the pre_add row, + the output format's bytes:
+  // 2 bf16 / fp16, 4 fp32 / KX_F16C [h | e | r], 6 KX_BF16X3) — bench.py's LayerNorm byte model
+  const int out_b = ydt == KX_F16C ? 4 : ydt == KX_BF16X3 ? 6 : (ydt == KX_BF16 || ydt == KX_F16) ? 2 : 4;
+  KxProfScope prof(KX_K_LAYERNORM, rows, cols, 4 + (pre_add ? 4 : 0) + out_b, s);
   // measured (tools/ln_bench.py): wave-per-row wins up to 2048 columns (3.6-5.1 vs 2.3-4.0 TB/s), workgroup-per-row
   // wins on the 8192-wide ffn_layernorm rows (4.6 vs 3.2 TB/s: 204 VGPRs/lane cap the wave variant at 2 waves/SIMD)
   const int variant = kx_tuning_get(KX_TUNE_LN_VARIANT);

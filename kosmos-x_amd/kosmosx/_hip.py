@@ -13,7 +13,7 @@ from pathlib import Path
 
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libkosmosx_hip.so"
 _lib = None
-ABI_VERSION = 6   # KX_ABI_VERSION of include/kosmosx_hip.h
+ABI_VERSION = 7   # KX_ABI_VERSION of include/kosmosx_hip.h
 
 KX_PREC_BF16, KX_PREC_F32, KX_PREC_BF16X3, KX_PREC_F16C, KX_PREC_F16, KX_PREC_F32W24, KX_PREC_F32W16, KX_PREC_F16CHL = 0, 1, 2, 3, 4, 5, 6, 7
 KX_F32, KX_BF16, KX_BF16X3, KX_F16C, KX_F16, KX_F16P, KX_F16HL = 0, 1, 2, 3, 4, 5, 6
@@ -57,7 +57,7 @@ class GemmArgs(C.Structure):
                 ("ln_out", vp), ("ln_out_dt", i32), ("ln_out_gamma", vp), ("ln_out_beta", vp), ("ln_out_eps", f32),
                 ("w_scale", vp), ("ln_operand_out", vp), ("ln_operand_dt", i32), ("ln_operand_stats", vp),
                 ("w_tiled", i32), ("ksplit", i32), ("C2", vp), ("residual2", vp), ("a_add", vp),
-                ("pair_ws", vp), ("pair_ws_bytes", C.c_size_t)]
+                ("pair_ws", vp), ("pair_ws_bytes", C.c_size_t), ("row_stats_scratch", vp), ("f16c_corr", i32)]
 
 
 class AttnArgs(C.Structure):
@@ -142,6 +142,7 @@ SYMBOLS = {
     "kx_struct_bytes": (C.c_size_t, [i32]),
     "kx_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, i64, i64, f32, i64, i64, i64, vp]),
     "kx_gemm": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "kx_pair_split_errors": (C.c_int, [C.POINTER(C.c_uint)]),
     "kx_attention": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "kx_row_stats_finalize": (C.c_int, [vp, i64, i64, i64, f32, vp, vp]),
     "kx_embed_splice": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i64, vp]),

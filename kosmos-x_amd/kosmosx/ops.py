@@ -111,6 +111,8 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
     if stats_partials is not None:
         g.stats_partials, g.stats_in_nseg = H.ptr(stats_partials), stats_partials.shape[1]
         g.stats_in_seg, g.stats_eps = stats_in_seg, float(stats_eps)
+        if row_stats is not None and tile != 16:      # tile kernels: `row_stats` is the [M, 2] OUTPUT scratch of the finalize pass (ABI 7)
+            g.row_stats, g.row_stats_scratch = None, H.ptr(row_stats)
     g.stats_out_seg = stats_out_seg
     # tile 16, the residual stream as a pair (kx_gemm_args.ksplit): out2 receives part 1's product
     g.ksplit, g.C2, g.residual2, g.a_add = ksplit, H.ptr(out2), H.ptr(residual2), H.ptr(a_add)
@@ -236,7 +238,7 @@ def f16_pieces_values(rows: torch.Tensor) -> torch.Tensor:
 
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,
               xpos=None, xpos_dim=0, tile=0, row_stats=None, colsum=None, stats_out=None, splitk_ws=None, splitk=0,
-              ln_operand=None, pair_ws=None, out_hilo=False, stats_partials=None, stats_in_seg=64, stats_eps=1e-5):
+              ln_operand=None, pair_ws=None, out_hilo=False, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, corr="both"):
     """KX_PREC_F16C GEMM: a_rows [M, 4K] uint8 (KX_F16C activation rows), w_packed = the flat packed weight matrix
     (N rows of 4K bytes + N scale bytes, model._operand_f16c).  Output fp32 [M, N] or KX_F16C rows [M, 4N] uint8.
     out_hilo (with xpos): the fp32-shaped output holds KX_F16HL head slots — [64 fp16 hi | 64 fp16 lo] of 2^8 x per 64 columns."""
@@ -257,9 +259,12 @@ def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_
         g.xpos_T, g.xpos_dim = xpos[0].shape[0], xpos_dim
     g.prec, g.tile = H.KX_PREC_F16C, tile
     g.row_stats, g.colsum, g.stats_out = H.ptr(row_stats), H.ptr(colsum), H.ptr(stats_out)
-    if stats_partials is not None:      # with row_stats (scratch): finalised inside the pair-split launch, else by kx_gemm's own pass
+    if stats_partials is not None:      # with row_stats (the OUTPUT scratch, kx_gemm_args.row_stats_scratch): finalised by kx_gemm's own pass
         g.stats_partials, g.stats_in_nseg = H.ptr(stats_partials), stats_partials.shape[1]
         g.stats_in_seg, g.stats_eps = stats_in_seg, float(stats_eps)
+        if row_stats is not None:
+            g.row_stats, g.row_stats_scratch = None, H.ptr(row_stats)
+    g.f16c_corr = {"both": 0, "weight": 1, "act": 2, "none": 3}[corr]
     if splitk_ws is not None:
         g.splitk_ws, g.splitk_ws_bytes, g.splitk = H.ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size(), splitk
     if pair_ws is not None:
@@ -273,6 +278,15 @@ def pair_scratch(device="cuda", workgroups=256):
     """kx_gemm_args.pair_ws: 4 KB of hand-off words (zero now, zero again after every completed call) + one 128 KB slab per
     workgroup of the pair split."""
     return torch.zeros(4096 + workgroups * 131072, dtype=torch.uint8, device=device)
+
+
+def pair_split_errors() -> int:
+    """kx_pair_split_errors: 0 when every pair-split hand-off since the last call met its partner, else 1 + the index of the
+    last workgroup whose bounded poll gave up (the word is cleared).  Synchronises the device: diagnostics only."""
+    import ctypes
+    w = ctypes.c_uint(0)
+    H.check(H.load().kx_pair_split_errors(ctypes.byref(w)), "kx_pair_split_errors")
+    return int(w.value)
 
 
 def row_stats_finalize(partials, seg_size, eps=1e-5):

@@ -60,7 +60,7 @@ def test_struct_layouts_match_the_header_field_order():
 
 def test_version_and_error_plumbing(lib):
     from kosmosx import _hip
-    assert lib.kx_version() == 6
+    assert lib.kx_version() == 7
     # null args -> KX_ERR_INVALID_ARG with a message, no exception, no launch
     assert lib.kx_gemm(None, None) == 1
     assert "null" in _hip.last_error()

@@ -151,6 +151,58 @@ def test_gemm_f16c_matches_exact_arithmetic_on_the_packed_operands(shape, tile):
     assert e < 2e-5, (shape, tile, e)
 
 
+def _exact_corr(a_rows, wp, N, K, corr):
+    """kx_gemm_args.f16c_corr (ABI 7): the fp16 product plus the selected fp8 correction product(s), in float64."""
+    ah, ae, ar = (t.cpu().double() for t in ops.unpack_f16c_rows(a_rows, K))
+    wh, wr, we, s = _w_parts(wp, N, K)
+    c = torch.zeros(ah.shape[0], N, dtype=torch.float64)
+    if corr in ("both", "weight"):
+        c += ae @ wr.t()                 # e_a . r_w: the weight's residual against the activation's fp8 image
+    if corr in ("both", "act"):
+        c += ar @ we.t()                 # r_a . e_w
+    return ah @ wh.t() + c * torch.exp2(-(s + 11.0))[None, :]
+
+
+@pytest.mark.parametrize("corr", ["weight", "act", "none"])
+@pytest.mark.parametrize("tile", [0, 64, 128, 160, 256, 384, 512])
+@pytest.mark.parametrize("shape", [(114, 2048, 2048), (300, 1002, 640), (513, 768, 256), (3648, 512, 2048)])
+def test_gemm_f16c_one_sided_corrections_contract_exactly_the_selected_products(shape, tile, corr):
+    """One correction product (or none) on the same rows: every tile kernel computes h_a.h_w + the SELECTED fp8 product(s) —
+    KX_CORR_WEIGHT / NONE shorten the K loop, KX_CORR_ACT reads its fp8 tiles from the rows' second region (GemmParams.kskip).
+    The reference separates the variants by far more than the bound: the dropped term is ~1e-4 of the rms here."""
+    M, N, K = shape
+    g = _g(M + N + K)
+    a = ops.pack_f16c_rows((torch.randn(M, K, generator=g) * 1.3).to(DEV))
+    wp = _operand_f16c((torch.randn(N, K, generator=g) * torch.logspace(-2, 0, N)[:, None]).to(DEV))
+    ref = _exact_corr(a, wp, N, K, corr)
+    out = ops.gemm_f16c(a, wp, N, K, tile=tile, corr=corr).cpu().double()
+    rms = float(ref.pow(2).mean().sqrt())
+    assert float((out - ref).abs().max()) / rms < 2e-5, (shape, tile, corr)
+    other = _exact_corr(a, wp, N, K, "both")
+    assert float((other - ref).abs().max()) / rms > 4e-5          # the test can tell the variants apart
+
+
+@pytest.mark.parametrize("corr", ["weight", "act"])
+def test_gemm_f16c_one_sided_corrections_under_split_k_and_the_pair_split(corr):
+    g = _g(17)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    M, N, K = 114, 2048, 2048
+    a = ops.pack_f16c_rows(torch.randn(M, K, generator=g).to(DEV))
+    wp = _operand_f16c((torch.randn(N, K, generator=g) * 0.03).to(DEV))
+    ref = _exact_corr(a, wp, N, K, corr)
+    for splitk in (0, 2, 7):
+        out = ops.gemm_f16c(a, wp, N, K, splitk_ws=ws, splitk=splitk, corr=corr).cpu().double()
+        assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max()), splitk
+    M, N, K = 3648, 2048, 8192                                     # 3K/128 = 192 K-tiles: the pair split takes it (tile 1024)
+    a = ops.pack_f16c_rows(torch.randn(M, K, generator=g).to(DEV))
+    wp = _operand_f16c((torch.randn(N, K, generator=g) * 0.02).to(DEV))
+    res = torch.randn(M, N, generator=g).to(DEV)
+    ref = _exact_corr(a, wp, N, K, corr) + res.cpu().double()
+    out = ops.gemm_f16c(a, wp, N, K, residual=res.clone(), tile=1024, pair_ws=ops.pair_scratch(), corr=corr).cpu().double()
+    assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert ops.pair_split_errors() == 0
+
+
 def test_gemm_f16c_split_k_and_epilogues():
     g = _g(5)
     M, N, K = 114, 2048, 2048

@@ -19,7 +19,10 @@ from kosmosx.model import Kosmos, KosmosLanguage
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = {"fp32": 1e-5, "f16c": 1e-3, "mixed": 1e-3, "bf16": 6e-2}      # north star: 1e-5 fp32, 1e-3 "bf16"; bf16 operands: DESIGN §5
+# north star: 1e-5 fp32, 1e-3 "bf16".  bf16 OPERANDS are outside it by construction: the bound here is a regression
+# bound on the mode's own distance at full size (measured 3.6-4.0e-2 over rounds 3-5), not a tolerance; the bf16 kernels
+# themselves are pinned per op at 2e-5 on bf16-representable inputs (tests/test_gemm_gpu.py, test_attention_gpu.py)
+TOL = {"fp32": 1e-5, "f16c": 1e-3, "mixed": 1e-3, "bf16": 4.5e-2}
 
 
 # ------------------------------------------------------------------------------------------------------------------

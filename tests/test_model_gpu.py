@@ -24,7 +24,10 @@ from helpers import max_abs, oracle_cfg, oracle_switches, oracle_weights, rel_er
 DEV = "cuda"
 FP32_TOL = 1e-5          # north star, fp32
 BF16_KERNEL_TOL = 1e-3   # north star, bf16: vs the oracle with identical operand rounding
-BF16_VS_FP32_TOL = 6e-2  # bf16 operands vs un-rounded fp32 oracle (max-abs / rms), documented bound
+# bf16 operands vs the un-rounded fp32 oracle (max-abs / rms): the mode's own distance (3.6-4.0e-2 at full size, more on the
+# few-layer toy widths whose logits rms is small), NOT the north star's tolerance — context only.  What pins the
+# bf16 kernels is the per-op 2e-5 on bf16-representable inputs; the full-size bound lives in test_fullsize_parity_gpu.py (4.5e-2)
+BF16_VS_FP32_TOL = 6e-2
 BF16X3_TOL = 1e-3        # north star's bf16 figure, met by "bf16x3": bf16 MFMA arithmetic on split (hi, lo) operands
 
 

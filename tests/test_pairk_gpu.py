@@ -1,4 +1,4 @@
-"""Pair split of the 256x256 GEMM kernel (kx_gemm_args.pair_ws, ABI 6; the decoder's out_proj / fc2 at M = 32 x 114,
+"""Pair split of the 256x256 GEMM kernel (kx_gemm_args.pair_ws, ABI 6+; the decoder's out_proj / fc2 at M = 32 x 114,
 /root/reference/kosmosx/model.py:170-183 shapes).  The two workgroups of a pair exchange accumulators inside the launch, so
 what is pinned here is (i) the result against the unsplit kernels on the same operands and epilogue, (ii) that NO stale slab
 is ever read — fresh operands call after call, L1-warm, other kernels in between — (iii) the hand-off words are zero again
@@ -87,3 +87,28 @@ def test_pair_split_automatic_choice_and_refusals():
         _case("bf16", 3648, 2048, 2048, seed=6, epi="plain")(1024, None)
     with pytest.raises(RuntimeError, match="pair split"):      # scratch too small
         _case("bf16", 3648, 2048, 2048, seed=6, epi="plain")(1024, ws[: 4096 + 100 * 131072])
+
+
+def test_pair_split_hand_off_is_bounded_and_reports():
+    """a partner that never publishes its flag must end as an error word, not as a hung GPU.  Fault
+    injection (tuning key 13 = 2): the odd workgroup of every pair skips its publish and the poll's bound is 2 ms — the launch
+    completes, kx_pair_split_errors names a workgroup and clears the word; the next healthy launch on the same scratch (hand-off
+    words re-zeroed, as the stage entry points do per call) is exact again and reports nothing."""
+    from kosmosx import _hip
+    lib = _hip.load()
+    ws = ops.pair_scratch()
+    call = _case("bf16", 3648, 2048, 8192, seed=11, epi="resid")
+    ref = call(512, None).float()
+    assert ops.pair_split_errors() == 0
+    lib.kx_set_tuning(13, 2)
+    try:
+        call(1024, ws)
+        torch.cuda.synchronize()                       # returns: nobody spins forever
+    finally:
+        lib.kx_set_tuning(13, 0)
+    assert ops.pair_split_errors() > 0                 # 1 + index of a workgroup that gave up
+    assert ops.pair_split_errors() == 0                # read-and-clear
+    ws[:4096].zero_()                                  # unpublished / unconsumed flags of the faulted call
+    got = call(1024, ws).float()
+    assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert ops.pair_split_errors() == 0
