@@ -103,10 +103,25 @@ extern "C" int kx_prof_collect(kx_prof_record* out, int max_records) {
 thread_local void* g_splitk_ws = nullptr;
 thread_local size_t g_splitk_ws_bytes = 0;
 constexpr size_t KX_SPLITK_WS = 32u << 20;   // 32 MB: enough for 16 slices of every batch-1 GEMM on the path
+// The last 4 KB of the stage's split-K scratch are 1024 arrival counters of the in-launch reduction (kx_gemm_args.splitk_counter):
+// cleared ONCE per stage call on the stage's stream, one fresh word per split-K launch of the call (a launch past the 1024th
+// gets none and keeps the separate reduce kernel).
+thread_local unsigned* g_coop_counters = nullptr;
+thread_local int g_coop_next = 0;
+constexpr size_t KX_COOP_WORDS = 1024;
 struct SplitkScope {
-  SplitkScope(void* p, size_t n) { g_splitk_ws = p; g_splitk_ws_bytes = n; }
-  ~SplitkScope() { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; }
+  bool ok = true;
+  SplitkScope(void* p, size_t n, hipStream_t s) {
+    g_splitk_ws = p; g_splitk_ws_bytes = n - KX_COOP_WORDS * 4;
+    g_coop_counters = p ? (unsigned*)((char*)p + n - KX_COOP_WORDS * 4) : nullptr; g_coop_next = 0;
+    if (g_coop_counters && hipMemsetAsync(g_coop_counters, 0, KX_COOP_WORDS * 4, s) != hipSuccess) {
+      kx_set_error("clearing the split-K arrival counters failed");
+      ok = false;
+    }
+  }
+  ~SplitkScope() { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; g_coop_counters = nullptr; g_coop_next = 0; }
 };
+#define KX_SPLITK_SCOPE(ptr, stream) SplitkScope sk((ptr), KX_SPLITK_WS, (stream)); if (!sk.ok) return KX_ERR_LAUNCH
 // scratch of the 256x256 kernel's pair split (kx_gemm_args.pair_ws) of the stage being launched: 4 KB of hand-off words,
 // cleared once per stage call, + one 128 KB slab per workgroup of a full round
 thread_local void* g_pair_ws = nullptr;
@@ -195,6 +210,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
   g.row_stats = row_stats; g.colsum = colsum; g.stats_out = stats_out;
   g.splitk_ws = g_splitk_ws; g.splitk_ws_bytes = g_splitk_ws_bytes; g.splitk = 0;
+  if (g_coop_counters && g_coop_next < (int)KX_COOP_WORDS) g.splitk_counter = g_coop_counters + g_coop_next++;
   g.pair_ws = g_pair_ws; g.pair_ws_bytes = g_pair_ws_bytes;
   if (rf) {
     g.stats_partials = rf->partials; g.stats_in_nseg = rf->nseg; g.stats_in_seg = rf->seg; g.stats_eps = rf->eps;
@@ -380,7 +396,7 @@ extern "C" int kx_vit_forward(const kx_vit_weights* w, const float* pixels, int6
     return KX_ERR_WORKSPACE;
   }
   const int64_t G = w->image / w->patch, P = G * G, S = P + 1, M = B * S, MP = B * P, D = w->dim;
-  SplitkScope sk(v.splitk, KX_SPLITK_WS);
+  KX_SPLITK_SCOPE(v.splitk, s);
   const int ct = cdt(prec);
   KX_TRY(kx_launch_patchify(pixels, v.patches, B, w->image, w->patch, w->kpad, prec, s));
   KX_TRY(gemm(v.patches, w->kpad, w->wpatch, w->kpad, v.patch_out, D, KX_F32, MP, D, nullptr, nullptr, 0, 1.f, 0,
@@ -452,7 +468,7 @@ extern "C" int kx_perceiver_forward(const kx_perceiver_weights* w, const float* 
     return KX_ERR_WORKSPACE;
   }
   const int64_t n = w->latents, D = w->dim, inner = (int64_t)w->heads * 64, MQ = B * n, MK = B * (m + n);
-  SplitkScope sk(p.splitk, KX_SPLITK_WS);
+  KX_SPLITK_SCOPE(p.splitk, s);
   const int64_t F = D * w->ff_mult;
   const int ct = cdt(prec);
   KX_TRY(kx_launch_rows_bcast(w->latents_p, p.lat, B, n, D, s));
@@ -521,7 +537,7 @@ static int decoder_forward_impl(const kx_decoder_weights* w, float* x, int64_t B
     return KX_ERR_WORKSPACE;
   }
   const int64_t M = B * T, D = w->dim, F = w->ffn;
-  SplitkScope sk(d.splitk, KX_SPLITK_WS);
+  KX_SPLITK_SCOPE(d.splitk, s);
   PairScope pk(d.pair, KX_PAIR_WS);
   if (d.pair && hipMemsetAsync(d.pair, 0, 4096, s) != hipSuccess) {      // hand-off words: zero when a call is issued
     kx_set_error("kx_decoder_forward: clearing the pair-split hand-off words failed");
@@ -687,7 +703,7 @@ extern "C" int kx_decoder_decode_step(const kx_decoder_weights* w, float* x, int
     return KX_ERR_WORKSPACE;
   }
   const int64_t M = B, D = w->dim, F = w->ffn;
-  SplitkScope sk(d.splitk, KX_SPLITK_WS);
+  KX_SPLITK_SCOPE(d.splitk, s);
   const int ct = cdt(prec);
   const size_t es = esz(prec);
   const size_t layer_bytes = (size_t)B * Tmax * D * qes(prec);   // the cache holds q/k/v-typed values (fp32 for f16c)

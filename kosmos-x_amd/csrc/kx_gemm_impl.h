@@ -64,6 +64,12 @@ struct GemmParams {
   // word the host reads with kx_pair_split_errors().  The launch then completes with WRONG rows instead of hanging the
   // GPU.  pk_fault (tuning key 13 = 2, tests only): workgroups with an odd pair index never publish, spin bound 2 ms.
   unsigned* pk_err; unsigned pk_spin_ticks; int pk_fault;
+  // In-launch split-K reduction of the 64 x 64 kernel (kx_gemm_args.splitk_counter, ABI 7; "coop"): every (tile, K slice)
+  // workgroup writes its partial tile write-through, drains, and arrives on *coop_counter (zero when the call is issued); the
+  // LAST min(M, workgroups) workgroups in dispatch order then wait for all arrivals (bounded poll, pk_err) and each reduces whole
+  // output rows with the row-owning reduce's arithmetic — slices in slice order, epilogue, the LayerNorm that follows.  One
+  // launch where the split-K pair took two; bit-identical to it.  Needs every workgroup resident (2 per CU: kx_gemm checks).
+  int coop; unsigned* coop_counter;
   // weight-streaming variant (gemv_fused_kernel) only
   const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
   const float* stats_partials; int stats_in_nseg; float stats_in_seg, stats_eps;
@@ -839,8 +845,12 @@ __device__ __forceinline__ void lean_store_f16c(const GemmParams& p, const f32x4
 // tile covers the latency).  4 (the skinny 64x64 launches): a ring with THREE K-tiles in flight and a counted s_waitcnt —
 // a 64x64x64 tile is 16 MFMAs per wave, so with one tile in flight every K-tile costs a full memory latency (measured
 // ~1.5 us per K-tile on the batch-1 shapes: 12 us for the 8 K-tiles of a ViT fc1 slice).
-template <typename T, int BM, int BN, int ACT, int EPI = 0, int NST = 2>   // EPI 1: lean bf16 epilogue (see above)
+template <int ACT, bool SC1>
+__device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int m, float* red, float* st);
+// COOP (64 x 64 split-K launches): the reduce runs inside the launch, see GemmParams.coop; ACT is then the REDUCE's activation
+template <typename T, int BM, int BN, int ACT, int EPI = 0, int NST = 2, bool COOP = false>   // EPI 1: lean bf16 epilogue (see above)
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+  static_assert(!COOP || (BM == 64 && BN == 64 && EPI == 0), "the in-launch reduction belongs to the 64 x 64 split-K launches");
   constexpr int ROWB = 128;                 // bytes per staged tile row = one BK slice
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
   constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave (2x2 waves)
@@ -1072,8 +1082,39 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + ml * WN + ((cl ^ (ml & (CH - 1))) << 2));
       if (m < p.M && nbase < p.N) {
         float* dst = p.partial + ((long long)blockIdx.y * p.M + m) * p.N + nbase;
+        if constexpr (COOP) {                 // write-through (sc1): visible to a reducer on any XCD after the drain below (N % 4 == 0)
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, (int)((long long)p.splitk * p.M * p.N * 4), 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)((dst - p.partial) * 4), 0, /*aux: sc1*/ 16);
+        } else
         if (nbase + 3 < p.N && (p.N & 3) == 0) *reinterpret_cast<f32x4_t*>(dst) = v;
         else for (int j = 0; j < 4; ++j) if (nbase + j < p.N) dst[j] = v[j];
+      }
+    }
+    if constexpr (COOP) {
+      // guide G16 recipe R1, counter form: every writing wave drains, one lane arrives (relaxed, agent scope)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+      if (threadIdx.x == 0) __hip_atomic_fetch_add((gu32_t*)p.coop_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the reducers are the LAST workgroups in dispatch order: by the time they have written their own partial most of the
+      // grid has arrived, and the slots they hold while they poll are never the ones an undispatched workgroup waits for
+      const unsigned nred = min((unsigned)p.M, total);
+      if (lin < total - nred) return;
+      if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load((gu32_t*)p.coop_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 > (unsigned long long)p.pk_spin_ticks) {      // bounded: an error word, not a hung GPU
+            __hip_atomic_store((gu32_t*)p.pk_err, 0x80000000u | (lin + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);      // (the parked tile has been read back: barrier above)
+      for (int m = (int)(lin - (total - nred)); m < p.M; m += (int)nred) {
+        splitk_reduce_row<ACT, true>(p, m, red, red + 4);
+        __syncthreads();
       }
     }
   } else if (pre) {
@@ -1109,11 +1150,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 // partials (no kx_row_stats_finalize launch) and (b) apply the LayerNorm that FOLLOWS this GEMM to the finished row and
 // write it as a second output (no kx_layernorm launch).  At batch 1 the forward is a chain of ~420 dependent launches of
 // ~12 us each; these two fusions remove ~100 of them.
-template <int ACT>
-__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParams p) {
-  __shared__ float red[4];
-  __shared__ float st[2];
-  const int m = blockIdx.x, tid = threadIdx.x;
+// SC1 (the in-launch form, gemm_kernel<..., COOP>): the partials were stored write-through by workgroups on any XCD and are read
+// with sc1 loads (L1 bypassed) — guide G16 recipe R1, no acquire fence.  red [4] / st [2]: LDS words of the caller.
+template <int ACT, bool SC1>
+__device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int m, float* red, float* st) {
+  const int tid = threadIdx.x;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+      p.partial, 0, SC1 ? (int)((long long)p.splitk * p.M * p.N * 4) : 0, 0x00020000);
+  auto pload = [&](const float* src) -> f32x4_t {
+    if constexpr (SC1)
+      return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((src - p.partial) * 4), 0, /*aux: sc1*/ 16));
+    else
+      return *reinterpret_cast<const f32x4_t*>(src);
+  };
   auto bsum = [&](float v) {
     v = wave_sum(v);
     __syncthreads();
@@ -1136,11 +1185,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
       const long long zs = (long long)p.M * p.N;
       int z = 0;
       for (; z + 4 <= p.splitk; z += 4) {
-        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src + (z + 0) * zs), v1 = *reinterpret_cast<const f32x4_t*>(src + (z + 1) * zs);
-        const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(src + (z + 2) * zs), v3 = *reinterpret_cast<const f32x4_t*>(src + (z + 3) * zs);
+        const f32x4_t v0 = pload(src + (z + 0) * zs), v1 = pload(src + (z + 1) * zs);
+        const f32x4_t v2 = pload(src + (z + 2) * zs), v3 = pload(src + (z + 3) * zs);
         accs[j] += v0; accs[j] += v1; accs[j] += v2; accs[j] += v3;
       }
-      for (; z < p.splitk; ++z) accs[j] += *reinterpret_cast<const f32x4_t*>(src + z * zs);
+      for (; z < p.splitk; ++z) accs[j] += pload(src + z * zs);
     }
   }
   if (p.stats_partials) {
@@ -1227,6 +1276,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.ln_out) + (long long)m * p.N + n) = make_float4(o0, o1, o2, o3);
     }
   }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParams p) {
+  __shared__ float red[4];
+  __shared__ float st[2];
+  splitk_reduce_row<ACT, false>(p, (int)blockIdx.x, red, st);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -3316,6 +3372,24 @@ int launch(GemmParams& p, hipStream_t s) {
   if (p.splitk > 1) {
     // skinny problem: the tile kernels only produce partials (activation-free), the reduce kernel owns the epilogue
     if constexpr (BM == 64 && BN == 64) {
+      if (p.coop) {                      // ... or the launch reduces them itself (GemmParams.coop)
+#define KX_COOP_LAUNCH(NSTV)                                                                                                   \
+  switch (p.act) {                                                                                                             \
+    case KX_ACT_NONE: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, KX_ACT_NONE, 0, NSTV, true>), grid, block, 0, s, p); break;    \
+    case KX_ACT_GELU: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, KX_ACT_GELU, 0, NSTV, true>), grid, block, 0, s, p); break;    \
+    case KX_ACT_GELU_FAST: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, KX_ACT_GELU_FAST, 0, NSTV, true>), grid, block, 0, s, p); break; \
+    case KX_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, KX_ACT_QUICK_GELU, 0, NSTV, true>), grid, block, 0, s, p); break; \
+    default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;                                  \
+  }
+        if (p.ring) { KX_COOP_LAUNCH(4) }
+        else {
+          if constexpr (kIsF16c<T>) { KX_COOP_LAUNCH(2) }
+          else { kx_set_error("kx_gemm: the in-launch split-K reduction of this precision needs the ring kernel"); return KX_ERR_UNSUPPORTED; }
+        }
+#undef KX_COOP_LAUNCH
+        KX_CHECK_LAUNCH("kx_gemm(split-K, in-launch reduce)");
+        return KX_OK;
+      }
       if (p.ring) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE, 0, 4>), grid, block, 0, s, p);
       else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KX_ACT_NONE>), grid, block, 0, s, p);
     } else {

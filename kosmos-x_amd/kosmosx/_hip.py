@@ -57,7 +57,8 @@ class GemmArgs(C.Structure):
                 ("ln_out", vp), ("ln_out_dt", i32), ("ln_out_gamma", vp), ("ln_out_beta", vp), ("ln_out_eps", f32),
                 ("w_scale", vp), ("ln_operand_out", vp), ("ln_operand_dt", i32), ("ln_operand_stats", vp),
                 ("w_tiled", i32), ("ksplit", i32), ("C2", vp), ("residual2", vp), ("a_add", vp),
-                ("pair_ws", vp), ("pair_ws_bytes", C.c_size_t), ("row_stats_scratch", vp), ("f16c_corr", i32)]
+                ("pair_ws", vp), ("pair_ws_bytes", C.c_size_t), ("row_stats_scratch", vp), ("f16c_corr", i32),
+                ("splitk_counter", vp)]
 
 
 class AttnArgs(C.Structure):
