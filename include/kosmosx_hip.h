@@ -250,15 +250,18 @@ typedef struct {
    * The stage-level entry points take their per-family assignment from tuning key 16 (DESIGN.md §5 has the measured table). */
   float* row_stats_scratch;
   int32_t f16c_corr;
-  /* ABI 7 — IN-LAUNCH split-K reduction (optional; batch-1-sized problems, the 64 x 64 split-K launches with N <= 8192,
-   * N % 4 == 0, 16-byte aligned rows, at most two workgroups per CU in total).  splitk_counter = one 4-byte word, ZERO when the
-   * call is issued (a word per launch: it is left at the launch's workgroup count).  The (tile, K slice) workgroups then store
-   * their partial tiles write-through, arrive on the word, and the last min(M, workgroups) workgroups in dispatch order each
-   * reduce whole output rows — slices in slice order, the fused epilogue, folded-LN statistics from the producer's partials,
-   * the LayerNorm that follows (ln_out): the row-owning reduce kernel's arithmetic bit for bit, one launch instead of two.
-   * NULL (or a problem that does not qualify, or tuning key 17 = 1): the separate reduce launch.  The arrival poll is bounded
-   * like the pair split's (kx_pair_split_errors reports 0x80000000 | (1 + workgroup)). */
-  uint32_t* splitk_counter;
+  /* ABI 7 — IN-LAUNCH split-K reduction (optional; batch-1-sized problems: the 64 x 64 split-K launches with N <= 8192,
+   * N % 4 == 0, 16-byte aligned rows, M <= workgroups <= 2 per CU).  splitk_flags = 2 x CUs 4-byte words (2 KB on MI355X), one
+   * per workgroup, owned by ONE stream at a time like the scratch itself; cleared once when allocated (any later contents are
+   * fine: every launch has its own epoch value).  The (tile, K slice) workgroups then store their partial tiles write-through,
+   * each stores the launch's epoch into its own word, and the last M workgroups in dispatch order wait until every word shows
+   * it and each reduces ONE whole output row — slices in slice order, the fused epilogue, folded-LN statistics from the
+   * producer's partials, the LayerNorm that follows (ln_out): the row-owning reduce kernel's arithmetic bit for bit, one launch
+   * instead of two.  NULL (or a problem that does not qualify, or tuning key 17 = 2): the separate reduce launch.  MEASURED on
+   * MI355X (tools/coop_bench.py, profiles/r06_d_*): not faster than the two launches on any batch-1 shape — the write-through
+   * partials and the arrival poll cost what the launch boundary they replace costs; kept as an opt-in, tested form.  The poll is
+   * bounded like the pair split's (kx_pair_split_errors reports 0x80000000 | (1 + workgroup)). */
+  uint32_t* splitk_flags;
 } kx_gemm_args;
 int kx_gemm(const kx_gemm_args* args, void* stream);
 /* Diagnostics of the pair split's bounded hand-off: *word_out = 0 when every poll since the last call met its partner, else
@@ -684,7 +687,9 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
          to_kv; the rule never applies to launches with produced statistics, ln_operand_out, KX_F16C / KX_BF16X3 outputs or residual +
          16-bit output, which were not measured on these tiles); Bit 32 switches one rule ON:
  *         folded sub-LayerNorm statistics given as row_stats_scratch + stats_partials are finalised inside the pair-split launch (slower).
- * key 17: 1 = split-K launches never reduce in-launch (kx_gemm_args.splitk_counter is ignored; A/B).
+ * key 17: in-launch split-K reduction (kx_gemm_args.splitk_flags).  0 = kx_gemm honours the field, the stage entry points do not
+ *         pass it (MEASURED: 0.4-4 us slower per batch-1 GEMM than the reduce launch it replaces, batch-1 forward 4.52 vs 3.85 ms);
+ *         1 = the stage entry points hand every split-K launch their flag words (A/B); 2 = kx_gemm ignores the field.
  * key 16: per-family fp8-correction assignment of the KX_PREC_F16C stage entry points, two bits (a kx_f16c_corr value) per GEMM
  *         family: bits 0-1 decoder qkv, 2-3 out_proj, 4-5 fc1, 6-7 fc2, 8-9 output projection, 10-11 every Perceiver GEMM.
  *         0 = both corrections everywhere.  -1 = the library's shipped default. */

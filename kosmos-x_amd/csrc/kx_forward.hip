@@ -103,9 +103,9 @@ extern "C" int kx_prof_collect(kx_prof_record* out, int max_records) {
 thread_local void* g_splitk_ws = nullptr;
 thread_local size_t g_splitk_ws_bytes = 0;
 constexpr size_t KX_SPLITK_WS = 32u << 20;   // 32 MB: enough for 16 slices of every batch-1 GEMM on the path
-// The last 4 KB of the stage's split-K scratch are 1024 arrival counters of the in-launch reduction (kx_gemm_args.splitk_counter):
-// cleared ONCE per stage call on the stage's stream, one fresh word per split-K launch of the call (a launch past the 1024th
-// gets none and keeps the separate reduce kernel).
+// The last 4 KB of the stage's split-K scratch are the arrival words of the in-launch reduction (kx_gemm_args.splitk_flags: one
+// per workgroup; every launch writes its own epoch, so the launches of a stream share them): cleared once per stage call on
+// the stage's stream.
 thread_local unsigned* g_coop_counters = nullptr;
 thread_local int g_coop_next = 0;
 constexpr size_t KX_COOP_WORDS = 1024;
@@ -210,7 +210,10 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t K, void* C, int64_t 
   g.tile = kx_tuning_get(KX_TUNE_GEMM_TILE);
   g.row_stats = row_stats; g.colsum = colsum; g.stats_out = stats_out;
   g.splitk_ws = g_splitk_ws; g.splitk_ws_bytes = g_splitk_ws_bytes; g.splitk = 0;
-  if (g_coop_counters && g_coop_next < (int)KX_COOP_WORDS) g.splitk_counter = g_coop_counters + g_coop_next++;
+  // opt-in (tuning key 17 = 1): the in-launch reduction measured 0.4-4 us SLOWER per GEMM than the reduce launch it replaces on
+  // every batch-1 shape (write-through partials + the arrival poll against a 1.5-1.9 us launch boundary), the batch-1 forward
+  // 4.52 vs 3.85 ms (profiles/r06_d_coop_bench.log, r06_d_b1_ab.log)
+  g.splitk_flags = kx_tuning_get(KX_TUNE_SPLITK_COOP) == 1 ? g_coop_counters : nullptr;
   g.pair_ws = g_pair_ws; g.pair_ws_bytes = g_pair_ws_bytes;
   if (rf) {
     g.stats_partials = rf->partials; g.stats_in_nseg = rf->nseg; g.stats_in_seg = rf->seg; g.stats_eps = rf->eps;

@@ -178,7 +178,7 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
              "operand dtype and the prefetching store loop");
   p.stagger_ticks = 0; p.w_tiled = 0;
   p.pairk = 0; p.pk_slab = nullptr; p.pk_flag = nullptr; p.pk_epoch = 0; p.pk_err = nullptr; p.pk_spin_ticks = 100000000u; p.pk_fault = 0;
-  p.coop = 0; p.coop_counter = nullptr;
+  p.coop = 0; p.coop_flags = nullptr;
   p.gsplit = 1; p.kfull = p.K; p.C2 = nullptr; p.residual2 = nullptr; p.a_add = nullptr;
   p.no_rowreg = kx_tuning_get(KX_TUNE_GEMV_VARIANT) == 3; p.a_pieces = 0; p.hp = 0; p.valu = 0; p.gb_staged = 0;
   p.ln_g = p.ln_b = nullptr; p.ln_eps = 0.f;
@@ -406,12 +406,15 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
     if (sp > 1) {
       p.splitk = (int)sp;
       p.partial = (float*)a->splitk_ws;
-      // in-launch reduction (GemmParams.coop): every workgroup resident (64 KB of LDS / 256 threads: two per CU), the row-owning
+      // in-launch reduction (GemmParams.coop; the caller asks for it by passing splitk_flags — the stage entry points only with
+      // tuning key 17 = 1: MEASURED no faster than the reduce launch it replaces, profiles/r06_d_*): every workgroup resident (64 KB of LDS / 256 threads: two per CU), the row-owning
       // reduce's preconditions, and a kernel that exists in this form (the ring for bf16 / fp16 / fp32 rows, two stages for KX_F16C)
-      p.coop = a->splitk_counter && kx_tuning_get(KX_TUNE_SPLITK_COOP) != 1 && a->N <= 8192 && a->N % 4 == 0 && p.vec_ok &&
-               tiles64 * sp <= 2ll * kx_cu_count() && (p.ring == 1 || f16c) && !p.c_hilo && !p.c_pieces;
+      p.coop = a->splitk_flags && kx_tuning_get(KX_TUNE_SPLITK_COOP) != 2 && a->N <= 8192 && a->N % 4 == 0 && p.vec_ok &&
+               tiles64 * sp <= 2ll * kx_cu_count() && a->M <= tiles64 * sp && (p.ring == 1 || f16c) && !p.c_hilo && !p.c_pieces;
       if (p.coop) {
-        p.coop_counter = a->splitk_counter;
+        static std::atomic<unsigned> coop_epoch{0};
+        p.coop_flags = a->splitk_flags;
+        p.pk_epoch = coop_epoch.fetch_add(1, std::memory_order_relaxed) % 0xfffffff0u + 1u;     // never 0: a cleared word is "not arrived"
         p.pk_err = pair_err_word();
         KX_REQUIRE(p.pk_err != nullptr, "kx_gemm: the hand-off error word is unavailable");
       }

@@ -65,11 +65,11 @@ struct GemmParams {
   // GPU.  pk_fault (tuning key 13 = 2, tests only): workgroups with an odd pair index never publish, spin bound 2 ms.
   unsigned* pk_err; unsigned pk_spin_ticks; int pk_fault;
   // In-launch split-K reduction of the 64 x 64 kernel (kx_gemm_args.splitk_counter, ABI 7; "coop"): every (tile, K slice)
-  // workgroup writes its partial tile write-through, drains, and arrives on *coop_counter (zero when the call is issued); the
-  // LAST min(M, workgroups) workgroups in dispatch order then wait for all arrivals (bounded poll, pk_err) and each reduces whole
-  // output rows with the row-owning reduce's arithmetic — slices in slice order, epilogue, the LayerNorm that follows.  One
+  // workgroup writes its partial tile write-through, drains, and stores the launch's epoch (pk_epoch) into its own word of
+  // coop_flags [workgroups]; the LAST M workgroups in dispatch order then wait until every word shows the epoch (bounded poll,
+  // pk_err) and each reduces ONE whole output row with the row-owning reduce's arithmetic — slices in slice order, epilogue, the LayerNorm that follows.  One
   // launch where the split-K pair took two; bit-identical to it.  Needs every workgroup resident (2 per CU: kx_gemm checks).
-  int coop; unsigned* coop_counter;
+  int coop; unsigned* coop_flags;
   // weight-streaming variant (gemv_fused_kernel) only
   const float *ln_g, *ln_b; float ln_eps;            // A = raw fp32 rows, LayerNorm applied on the way to the operand
   const float* stats_partials; int stats_in_nseg; float stats_in_seg, stats_eps;
@@ -1095,27 +1095,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-      if (threadIdx.x == 0) __hip_atomic_fetch_add((gu32_t*)p.coop_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // arrival = ONE STORE of this launch's epoch into this workgroup's own flag word.  (First form: one fetch_add per workgroup
+      // on a shared counter — up to 512 agent-scope read-modify-writes on one address serialise at the memory side: the fused
+      // launch measured 10 us SLOWER than the two launches it replaces, profiles/r06_c_b1_ab.log.)
+      if (threadIdx.x == 0) __hip_atomic_store((gu32_t*)(p.coop_flags + lin), p.pk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // the reducers are the LAST workgroups in dispatch order: by the time they have written their own partial most of the
       // grid has arrived, and the slots they hold while they poll are never the ones an undispatched workgroup waits for
-      const unsigned nred = min((unsigned)p.M, total);
+      const unsigned nred = (unsigned)p.M;                // kx_gemm takes this form only when M <= workgroups: one row per reducer
       if (lin < total - nred) return;
-      if (threadIdx.x == 0) {
+      {
+        // every thread polls its share of the flag words (<= 2 per thread), block-wide AND; bounded like the pair split's poll
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load((gu32_t*)p.coop_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
-          __builtin_amdgcn_s_sleep(1);
-          if (wall_clock64() - t0 > (unsigned long long)p.pk_spin_ticks) {      // bounded: an error word, not a hung GPU
-            __hip_atomic_store((gu32_t*)p.pk_err, 0x80000000u | (lin + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+          int ok = 1;
+          for (unsigned i = threadIdx.x; i < total; i += 256)
+            ok &= __hip_atomic_load((gu32_t*)(p.coop_flags + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.pk_epoch;
+          if (__syncthreads_and(ok)) break;
+          // the bound is ONE thread's decision, broadcast: an error word, not a hung GPU
+          if (__syncthreads_or(threadIdx.x == 0 && wall_clock64() - t0 > (unsigned long long)p.pk_spin_ticks)) {
+            if (threadIdx.x == 0)
+              __hip_atomic_store((gu32_t*)p.pk_err, 0x80000000u | (lin + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
+          __builtin_amdgcn_s_sleep(2);
         }
       }
-      __syncthreads();
       float* red = reinterpret_cast<float*>(smem);      // (the parked tile has been read back: barrier above)
-      for (int m = (int)(lin - (total - nred)); m < p.M; m += (int)nred) {
-        splitk_reduce_row<ACT, true>(p, m, red, red + 4);
-        __syncthreads();
-      }
+      // ONE row per reducer, no loop: around a row loop LICM hoisted the reduce's per-column operands (bias, colsum, gamma, beta:
+      // 32 VGPRs each) above it and the kernel spilled (256 VGPRs + 380 B of scratch; the fused launch then measured 15 us
+      // SLOWER than the two launches it replaces, profiles/r06_b_*)
+      splitk_reduce_row<ACT, true>(p, (int)(lin - (total - nred)), red, red + 4);
     }
   } else if (pre) {
     store_loop<KX_ACT_NONE, WN>(q, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);

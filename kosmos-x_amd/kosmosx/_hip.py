@@ -58,7 +58,7 @@ class GemmArgs(C.Structure):
                 ("w_scale", vp), ("ln_operand_out", vp), ("ln_operand_dt", i32), ("ln_operand_stats", vp),
                 ("w_tiled", i32), ("ksplit", i32), ("C2", vp), ("residual2", vp), ("a_add", vp),
                 ("pair_ws", vp), ("pair_ws_bytes", C.c_size_t), ("row_stats_scratch", vp), ("f16c_corr", i32),
-                ("splitk_counter", vp)]
+                ("splitk_flags", vp)]
 
 
 class AttnArgs(C.Structure):

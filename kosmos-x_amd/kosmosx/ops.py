@@ -72,7 +72,7 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
          xpos=None, xpos_dim=0, tile=0, out=None, row_stats=None, colsum=None, stats_out=None, splitk_ws=None,
          splitk=0, ln=None, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, stats_out_seg=0, out_x3=False,
          ln_out=None, ln_operand=None, w_tiled_rows=0, ksplit=0, out2=None, residual2=None, a_add=None, out_pieces=False,
-         a_pieces=False, pair_ws=None, splitk_counter=None):
+         a_pieces=False, pair_ws=None, splitk_flags=None):
     """epilogue(a [M,K] @ w[N,K]^T).  a/w both bf16 or both fp32.  xpos = (xq_cs, xq_ss, xk_cs, xk_ss) [T,32].
     tile=16 (weight streaming, bf16, M <= 16) extras: ln = (gamma, beta, eps) with `a` the raw fp32 rows;
     stats_partials [M,nseg,2] instead of row_stats; stats_out_seg=16.
@@ -106,8 +106,8 @@ def gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.float32, qs
         g.splitk_ws, g.splitk_ws_bytes, g.splitk = H.ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size(), splitk
     if pair_ws is not None:         # scratch of the 256x256 kernel's pair split (first 4 KB zero: pair_scratch())
         g.pair_ws, g.pair_ws_bytes = H.ptr(pair_ws), pair_ws.numel() * pair_ws.element_size()
-    if splitk_counter is not None:  # one ZERO int32 word: the split-K launch reduces its partials itself (kx_gemm_args.splitk_counter)
-        g.splitk_counter = H.ptr(splitk_counter)
+    if splitk_flags is not None:    # >= 2 x CUs int32 words (splitk_flags()): the split-K launch reduces its partials itself
+        g.splitk_flags = H.ptr(splitk_flags)
     if ln is not None:
         g.ln_gamma, g.ln_beta, g.ln_eps = H.ptr(ln[0]), H.ptr(ln[1]), float(ln[2])
     if stats_partials is not None:
@@ -241,7 +241,7 @@ def f16_pieces_values(rows: torch.Tensor) -> torch.Tensor:
 def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_f16c=False, qscale=1.0, qcols=0,
               xpos=None, xpos_dim=0, tile=0, row_stats=None, colsum=None, stats_out=None, splitk_ws=None, splitk=0,
               ln_operand=None, pair_ws=None, out_hilo=False, stats_partials=None, stats_in_seg=64, stats_eps=1e-5, corr="both",
-              splitk_counter=None):
+              splitk_flags=None):
     """KX_PREC_F16C GEMM: a_rows [M, 4K] uint8 (KX_F16C activation rows), w_packed = the flat packed weight matrix
     (N rows of 4K bytes + N scale bytes, model._operand_f16c).  Output fp32 [M, N] or KX_F16C rows [M, 4N] uint8.
     out_hilo (with xpos): the fp32-shaped output holds KX_F16HL head slots — [64 fp16 hi | 64 fp16 lo] of 2^8 x per 64 columns."""
@@ -272,8 +272,8 @@ def gemm_f16c(a_rows, w_packed, N, K, bias=None, residual=None, act="none", out_
         g.splitk_ws, g.splitk_ws_bytes, g.splitk = H.ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size(), splitk
     if pair_ws is not None:
         g.pair_ws, g.pair_ws_bytes = H.ptr(pair_ws), pair_ws.numel() * pair_ws.element_size()
-    if splitk_counter is not None:
-        g.splitk_counter = H.ptr(splitk_counter)
+    if splitk_flags is not None:
+        g.splitk_flags = H.ptr(splitk_flags)
     lop = _ln_operand_buffers(g, ln_operand, M, N, a_rows.device) if ln_operand is not None else None
     H.check(H.load().kx_gemm(C.byref(g), _stream()), "kx_gemm")
     return out if lop is None else (out,) + lop
@@ -283,6 +283,11 @@ def pair_scratch(device="cuda", workgroups=256):
     """kx_gemm_args.pair_ws: 4 KB of hand-off words (zero now, zero again after every completed call) + one 128 KB slab per
     workgroup of the pair split."""
     return torch.zeros(4096 + workgroups * 131072, dtype=torch.uint8, device=device)
+
+
+def splitk_flags(device="cuda"):
+    """kx_gemm_args.splitk_flags: one word per workgroup of an in-launch split-K reduction (2 per CU), cleared once."""
+    return torch.zeros(1024, dtype=torch.int32, device=device)
 
 
 def pair_split_errors() -> int:
