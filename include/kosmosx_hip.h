@@ -650,7 +650,10 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  * key 2: attention variant (0 = bf16 v2: 32 queries/wave, transpose-read V, prefetched tiles / fp32 on the matrix
  *        cores; 1 = the first versions: bf16 v1 / fp32 wave-per-query VALU kernel; 4 = KX_PREC_F16C attention with P and V as
  *        plain fp16 — one product for O += P V instead of three; A/B only: 1.5e-3 on the logits, outside the tolerance; 5 = unmasked bf16 / fp16
- *        launches fold a last query block of <= 32 queries into a fifth wave — bit-identical, 0.8 % slower in situ);
+ *        launches fold a last query block of <= 32 queries into a fifth wave — bit-identical, 0.8 % slower in situ;
+ *        6 / 7 = KX_PREC_F16C causal attention with ONE cross term of O += P V dropped (6: P plain, V split; 7: P split, V plain:
+ *        two products instead of three; A/B); 8 = causal KX_PREC_F16C launches keep 32 consecutive queries per wave
+ *        instead of two 16-query blocks 64 rows apart (bit-identical, A/B));
  * key 3: 256x256 GEMM start stagger per phase group in 10 ns ticks (0 = none; measured useless, kept for A/B);
  * key 4: GEMM epilogue (0 auto: lean bf16 tile store where it applies, prefetching store loop for residual / statistics /
  *        XPos operands; 1 rolled per-pass loop everywhere, no lean epilogue; 2 prefetching loop everywhere);

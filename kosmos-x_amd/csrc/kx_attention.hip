@@ -39,6 +39,7 @@ struct AttnParams {
   float* stats_out;   // [B*Tq, H, 2] partial LayerNorm statistics of the output rows (folded inner_attn_ln), or null
   float* lse_out;     // [B, H, Tq] log-sum-exp of the scores (fp32 matrix-core kernel; for the backward pass), or null
   float drop_inv_keep; unsigned drop_thresh; unsigned long long drop_seed; unsigned drop_site;   // attention dropout (training)
+  int interleave;     // causal split-fp16 launches: a wave's two 16-query blocks sit 64 rows apart (attn_f16s_kernel, IL); tuning key 2 = 8: off
 };
 
 constexpr int KSTR = 72;  // LDS row stride (elements) for the 64-wide K / Vᵀ tiles: 144 B, 16-B aligned rows
@@ -493,7 +494,14 @@ __device__ __forceinline__ f32x4_t mma_f16(u32x4_t a, u32x4_t b, f32x4_t c) {
 // the LDS planes and Q needs no arithmetic at all: the ~160 VALU instructions per key tile and wave that re-derived the
 // pieces of K and V (of ~410, against 96 MFMAs: the kernel was VALU-bound, MfmaUtil 7-9 %) are gone.  Same pieces, same
 // products: bit-identical to the fp32-input form.
-template <bool CAUSAL, bool PVS, bool HL = false>
+// PVS (int): 1 = P and V split (default); 0 = both plain; A/B of ONE dropped cross term (round 6): 2 = P plain,
+// V split (O += vh ph + vl ph: no P split on the VALU, two MFMAs per product); 3 = P split, V plain (vh ph + vh pl: no lo plane of V).
+// IL (causal launches, p.interleave): a wave's two 16-query blocks are rows [16 w, 16 w + 16) and [64 + 16 w, 64 + 16 w + 16) of the
+// 128-query block instead of 32 consecutive rows, and each block skips the key tiles above ITS diagonal: every wave then does
+// one and a half tiles of the block's last two instead of waves 0-1 one and waves 2-3 two (T = 114: 6 wave-tiles in 1.5 tile
+// times instead of 2).  Per query nothing changes — same tiles in the same order, a skipped tile is one whose every score was
+// masked (alpha = 1, p = 0 exactly): bit-identical to the consecutive mapping.
+template <bool CAUSAL, int PVS, bool HL = false>
 __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned short Kh[2][64 * 64], Kl[2][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned short Vh[2][64 * VSTR], Vl[2][64 * VSTR];
@@ -507,8 +515,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
   const int npass = (CAUSAL && qb_second > (int)blockIdx.y) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
   const int qblk0 = (pass == 0 ? (int)blockIdx.y : qb_second) * 128;
+  const bool il = CAUSAL && p.interleave;
   const int qw0 = qblk0 + wave * 32;
-  const bool wave_live = qw0 < p.Tq;
+  const int qrow[2] = {il ? qblk0 + wave * 16 : qw0, il ? qblk0 + 64 + wave * 16 : qw0 + 16};   // first query of block qb
+  const bool wave_live = qrow[0] < p.Tq;
   const float* qp = reinterpret_cast<const float*>(p.q) + (long long)b * p.qbs + (long long)h * 64;
   const float* kp = reinterpret_cast<const float*>(p.k) + (long long)b * p.kbs + (long long)h * 64;
   const float* vp = reinterpret_cast<const float*>(p.v) + (long long)b * p.kbs + (long long)h * 64;
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
   u32x4_t qh[2][2], ql[2][2];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    const float* qr = qp + (long long)min(qw0 + qb * 16 + li, p.Tq - 1) * p.qrs + 8 * g;
+    const float* qr = qp + (long long)min(qrow[qb] + li, p.Tq - 1) * p.qrs + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if constexpr (HL) {       // values 32 ks + 8 g .. + 7 of the head: hi at byte 2 * that of the slot, lo 128 bytes on
@@ -570,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
         *reinterpret_cast<u32x4_t*>(&Kh[buf][row * 64 + ((part ^ (row & 7)) << 3)]) = kpc[j][0];
         *reinterpret_cast<u32x4_t*>(&Kl[buf][row * 64 + ((part ^ (row & 7)) << 3)]) = kpc[j][1];
         *reinterpret_cast<u32x4_t*>(&Vh[buf][row * VSTR + part * 8]) = vpc[j][0];
-        if constexpr (PVS) *reinterpret_cast<u32x4_t*>(&Vl[buf][row * VSTR + part * 8]) = vpc[j][1];
+        if constexpr (PVS == 1 || PVS == 2) *reinterpret_cast<u32x4_t*>(&Vl[buf][row * VSTR + part * 8]) = vpc[j][1];
       } else {
       u32x4_t hi, lo;
       const float kx[8] = {kreg[j][0].x * SC, kreg[j][0].y * SC, kreg[j][0].z * SC, kreg[j][0].w * SC,
@@ -580,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
       *reinterpret_cast<u32x4_t*>(&Kl[buf][row * 64 + ((part ^ (row & 7)) << 3)]) = lo;
       const float vx[8] = {vreg[j][0].x * SC, vreg[j][0].y * SC, vreg[j][0].z * SC, vreg[j][0].w * SC,
                            vreg[j][1].x * SC, vreg[j][1].y * SC, vreg[j][1].z * SC, vreg[j][1].w * SC};
-      if constexpr (PVS) {
+      if constexpr (PVS == 1 || PVS == 2) {
         split_f16x8(vx, hi, lo);
         *reinterpret_cast<u32x4_t*>(&Vl[buf][row * VSTR + part * 8]) = lo;
       } else {
@@ -598,8 +608,12 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1, kv0 = t * 64;
     if (t + 1 < ntiles) gload(t + 1);
-    const bool work = wave_live && (!CAUSAL || kv0 <= min(qw0 + 31, p.Tq - 1));
-    if (work) {
+    // block qb of this wave has work in this tile when the tile starts at or below its last query (causal); block 1 holds the
+    // later rows, so block 0 working implies block 1 working — two forms of the tile body: both blocks, or block 1 alone
+    const bool work1 = wave_live && (!CAUSAL || kv0 <= min(qrow[1] + 15, p.Tq - 1));
+    const bool work0 = wave_live && (!CAUSAL || kv0 <= min(qrow[0] + 15, p.Tq - 1));
+    auto tile_body = [&](auto q0_c) __attribute__((always_inline)) {
+      constexpr int Q0 = decltype(q0_c)::value;
       // ---- S'^T = K' Q'^T, three products per (key block, k-step, query block) ----
       f32x4_t st[2][4];
 #pragma unroll
@@ -613,21 +627,21 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
           const u32x4_t kh = *reinterpret_cast<const u32x4_t*>(&Kh[buf][ko]);
           const u32x4_t kl = *reinterpret_cast<const u32x4_t*>(&Kl[buf][ko]);
 #pragma unroll
-          for (int qb = 0; qb < 2; ++qb) {
+          for (int qb = Q0; qb < 2; ++qb) {
             st[qb][kb] = mma_f16(kl, qh[qb][ks], st[qb][kb]);
             st[qb][kb] = mma_f16(kh, ql[qb][ks], st[qb][kb]);
             st[qb][kb] = mma_f16(kh, qh[qb][ks], st[qb][kb]);
           }
         }
       }
-      const bool need_mask = (kv0 + 63 >= p.Tk) || (CAUSAL && kv0 + 63 > qw0);
       u32x4_t ph[2][2], pl[2][2];
-      float mneg[2], alpha[2];
+      float mneg[2], alpha[2] = {1.0f, 1.0f};
       constexpr float L2S = 1.44269504088896340736f / (SC * SC);     // exp(S) = exp2(S' * log2e / 2^16)
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = Q0; qb < 2; ++qb) {
+        const bool need_mask = (kv0 + 63 >= p.Tk) || (CAUSAL && kv0 + 63 > qrow[qb]);
         if (need_mask) {
-          const int qi = qw0 + qb * 16 + li;
+          const int qi = qrow[qb] + li;
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -652,14 +666,14 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
       }
       if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = Q0; qb < 2; ++qb) {
 #pragma unroll
           for (int d = 0; d < 4; ++d) ot[qb][d] *= alpha[qb];
           l_run[qb] *= alpha[qb];
         }
       }
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = Q0; qb < 2; ++qb) {
         float ps = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -673,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
         for (int c = 0; c < 2; ++c) {
           const float x[8] = {st[qb][2 * c][0], st[qb][2 * c][1], st[qb][2 * c][2], st[qb][2 * c][3],
                               st[qb][2 * c + 1][0], st[qb][2 * c + 1][1], st[qb][2 * c + 1][2], st[qb][2 * c + 1][3]};
-          if constexpr (PVS) split_f16x8(x, ph[qb][c], pl[qb][c]);
+          if constexpr (PVS == 1 || PVS == 3) split_f16x8(x, ph[qb][c], pl[qb][c]);
           else {
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) ph[qb][c][j2] = pack_f16x2(x[2 * j2], x[2 * j2 + 1]);
@@ -689,22 +703,27 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
           const u32x2_t h0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vh[buf][vo]));
           const u32x2_t h1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vh[buf][vo + 16 * VSTR]));
           const u32x4_t vh = (u32x4_t){h0[0], h0[1], h1[0], h1[1]};
-          if constexpr (PVS) {
+          if constexpr (PVS == 1 || PVS == 2) {
             const u32x2_t l0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vl[buf][vo]));
             const u32x2_t l1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)&Vl[buf][vo + 16 * VSTR]));
             const u32x4_t vl = (u32x4_t){l0[0], l0[1], l1[0], l1[1]};
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = Q0; qb < 2; ++qb) {
               ot[qb][d] = mma_f16(vl, ph[qb][c], ot[qb][d]);
-              ot[qb][d] = mma_f16(vh, pl[qb][c], ot[qb][d]);
+              if constexpr (PVS == 1) ot[qb][d] = mma_f16(vh, pl[qb][c], ot[qb][d]);
               ot[qb][d] = mma_f16(vh, ph[qb][c], ot[qb][d]);
             }
           } else {
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) ot[qb][d] = mma_f16(vh, ph[qb][c], ot[qb][d]);
+            for (int qb = Q0; qb < 2; ++qb) {
+              if constexpr (PVS == 3) ot[qb][d] = mma_f16(vh, pl[qb][c], ot[qb][d]);
+              ot[qb][d] = mma_f16(vh, ph[qb][c], ot[qb][d]);
+            }
           }
         }
-    }
+    };
+    if (work0) tile_body(std::integral_constant<int, 0>{});
+    else if (work1) tile_body(std::integral_constant<int, 1>{});
     if (t + 1 < ntiles) lstore(buf ^ 1);
     __syncthreads();
   }
@@ -714,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / (l * SC);               // O' = 2^16 sum(p v), l' = 2^8 sum(p)
-    const int qi = qw0 + qb * 16 + li;
+    const int qi = qrow[qb] + li;
     if (p.lse_out && g == 0 && qi < p.Tq)
       p.lse_out[((long long)b * p.H + h) * p.Tq + qi] = m_run[qb] * (1.0f / (SC * SC)) + logf(l * (1.0f / SC));
 #pragma unroll
@@ -1008,6 +1027,7 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
   p.stats_out = a->stats_out;
   p.lse_out = a->lse_out;
+  p.interleave = kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 8;
   const bool drop = a->dropout_p > 0.f;
   // attention dropout: fp32 q/k/v on the wave-per-query kernel, or bf16 q/k/v on the matrix-core kernel
   const bool drop_mfma = drop && a->prec == KX_PREC_BF16 && kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 1;
@@ -1030,18 +1050,24 @@ extern "C" int kx_attention(const kx_attn_args* a, void* stream) {
   if (a->prec == KX_PREC_F16CHL) {                                    // the same kernel on pre-split KX_F16HL rows
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
     const dim3 gc((unsigned)a->H, (nx + 1) / 2, (unsigned)a->B), gf((unsigned)a->H, nx, (unsigned)a->B);
-    if (a->mask == KX_ATTN_CAUSAL) hipLaunchKernelGGL((attn_f16s_kernel<true, true, true>), gc, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_f16s_kernel<false, true, true>), gf, dim3(256), 0, s, p);
+    const int av = kx_tuning_get(KX_TUNE_ATTN_VARIANT);              // 6 / 7 = A/B: one cross term of P V dropped (see the kernel)
+    if (a->mask == KX_ATTN_CAUSAL) {
+      if (av == 6) hipLaunchKernelGGL((attn_f16s_kernel<true, 2, true>), gc, dim3(256), 0, s, p);
+      else if (av == 7) hipLaunchKernelGGL((attn_f16s_kernel<true, 3, true>), gc, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_f16s_kernel<true, 1, true>), gc, dim3(256), 0, s, p);
+    } else hipLaunchKernelGGL((attn_f16s_kernel<false, 1, true>), gf, dim3(256), 0, s, p);
   } else if (a->prec == KX_PREC_F16C) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);
-    const bool pvs = kx_tuning_get(KX_TUNE_ATTN_VARIANT) != 4;       // 4 = A/B: P and V as plain fp16 (misses the tolerance)
+    const int av = kx_tuning_get(KX_TUNE_ATTN_VARIANT);              // 4 = A/B: P and V as plain fp16 (misses the tolerance); 6 / 7: one of them
     const dim3 gc((unsigned)a->H, (nx + 1) / 2, (unsigned)a->B), gf((unsigned)a->H, nx, (unsigned)a->B);
     if (a->mask == KX_ATTN_CAUSAL) {
-      if (pvs) hipLaunchKernelGGL((attn_f16s_kernel<true, true>), gc, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((attn_f16s_kernel<true, false>), gc, dim3(256), 0, s, p);
+      if (av == 4) hipLaunchKernelGGL((attn_f16s_kernel<true, 0>), gc, dim3(256), 0, s, p);
+      else if (av == 6) hipLaunchKernelGGL((attn_f16s_kernel<true, 2>), gc, dim3(256), 0, s, p);
+      else if (av == 7) hipLaunchKernelGGL((attn_f16s_kernel<true, 3>), gc, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_f16s_kernel<true, 1>), gc, dim3(256), 0, s, p);
     } else {
-      if (pvs) hipLaunchKernelGGL((attn_f16s_kernel<false, true>), gf, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((attn_f16s_kernel<false, false>), gf, dim3(256), 0, s, p);
+      if (av == 4) hipLaunchKernelGGL((attn_f16s_kernel<false, 0>), gf, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_f16s_kernel<false, 1>), gf, dim3(256), 0, s, p);
     }
   } else if (f16) {
     const unsigned nx = (unsigned)((a->Tq + 127) / 128);

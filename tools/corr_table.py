@@ -35,8 +35,12 @@ def main():
     ap.add_argument("--rows", default="0,13,31")
     ap.add_argument("--out", default="gpurun_out/corr_table.json")
     ap.add_argument("--combos", default="", help="extra assignments: fam=side+fam=side,fam=side ...")
+    ap.add_argument("--only-base", action="store_true", help="only the 'both everywhere' row (with --tune: parity of another A/B key)")
+    ap.add_argument("--tune", default="", help="kx_set_tuning pairs applied to every run, e.g. 2=6")
     a = ap.parse_args()
     lib = _hip.load()
+    for kv in filter(None, a.tune.split(",")):
+        lib.kx_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     rows = [int(r) for r in a.rows.split(",")]
     from kosmosx.config import DecoderConfig, KosmosConfig
     m = Kosmos._from_config(KosmosConfig(decoder=DecoderConfig()), seed=0, perturb=0.05).eval()
@@ -66,7 +70,7 @@ def main():
         finally:
             lib.kx_set_tuning(16, 0)
 
-    cases = [{}] + [{f: s} for f in FAMILIES for s in ("weight", "act")]
+    cases = [{}] + ([] if a.only_base else [{f: s} for f in FAMILIES for s in ("weight", "act")])
     for combo in filter(None, a.combos.split(",")):
         cases.append(dict(kv.split("=") for kv in combo.split("+")))
     table = {"workload_c1": f"B = 32 multimodal forward, `mixed`, rows {rows} against the fp32 CPU oracle", "c1": []}
