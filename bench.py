@@ -76,8 +76,8 @@ def parse():
 _PMC_TILES = {"160x128": "gemm_kernel<{T},160,128", "128x128": "gemm_kernel<{T},128,128", "64x64": "gemm_kernel<{T},64,64",
               "256x128_phased": "gemm_kernel_p3<{T}", "256x256_phased": "gemm_kernel_p5<{T}"}
 _PMC_TYPES = {"bf16": "bf16", "f16c": "f16c_t", "f16": "f16c_t"}      # KX_PREC_F16 rows run the f16c_t kernels without correction tiles
-_PMC_FILES = {"mixed": ("profiles/r05_pmc.json", "profiles/r05_pmc_summary.md")}
-_PMC_DECODE = "profiles/r05_decode_pmc.json"      # tools/pmc_round.sh on tools/bench_decode.py (bf16 and mixed), same digest guard
+_PMC_FILES = {"mixed": ("profiles/r06_pmc.json", "profiles/r06_pmc_summary.md")}
+_PMC_DECODE = "profiles/r06_decode_pmc.json"      # tools/pmc_round.sh on tools/bench_decode.py (bf16 and mixed), same digest guard
 
 
 def pmc_kernel_prefix(kind):
@@ -210,6 +210,15 @@ def modes_block(head, head_value, head_s_per_step, other, parity_all, flops_per_
             v["meets_tolerance"] = bool(parity_all[m] <= TOL[m])
     ok = [m for m, v in rows.items() if v.get("meets_tolerance")]
     rows["fastest_meeting_tolerance"] = max(ok, key=lambda m: rows[m]["samples_per_s"]) if ok else None
+    # which fp8 correction products the KX_PREC_F16C launches of `mixed` / `f16c` contract (kx_gemm_args.f16c_corr,
+    # tuning key 16) and the measured reason: every decoder family one-sided ALONE leaves >= 9.6e-4 on the logits (C1 rows of this
+    # workload and a C3 row; acceptance line 5e-4), the Perceiver weight-side only 5.1e-4 for 0.6 % of the step
+    rows["f16c_correction_assignment"] = {
+        "tuning_key_16": 0, "assignment": "both corrections in every GEMM family (qkv, out_proj, fc1, fc2, output projection, Perceiver)",
+        "one_sided_table": "profiles/r06_a_corr_table_one_sided_corrections.json (tools/corr_table.py --c3; DESIGN.md section 5)",
+        "cheapest_single_family_one_sided": {"fc2 weight-side only": {"c1_max_abs_over_rms": 1.038e-3, "c3": 9.608e-4, "step_gain": "4.3 %"}},
+        "split_fp16_attention": "three products per matrix product; P plain / V split (tuning key 2 = 6) measured 5.8e-4 (C1) / 5.1e-4 (C3) "
+                                "for -17 % of the T = 2046 kernel: over the 5e-4 acceptance line, opt-in"}
     return rows
 
 
