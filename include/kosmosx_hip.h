@@ -656,7 +656,8 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  *        instead of two 16-query blocks 64 rows apart (bit-identical, A/B));
  * key 3: 256x256 GEMM start stagger per phase group in 10 ns ticks (0 = none; measured useless, kept for A/B);
  * key 4: GEMM epilogue (0 auto: lean bf16 tile store where it applies, prefetching store loop for residual / statistics /
- *        XPos operands; 1 rolled per-pass loop everywhere, no lean epilogue; 2 prefetching loop everywhere);
+ *        XPos operands; 1 rolled per-pass loop everywhere, no lean epilogue; 2 prefetching loop everywhere; 10 = the row-owning
+ *        split-K reduce keeps its unspecialised form (eight column groups per thread, operands loaded where they are used; A/B));
  * key 5: phased GEMM kernels skip the MFMAs of waves whose rows are all beyond M (0 on, 1 off);
  * key 6: kx_clip_preprocess reads its taps from global memory instead of the LDS-staged row (0 auto, 1 force);
  * key 7: the 256-column GEMM kernel is launched persistently, each workgroup walking its own tiles (0 = one workgroup

@@ -845,7 +845,7 @@ __device__ __forceinline__ void lean_store_f16c(const GemmParams& p, const f32x4
 // tile covers the latency).  4 (the skinny 64x64 launches): a ring with THREE K-tiles in flight and a counted s_waitcnt —
 // a 64x64x64 tile is 16 MFMAs per wave, so with one tile in flight every K-tile costs a full memory latency (measured
 // ~1.5 us per K-tile on the batch-1 shapes: 12 us for the 8 K-tiles of a ViT fc1 slice).
-template <int ACT, bool SC1>
+template <int ACT, bool SC1, int NJ>
 __device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int m, float* red, float* st);
 // COOP (64 x 64 split-K launches): the reduce runs inside the launch, see GemmParams.coop; ACT is then the REDUCE's activation
 template <typename T, int BM, int BN, int ACT, int EPI = 0, int NST = 2, bool COOP = false>   // EPI 1: lean bf16 epilogue (see above)
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       // ONE row per reducer, no loop: around a row loop LICM hoisted the reduce's per-column operands (bias, colsum, gamma, beta:
       // 32 VGPRs each) above it and the kernel spilled (256 VGPRs + 380 B of scratch; the fused launch then measured 15 us
       // SLOWER than the two launches it replaces, profiles/r06_b_*)
-      splitk_reduce_row<ACT, true>(p, (int)(lin - (total - nred)), red, red + 4);
+      splitk_reduce_row<ACT, true, 8>(p, (int)(lin - (total - nred)), red, red + 4);
     }
   } else if (pre) {
     store_loop<KX_ACT_NONE, WN>(q, cw, WM, lane, m0 + wm * WM, n0 + wn * WN);
@@ -1161,8 +1161,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 // ~12 us each; these two fusions remove ~100 of them.
 // SC1 (the in-launch form, gemm_kernel<..., COOP>): the partials were stored write-through by workgroups on any XCD and are read
 // with sc1 loads (L1 bypassed) — guide G16 recipe R1, no acquire fence.  red [4] / st [2]: LDS words of the caller.
-template <int ACT, bool SC1>
+// NJ = 16-byte column groups per thread (N <= 1024 NJ).  NJ <= 2 (N <= 2048: every row-owning reduce of the batch-1 forward) also
+// requests the row's epilogue operands — bias, residual, colsum, the following LayerNorm's gamma / beta — BEFORE the first block
+// reduction: behind the barriers they were three more dependent round trips of a kernel that is nothing but round trips.
+// Same operations in the same order: bit-identical to the unspecialised form.
+template <int ACT, bool SC1, int NJ>
 __device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int m, float* red, float* st) {
+  constexpr bool PRE = NJ <= 2;
   const int tid = threadIdx.x;
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
       p.partial, 0, SC1 ? (int)((long long)p.splitk * p.M * p.N * 4) : 0, 0x00020000);
@@ -1184,9 +1189,9 @@ __device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int
   // The K-slice partials first: their loads depend on nothing, so they are in flight while the row statistics below go
   // through their two block reductions (the kernel is a chain of dependent round trips: 12 us per launch at 114 rows).
   // Slices are summed in slice order (deterministic), four loads in flight per 16-byte column group.
-  f32x4_t accs[8];
+  f32x4_t accs[NJ];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int n = 4 * (tid + 256 * j);
     accs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (n < p.N) {
@@ -1199,6 +1204,21 @@ __device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int
         accs[j] += v0; accs[j] += v1; accs[j] += v2; accs[j] += v3;
       }
       for (; z < p.splitk; ++z) accs[j] += pload(src + z * zs);
+    }
+  }
+  const bool pre_bias = PRE && p.bias && (!p.row_stats || p.stats_partials);   // (a row_stats fold inside epilogue_compute4 precedes the bias)
+  const bool pre_res = PRE && p.residual && p.vec_ok;
+  [[maybe_unused]] float4 pb[PRE ? NJ : 1], pr_[PRE ? NJ : 1], pc[PRE ? NJ : 1], pg[PRE ? NJ : 1], pbe[PRE ? NJ : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = 4 * (tid + 256 * j);
+      if (n < p.N) {
+        if (pre_bias) pb[j] = *reinterpret_cast<const float4*>(p.bias + n);
+        if (pre_res) pr_[j] = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + n);
+        if (p.stats_partials) pc[j] = *reinterpret_cast<const float4*>(p.colsum + n);
+        if (p.ln_out) { pg[j] = *reinterpret_cast<const float4*>(p.ln_out_g + n); pbe[j] = *reinterpret_cast<const float4*>(p.ln_out_b + n); }
+      }
     }
   }
   if (p.stats_partials) {
@@ -1217,21 +1237,31 @@ __device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int
     __syncthreads();
     q.row_stats = nullptr;                             // the fold is applied below with (mean, rstd) from LDS
   }
-  float x[8][4];
+  float x[NJ][4];
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int n = 4 * (tid + 256 * j);
     x[j][0] = x[j][1] = x[j][2] = x[j][3] = 0.f;
     if (n < p.N) {
       f32x4_t acc = accs[j];
       if (p.stats_partials) {                          // rstd * (acc - mean * colsum): first step of the epilogue
-        const float4 c = *reinterpret_cast<const float4*>(p.colsum + n);
+        float4 c;
+        if constexpr (PRE) c = pc[j]; else c = *reinterpret_cast<const float4*>(p.colsum + n);
         const float mu = st[0], rs = st[1];
         acc[0] = rs * (acc[0] - mu * c.x); acc[1] = rs * (acc[1] - mu * c.y);
         acc[2] = rs * (acc[2] - mu * c.z); acc[3] = rs * (acc[3] - mu * c.w);
       }
-      epilogue_compute4<ACT>(q, m, n, acc, x[j]);
+      if constexpr (PRE) {
+        // the prefetched bias goes on first and the prefetched residual last — where epilogue_compute4 applies them
+        GemmParams qq = q;
+        if (pre_bias) { acc[0] += pb[j].x; acc[1] += pb[j].y; acc[2] += pb[j].z; acc[3] += pb[j].w; qq.bias = nullptr; }
+        if (pre_res) qq.residual = nullptr;
+        epilogue_compute4<ACT>(qq, m, n, acc, x[j]);
+        if (pre_res) { x[j][0] += pr_[j].x; x[j][1] += pr_[j].y; x[j][2] += pr_[j].z; x[j][3] += pr_[j].w; }
+      } else {
+        epilogue_compute4<ACT>(q, m, n, acc, x[j]);
+      }
       const long long off = (long long)m * p.ldc + n;
       if (p.c_f16c) {
         f16c_store4(reinterpret_cast<char*>(p.C) + (long long)m * p.ldc * 2, n, p.N, x[j]);
@@ -1253,7 +1283,7 @@ __device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int
   const float mean = bsum(s) / (float)p.N;
   float qv = 0.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     if (4 * (tid + 256 * j) < p.N) {
       const float a = x[j][0] - mean, b = x[j][1] - mean, c = x[j][2] - mean, d = x[j][3] - mean;
       qv += (a * a + b * b) + (c * c + d * d);
@@ -1261,10 +1291,12 @@ __device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int
   }
   const float rstd = rsqrtf(bsum(qv) / (float)p.N + p.ln_out_eps);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int n = 4 * (tid + 256 * j);
     if (n >= p.N) continue;
-    const float4 gm = *reinterpret_cast<const float4*>(p.ln_out_g + n), bt = *reinterpret_cast<const float4*>(p.ln_out_b + n);
+    float4 gm, bt;
+    if constexpr (PRE) { gm = pg[j]; bt = pbe[j]; }
+    else { gm = *reinterpret_cast<const float4*>(p.ln_out_g + n); bt = *reinterpret_cast<const float4*>(p.ln_out_b + n); }
     const float o0 = (x[j][0] - mean) * rstd * gm.x + bt.x, o1 = (x[j][1] - mean) * rstd * gm.y + bt.y;
     const float o2 = (x[j][2] - mean) * rstd * gm.z + bt.z, o3 = (x[j][3] - mean) * rstd * gm.w + bt.w;
     if (p.ln_out_dt == KX_F16C) {
@@ -1287,11 +1319,11 @@ __device__ __forceinline__ void splitk_reduce_row(const GemmParams& p, const int
   }
 }
 
-template <int ACT>
+template <int ACT, int NJ>
 __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParams p) {
   __shared__ float red[4];
   __shared__ float st[2];
-  splitk_reduce_row<ACT, false>(p, (int)blockIdx.x, red, st);
+  splitk_reduce_row<ACT, false, NJ>(p, (int)blockIdx.x, red, st);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2357,13 +2389,18 @@ int kx_cu_count() {
 int launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
   if (p.ln_out || (p.stats_partials && p.splitk > 1 && !p.ln_g)) {          // row-owning reduce with its fusions
     const dim3 rg((unsigned)p.M), rb(256);
+    // 16-byte column groups per thread: 2 (N <= 2048: operands prefetched, see splitk_reduce_row) or 8; tuning key 4 = 10: always 8 (A/B)
+    const bool nj2 = p.N <= 2048 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) != 10;
+#define KX_RR(ACTV) if (nj2) hipLaunchKernelGGL((splitk_reduce_rows_kernel<ACTV, 2>), rg, rb, 0, s, p); \
+                    else hipLaunchKernelGGL((splitk_reduce_rows_kernel<ACTV, 8>), rg, rb, 0, s, p)
     switch (p.act) {
-      case KX_ACT_NONE: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_NONE>, rg, rb, 0, s, p); break;
-      case KX_ACT_GELU: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_GELU>, rg, rb, 0, s, p); break;
-      case KX_ACT_GELU_FAST: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_GELU_FAST>, rg, rb, 0, s, p); break;
-      case KX_ACT_QUICK_GELU: hipLaunchKernelGGL(splitk_reduce_rows_kernel<KX_ACT_QUICK_GELU>, rg, rb, 0, s, p); break;
+      case KX_ACT_NONE: KX_RR(KX_ACT_NONE); break;
+      case KX_ACT_GELU: KX_RR(KX_ACT_GELU); break;
+      case KX_ACT_GELU_FAST: KX_RR(KX_ACT_GELU_FAST); break;
+      case KX_ACT_QUICK_GELU: KX_RR(KX_ACT_QUICK_GELU); break;
       default: kx_set_error("kx_gemm: unknown activation %d", p.act); return KX_ERR_INVALID_ARG;
     }
+#undef KX_RR
     KX_CHECK_LAUNCH("kx_gemm(split-K row reduce)");
     return KX_OK;
   }
