@@ -114,7 +114,8 @@ struct SplitkScope {
   SplitkScope(void* p, size_t n, hipStream_t s) {
     g_splitk_ws = p; g_splitk_ws_bytes = n - KX_COOP_WORDS * 4;
     g_coop_counters = p ? (unsigned*)((char*)p + n - KX_COOP_WORDS * 4) : nullptr; g_coop_next = 0;
-    if (g_coop_counters && hipMemsetAsync(g_coop_counters, 0, KX_COOP_WORDS * 4, s) != hipSuccess) {
+    // (only when the in-launch reduction is switched on, tuning key 17 = 1: the shipped path never reads these words)
+    if (g_coop_counters && kx_tuning_get(KX_TUNE_SPLITK_COOP) == 1 && hipMemsetAsync(g_coop_counters, 0, KX_COOP_WORDS * 4, s) != hipSuccess) {
       kx_set_error("clearing the split-K arrival counters failed");
       ok = false;
     }
