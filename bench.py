@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3, help="instrumented steps for the roofline leg")
+    ap.add_argument("--objective", default="auto", choices=["auto", "latency", "throughput"],
+                    help="scheduling objective of the library's kernel choice (kx_set_tuning key 18); auto = throughput when "
+                         "--pipeline >= 2, else latency (tools/r6_round.sh prof32 profiles the headline's kernels on one stream)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="issue consecutive steps round-robin on P HIP streams (independent requests overlap: one "
                          "step's partial kernel waves are filled by its neighbour's)")
@@ -439,6 +442,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Scheduling objective (kx_set_tuning key 18): with two or more steps in flight the library is asked for the
+    # launches with the fewest CU-microseconds (a launch's idle CUs are filled by the other step), with one step for the launches
+    # that finish soonest alone.  The headline loop, the instrumented roofline pass, the other precision modes and the parity
+    # forward all run under THIS objective; the single-request legs (training, C3, decode, batch 1) under "latency".
+    from kosmosx import ops as _ops
+    objective = args.objective if args.objective != "auto" else ("throughput" if P > 1 else "latency")
+    _ops.set_objective(objective)
     for _ in range(args.warmup):
         step()
     fence()
@@ -516,6 +526,7 @@ def main():
             model.invalidate_packed()
         model.precision = args.precision
 
+    _ops.set_objective("latency")                            # the legs below issue one request at a time
     # ---- SURVEY 8f row 1 next to the headline: one training step of the text decoder (never part of `value`) ----
     training = None
     if rank == 0 and world == 1 and not force_dist and not args.no_cpu_baseline and not args.no_extra:
@@ -667,6 +678,7 @@ def main():
         model.precision = args.precision
 
     # ---- cpu_baseline: the oracle (a port — the reference's third-party stack is absent) on the host cores ----
+    _ops.set_objective(objective)                            # parity is measured on the headline's kernels
     cpu_baseline, parity_all = None, None
     if cpu_weights is not None:
         from helpers import oracle_cfg
@@ -802,7 +814,13 @@ def main():
                        "logits_gather_note": (None if gatherer is None else
                                               f"default schedule is all_gather since round 5; `auto` would pick "
                                               f"{'direct' if world > 2 else 'all_gather'} at {world} ranks for this shard (pass --gather-algo auto)"),
-                       "micro_batch_streams": S, "pipelined_steps": P, "hip_graph": bool(args.graph)},
+                       "micro_batch_streams": S, "pipelined_steps": P, "hip_graph": bool(args.graph),
+                       "schedule_objective": (f"{objective} (kx_set_tuning key 18 = {1 if objective == 'throughput' else 0}: " +
+                                              ("steps in flight on separate streams -> launches chosen for the fewest CU-microseconds "
+                                               "(256-row tiles where 192-row ones only saved padding); bit-identical results; "
+                                               "+2.7 % against the latency objective with two steps in flight, -3 % with one: "
+                                               "profiles/r06_h_cutime_ab*.log)" if objective == "throughput" else
+                                               "one step at a time -> launches chosen to finish soonest alone on the chip)"))},
             "algorithmic_gflop_per_sample": round(fl["total"] / 1e9, 2),
             "model_tflops": round(fl["total"] * total / elapsed / 1e12, 2),
             "mfma_peak_frac_end_to_end": round(fl["total"] * total / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world), 4),

@@ -42,7 +42,7 @@ void kx_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- runtime tuning knobs (kx_set_tuning) ----
-enum { KX_TUNE_LN_VARIANT = 0, KX_TUNE_GEMM_TILE = 1, KX_TUNE_ATTN_VARIANT = 2, KX_TUNE_GEMM_STAGGER = 3, KX_TUNE_GEMM_EPILOGUE = 4, KX_TUNE_GEMM_IDLE_SKIP = 5, KX_TUNE_PREPROCESS_NO_LDS = 6, KX_TUNE_GEMM_PERSISTENT = 7, KX_TUNE_GEMV_VARIANT = 8, KX_TUNE_CACHE_LAYOUT = 9, KX_TUNE_DECODE_STREAM_F32 = 10, KX_TUNE_DECODE_KSPLIT = 11, KX_TUNE_DECODE_PIECES = 12, KX_TUNE_GEMM_PAIRK = 13, KX_TUNE_GEMM_KLOOP = 14, KX_TUNE_GEMM_RULES = 15, KX_TUNE_F16C_CORR = 16, KX_TUNE_SPLITK_COOP = 17, KX_TUNE_COUNT = 18 };
+enum { KX_TUNE_LN_VARIANT = 0, KX_TUNE_GEMM_TILE = 1, KX_TUNE_ATTN_VARIANT = 2, KX_TUNE_GEMM_STAGGER = 3, KX_TUNE_GEMM_EPILOGUE = 4, KX_TUNE_GEMM_IDLE_SKIP = 5, KX_TUNE_PREPROCESS_NO_LDS = 6, KX_TUNE_GEMM_PERSISTENT = 7, KX_TUNE_GEMV_VARIANT = 8, KX_TUNE_CACHE_LAYOUT = 9, KX_TUNE_DECODE_STREAM_F32 = 10, KX_TUNE_DECODE_KSPLIT = 11, KX_TUNE_DECODE_PIECES = 12, KX_TUNE_GEMM_PAIRK = 13, KX_TUNE_GEMM_KLOOP = 14, KX_TUNE_GEMM_RULES = 15, KX_TUNE_F16C_CORR = 16, KX_TUNE_SPLITK_COOP = 17, KX_TUNE_OBJECTIVE = 18, KX_TUNE_COUNT = 19 };
 int kx_tuning_get(int key);
 // number of K slices kx_gemm's automatic choice gives an (M, N, K) problem with `ws_bytes` of split-K scratch (1 = no split)
 int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_bytes);

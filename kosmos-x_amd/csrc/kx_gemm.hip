@@ -269,8 +269,12 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
                "0.85 CUs <= 2 tiles <= CUs, an even number of K-tiles, no activation / statistics (M=%lld N=%lld K=%lld)",
                (long long)a->M, (long long)a->N, (long long)a->K);
     p.pairk = 1; tile = 512;
-  } else if (tile == 0 && kx_tuning_get(KX_TUNE_GEMM_PAIRK) != 1 && pair_ok()) {
+  } else if (tile == 0 && kx_tuning_get(KX_TUNE_GEMM_PAIRK) != 1 && !(kx_tuning_get(KX_TUNE_GEMM_RULES) & 128) && pair_ok()) {
     p.pairk = 1; tile = 512;
+  } else if (tile == 0 && (kx_tuning_get(KX_TUNE_GEMM_RULES) & 128) && pair_ok()) {
+    // A/B (tuning key 15 & 128, "CU-time" experiment of round 6): what the pair split would take runs as HALF a round of whole
+    // 256 x 256 tiles instead — longer per launch, fewer CU-microseconds, the other CUs left to the second stream in flight
+    tile = 512;
   }
   if (p.pairk) {
     static std::atomic<unsigned> epoch{0};
@@ -337,6 +341,16 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
       if ((f16c || f16) && tile == 256 && kx_tuning_get(KX_TUNE_GEMM_EPILOGUE) == 6) tile = cost(160) <= cost(128) ? 160 : 128;
     }
   }
+  // THROUGHPUT objective (tuning key 18 = 1; A/B alone: key 15 & 256): 256-row tiles wherever the rules above chose 192-row ones.
+  // The rules above minimise the time of ONE launch alone on the chip (rounds x tile time).  A caller that keeps two steps in
+  // flight on two streams fills a launch's idle CUs with the other step's kernels, and what counts then is the launch's
+  // CU-microseconds = tiles x tile time: since the balanced K loop a K-tile costs the same at both heights (2436 vs 2450 cycles),
+  // so 19 x 24 tiles of 192 rows (decoder qkv at M = 3648) are 27 % more CU time than 15 x 24 of 256 — for the same two rounds.
+  // Measured, same box, alternating (tools/cutime_ab.sh, profiles/r06_h_*): two steps in flight 1280 -> 1314 samples/s (+2.7 %,
+  // two boxes); ONE step at a time 27.7 -> 28.5 ms (-3 %: there the rounds are what counts) — hence an objective, not a default.
+  // (The other CU-time candidate — whole 256 x 256 tiles on half the chip instead of the pair split, key 15 & 128 — measured
+  // +1.3 % alone, +0.2 % on top of this rule, and -10 % with one step at a time: A/B only.)
+  if (tile == 384 && a->tile == 0 && ((kx_tuning_get(KX_TUNE_GEMM_RULES) & 256) || kx_tuning_get(KX_TUNE_OBJECTIVE) == 1)) tile = 512;
   // A 64x64 wave owns 32 columns only: the statistics producer needs the split-K reduce kernel (whose threads walk whole
   // 64-column segments) — when the call will not actually be split, take 128x128 instead (its waves own 64 columns).
   if (tile == 64 && a->ln_operand_out) tile = 128;        // the producer lives in the 64-column store loops

@@ -285,6 +285,15 @@ def pair_scratch(device="cuda", workgroups=256):
     return torch.zeros(4096 + workgroups * 131072, dtype=torch.uint8, device=device)
 
 
+def set_objective(name: str) -> None:
+    """Scheduling objective of the library's automatic kernel choice (kx_set_tuning key 18): "latency" (default; every launch
+    chosen to finish soonest alone on the chip — one step at a time) or "throughput" (the caller keeps two or more steps in flight
+    on separate streams: fewest CU-microseconds per launch).  Results are bit-identical either way."""
+    v = {"latency": 0, "throughput": 1}[name]
+    if H.load().kx_set_tuning(18, v) != 0:
+        raise RuntimeError("kx_set_tuning(18) refused")
+
+
 def splitk_flags(device="cuda"):
     """kx_gemm_args.splitk_flags: one word per workgroup of an in-launch split-K reduction (2 per CU), cleared once."""
     return torch.zeros(1024, dtype=torch.int32, device=device)

@@ -514,3 +514,25 @@ def test_qkv_gemm_writes_f16hl_pieces_and_the_attention_kernel_reads_them_bit_fo
     of = ops.attention(sl(qhl, 0), sl(qhl, 1), sl(qhl, 2), causal=True, hilo=True, out_f16c=True)       # KX_F16C rows out, as the decoder asks
     og = ops.attention(sl(q32, 0), sl(q32, 1), sl(q32, 2), causal=True, out_f16c=True)
     assert torch.equal(of, og)
+
+
+def test_throughput_objective_takes_256_row_tiles_and_changes_no_bit():
+    """kx_set_tuning key 18 = 1: the automatic choice for the decoder's qkv GEMM at M = 32 x 114 is 15 x 24 tiles
+    of 256 rows instead of 19 x 24 of 192 (fewest CU-microseconds instead of soonest alone).  The tile height does not change an
+    element's summation order and both epilogues are bit-equal to the generic store loop: same bits as the latency objective and as
+    the two explicit tile requests."""
+    M, N, K, T = 3648, 6144, 2048, 114
+    g = _g(7)
+    a = ops.pack_f16c_rows((torch.randn(M, K, generator=g) * 1.3).to(DEV))
+    wp = _operand_f16c((torch.randn(N, K, generator=g) * 0.05).to(DEV))
+    bias = torch.randn(N, generator=g).to(DEV)
+    tabs = tuple((torch.rand(T, 32, generator=g) * 2 - 1).to(DEV) for _ in range(4))
+    kw = dict(bias=bias, qscale=0.125, qcols=N // 3, xpos=tabs, xpos_dim=N // 3)
+    lat = ops.gemm_f16c(a, wp, N, K, **kw)
+    t384, t512 = ops.gemm_f16c(a, wp, N, K, tile=384, **kw), ops.gemm_f16c(a, wp, N, K, tile=512, **kw)
+    try:
+        ops.set_objective("throughput")
+        thr = ops.gemm_f16c(a, wp, N, K, **kw)
+    finally:
+        ops.set_objective("latency")
+    assert torch.equal(lat, t384) and torch.equal(thr, t512) and torch.equal(lat, thr)

@@ -29,7 +29,7 @@ case $WHAT in
     grep -E "passed|failed" $O/pytest_gpu.log | tail -3; grep -E "^(FAILED|ERROR)" $O/pytest_gpu.log | head -30 ;;
   bench)
     timeout 1200 python bench.py --steps 10 --warmup 3 > $O/bench_default.json 2> $O/bench.err; tail -c 400 $O/bench_default.json; echo; tail -3 $O/bench.err ;;
-  prof32)  stats mixed_b32_step_only python $PWD/bench.py --steps 5 --warmup 2 --pipeline 1 --no-cpu-baseline --no-extra --prof-steps 0 ;;   # one stream: durations are each kernel alone on the chip
+  prof32)  stats mixed_b32_step_only python $PWD/bench.py --steps 5 --warmup 2 --pipeline 1 --objective throughput --no-cpu-baseline --no-extra --prof-steps 0 ;;   # one stream: durations are each kernel alone on the chip
   profdec) stats decode_mixed python $PWD/tools/bench_decode.py --precision mixed
            stats decode_bf16 python $PWD/tools/bench_decode.py --precision bf16 ;;
   profb1)  stats b1_bf16 python $PWD/bench.py --batch 1 --precision bf16 --pipeline 1 --steps 30 --warmup 5 --no-extra --no-cpu-baseline --prof-steps 0 ;;
