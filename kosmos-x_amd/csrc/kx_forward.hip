@@ -107,20 +107,19 @@ constexpr size_t KX_SPLITK_WS = 32u << 20;   // 32 MB: enough for 16 slices of e
 // per workgroup; every launch writes its own epoch, so the launches of a stream share them): cleared once per stage call on
 // the stage's stream.
 thread_local unsigned* g_coop_counters = nullptr;
-thread_local int g_coop_next = 0;
 constexpr size_t KX_COOP_WORDS = 1024;
 struct SplitkScope {
   bool ok = true;
   SplitkScope(void* p, size_t n, hipStream_t s) {
     g_splitk_ws = p; g_splitk_ws_bytes = n - KX_COOP_WORDS * 4;
-    g_coop_counters = p ? (unsigned*)((char*)p + n - KX_COOP_WORDS * 4) : nullptr; g_coop_next = 0;
+    g_coop_counters = p ? (unsigned*)((char*)p + n - KX_COOP_WORDS * 4) : nullptr;
     // (only when the in-launch reduction is switched on, tuning key 17 = 1: the shipped path never reads these words)
     if (g_coop_counters && kx_tuning_get(KX_TUNE_SPLITK_COOP) == 1 && hipMemsetAsync(g_coop_counters, 0, KX_COOP_WORDS * 4, s) != hipSuccess) {
       kx_set_error("clearing the split-K arrival counters failed");
       ok = false;
     }
   }
-  ~SplitkScope() { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; g_coop_counters = nullptr; g_coop_next = 0; }
+  ~SplitkScope() { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; g_coop_counters = nullptr; }
 };
 #define KX_SPLITK_SCOPE(ptr, stream) SplitkScope sk((ptr), KX_SPLITK_WS, (stream)); if (!sk.ok) return KX_ERR_LAUNCH
 // scratch of the 256x256 kernel's pair split (kx_gemm_args.pair_ws) of the stage being launched: 4 KB of hand-off words,

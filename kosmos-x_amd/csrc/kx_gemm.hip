@@ -47,12 +47,18 @@ int kx_gemm_auto_splits(int64_t M, int64_t N, int64_t K, int prec, size_t ws_byt
 // Sticky device word of the pair split's bounded hand-off (GemmParams.pk_err): 0, or 1 + the index of the last workgroup that
 // gave up waiting for its partner's flag.  One word per process and device context; kx_pair_split_errors reads and clears it.
 __device__ unsigned g_kx_pair_err;
-static unsigned* pair_err_word() {
-  static unsigned* ptr = [] {
+static unsigned* pair_err_word() {          // the CURRENT device's copy of the word (cached per device ordinal, like kx_cu_count)
+  static std::atomic<unsigned*> ptr[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  unsigned* w = ptr[dev].load(std::memory_order_relaxed);
+  if (!w) {
     void* q = nullptr;
-    return hipGetSymbolAddress(&q, HIP_SYMBOL(g_kx_pair_err)) == hipSuccess ? (unsigned*)q : (unsigned*)nullptr;
-  }();
-  return ptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_kx_pair_err)) != hipSuccess) return nullptr;
+    w = (unsigned*)q;
+    ptr[dev].store(w, std::memory_order_relaxed);
+  }
+  return w;
 }
 extern "C" int kx_pair_split_errors(unsigned* word_out) {
   KX_REQUIRE(word_out != nullptr, "kx_pair_split_errors: null output");
@@ -421,8 +427,9 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
       p.splitk = (int)sp;
       p.partial = (float*)a->splitk_ws;
       // in-launch reduction (GemmParams.coop; the caller asks for it by passing splitk_flags — the stage entry points only with
-      // tuning key 17 = 1: MEASURED no faster than the reduce launch it replaces, profiles/r06_d_*): every workgroup resident (64 KB of LDS / 256 threads: two per CU), the row-owning
-      // reduce's preconditions, and a kernel that exists in this form (the ring for bf16 / fp16 / fp32 rows, two stages for KX_F16C)
+      // tuning key 17 = 1: MEASURED no faster than the reduce launch it replaces, profiles/r06_d_*): every workgroup resident
+      // (64 KB of LDS / 256 threads: two per CU), the row-owning reduce's preconditions, and a kernel that exists in this form
+      // (the ring for bf16 / fp16 / fp32 rows, two stages for KX_F16C)
       p.coop = a->splitk_flags && kx_tuning_get(KX_TUNE_SPLITK_COOP) != 2 && a->N <= 8192 && a->N % 4 == 0 && p.vec_ok &&
                tiles64 * sp <= 2ll * kx_cu_count() && a->M <= tiles64 * sp && (p.ring == 1 || f16c) && !p.c_hilo && !p.c_pieces;
       if (p.coop) {
