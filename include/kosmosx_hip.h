@@ -697,7 +697,7 @@ int kx_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, int32_t si
  *         idle CUs are filled by the other steps' kernels and what counts is its CU-microseconds: 256-row tiles wherever 192-row
  *         ones were chosen to save nothing but padding.  Same results bit for bit (the tile height does not change an element's
  *         summation order); measured +2.7 % with two steps in flight, -3 % with one.
- *         key 15 & 256 is the same rule as an A/B bit; key 15 & 128 = whole 256 x 256 tiles on half the chip instead of the pair
+ *         key 15 & 256 is the same rule as an A/B bit (15 & 1024 / 2048 exclude the XPos launches / all the others from it); key 15 & 128 = whole 256 x 256 tiles on half the chip instead of the pair
  *         split (+0.2 % on top with two steps in flight, -10 % with one: A/B only).
  * key 17: in-launch split-K reduction (kx_gemm_args.splitk_flags).  0 = kx_gemm honours the field, the stage entry points do not
  *         pass it (MEASURED: 0.4-4 us slower per batch-1 GEMM than the reduce launch it replaces, batch-1 forward 4.52 vs 3.85 ms);

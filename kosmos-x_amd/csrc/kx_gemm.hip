@@ -356,7 +356,9 @@ extern "C" int kx_gemm(const kx_gemm_args* a_in, void* stream) {
   // two boxes); ONE step at a time 27.7 -> 28.5 ms (-3 %: there the rounds are what counts) — hence an objective, not a default.
   // (The other CU-time candidate — whole 256 x 256 tiles on half the chip instead of the pair split, key 15 & 128 — measured
   // +1.3 % alone, +0.2 % on top of this rule, and -10 % with one step at a time: A/B only.)
-  if (tile == 384 && a->tile == 0 && ((kx_tuning_get(KX_TUNE_GEMM_RULES) & 256) || kx_tuning_get(KX_TUNE_OBJECTIVE) == 1)) tile = 512;
+  if (tile == 384 && a->tile == 0 && ((kx_tuning_get(KX_TUNE_GEMM_RULES) & 256) || kx_tuning_get(KX_TUNE_OBJECTIVE) == 1) &&
+      !((kx_tuning_get(KX_TUNE_GEMM_RULES) & 1024) && a->xpos_dim) && !((kx_tuning_get(KX_TUNE_GEMM_RULES) & 2048) && !a->xpos_dim))
+    tile = 512;                          // (A/B bits 15 & 1024 / 2048: the XPos launches / all the others keep their 192-row tiles)
   // A 64x64 wave owns 32 columns only: the statistics producer needs the split-K reduce kernel (whose threads walk whole
   // 64-column segments) — when the call will not actually be split, take 128x128 instead (its waves own 64 columns).
   if (tile == 64 && a->ln_operand_out) tile = 128;        // the producer lives in the 64-column store loops

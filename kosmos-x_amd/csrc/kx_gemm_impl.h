@@ -620,14 +620,28 @@ __device__ __forceinline__ void lean_bias_qscale_xpos(const GemmParams& p, f32x4
 #pragma unroll
   for (int a = 0; a < FN; ++a)
     bias[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + ncol0 + a * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!rot) {
+    // v columns (tile-uniform): bias only (q-scale is 1 there or applies alike) — its own straight-line loop.  (Round 6: one loop
+    // with `rot ? table : identity` selects compiled to a branch around every table read, ~130 basic blocks per tile, and the
+    // register allocator spilled 92 values in the 256-row form.)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int a = 0; a < FN; ++a) {
+        f32x4_t v = acc[a][b];
+        v[0] = (v[0] + bias[a].x) * qsc; v[1] = (v[1] + bias[a].y) * qsc;
+        v[2] = (v[2] + bias[a].z) * qsc; v[3] = (v[3] + bias[a].w) * qsc;
+        acc[a][b] = v;
+      }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
     const float* tr = tab + (row_w0 + b * 16 + li) * XPOS_PITCH + 2 * g;
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
-      // v columns: the identity rotation (1, 0) — exact — keeps the arithmetic straight-line
-      const float2 c = rot ? *reinterpret_cast<const float2*>(tr + a * 8) : make_float2(1.f, 1.f);
-      const float2 sn = rot ? *reinterpret_cast<const float2*>(tr + 32 + a * 8) : make_float2(0.f, 0.f);
+      const float2 c = *reinterpret_cast<const float2*>(tr + a * 8);
+      const float2 sn = *reinterpret_cast<const float2*>(tr + 32 + a * 8);
       f32x4_t v = acc[a][b];
       const float x0 = (v[0] + bias[a].x) * qsc, x1 = (v[1] + bias[a].y) * qsc;
       const float x2 = (v[2] + bias[a].z) * qsc, x3 = (v[3] + bias[a].w) * qsc;
@@ -2231,7 +2245,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     const bool rot = n0 < 2 * p.xpos_dim;                 // tile-uniform: xpos_dim % 256 == 0 (kx_gemm checks)
     float* tab = reinterpret_cast<float*>(smem);
     __syncthreads();                                      // the K loop's last fragment reads are done
-    if (rot) stage_xpos_rows<BM>(p, tab, m0, n0, threadIdx.x);
+    // (the thread index is laundered like lane_e above: what stage_xpos_rows derives from it is tile-invariant, was hoisted above
+    //  the tile loop and kept live through the K loop — the 256-row form reloaded DMA source offsets from scratch inside the loop)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    if (rot) stage_xpos_rows<BM>(p, tab, m0, n0, tid_e);
     __syncthreads();
     lean_bias_qscale_xpos<FM, FN>(p, acc, n0 + wn * WN, g, wm * (BM / 2), li, tab, rot);
     KX_TL_STAMP(3);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# (needs the two A/B bits of the experiment, not in the tree: rule excluded for XPos launches = 1024, for the others = 2048)
+# (A/B bits: rule excluded for the XPos launches = 15 & 1024, for the others = 15 & 2048)
 # which launches carry the throughput objective's gain (round 6): A/B bits 15 & 1024 (the decoder's XPos qkv launches keep 192-row
 # tiles and their lean epilogue) and 15 & 2048 (only they take 256-row tiles).   GPU box only.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
