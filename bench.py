@@ -12,7 +12,12 @@ input already resident in HBM: `--batch` samples (default 32 = BASELINE.json con
 with the all-gather of logits (bf16 on the wire, overlapped with the next step's compute).
 Weak scaling: per-GPU work is fixed as N grows.  Rank 0 prints ONE JSON line.
 
-Headline arithmetic (`--precision`, default f16c): the fastest mode that holds the north star's 1e-3 logit tolerance
+Two steps are kept in flight on two streams (`--pipeline`), and the library is told so (`--objective`, kx_set_tuning key 18 =
+"throughput": per GEMM the launch with the fewest CU-microseconds; with `--pipeline 1` "latency": the launch that finishes soonest
+alone — same bits either way); `config.schedule_objective` records it, `roofline` is measured on the timed
+loop's launches and also reports the family's rate under the latency objective.
+
+Headline arithmetic (`--precision`, default mixed): the fastest mode that holds the north star's 1e-3 logit tolerance
 against the fp32 CPU path — `parity` in the JSON is measured in the same run.  Plain bf16 operands (3.5e-2) are
 reported in `precision_modes` with their parity next to their (higher) throughput; `c3` is BASELINE.json configs[2]
 (text-only B=32, T=2046: the config of the >= 40 % MFMA target), `batch1` configs[1] (HBM roofline).
