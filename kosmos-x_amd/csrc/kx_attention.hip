@@ -480,6 +480,19 @@ __device__ __forceinline__ void split_f16x8(const float (&x)[8], u32x4_t& hi, u3
     lo[j] = pack_f16x2(x[2 * j] - (float)h[0], x[2 * j + 1] - (float)h[1]);
   }
 }
+// The same split for values known to lie in [0, 2^8] (the probabilities P' = 2^8 exp(S - m)): no clamps, and the lo piece in ONE
+// instruction per value — v_fma_mixlo / mixhi_f16 computes fp16(x - hi) with hi read as the fp16 it is (the fp32 difference is
+// exact, so the single rounding is the rounding of the two-step form: bit-identical).  3 instructions per value pair instead of 6-14.
+__device__ __forceinline__ void split_f16x8_unit(const float (&x)[8], u32x4_t& hi, u32x4_t& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((kx_f32x2_t){x[2 * j], x[2 * j + 1]}, kx_f16x2_t));
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x[2 * j]));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x[2 * j + 1]));
+    hi[j] = h; lo[j] = l;
+  }
+}
 __device__ __forceinline__ f32x4_t mma_f16(u32x4_t a, u32x4_t b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16s_kernel(const AttnParams p) {
         for (int c = 0; c < 2; ++c) {
           const float x[8] = {st[qb][2 * c][0], st[qb][2 * c][1], st[qb][2 * c][2], st[qb][2 * c][3],
                               st[qb][2 * c + 1][0], st[qb][2 * c + 1][1], st[qb][2 * c + 1][2], st[qb][2 * c + 1][3]};
-          if constexpr (PVS == 1 || PVS == 3) split_f16x8(x, ph[qb][c], pl[qb][c]);
+          if constexpr (PVS == 1 || PVS == 3) split_f16x8_unit(x, ph[qb][c], pl[qb][c]);
           else {
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) ph[qb][c][j2] = pack_f16x2(x[2 * j2], x[2 * j2 + 1]);
