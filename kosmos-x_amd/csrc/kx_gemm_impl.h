@@ -1740,7 +1740,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;   // 64 KB
   constexpr int FM = BM / 32, FN = 4;        // (BM/2)(m) x 64(n) per wave
   constexpr int IA = BM / 64, IW = 4;        // glds instructions per wave per stage (8 rows each)
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  // + 256 bytes behind the ring: the E8M0 scale bytes of the tile's 256 weight rows (KX_F16C), see the prologue.  ONE LDS object
+  // (a second one makes the compiler drain vmcnt before every ds_read of a glds pipeline: guide trap 4a)
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 256];
 
   const int nwg = p.tiles_m * p.tiles_n;
   // persistent launch (grid = one workgroup per CU, p.persistent): the workgroup walks tiles bid, bid + grid, ... itself
@@ -1873,8 +1875,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
   // in the one instantiation whose register allocation reused such a register for a fragment (f16c, generic fp32 store),
   // put its own s_waitcnt vmcnt(0) between R0's ds_reads — a drain of the LDS-DMA ring every K-tile: the balanced loop
   // measured 9-11 % SLOWER than the first form there while every other instantiation gained (profiles/r05_b_*).
+  // KX_F16C: the weight rows' scale bytes are requested HERE, with the tile's first K-tiles, and parked in LDS.  (Until round 6
+  // the four bytes a lane needs were loaded at the fp16 -> fp8 transition of the K loop and waited for on the spot: a dependent
+  // global round trip per tile with the matrix pipe idle, behind a compiler-placed vmcnt(0) that also drained the LDS-DMA ring —
+  // found in the ISA of every f16c instantiation.)
+  [[maybe_unused]] unsigned wsb = 127u;
+  if constexpr (kIsF16c<T>) {
+    if (p.wscale && tid < 256) wsb = p.wscale[min(n0 + tid, p.N - 1)];
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (kIsF16c<T>) {
+    if (tid < 256) smem[2 * STAGE + tid] = (char)wsb;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // landed before the barrier: a pair-split partner whose K half is all fp8 tiles reads it at once
+  }
   __builtin_amdgcn_s_barrier();
   KX_TL_STAMP(1);
   const bool lag = wave >= 4;
@@ -2036,7 +2050,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p5(const GemmParams p) {
     constexpr int FH = FM / 2;
     int wsc[FN];
 #pragma unroll
-    for (int a = 0; a < FN; ++a) wsc[a] = p.wscale ? p.wscale[min(n0 + wn * 64 + a * 16 + lk, p.N - 1)] : 127;
+    for (int a = 0; a < FN; ++a) wsc[a] = (int)(unsigned char)smem[2 * STAGE + wn * 64 + a * 16 + lk];
     KX_TLP_BEGIN();
     for (int kt = KS2 ? max(nk1, k0) : nk1; kt < k1; ++kt) {
       const char* base = smem + (kt & 1) * STAGE;
